@@ -1,0 +1,124 @@
+/*
+ * smcp_amd.h -- C ABI of the MI355X-native chordal-matrix Newton-KKT kernels.
+ *
+ * The reference (cvxopt/smcp) has no plugin registry: its hot path is the set of Python
+ * callables it imports from CHOMPACK / CVXOPT / its own misc extension inside
+ * chordalsolver_feas/_esd (src/python/solvers.py:77-99).  Every entry point below names the
+ * call it replaces.  Conventions (observed at the reference's call sites):
+ *   - operations are IN PLACE on a flat fp64 vector `blkval` (clique k owns a dense
+ *     column-major (nn+na) x nn block at blkptr[k]); the caller owns all numeric buffers;
+ *   - all numeric pointers are DEVICE pointers (HBM) unless a parameter says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return value: 0 ok; k>0 = clique k-1 (or pivot) was not positive definite, which the
+ *     Python shim turns into ArithmeticError exactly like CHOMPACK does
+ *     (caught at solvers.py:628,643,658,...); <0 = usage / HIP error.
+ * No CPU fallback exists: compute entry points fail with SMCP_ENODEV when no GPU is present.
+ */
+#ifndef SMCP_AMD_H
+#define SMCP_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct csp_ctx csp_ctx;
+
+#define SMCP_EINVAL (-1)
+#define SMCP_ENODEV (-2)
+#define SMCP_EHIP (-3)
+#define SMCP_ENOMEM (-4)
+
+/* ---- symbolic layer (host only, no GPU needed) ------------------------------------- */
+
+/* chompack.symbolic(A, p) (solvers.py:305,308,314; analysis.py:49-51).
+ * colptr/rowind: CCS lower-triangular pattern of the n x n aggregate sparsity pattern (host,
+ * 64-bit indices as cvxopt int_t, src/C/cvxopt.h:46); perm: perm[new] = orig or NULL.
+ * On failure returns NULL and writes a negative code to *info. */
+csp_ctx* csp_symbolic_create(int64_t n, const int64_t* colptr, const int64_t* rowind,
+                             const int64_t* perm, int64_t* info);
+void csp_symbolic_destroy(csp_ctx* ctx);
+
+/* symb.p / snode / snptr / relptr / blkptr ... (cspmatrix internals [EXT], SURVEY App. A.1;
+ * supernodes()/separators()/cliques() at analysis.py:173-175).  Returns the number of
+ * elements of array `what`; when out != NULL copies them as int64 (host). */
+enum {
+  CSP_Q_SCALARS = 0, /* [n, nnz, nsn, fill, blklen, updlen, nlev, max_nn, max_na, max_front] */
+  CSP_Q_PERM = 1, CSP_Q_IPERM = 2, CSP_Q_SNPTR = 3, CSP_Q_SNPAR = 4, CSP_Q_ROWPTR = 5,
+  CSP_Q_ROWIDX = 6, CSP_Q_SEPPTR = 7, CSP_Q_RELIDX = 8, CSP_Q_BLKPTR = 9, CSP_Q_UPDPTR = 10,
+  CSP_Q_CHPTR = 11, CSP_Q_CHIDX = 12, CSP_Q_LEVPTR = 13, CSP_Q_LEVIDX = 14, CSP_Q_CCSPTR = 15,
+  CSP_Q_SNODE = 16
+};
+int64_t csp_symbolic_query(const csp_ctx* ctx, int what, int64_t* out);
+
+/* chompack.maxcardsearch (solvers.py:301); order[new] = orig (host). */
+int csp_maxcardsearch(int64_t n, const int64_t* colptr, const int64_t* rowind, int64_t* order);
+/* fill-reducing ordering for non-chordal input, in place of cvxopt.amd.order (solvers.py:278-279). */
+int csp_mindegree(int64_t n, const int64_t* colptr, const int64_t* rowind, int64_t* order);
+/* position in blkval of original-coordinate entries (I[e],J[e]); -1 outside V (host arrays).
+ * Replaces the LI/lp/Ip/Jp index algebra of solvers.py:310-319. */
+int csp_index_map(const csp_ctx* ctx, int64_t cnt, const int64_t* I, const int64_t* J, int64_t* out);
+
+/* ---- device context ---------------------------------------------------------------- */
+
+/* Upload the index arrays to `device` and allocate the internal update-matrix workspace for
+ * up to max_rhs simultaneous right-hand sides (>= 1).  Idempotent for the same arguments. */
+int csp_device_init(csp_ctx* ctx, int device, int64_t max_rhs);
+/* Bytes of HBM held by the context (index arrays + workspaces). */
+int64_t csp_device_bytes(const csp_ctx* ctx);
+
+/* ---- chordal kernels (all in place, device pointers) ------------------------------- */
+
+/* chompack.cholesky(X): X -> L, L L^T = X with zero fill (solvers.py:640,884,...). */
+int csp_cholesky(csp_ctx* ctx, double* blkval, void* stream);
+/* chompack.llt(L): L -> L L^T on V (solvers.py:904,1721). */
+int csp_llt(csp_ctx* ctx, double* blkval, void* stream);
+/* chompack.projected_inverse(L): L -> P_V((L L^T)^-1) (solvers.py:891,2361). */
+int csp_projected_inverse(csp_ctx* ctx, double* blkval, void* stream);
+/* chompack.completion(X): X -> L with P_V((L L^T)^-1) = X (solvers.py:625,874,...). */
+int csp_completion(csp_ctx* ctx, double* blkval, void* stream);
+/* chompack.hessian(L, Y, U, adj, inv) (solvers.py:405,415,483,524,531,...): U holds nrhs
+ * matrices, matrix r at U + r*ldu (the reference passes a Python list).  adj: 0 = False,
+ * 1 = True, 2 = None (both factors).  inv: 0/1. */
+int csp_hessian(csp_ctx* ctx, const double* L, const double* Y, double* U, int64_t nrhs,
+                int64_t ldu, int adj, int inv, void* stream);
+/* chompack.trsm(L, B, trans) (solvers.py:491-492): B is a dense n x nrhs column-major matrix
+ * with rows in the permuted (symbolic) order; trans 0: L^-1 B, 1: L^-T B. */
+int csp_trsm(csp_ctx* ctx, const double* L, double* B, int64_t nrhs, int64_t ldb, int trans,
+             void* stream);
+/* chompack.dot(X, Y) = tr(XY) on V (solvers.py:399,836,...); result written to *out (host). */
+int csp_dot(csp_ctx* ctx, const double* X, const double* Y, double* out, void* stream);
+/* sum(log(X.diag())) (solvers.py:395,925,934); *out host. */
+int csp_logdiagsum(csp_ctx* ctx, const double* X, double* out, void* stream);
+/* cspmatrix copy / +,- / a*X and blas.scal(a, X.blkval) (solvers.py:407,622,905):
+ * y <- a*x + b*y over len doubles. */
+int csp_axpby(int64_t len, double a, const double* x, double b, double* y, void* stream);
+
+/* ---- KKT layer --------------------------------------------------------------------- */
+
+/* Constraint data in blkval coordinates (replaces Av/Ip/Jp/Id, solvers.py:323-349):
+ * host CSC arrays: constraint j has entries cptr[j]..cptr[j+1]-1 at blkval positions cidx with
+ * values cval (lower-triangle values, diagonal positions flagged by the context itself). */
+int kkt_set_constraints(csp_ctx* ctx, int64_t m, const int64_t* cptr, const int64_t* cidx,
+                        const double* cval);
+/* Amap (solvers.py:369-380): y[i] = <A_i, X>, i < m;  y device, length m. */
+int kkt_amap(csp_ctx* ctx, const double* X, double* y, void* stream);
+/* Aadj (solvers.py:382-386): X <- sum_i y[i] A_i (overwrites X). */
+int kkt_aadj(csp_ctx* ctx, const double* y, double* X, void* stream);
+/* kkt_chol factor step (solvers.py:479-501 + misc.c:620-663): builds the m x m Schur
+ * complement H_ij = <A_i, hessian(L,Y)(A_j)> (lower) into H (device, ldh >= m) and factors it
+ * in place (lapack.potrf, solvers.py:501). */
+int kkt_schur_factor(csp_ctx* ctx, const double* L, const double* Y, double* H, int64_t ldh,
+                     void* stream);
+/* lapack.potrf / potrs on a dense device matrix (solvers.py:501,526). */
+int dense_potrf(csp_ctx* ctx, double* A, int64_t n, int64_t lda, void* stream);
+int dense_potrs(csp_ctx* ctx, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs,
+                int64_t ldb, void* stream);
+/* solve_ closure (solvers.py:506-541): given the factored H, overwrites bx (blkval) with x
+ * and by (length m) with y for  [-kk*W^-1  A^adj; A 0][x;y] = [bx;by]. */
+int kkt_solve(csp_ctx* ctx, const double* L, const double* Y, const double* H, int64_t ldh,
+              double kk, double* bx, double* by, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,254 @@
+"""ctypes binding of oracle/liboracle.so (chordal_oracle.c) + dense helpers for the checks.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by anything under smcp_amd/.  Parity unpinned (no reference golden
+vectors exist for this path, see chordal_oracle.c header); pinned by dense identities instead.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "chordal_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+class _CSym(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int64), ("nsn", ctypes.c_int64),
+                ("snptr", ctypes.c_void_p), ("snpar", ctypes.c_void_p), ("rowptr", ctypes.c_void_p),
+                ("rowidx", ctypes.c_void_p), ("sepptr", ctypes.c_void_p), ("relidx", ctypes.c_void_p),
+                ("blkptr", ctypes.c_void_p), ("updptr", ctypes.c_void_p), ("chptr", ctypes.c_void_p),
+                ("chidx", ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB)
+        P = ctypes.c_void_p
+        S = ctypes.POINTER(_CSym)
+        for name in ("orc_cholesky", "orc_llt", "orc_projected_inverse", "orc_completion"):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = [S, P, P]
+        L.orc_hessian.restype = ctypes.c_int
+        L.orc_hessian.argtypes = [S, P, P, P, ctypes.c_int, ctypes.c_int, P]
+        L.orc_trsm.restype = ctypes.c_int
+        L.orc_trsm.argtypes = [S, P, P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
+        L.orc_dot.restype = ctypes.c_double
+        L.orc_dot.argtypes = [S, P, P]
+        L.orc_logdiagsum.restype = ctypes.c_double
+        L.orc_logdiagsum.argtypes = [S, P]
+        L.orc_dense_potrf.restype = ctypes.c_int
+        L.orc_dense_potrf.argtypes = [ctypes.c_int64, P, ctypes.c_int64]
+        L.orc_dense_potrs.restype = None
+        L.orc_dense_potrs.argtypes = [ctypes.c_int64, ctypes.c_int64, P, ctypes.c_int64, P, ctypes.c_int64]
+        L.orc_scmcolumn2.restype = None
+        L.orc_scmcolumn2.argtypes = [ctypes.c_int64, ctypes.c_int64, P, P, P, P, P, P, P, ctypes.c_int64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Sym:
+    """Symbolic arrays in the shared flat layout.  Build from any object exposing the arrays
+    (the product's Symbolic, or oracle.symbolic_ref.symbolic_ref)."""
+
+    FIELDS64 = ("snptr", "snpar", "rowptr", "sepptr", "blkptr", "updptr", "chptr", "chidx")
+    FIELDS32 = ("rowidx", "relidx")
+
+    def __init__(self, src):
+        get = (lambda k: src[k]) if isinstance(src, dict) else (lambda k: getattr(src, k))
+        self.n = int(get("n"))
+        for f in self.FIELDS64:
+            setattr(self, f, np.ascontiguousarray(get(f), dtype=np.int64))
+        for f in self.FIELDS32:
+            setattr(self, f, np.ascontiguousarray(get(f), dtype=np.int32))
+        self.p = np.ascontiguousarray(get("p"), dtype=np.int64)
+        self.nsn = len(self.snptr) - 1
+        self.blklen = int(self.blkptr[-1])
+        self.updlen = int(self.updptr[-1])
+        self.c = _CSym(self.n, self.nsn, *[_p(getattr(self, f)) for f in
+                                          ("snptr", "snpar", "rowptr", "rowidx", "sepptr", "relidx",
+                                           "blkptr", "updptr", "chptr", "chidx")])
+        self._upd = None
+        self._work = None
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+    def upd(self):
+        if self._upd is None:
+            self._upd = np.zeros(max(1, self.updlen))
+        return self._upd
+
+    def work(self):
+        if self._work is None:
+            self._work = np.zeros(max(1, 3 * self.updlen))
+        return self._work
+
+    # ---- dense <-> blkval helpers (PERMUTED coordinates) -------------------------------
+    def _iter(self):
+        for k in range(self.nsn):
+            nn = int(self.snptr[k + 1] - self.snptr[k])
+            rows = self.rowidx[self.rowptr[k]:self.rowptr[k + 1]].astype(np.int64)
+            yield k, nn, rows
+
+    def project(self, M):
+        """blkval of P_V(M) for a dense symmetric M in permuted coordinates."""
+        out = np.zeros(self.blklen)
+        for k, nn, rows in self._iter():
+            nf = len(rows)
+            blk = M[np.ix_(rows, rows[:nn])].copy()
+            blk[:nn, :nn] = np.tril(blk[:nn, :nn])
+            out[self.blkptr[k]:self.blkptr[k] + nf * nn] = blk.reshape(-1, order="F")
+        return out
+
+    def dense(self, blkval, symmetric=True):
+        M = np.zeros((self.n, self.n))
+        for k, nn, rows in self._iter():
+            nf = len(rows)
+            blk = blkval[self.blkptr[k]:self.blkptr[k] + nf * nn].reshape((nf, nn), order="F").copy()
+            blk[:nn, :nn] = np.tril(blk[:nn, :nn])
+            M[np.ix_(rows, rows[:nn])] = blk
+        if symmetric:
+            M = M + np.tril(M, -1).T
+        return M
+
+    def mask(self):
+        """Boolean mask of V (symmetric) in permuted coordinates."""
+        M = np.zeros((self.n, self.n), dtype=bool)
+        for k, nn, rows in self._iter():
+            M[np.ix_(rows, rows[:nn])] = True
+        return M | M.T
+
+
+def _chk(rc, what):
+    if rc > 0:
+        raise ArithmeticError("%s: not positive definite (clique %d)" % (what, rc - 1))
+    if rc < 0:
+        raise RuntimeError("%s failed %d" % (what, rc))
+
+
+def cholesky(S, x):
+    _chk(lib().orc_cholesky(S.ref(), _p(x), _p(S.upd())), "cholesky")
+
+
+def llt(S, x):
+    _chk(lib().orc_llt(S.ref(), _p(x), _p(S.upd())), "llt")
+
+
+def projected_inverse(S, x):
+    _chk(lib().orc_projected_inverse(S.ref(), _p(x), _p(S.upd())), "projected_inverse")
+
+
+def completion(S, x):
+    _chk(lib().orc_completion(S.ref(), _p(x), _p(S.upd())), "completion")
+
+
+_ADJ = {False: 0, True: 1, None: 2}
+
+
+def hessian(S, L, Y, U, adj=False, inv=False):
+    _chk(lib().orc_hessian(S.ref(), _p(L), _p(Y), _p(U), _ADJ[adj], 1 if inv else 0, _p(S.work())), "hessian")
+
+
+def trsm(S, L, B, trans="N"):
+    """B: (k, n) C-contiguous array = n x k column-major, rows in permuted order."""
+    assert B.flags.c_contiguous and B.shape[1] == S.n
+    _chk(lib().orc_trsm(S.ref(), _p(L), _p(B), B.shape[0], B.shape[1], 1 if trans == "T" else 0), "trsm")
+
+
+def dot(S, x, y):
+    return lib().orc_dot(S.ref(), _p(x), _p(y))
+
+
+def logdiagsum(S, x):
+    return lib().orc_logdiagsum(S.ref(), _p(x))
+
+
+def dense_potrf(A):
+    """A: (n, n) Fortran-ordered, lower factor in place."""
+    assert A.flags.f_contiguous
+    _chk(lib().orc_dense_potrf(A.shape[0], _p(A), A.shape[0]), "potrf")
+
+
+def dense_potrs(A, B):
+    assert A.flags.f_contiguous and B.flags.f_contiguous
+    nrhs = 1 if B.ndim == 1 else B.shape[1]
+    lib().orc_dense_potrs(A.shape[0], nrhs, _p(A), A.shape[0], _p(B), A.shape[0])
+
+
+# ---- KKT layer restated in numpy around the C kernels (solvers.py:369-386, 477-541) -----
+class KKT:
+    """Constraints given as CSC over blkval positions: cptr (m+1), cidx, cval (lower-triangle values)."""
+
+    def __init__(self, S, cptr, cidx, cval):
+        self.S, self.cptr, self.cidx, self.cval = S, np.asarray(cptr), np.asarray(cidx), np.asarray(cval, dtype=float)
+        self.m = len(cptr) - 1
+        # diagonal flag of every position
+        k = np.searchsorted(S.blkptr, self.cidx, side="right") - 1
+        nf = (S.rowptr[k + 1] - S.rowptr[k])
+        off = self.cidx - S.blkptr[k]
+        self.isdiag = (off // nf) == (off % nf)
+        self.w = np.where(self.isdiag, 1.0, 2.0) * self.cval
+        self.con = np.repeat(np.arange(self.m), np.diff(self.cptr))
+
+    def amap(self, x):
+        return np.bincount(self.con, weights=self.w * x[self.cidx], minlength=self.m)
+
+    def aadj(self, y):
+        out = np.zeros(self.S.blklen)
+        np.add.at(out, self.cidx, self.cval * y[self.con])
+        return out
+
+    def constraint(self, j):
+        u = np.zeros(self.S.blklen)
+        sl = slice(self.cptr[j], self.cptr[j + 1])
+        u[self.cidx[sl]] = self.cval[sl]
+        return u
+
+    def schur_factor(self, L, Y, ncols=None):
+        """Reference formulation: one Hessian application per constraint (the Python loop at
+        solvers.py:479-487), then lapack.potrf (501).  ncols limits the loop (bounded timing sample)."""
+        m = self.m
+        H = np.zeros((m, m), order="F")
+        for j in range(m if ncols is None else ncols):
+            u = self.constraint(j)
+            hessian(self.S, L, Y, u, adj=None, inv=False)
+            H[:, j] = self.amap(u)
+        if ncols is None:
+            dense_potrf(H)
+        return H
+
+    def solve(self, L, Y, H, bx, by, kk):
+        r1 = bx.copy()
+        hessian(self.S, L, Y, r1, adj=None, inv=False)
+        y = np.asfortranarray(kk * by + self.amap(r1))
+        dense_potrs(H, y)
+        x = self.aadj(y) - bx
+        hessian(self.S, L, Y, x, adj=None, inv=False)
+        x *= 1.0 / kk
+        return x, y
+
+    def residual(self, L, Y, x, y, bx, by, kk):
+        """kkt_res (solvers.py:401-411): r = -kk*W^-1 x + Aadj(y) - bx ; Amap(x) - by."""
+        r = x.copy()
+        hessian(self.S, L, Y, r, adj=None, inv=True)
+        r *= -kk
+        r += self.aadj(y) - bx
+        return r, self.amap(x) - by

@@ -1,0 +1,141 @@
+"""Chordal sparse matrix handle: a Symbolic plus a flat fp64 ``blkval`` resident in HBM.
+
+Counterpart of ``chompack.cspmatrix`` as the reference uses it (solvers.py:367,384,407,622):
+``X.blkval`` is a flat vector that may be scaled in place, ``copy``, ``+``, ``-``, ``a*X``,
+``X.diag()``, ``X.spmatrix()``.  Storage is a torch CUDA (HIP) tensor; torch is plumbing only.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+
+
+class cspmatrix:
+    def __init__(self, symb, blkval=None, device=None):
+        self.symb = symb
+        if blkval is None:
+            dev = device if device is not None else ("cuda:%d" % symb._device if symb._device is not None else "cpu")
+            blkval = torch.zeros(symb.blklen, dtype=torch.float64, device=dev)
+        self.blkval = blkval
+
+    # ---- construction ------------------------------------------------------------------
+    @classmethod
+    def from_entries(cls, symb, I, J, V, device=None):
+        """Symmetric matrix given by lower- (or upper-) triangular entries in ORIGINAL coordinates."""
+        pos = symb.index_map(I, J)
+        if (pos < 0).any():
+            raise ValueError("entry outside the sparsity pattern")
+        h = np.zeros(symb.blklen)
+        np.add.at(h, pos, np.asarray(V, dtype=np.float64))
+        X = cls(symb, device=device)
+        X.blkval.copy_(torch.from_numpy(h))
+        return X
+
+    @classmethod
+    def from_scipy(cls, symb, A, device=None):
+        import scipy.sparse as sp
+        A = sp.tril(sp.coo_matrix(A)).tocoo()
+        return cls.from_entries(symb, A.row, A.col, A.data, device=device)
+
+    @classmethod
+    def from_dense_projection(cls, symb, M, device=None):
+        """P_V(M) for a dense symmetric matrix M in ORIGINAL coordinates."""
+        cp, ri = symb.sparsity_pattern()
+        cols = np.repeat(np.arange(symb.n), np.diff(cp))
+        p = symb.p
+        vals = np.asarray(M)[p[ri], p[cols]]
+        h = np.zeros(symb.blklen)
+        h[symb.ccs_to_blk()] = vals
+        X = cls(symb, device=device)
+        X.blkval.copy_(torch.from_numpy(h))
+        return X
+
+    # ---- conversions -------------------------------------------------------------------
+    def to_dense(self, reordered=False):
+        """Dense symmetric numpy matrix (ORIGINAL coordinates unless reordered=True)."""
+        s = self.symb
+        cp, ri = s.sparsity_pattern()
+        cols = np.repeat(np.arange(s.n), np.diff(cp))
+        v = self.blkval.detach().cpu().numpy()[s.ccs_to_blk()]
+        M = np.zeros((s.n, s.n))
+        M[ri, cols] = v
+        M[cols, ri] = v
+        if not reordered:
+            ip = s.ip
+            M = M[np.ix_(ip, ip)]
+        return M
+
+    def to_dense_factor(self):
+        """Dense lower-triangular factor in PERMUTED coordinates (for L produced by cholesky/completion)."""
+        s = self.symb
+        cp, ri = s.sparsity_pattern()
+        cols = np.repeat(np.arange(s.n), np.diff(cp))
+        v = self.blkval.detach().cpu().numpy()[s.ccs_to_blk()]
+        M = np.zeros((s.n, s.n))
+        M[ri, cols] = v
+        return M
+
+    def spmatrix(self, reordered=True, symmetric=False):
+        """scipy CSC of the lower triangle (permuted coordinates), like X.spmatrix(...) at solvers.py:370."""
+        import scipy.sparse as sp
+        s = self.symb
+        cp, ri = s.sparsity_pattern()
+        v = self.blkval.detach().cpu().numpy()[s.ccs_to_blk()]
+        L = sp.csc_matrix((v, ri, cp), shape=(s.n, s.n))
+        if symmetric:
+            L = L + sp.tril(L, -1).T
+        if not reordered:
+            ip = s.ip
+            L = sp.csc_matrix(L.tocsr()[ip][:, ip])
+        return L
+
+    def diag(self):
+        s = self.symb
+        nn, na = s.clique_sizes()
+        nf = nn + na
+        idx = np.concatenate([s.blkptr[k] + np.arange(nn[k]) * (nf[k] + 1) for k in range(s.Nsn)])
+        return self.blkval[torch.as_tensor(idx, device=self.blkval.device)]
+
+    # ---- arithmetic (flat, on blkval) --------------------------------------------------
+    def copy(self):
+        return cspmatrix(self.symb, self.blkval.clone())
+
+    def _axpby(self, a, x, b):
+        rc = _lib.lib().csp_axpby(self.symb.blklen, a, x.blkval.data_ptr() if x is not None else None, b,
+                                  self.blkval.data_ptr(), _stream())
+        if rc:
+            raise RuntimeError("csp_axpby failed (%d)" % rc)
+        return self
+
+    def __add__(self, other):
+        return cspmatrix(self.symb, self.blkval + other.blkval)
+
+    def __sub__(self, other):
+        return cspmatrix(self.symb, self.blkval - other.blkval)
+
+    def __iadd__(self, other):
+        self.blkval += other.blkval
+        return self
+
+    def __isub__(self, other):
+        self.blkval -= other.blkval
+        return self
+
+    def __mul__(self, a):
+        return cspmatrix(self.symb, self.blkval * float(a))
+
+    __rmul__ = __mul__
+
+    def __imul__(self, a):
+        self.blkval *= float(a)
+        return self
+
+    def __neg__(self):
+        return cspmatrix(self.symb, -self.blkval)
+
+    def __pos__(self):
+        return self.copy()

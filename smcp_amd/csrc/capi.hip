@@ -1,0 +1,397 @@
+// C-ABI implementation (include/smcp_amd.h): host-side drivers that walk the clique tree
+// level by level and launch the HIP kernels.  No CPU compute fallback exists here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+
+#include "../../include/smcp_amd.h"
+#include "context.hpp"
+#include "front_generic.hip"
+
+using namespace smcp;
+
+#define HIPCHK(x)                                                                        \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "smcp_amd: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return SMCP_EHIP;                                                                  \
+    }                                                                                    \
+  } while (0)
+
+namespace {
+
+template <class T>
+int dev_upload(T** dst, const std::vector<T>& src, int64_t& bytes) {
+  size_t n = std::max<size_t>(src.size(), 1) * sizeof(T);
+  if (hipMalloc((void**)dst, n) != hipSuccess) return SMCP_ENOMEM;
+  if (!src.empty() && hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+    return SMCP_EHIP;
+  bytes += (int64_t)n;
+  return 0;
+}
+template <class T>
+int dev_alloc(T** dst, int64_t count, int64_t& bytes) {
+  size_t n = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
+  if (hipMalloc((void**)dst, n) != hipSuccess) return SMCP_ENOMEM;
+  bytes += (int64_t)n;
+  return 0;
+}
+
+TreeArgs tree_args(csp_ctx* c) {
+  TreeArgs a;
+  a.cl = c->D.cl;
+  a.relidx = c->D.relidx;
+  a.chidx = c->D.chidx;
+  a.lev = c->D.levidx;
+  a.updlen = c->S.updlen();
+  a.tmplen = c->D.tmplen;
+  a.tmpptr = c->D.tmpptr;
+  a.upd = c->D.upd;
+  a.tmp = c->D.tmp;
+  a.info = c->D.info;
+  return a;
+}
+
+int ready(csp_ctx* c) {
+  if (!c) return SMCP_EINVAL;
+  if (c->D.device < 0) return SMCP_ENODEV;
+  return 0;
+}
+
+// read back the device failure flag (synchronises the stream)
+int fetch_info(csp_ctx* c, hipStream_t st) {
+  HIPCHK(hipMemcpyAsync(c->D.info_host, c->D.info, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return *c->D.info_host;
+}
+
+constexpr int NT = 256;
+
+template <class F>
+void for_levels_up(csp_ctx* c, F f) {
+  for (int64_t l = 0; l < c->S.nlev; ++l) {
+    int64_t b = c->S.levptr[l], e = c->S.levptr[l + 1];
+    f(c->D.levidx + b, (int)(e - b));
+  }
+}
+template <class F>
+void for_levels_down(csp_ctx* c, F f) {
+  for (int64_t l = c->S.nlev - 1; l >= 0; --l) {
+    int64_t b = c->S.levptr[l], e = c->S.levptr[l + 1];
+    f(c->D.levidx + b, (int)(e - b));
+  }
+}
+
+// upd[r][k] <- X_r[A_k, A_k] for all cliques, top-down
+void gather_all(csp_ctx* c, const double* x, int64_t ldx, int nrhs, double* updbase, hipStream_t st) {
+  TreeArgs a = tree_args(c);
+  for_levels_down(c, [&](const int32_t* lev, int cnt) {
+    a.lev = lev;
+    hipLaunchKernelGGL(k_gather_level, dim3(cnt, nrhs), dim3(NT), 0, st, a, x, ldx, updbase);
+  });
+}
+
+int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st) {
+  TreeArgs a = tree_args(c);
+  gather_all(c, Y, 0, 1, c->D.yaa, st);
+  if (need_fac) {
+    hipLaunchKernelGGL(k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), 0, st, a, c->D.yaa, c->D.fac);
+  }
+  return 0;
+}
+
+int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t ldu, int adj, int inv,
+                 hipStream_t st) {
+  TreeArgs a = tree_args(c);
+  const int nsn = (int)c->S.nsn;
+  auto up = [&]() {
+    for_levels_up(c, [&](const int32_t* lev, int cnt) {
+      a.lev = lev;
+      hipLaunchKernelGGL(k_hess_up_level, dim3(cnt, (int)nrhs), dim3(NT), 0, st, a, L, U, ldu);
+    });
+  };
+  auto down = [&]() {
+    for_levels_down(c, [&](const int32_t* lev, int cnt) {
+      a.lev = lev;
+      hipLaunchKernelGGL(k_hess_down_level, dim3(cnt, (int)nrhs), dim3(NT), 0, st, a, L, U, ldu);
+    });
+  };
+  auto up_inv = [&]() {
+    for_levels_up(c, [&](const int32_t* lev, int cnt) {
+      a.lev = lev;
+      hipLaunchKernelGGL(k_hess_up_inv_level, dim3(cnt, (int)nrhs), dim3(NT), 0, st, a, L, U, ldu);
+    });
+  };
+  auto down_inv = [&]() {
+    gather_all(c, U, ldu, (int)nrhs, c->D.upd, st);
+    hipLaunchKernelGGL(k_hess_down_inv_all, dim3(nsn, (int)nrhs), dim3(NT), 0, st, a, L, U, ldu);
+  };
+  auto scale = [&](int mode) {
+    hipLaunchKernelGGL(k_scale_an, dim3(nsn, (int)nrhs), dim3(NT), 0, st, a, c->D.yaa, c->D.fac, U, ldu, mode);
+  };
+  if (!inv) {
+    if (adj == 0) { up(); scale(0); }
+    else if (adj == 1) { scale(1); down(); }
+    else { up(); scale(4); down(); }
+  } else {
+    if (adj == 0) { scale(2); up_inv(); }
+    else if (adj == 1) { down_inv(); scale(3); }
+    else { down_inv(); scale(5); up_inv(); }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+csp_ctx* csp_symbolic_create(int64_t n, const int64_t* colptr, const int64_t* rowind,
+                             const int64_t* perm, int64_t* info) {
+  csp_ctx* c = new (std::nothrow) csp_ctx();
+  if (!c) { if (info) *info = SMCP_ENOMEM; return nullptr; }
+  int rc = symbolic_build(n, colptr, rowind, perm, c->S);
+  if (info) *info = rc;
+  if (rc) { delete c; return nullptr; }
+  return c;
+}
+
+void csp_symbolic_destroy(csp_ctx* c) {
+  if (!c) return;
+  DeviceCtx& D = c->D;
+  if (D.device >= 0) {
+    hipSetDevice(D.device);
+    void* ptrs[] = {D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+                    D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (D.info_host) hipHostFree(D.info_host);
+  }
+  delete c;
+}
+
+int64_t csp_symbolic_query(const csp_ctx* c, int what, int64_t* out) {
+  if (!c) return SMCP_EINVAL;
+  const Symbolic& S = c->S;
+  auto put64 = [&](const std::vector<int64_t>& v) { if (out) std::copy(v.begin(), v.end(), out); return (int64_t)v.size(); };
+  auto put32 = [&](const std::vector<int32_t>& v) { if (out) std::copy(v.begin(), v.end(), out); return (int64_t)v.size(); };
+  switch (what) {
+    case CSP_Q_SCALARS: {
+      int64_t s[10] = {S.n, S.nnz, S.nsn, S.fill, S.blklen(), S.updlen(), S.nlev, S.max_nn, S.max_na, S.max_front};
+      if (out) std::copy(s, s + 10, out);
+      return 10;
+    }
+    case CSP_Q_PERM: return put64(S.p);
+    case CSP_Q_IPERM: return put64(S.ip);
+    case CSP_Q_SNPTR: return put64(S.snptr);
+    case CSP_Q_SNPAR: return put64(S.snpar);
+    case CSP_Q_ROWPTR: return put64(S.rowptr);
+    case CSP_Q_ROWIDX: return put32(S.rowidx);
+    case CSP_Q_SEPPTR: return put64(S.sepptr);
+    case CSP_Q_RELIDX: return put32(S.relidx);
+    case CSP_Q_BLKPTR: return put64(S.blkptr);
+    case CSP_Q_UPDPTR: return put64(S.updptr);
+    case CSP_Q_CHPTR: return put64(S.chptr);
+    case CSP_Q_CHIDX: return put64(S.chidx);
+    case CSP_Q_LEVPTR: return put64(S.levptr);
+    case CSP_Q_LEVIDX: return put64(S.levidx);
+    case CSP_Q_CCSPTR: return put64(S.ccsptr);
+    case CSP_Q_SNODE: return put64(S.snode);
+  }
+  return SMCP_EINVAL;
+}
+
+int csp_maxcardsearch(int64_t n, const int64_t* colptr, const int64_t* rowind, int64_t* order) {
+  if (n <= 0 || !colptr || !rowind || !order) return SMCP_EINVAL;
+  maxcardsearch(n, colptr, rowind, order);
+  return 0;
+}
+int csp_mindegree(int64_t n, const int64_t* colptr, const int64_t* rowind, int64_t* order) {
+  if (n <= 0 || !colptr || !rowind || !order) return SMCP_EINVAL;
+  mindegree(n, colptr, rowind, order);
+  return 0;
+}
+int csp_index_map(const csp_ctx* c, int64_t cnt, const int64_t* I, const int64_t* J, int64_t* out) {
+  if (!c || cnt < 0) return SMCP_EINVAL;
+  index_map(c->S, cnt, I, J, out);
+  return 0;
+}
+
+int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
+  if (!c || max_rhs < 1) return SMCP_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SMCP_ENODEV;
+  if (device < 0 || device >= ndev) return SMCP_EINVAL;
+  DeviceCtx& D = c->D;
+  const Symbolic& S = c->S;
+  if (D.device == device && D.max_rhs >= max_rhs) return 0;
+  HIPCHK(hipSetDevice(device));
+  if (D.device < 0) {
+    std::vector<CliqueDesc> cl(S.nsn);
+    for (int64_t k = 0; k < S.nsn; ++k) {
+      CliqueDesc& d = cl[k];
+      d.blk = S.blkptr[k];
+      d.upd = S.updptr[k];
+      d.rows = S.rowptr[k];
+      d.rel = S.sepptr[k];
+      d.nn = (int32_t)S.nn(k);
+      d.na = (int32_t)S.na(k);
+      d.parent = (int32_t)S.snpar[k];
+      d.chbeg = (int32_t)S.chptr[k];
+      d.chend = (int32_t)S.chptr[k + 1];
+      d.first = (int32_t)S.snptr[k];
+      d.pad = 0;
+    }
+    std::vector<int32_t> ch(S.chidx.begin(), S.chidx.end()), lev(S.levidx.begin(), S.levidx.end());
+    c->h_tmpptr.resize(S.nsn + 1);
+    for (int64_t k = 0; k <= S.nsn; ++k) c->h_tmpptr[k] = 2 * S.blkptr[k];
+    D.tmplen = 2 * S.blklen();
+    int rc = 0;
+    if ((rc = dev_upload(&D.cl, cl, D.bytes))) return rc;
+    if ((rc = dev_upload(&D.rowidx, S.rowidx, D.bytes))) return rc;
+    if ((rc = dev_upload(&D.relidx, S.relidx, D.bytes))) return rc;
+    if ((rc = dev_upload(&D.chidx, ch, D.bytes))) return rc;
+    if ((rc = dev_upload(&D.levidx, lev, D.bytes))) return rc;
+    if ((rc = dev_upload(&D.tmpptr, c->h_tmpptr, D.bytes))) return rc;
+    if ((rc = dev_alloc(&D.yaa, S.updlen(), D.bytes))) return rc;
+    if ((rc = dev_alloc(&D.fac, S.updlen(), D.bytes))) return rc;
+    if ((rc = dev_alloc(&D.red, 1024, D.bytes))) return rc;
+    if ((rc = dev_alloc(&D.info, 4, D.bytes))) return rc;
+    HIPCHK(hipMemset(D.info, 0, sizeof(int) * 4));
+    HIPCHK(hipHostMalloc((void**)&D.info_host, 64));
+    D.device = device;
+  } else {
+    if (D.upd) { hipFree(D.upd); D.bytes -= D.max_rhs * S.updlen() * 8; D.upd = nullptr; }
+    if (D.tmp) { hipFree(D.tmp); D.bytes -= D.max_rhs * D.tmplen * 8; D.tmp = nullptr; }
+  }
+  int rc = 0;
+  if ((rc = dev_alloc(&D.upd, max_rhs * S.updlen(), D.bytes))) return rc;
+  if ((rc = dev_alloc(&D.tmp, max_rhs * D.tmplen, D.bytes))) return rc;
+  D.max_rhs = max_rhs;
+  return 0;
+}
+
+int64_t csp_device_bytes(const csp_ctx* c) { return c ? c->D.bytes : 0; }
+
+int csp_cholesky(csp_ctx* c, double* x, void* stream) {
+  if (int rc = ready(c)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TreeArgs a = tree_args(c);
+  HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
+  for_levels_up(c, [&](const int32_t* lev, int cnt) {
+    a.lev = lev;
+    hipLaunchKernelGGL(k_chol_level, dim3(cnt), dim3(NT), 0, st, a, x);
+  });
+  HIPCHK(hipGetLastError());
+  return fetch_info(c, st);
+}
+
+int csp_llt(csp_ctx* c, double* x, void* stream) {
+  if (int rc = ready(c)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TreeArgs a = tree_args(c);
+  for_levels_up(c, [&](const int32_t* lev, int cnt) {
+    a.lev = lev;
+    hipLaunchKernelGGL(k_llt_level, dim3(cnt), dim3(NT), 0, st, a, x);
+  });
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int csp_projected_inverse(csp_ctx* c, double* x, void* stream) {
+  if (int rc = ready(c)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TreeArgs a = tree_args(c);
+  for_levels_down(c, [&](const int32_t* lev, int cnt) {
+    a.lev = lev;
+    hipLaunchKernelGGL(k_pinv_level, dim3(cnt), dim3(NT), 0, st, a, x);
+  });
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int csp_completion(csp_ctx* c, double* x, void* stream) {
+  if (int rc = ready(c)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  TreeArgs a = tree_args(c);
+  HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
+  gather_all(c, x, 0, 1, c->D.upd, st);
+  hipLaunchKernelGGL(k_completion_all, dim3((int)c->S.nsn), dim3(NT), 0, st, a, x);
+  HIPCHK(hipGetLastError());
+  return fetch_info(c, st);
+}
+
+int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t nrhs, int64_t ldu,
+                int adj, int inv, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (nrhs < 1 || adj < 0 || adj > 2 || (nrhs > 1 && ldu < c->S.blklen())) return SMCP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  bool need_fac = !(adj == 2 && inv == 0);
+  HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
+  prepare_yaa(c, Y, need_fac, st);
+  for (int64_t r0 = 0; r0 < nrhs; r0 += c->D.max_rhs) {
+    int64_t nr = std::min(c->D.max_rhs, nrhs - r0);
+    hessian_impl(c, L, U + r0 * ldu, nr, ldu, adj, inv, st);
+  }
+  HIPCHK(hipGetLastError());
+  if (need_fac) return fetch_info(c, st);
+  return 0;
+}
+
+int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, int trans, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (nrhs < 1 || ldb < c->S.n) return SMCP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (c->S.sepptr[c->S.nsn] * nrhs > c->D.max_rhs * c->D.tmplen) return SMCP_ENOMEM;
+  TreeArgs a = tree_args(c);
+  if (!trans) {
+    for_levels_up(c, [&](const int32_t* lev, int cnt) {
+      a.lev = lev;
+      hipLaunchKernelGGL(k_trsm_fwd_level, dim3(cnt), dim3(NT), 0, st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
+    });
+  } else {
+    for_levels_down(c, [&](const int32_t* lev, int cnt) {
+      a.lev = lev;
+      hipLaunchKernelGGL(k_trsm_bwd_level, dim3(cnt), dim3(NT), 0, st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
+    });
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int reduce_impl(csp_ctx* c, const double* X, const double* Y, int mode, double* out, hipStream_t st) {
+  int nb = (int)std::min<int64_t>(c->S.nsn, 512);
+  hipLaunchKernelGGL(k_reduce_cliques, dim3(nb), dim3(NT), 0, st, c->D.cl, (int)c->S.nsn, X, Y, mode, c->D.red);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(NT), 0, st, c->D.red, nb, c->D.red + 512);
+  HIPCHK(hipGetLastError());
+  double* h = (double*)(c->D.info_host + 2);
+  HIPCHK(hipMemcpyAsync(h, c->D.red + 512, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *out = *h;
+  return 0;
+}
+int csp_dot(csp_ctx* c, const double* X, const double* Y, double* out, void* stream) {
+  if (int rc = ready(c)) return rc;
+  return reduce_impl(c, X, Y, 0, out, (hipStream_t)stream);
+}
+int csp_logdiagsum(csp_ctx* c, const double* X, double* out, void* stream) {
+  if (int rc = ready(c)) return rc;
+  return reduce_impl(c, X, nullptr, 1, out, (hipStream_t)stream);
+}
+
+int csp_axpby(int64_t len, double a, const double* x, double b, double* y, void* stream) {
+  if (len < 0 || !y) return SMCP_EINVAL;
+  if (len == 0) return 0;
+  int nb = (int)std::min<int64_t>((len + NT - 1) / NT, 2048);
+  hipLaunchKernelGGL(k_axpby, dim3(nb), dim3(NT), 0, (hipStream_t)stream, len, a, x, b, y);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
+
+#include "kkt.hip"

@@ -1,0 +1,66 @@
+// Device context behind the opaque csp_ctx of include/smcp_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "symbolic.hpp"
+
+namespace smcp {
+
+// Per-clique descriptor as the kernels see it (device resident, one per clique).
+struct CliqueDesc {
+  int64_t blk;     // offset of the (nf x nn) panel in blkval
+  int64_t upd;     // offset of the (na x na) update matrix in the update workspace
+  int64_t rows;    // offset into rowidx (nf entries)
+  int64_t rel;     // offset into relidx (na entries)
+  int32_t nn, na;  // supernode / separator size
+  int32_t parent;  // parent clique or -1
+  int32_t chbeg, chend;  // children list range in chidx
+  int32_t first;   // first permuted column (snptr[k])
+  int32_t pad;
+};
+
+struct DeviceCtx {
+  int device = -1;
+  int64_t max_rhs = 0;
+  // index arrays
+  CliqueDesc* cl = nullptr;
+  int32_t* rowidx = nullptr;
+  int32_t* relidx = nullptr;
+  int32_t* chidx = nullptr;
+  int32_t* levidx = nullptr;  // cliques sorted by level
+  // workspaces
+  double* upd = nullptr;   // max_rhs * updlen : update matrices
+  double* yaa = nullptr;   // updlen : Y[A_k,A_k] cache (Hessian)
+  double* fac = nullptr;   // updlen : chol(Y_AA) cache
+  double* tmp = nullptr;   // max_rhs * tmplen : per-clique scratch (tmpptr)
+  int64_t* tmpptr = nullptr;
+  int64_t tmplen = 0;
+  double* red = nullptr;   // reduction scratch
+  int* info = nullptr;     // device failure flag
+  int* info_host = nullptr;  // pinned host mirror
+  // constraints
+  int64_t m = 0, cnnz = 0;
+  int64_t* cptr = nullptr;   // CSC by constraint (m+1)
+  int64_t* cidx = nullptr;   // blkval positions
+  double* cval = nullptr;    // values
+  double* cwval = nullptr;   // values with off-diagonals doubled (Amap weights)
+  int64_t rnnz = 0;          // CSR by blkval position (for Aadj)
+  int64_t* rpos = nullptr;   // distinct blkval positions (rnnz)
+  int64_t* rptr = nullptr;   // rnnz+1
+  int32_t* rcon = nullptr;   // constraint index per entry
+  double* rval = nullptr;
+  double* ustack = nullptr;  // m * blklen : constraint matrices swept by the Hessian
+  int64_t bytes = 0;
+};
+
+}  // namespace smcp
+
+struct csp_ctx {
+  smcp::Symbolic S;
+  smcp::DeviceCtx D;
+  std::vector<int64_t> h_tmpptr;
+  std::vector<uint8_t> is_diag_cache;
+};

@@ -1,0 +1,218 @@
+// KKT layer on device: Amap / Aadj, Schur-complement build + factor, solve_ closure.
+// Mirrors kkt_chol of src/python/solvers.py:477-541 (and Amap/Aadj 369-386); included by capi.hip.
+
+namespace {
+
+using namespace smcp;
+
+// y[i] = sum_e w_e a_e X[idx_e], one wave per (constraint i, rhs r); X_r = X + r*ldx; y_r = y + r*ldy
+__global__ void k_amap(int64_t m, const int64_t* cptr, const int64_t* cidx, const double* cwval,
+                       const double* X, int64_t ldx, double* y, int64_t ldy) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  const int r = blockIdx.y;
+  if (i >= m) return;
+  const double* x = X + (int64_t)r * ldx;
+  double acc = 0.0;
+  for (int64_t e = cptr[i] + lane; e < cptr[i + 1]; e += 64) acc += cwval[e] * x[cidx[e]];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) y[i + (int64_t)r * ldy] = acc;
+}
+
+// X[rpos[q]] = sum over constraints touching that position of y[con] * val   (X pre-zeroed)
+__global__ void k_aadj(int64_t rnnz, const int64_t* rpos, const int64_t* rptr, const int32_t* rcon,
+                       const double* rval, const double* y, double* X) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= rnnz) return;
+  double acc = 0.0;
+  for (int64_t e = rptr[q]; e < rptr[q + 1]; ++e) acc += rval[e] * y[rcon[e]];
+  X[rpos[q]] = acc;
+}
+
+// U_r (pre-zeroed) <- A_{j0+r} scattered into blkval coordinates
+__global__ void k_scatter_constraints(int64_t j0, const int64_t* cptr, const int64_t* cidx,
+                                      const double* cval, double* U, int64_t ldu) {
+  const int r = blockIdx.y;
+  const int64_t j = j0 + r;
+  double* u = U + (int64_t)r * ldu;
+  for (int64_t e = cptr[j] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cptr[j + 1];
+       e += (int64_t)gridDim.x * blockDim.x)
+    u[cidx[e]] = cval[e];
+}
+
+// single-workgroup dense Cholesky / triangular solves (generic path)
+__global__ void k_dense_potrf(double* A, int n, int64_t lda, int* info) {
+  int f = wg::potrf(n, A, lda);
+  if (f && threadIdx.x == 0) *info = f;
+}
+__global__ void k_dense_potrs(const double* A, int n, int64_t lda, double* B, int nrhs, int64_t ldb) {
+  wg::trsm_llN(n, nrhs, A, lda, B, ldb);
+  wg::trsm_llT(n, nrhs, A, lda, B, ldb);
+}
+// y = a*y + x (length m), small
+__global__ void k_vec_axpby(int64_t m, double a, const double* x, double b, double* y) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) y[i] = a * x[i] + b * y[i];
+}
+
+int amap_impl(csp_ctx* c, const double* X, int64_t ldx, int nrhs, double* y, int64_t ldy, hipStream_t st) {
+  const DeviceCtx& D = c->D;
+  int wpb = 4;
+  hipLaunchKernelGGL(k_amap, dim3((unsigned)((D.m + wpb - 1) / wpb), nrhs), dim3(64 * wpb), 0, st, D.m,
+                     D.cptr, D.cidx, D.cwval, X, ldx, y, ldy);
+  return 0;
+}
+int aadj_impl(csp_ctx* c, const double* y, double* X, hipStream_t st) {
+  const DeviceCtx& D = c->D;
+  if (hipMemsetAsync(X, 0, sizeof(double) * c->S.blklen(), st) != hipSuccess) return SMCP_EHIP;
+  if (D.rnnz)
+    hipLaunchKernelGGL(k_aadj, dim3((unsigned)((D.rnnz + 255) / 256)), dim3(256), 0, st, D.rnnz, D.rpos,
+                       D.rptr, D.rcon, D.rval, y, X);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_t* cidx, const double* cval) {
+  if (int rc = ready(c)) return rc;
+  if (m < 1 || !cptr || !cidx || !cval) return SMCP_EINVAL;
+  DeviceCtx& D = c->D;
+  const Symbolic& S = c->S;
+  HIPCHK(hipSetDevice(D.device));
+  void* old[] = {D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
+  for (void* p : old) if (p) hipFree(p);
+  D.cptr = nullptr; D.cidx = nullptr; D.cval = nullptr; D.cwval = nullptr; D.rpos = nullptr;
+  D.rptr = nullptr; D.rcon = nullptr; D.rval = nullptr; D.ustack = nullptr;
+  const int64_t nnz = cptr[m];
+  // diagonal flags: position -> is it a diagonal entry of its NN block?
+  std::vector<double> w(nnz);
+  {
+    // locate clique by binary search on blkptr
+    for (int64_t e = 0; e < nnz; ++e) {
+      int64_t pos = cidx[e];
+      if (pos < 0 || pos >= S.blklen()) return SMCP_EINVAL;
+      int64_t k = (int64_t)(std::upper_bound(S.blkptr.begin(), S.blkptr.end(), pos) - S.blkptr.begin()) - 1;
+      int64_t nf = S.nf(k), off = pos - S.blkptr[k];
+      int64_t col = off / nf, row = off % nf;
+      if (row < col) return SMCP_EINVAL;  // upper triangle of the NN block is not part of V
+      w[e] = (row == col) ? cval[e] : 2.0 * cval[e];
+    }
+  }
+  // CSR by position
+  std::vector<int64_t> order(nnz);
+  for (int64_t e = 0; e < nnz; ++e) order[e] = e;
+  std::vector<int32_t> con(nnz);
+  for (int64_t j = 0; j < m; ++j)
+    for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) con[e] = (int32_t)j;
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return cidx[a] < cidx[b]; });
+  std::vector<int64_t> rpos, rptr;
+  std::vector<int32_t> rcon(nnz);
+  std::vector<double> rval(nnz);
+  for (int64_t q = 0; q < nnz; ++q) {
+    int64_t e = order[q];
+    if (q == 0 || cidx[e] != cidx[order[q - 1]]) { rpos.push_back(cidx[e]); rptr.push_back(q); }
+    rcon[q] = con[e];
+    rval[q] = cval[e];
+  }
+  rptr.push_back(nnz);
+  std::vector<int64_t> vcptr(cptr, cptr + m + 1), vcidx(cidx, cidx + nnz);
+  std::vector<double> vcval(cval, cval + nnz);
+  int rc = 0;
+  if ((rc = dev_upload(&D.cptr, vcptr, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.cidx, vcidx, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.cval, vcval, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.cwval, w, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.rpos, rpos, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.rptr, rptr, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.rcon, rcon, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.rval, rval, D.bytes))) return rc;
+  if ((rc = dev_alloc(&D.ustack, D.max_rhs * S.blklen(), D.bytes))) return rc;
+  D.m = m;
+  D.cnnz = nnz;
+  D.rnnz = (int64_t)rpos.size();
+  return 0;
+}
+
+int kkt_amap(csp_ctx* c, const double* X, double* y, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (!c->D.m) return SMCP_EINVAL;
+  amap_impl(c, X, 0, 1, y, 0, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int kkt_aadj(csp_ctx* c, const double* y, double* X, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (!c->D.m) return SMCP_EINVAL;
+  if (int rc = aadj_impl(c, y, X, (hipStream_t)stream)) return rc;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
+  if (int rc = ready(c)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_dense_potrf, dim3(1), dim3(1024), 0, st, A, (int)n, lda, c->D.info);
+  HIPCHK(hipGetLastError());
+  return fetch_info(c, st);
+}
+int dense_potrs(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs, int64_t ldb,
+                void* stream) {
+  if (int rc = ready(c)) return rc;
+  hipLaunchKernelGGL(k_dense_potrs, dim3(1), dim3(1024), 0, (hipStream_t)stream, A, (int)n, lda, B, (int)nrhs, ldb);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int kkt_schur_factor(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  const int64_t m = D.m, bl = c->S.blklen();
+  if (!m || ldh < m) return SMCP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  prepare_yaa(c, Y, false, st);
+  for (int64_t j0 = 0; j0 < m; j0 += D.max_rhs) {
+    int nr = (int)std::min(D.max_rhs, m - j0);
+    HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * nr * bl, st));
+    hipLaunchKernelGGL(k_scatter_constraints, dim3(8, nr), dim3(256), 0, st, j0, D.cptr, D.cidx, D.cval,
+                       D.ustack, bl);
+    hessian_impl(c, L, D.ustack, nr, bl, 2, 0, st);
+    // H[:, j0+r] = Amap(W(A_{j0+r}))  (full column; H is symmetric)
+    amap_impl(c, D.ustack, bl, nr, H + j0 * ldh, ldh, st);
+  }
+  HIPCHK(hipGetLastError());
+  return dense_potrf(c, H, m, ldh, stream);
+}
+
+int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int64_t ldh, double kk,
+              double* bx, double* by, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  const int64_t m = D.m, bl = c->S.blklen();
+  if (!m) return SMCP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  double* r1 = D.ustack;       // blkval-sized temporaries
+  double* ytmp = D.red + 600;  // (m <= 400 fits; larger m uses the tail of ustack)
+  if (m > 400) {
+    if (D.max_rhs < 2) return SMCP_ENOMEM;
+    ytmp = D.ustack + bl;
+  }
+  // the Y_AA cache must correspond to (L, Y): recompute (cheap, one gather sweep)
+  prepare_yaa(c, Y, false, st);
+  HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
+  hessian_impl(c, L, r1, 1, bl, 2, 0, st);                      // r1 = W(bx)
+  amap_impl(c, r1, 0, 1, ytmp, 0, st);                          // Amap(r1)
+  hipLaunchKernelGGL(k_vec_axpby, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, 1.0, ytmp, kk, by);  // y = kk*by + Amap(r1)
+  hipLaunchKernelGGL(k_dense_potrs, dim3(1), dim3(1024), 0, st, H, (int)m, ldh, by, 1, m);
+  if (int rc = aadj_impl(c, by, r1, st)) return rc;             // r1 = Aadj(y)
+  hipLaunchKernelGGL(k_axpby, dim3(1024), dim3(256), 0, st, bl, 1.0, (const double*)r1, -1.0, bx);  // bx = Aadj(y) - bx
+  hessian_impl(c, L, bx, 1, bl, 2, 0, st);
+  hipLaunchKernelGGL(k_axpby, dim3(1024), dim3(256), 0, st, bl, 0.0, (const double*)nullptr, 1.0 / kk, bx);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,431 @@
+// Host symbolic analysis. See symbolic.hpp for what it replaces in the reference.
+#include "symbolic.hpp"
+
+#include <algorithm>
+#include <numeric>
+#include <set>
+
+namespace smcp {
+namespace {
+
+// adjacency of the symmetric graph in "current" labels, strict lower part stored per
+// column (rows > col) and strict upper part per column (rows < col).
+struct Graph {
+  int64_t n;
+  std::vector<int64_t> lptr, uptr;
+  std::vector<int32_t> lidx, uidx;
+};
+
+// Build Graph from input pattern with labels mapped through ip (orig -> current).
+static int build_graph(int64_t n, const int64_t* colptr, const int64_t* rowind,
+                       const std::vector<int64_t>& ip, Graph& g) {
+  g.n = n;
+  g.lptr.assign(n + 1, 0);
+  g.uptr.assign(n + 1, 0);
+  for (int64_t j = 0; j < n; ++j) {
+    for (int64_t q = colptr[j]; q < colptr[j + 1]; ++q) {
+      int64_t i = rowind[q];
+      if (i < 0 || i >= n) return -1;
+      if (i == j) continue;
+      int64_t a = ip[i], b = ip[j];
+      int64_t lo = std::min(a, b), hi = std::max(a, b);
+      g.lptr[lo + 1]++;  // column lo has row hi below the diagonal
+      g.uptr[hi + 1]++;  // column hi has row lo above the diagonal
+    }
+  }
+  for (int64_t j = 0; j < n; ++j) {
+    g.lptr[j + 1] += g.lptr[j];
+    g.uptr[j + 1] += g.uptr[j];
+  }
+  g.lidx.resize(g.lptr[n]);
+  g.uidx.resize(g.uptr[n]);
+  std::vector<int64_t> lw(g.lptr.begin(), g.lptr.end() - 1), uw(g.uptr.begin(), g.uptr.end() - 1);
+  for (int64_t j = 0; j < n; ++j) {
+    for (int64_t q = colptr[j]; q < colptr[j + 1]; ++q) {
+      int64_t i = rowind[q];
+      if (i == j) continue;
+      int64_t a = ip[i], b = ip[j];
+      int64_t lo = std::min(a, b), hi = std::max(a, b);
+      g.lidx[lw[lo]++] = (int32_t)hi;
+      g.uidx[uw[hi]++] = (int32_t)lo;
+    }
+  }
+  // sort + dedupe each list (duplicates are harmless for etree/counts but not for sizes)
+  auto tidy = [n](std::vector<int64_t>& ptr, std::vector<int32_t>& idx) {
+    std::vector<int64_t> nptr(n + 1, 0);
+    int64_t w = 0;
+    for (int64_t j = 0; j < n; ++j) {
+      int64_t b = ptr[j], e = ptr[j + 1];
+      std::sort(idx.begin() + b, idx.begin() + e);
+      int64_t start = w;
+      for (int64_t q = b; q < e; ++q)
+        if (w == start || idx[w - 1] != idx[q]) idx[w++] = idx[q];
+      nptr[j + 1] = w;
+    }
+    idx.resize(w);
+    ptr.swap(nptr);
+  };
+  tidy(g.lptr, g.lidx);
+  tidy(g.uptr, g.uidx);
+  return 0;
+}
+
+// Liu's elimination tree with path compression.
+static void etree(const Graph& g, std::vector<int64_t>& parent) {
+  int64_t n = g.n;
+  parent.assign(n, -1);
+  std::vector<int64_t> anc(n, -1);
+  for (int64_t c = 0; c < n; ++c) {
+    for (int64_t q = g.uptr[c]; q < g.uptr[c + 1]; ++q) {
+      int64_t i = g.uidx[q];
+      while (i != -1 && i < c) {
+        int64_t nx = anc[i];
+        anc[i] = c;
+        if (nx == -1) parent[i] = c;
+        i = nx;
+      }
+    }
+  }
+}
+
+// Postorder of a forest given parent[]; children visited in ascending label order.
+static void postorder(const std::vector<int64_t>& parent, std::vector<int64_t>& post) {
+  int64_t n = (int64_t)parent.size();
+  std::vector<int64_t> head(n, -1), next(n, -1);
+  for (int64_t j = n - 1; j >= 0; --j) {
+    if (parent[j] >= 0) {
+      next[j] = head[parent[j]];
+      head[parent[j]] = j;
+    }
+  }
+  post.clear();
+  post.reserve(n);
+  std::vector<int64_t> stack;
+  for (int64_t r = 0; r < n; ++r) {
+    if (parent[r] >= 0) continue;
+    stack.push_back(r);
+    while (!stack.empty()) {
+      int64_t v = stack.back();
+      int64_t c = head[v];
+      if (c == -1) {
+        post.push_back(v);
+        stack.pop_back();
+      } else {
+        head[v] = next[c];
+        stack.push_back(c);
+      }
+    }
+  }
+}
+
+// Column counts of the Cholesky factor via row subtrees: O(|L|).
+static void colcounts(const Graph& g, const std::vector<int64_t>& parent, std::vector<int64_t>& cc) {
+  int64_t n = g.n;
+  cc.assign(n, 1);
+  std::vector<int64_t> mark(n, -1);
+  for (int64_t i = 0; i < n; ++i) {
+    mark[i] = i;
+    for (int64_t q = g.uptr[i]; q < g.uptr[i + 1]; ++q) {
+      int64_t j = g.uidx[q];
+      while (mark[j] != i) {
+        mark[j] = i;
+        cc[j]++;
+        j = parent[j];
+      }
+    }
+  }
+}
+
+static void relabel(const std::vector<int64_t>& order /*new->cur*/, std::vector<int64_t>& p /*cur->orig becomes new->orig*/) {
+  std::vector<int64_t> np(p.size());
+  for (size_t k = 0; k < order.size(); ++k) np[k] = p[order[k]];
+  p.swap(np);
+}
+
+}  // namespace
+
+int symbolic_build(int64_t n, const int64_t* colptr, const int64_t* rowind, const int64_t* perm,
+                   Symbolic& S) {
+  if (n <= 0) return -1;
+  S = Symbolic();
+  S.n = n;
+  S.p.resize(n);
+  S.ip.resize(n);
+  if (perm) {
+    std::vector<char> seen(n, 0);
+    for (int64_t i = 0; i < n; ++i) {
+      if (perm[i] < 0 || perm[i] >= n || seen[perm[i]]) return -2;
+      seen[perm[i]] = 1;
+      S.p[i] = perm[i];
+    }
+  } else {
+    std::iota(S.p.begin(), S.p.end(), 0);
+  }
+  for (int64_t i = 0; i < n; ++i) S.ip[S.p[i]] = i;
+
+  // ---- pass 1: etree + postorder in the user ordering
+  Graph g;
+  if (build_graph(n, colptr, rowind, S.ip, g)) return -1;
+  int64_t nnz_in = g.lptr[n] + n;
+  std::vector<int64_t> parent, post;
+  etree(g, parent);
+  postorder(parent, post);
+  relabel(post, S.p);
+  for (int64_t i = 0; i < n; ++i) S.ip[S.p[i]] = i;
+
+  // ---- pass 2: in postorder labels: etree, column counts, maximal supernodes (Pothen-Sun)
+  if (build_graph(n, colptr, rowind, S.ip, g)) return -1;
+  etree(g, parent);
+  std::vector<int64_t> cc;
+  colcounts(g, parent, cc);
+  // supernode membership: vertex j joins the supernode of a child c with cc[c] == cc[j]+1
+  std::vector<int64_t> sn(n, -1), snlast;  // snlast[s] = last (largest) vertex of supernode s
+  std::vector<int64_t> snfirst;
+  {
+    std::vector<int64_t> pick(n, -1);  // child chosen for merging
+    for (int64_t c = 0; c < n; ++c) {
+      int64_t j = parent[c];
+      if (j >= 0 && pick[j] == -1 && cc[c] == cc[j] + 1) pick[j] = c;
+    }
+    for (int64_t j = 0; j < n; ++j) {
+      if (pick[j] >= 0) {
+        sn[j] = sn[pick[j]];
+        snlast[sn[j]] = j;
+      } else {
+        sn[j] = (int64_t)snfirst.size();
+        snfirst.push_back(j);
+        snlast.push_back(j);
+      }
+    }
+  }
+  int64_t nsn = (int64_t)snfirst.size();
+  // supernodal tree + its postorder
+  std::vector<int64_t> spar(nsn, -1);
+  for (int64_t s = 0; s < nsn; ++s) {
+    int64_t pv = parent[snlast[s]];
+    spar[s] = pv >= 0 ? sn[pv] : -1;
+  }
+  std::vector<int64_t> spost;
+  postorder(spar, spost);
+  // vertices of each supernode in ascending order (chain order)
+  std::vector<int64_t> cnt(nsn + 1, 0);
+  for (int64_t j = 0; j < n; ++j) cnt[sn[j] + 1]++;
+  for (int64_t s = 0; s < nsn; ++s) cnt[s + 1] += cnt[s];
+  std::vector<int64_t> members(n), w(cnt.begin(), cnt.end() - 1);
+  for (int64_t j = 0; j < n; ++j) members[w[sn[j]]++] = j;
+  std::vector<int64_t> order2;
+  order2.reserve(n);
+  S.nsn = nsn;
+  S.snptr.assign(nsn + 1, 0);
+  std::vector<int64_t> newsn(nsn);  // old supernode id -> new id
+  for (int64_t k = 0; k < nsn; ++k) {
+    int64_t s = spost[k];
+    newsn[s] = k;
+    for (int64_t q = cnt[s]; q < cnt[s + 1]; ++q) order2.push_back(members[q]);
+    S.snptr[k + 1] = (int64_t)order2.size();
+  }
+  S.snpar.assign(nsn, -1);
+  for (int64_t s = 0; s < nsn; ++s)
+    if (spar[s] >= 0) S.snpar[newsn[s]] = newsn[spar[s]];
+  std::vector<int64_t> cc2(n);
+  for (int64_t k = 0; k < n; ++k) cc2[k] = cc[order2[k]];
+  relabel(order2, S.p);
+  for (int64_t i = 0; i < n; ++i) S.ip[S.p[i]] = i;
+  S.snode.resize(n);
+  for (int64_t k = 0; k < nsn; ++k)
+    for (int64_t j = S.snptr[k]; j < S.snptr[k + 1]; ++j) S.snode[j] = k;
+
+  // ---- pass 3: final labels: clique row structures
+  if (build_graph(n, colptr, rowind, S.ip, g)) return -1;
+  S.chptr.assign(nsn + 1, 0);
+  for (int64_t k = 0; k < nsn; ++k)
+    if (S.snpar[k] >= 0) S.chptr[S.snpar[k] + 1]++;
+  for (int64_t k = 0; k < nsn; ++k) S.chptr[k + 1] += S.chptr[k];
+  S.chidx.resize(S.chptr[nsn]);
+  {
+    std::vector<int64_t> cw(S.chptr.begin(), S.chptr.end() - 1);
+    for (int64_t k = 0; k < nsn; ++k)
+      if (S.snpar[k] >= 0) S.chidx[cw[S.snpar[k]]++] = k;
+  }
+  S.rowptr.assign(nsn + 1, 0);
+  for (int64_t k = 0; k < nsn; ++k) S.rowptr[k + 1] = S.rowptr[k] + cc2[S.snptr[k]];
+  S.rowidx.resize(S.rowptr[nsn]);
+  {
+    std::vector<int64_t> mark(n, -1);
+    std::vector<int32_t> tmp;
+    for (int64_t k = 0; k < nsn; ++k) {
+      int64_t f = S.snptr[k], l = S.snptr[k + 1] - 1;
+      tmp.clear();
+      for (int64_t j = f; j <= l; ++j) {
+        for (int64_t q = g.lptr[j]; q < g.lptr[j + 1]; ++q) {
+          int64_t r = g.lidx[q];
+          if (r > l && mark[r] != k) {
+            mark[r] = k;
+            tmp.push_back((int32_t)r);
+          }
+        }
+      }
+      for (int64_t q = S.chptr[k]; q < S.chptr[k + 1]; ++q) {
+        int64_t c = S.chidx[q];
+        int64_t cb = S.rowptr[c] + (S.snptr[c + 1] - S.snptr[c]), ce = S.rowptr[c + 1];
+        for (int64_t t = cb; t < ce; ++t) {
+          int64_t r = S.rowidx[t];
+          if (r > l && mark[r] != k) {
+            mark[r] = k;
+            tmp.push_back((int32_t)r);
+          }
+        }
+      }
+      std::sort(tmp.begin(), tmp.end());
+      int64_t nn = l - f + 1;
+      if ((int64_t)tmp.size() + nn != S.rowptr[k + 1] - S.rowptr[k]) return -3;  // internal inconsistency
+      int64_t o = S.rowptr[k];
+      for (int64_t j = f; j <= l; ++j) S.rowidx[o++] = (int32_t)j;
+      for (auto r : tmp) S.rowidx[o++] = r;
+    }
+  }
+  // ---- relative indices, block/update pointers, ccs pointers
+  S.sepptr.assign(nsn + 1, 0);
+  S.blkptr.assign(nsn + 1, 0);
+  S.updptr.assign(nsn + 1, 0);
+  for (int64_t k = 0; k < nsn; ++k) {
+    int64_t nn = S.nn(k), nf = S.nf(k), na = nf - nn;
+    S.sepptr[k + 1] = S.sepptr[k] + na;
+    S.blkptr[k + 1] = S.blkptr[k] + nf * nn;
+    S.updptr[k + 1] = S.updptr[k] + na * na;
+    S.max_nn = std::max(S.max_nn, nn);
+    S.max_na = std::max(S.max_na, na);
+    S.max_front = std::max(S.max_front, nf);
+  }
+  S.relidx.resize(S.sepptr[nsn]);
+  for (int64_t k = 0; k < nsn; ++k) {
+    int64_t pk = S.snpar[k];
+    int64_t na = S.na(k);
+    if (pk < 0) {
+      if (na != 0) return -4;
+      continue;
+    }
+    const int32_t* a = &S.rowidx[S.rowptr[k] + S.nn(k)];
+    const int32_t* pr = &S.rowidx[S.rowptr[pk]];
+    int64_t pnf = S.nf(pk), t = 0;
+    for (int64_t i = 0; i < na; ++i) {
+      while (t < pnf && pr[t] < a[i]) ++t;
+      if (t == pnf || pr[t] != a[i]) return -5;  // separator not contained in parent clique
+      S.relidx[S.sepptr[k] + i] = (int32_t)t;
+    }
+  }
+  S.ccsptr.assign(n + 1, 0);
+  for (int64_t k = 0; k < nsn; ++k) {
+    int64_t nf = S.nf(k);
+    for (int64_t t = 0; t < S.nn(k); ++t) S.ccsptr[S.snptr[k] + t + 1] = nf - t;
+  }
+  for (int64_t j = 0; j < n; ++j) S.ccsptr[j + 1] += S.ccsptr[j];
+  S.nnz = S.ccsptr[n];
+  S.fill = S.nnz - nnz_in;
+  // ---- levels (height based)
+  S.level.assign(nsn, 0);
+  for (int64_t k = 0; k < nsn; ++k) {
+    int64_t pk = S.snpar[k];
+    if (pk >= 0) S.level[pk] = std::max(S.level[pk], S.level[k] + 1);
+  }
+  S.nlev = 0;
+  for (int64_t k = 0; k < nsn; ++k) S.nlev = std::max(S.nlev, S.level[k] + 1);
+  S.levptr.assign(S.nlev + 1, 0);
+  for (int64_t k = 0; k < nsn; ++k) S.levptr[S.level[k] + 1]++;
+  for (int64_t l = 0; l < S.nlev; ++l) S.levptr[l + 1] += S.levptr[l];
+  S.levidx.resize(nsn);
+  {
+    std::vector<int64_t> lw(S.levptr.begin(), S.levptr.end() - 1);
+    for (int64_t k = 0; k < nsn; ++k) S.levidx[lw[S.level[k]]++] = k;
+  }
+  return 0;
+}
+
+void maxcardsearch(int64_t n, const int64_t* colptr, const int64_t* rowind, int64_t* order) {
+  std::vector<int64_t> id(n);
+  std::iota(id.begin(), id.end(), 0);
+  Graph g;
+  build_graph(n, colptr, rowind, id, g);
+  // bucket structure over cardinalities
+  std::vector<int64_t> card(n, 0), head(n + 1, -1), nxt(n, -1), prv(n, -1);
+  std::vector<char> done(n, 0);
+  auto push = [&](int64_t v, int64_t c) {
+    nxt[v] = head[c];
+    prv[v] = -1;
+    if (head[c] >= 0) prv[head[c]] = v;
+    head[c] = v;
+  };
+  auto pop = [&](int64_t v, int64_t c) {
+    if (prv[v] >= 0) nxt[prv[v]] = nxt[v]; else head[c] = nxt[v];
+    if (nxt[v] >= 0) prv[nxt[v]] = prv[v];
+  };
+  for (int64_t v = n - 1; v >= 0; --v) push(v, 0);
+  int64_t top = 0;
+  for (int64_t k = n - 1; k >= 0; --k) {
+    while (top > 0 && head[top] < 0) --top;
+    int64_t v = head[top];
+    pop(v, top);
+    done[v] = 1;
+    order[k] = v;  // visited first = eliminated last
+    auto bump = [&](int64_t u) {
+      if (done[u]) return;
+      pop(u, card[u]);
+      card[u]++;
+      push(u, card[u]);
+      if (card[u] > top) top = card[u];
+    };
+    for (int64_t q = g.lptr[v]; q < g.lptr[v + 1]; ++q) bump(g.lidx[q]);
+    for (int64_t q = g.uptr[v]; q < g.uptr[v + 1]; ++q) bump(g.uidx[q]);
+  }
+}
+
+void mindegree(int64_t n, const int64_t* colptr, const int64_t* rowind, int64_t* order) {
+  std::vector<int64_t> id(n);
+  std::iota(id.begin(), id.end(), 0);
+  Graph g;
+  build_graph(n, colptr, rowind, id, g);
+  std::vector<std::set<int32_t>> adj(n);
+  for (int64_t v = 0; v < n; ++v) {
+    for (int64_t q = g.lptr[v]; q < g.lptr[v + 1]; ++q) adj[v].insert(g.lidx[q]);
+    for (int64_t q = g.uptr[v]; q < g.uptr[v + 1]; ++q) adj[v].insert(g.uidx[q]);
+  }
+  std::set<std::pair<int64_t, int64_t>> pq;  // (degree, vertex)
+  for (int64_t v = 0; v < n; ++v) pq.insert({(int64_t)adj[v].size(), v});
+  std::vector<char> gone(n, 0);
+  for (int64_t k = 0; k < n; ++k) {
+    auto it = pq.begin();
+    int64_t v = it->second;
+    pq.erase(it);
+    gone[v] = 1;
+    order[k] = v;
+    std::vector<int32_t> nb(adj[v].begin(), adj[v].end());
+    for (int32_t u : nb) {
+      pq.erase({(int64_t)adj[u].size(), (int64_t)u});
+      adj[u].erase((int32_t)v);
+    }
+    for (size_t a = 0; a < nb.size(); ++a)
+      for (size_t b = a + 1; b < nb.size(); ++b) {
+        adj[nb[a]].insert(nb[b]);
+        adj[nb[b]].insert(nb[a]);
+      }
+    for (int32_t u : nb) pq.insert({(int64_t)adj[u].size(), (int64_t)u});
+    adj[v].clear();
+  }
+}
+
+void index_map(const Symbolic& S, int64_t cnt, const int64_t* I, const int64_t* J, int64_t* out) {
+  for (int64_t e = 0; e < cnt; ++e) {
+    out[e] = -1;
+    if (I[e] < 0 || I[e] >= S.n || J[e] < 0 || J[e] >= S.n) continue;
+    int64_t a = S.ip[I[e]], b = S.ip[J[e]];
+    int64_t c = std::min(a, b), r = std::max(a, b);
+    int64_t k = S.snode[c];
+    const int32_t* rb = &S.rowidx[S.rowptr[k]];
+    int64_t nf = S.nf(k);
+    const int32_t* pos = std::lower_bound(rb, rb + nf, (int32_t)r);
+    if (pos == rb + nf || *pos != r) continue;
+    out[e] = S.blkptr[k] + (c - S.snptr[k]) * nf + (pos - rb);
+  }
+}
+
+}  // namespace smcp

@@ -1,0 +1,193 @@
+"""Host-side symbolic analysis wrapper (counterpart of ``chompack.symbolic``).
+
+Reference call sites: src/python/solvers.py:301-319 (maxcardsearch / peo / symbolic /
+sparsity_pattern), analysis.py:49-51,173-175 (supernodes / separators / cliques).
+The arithmetic is done by the C-ABI (include/smcp_amd.h, ``csp_symbolic_*``).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_Q = dict(scalars=0, p=1, ip=2, snptr=3, snpar=4, rowptr=5, rowidx=6, sepptr=7, relidx=8, blkptr=9,
+          updptr=10, chptr=11, chidx=12, levptr=13, levidx=14, ccsptr=15, snode=16)
+
+
+def _lower_csc(A, n=None):
+    """Return (n, colptr, rowind) int64 of the lower-triangular pattern of A.
+
+    A may be a scipy sparse matrix (any triangle / symmetric) or a (n, colptr, rowind) tuple.
+    """
+    if isinstance(A, tuple):
+        n, cp, ri = A
+        return int(n), np.ascontiguousarray(cp, dtype=np.int64), np.ascontiguousarray(ri, dtype=np.int64)
+    import scipy.sparse as sp
+    A = sp.coo_matrix(A)
+    n = A.shape[0]
+    i = np.maximum(A.row, A.col).astype(np.int64)
+    j = np.minimum(A.row, A.col).astype(np.int64)
+    key = np.unique(j * n + i)
+    j, i = key // n, key % n
+    cp = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(cp, j + 1, 1)
+    cp = np.cumsum(cp)
+    return n, cp, np.ascontiguousarray(i)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def maxcardsearch(A):
+    """Maximum cardinality search; returns order with order[new] = orig (solvers.py:301)."""
+    n, cp, ri = _lower_csc(A)
+    out = np.empty(n, dtype=np.int64)
+    rc = _lib.lib().csp_maxcardsearch(n, _ptr(cp), _ptr(ri), _ptr(out))
+    if rc:
+        raise ValueError("csp_maxcardsearch failed (%d)" % rc)
+    return out
+
+
+def mindegree(A):
+    """Greedy minimum-degree ordering (stands in for cvxopt.amd.order, solvers.py:278-279)."""
+    n, cp, ri = _lower_csc(A)
+    out = np.empty(n, dtype=np.int64)
+    rc = _lib.lib().csp_mindegree(n, _ptr(cp), _ptr(ri), _ptr(out))
+    if rc:
+        raise ValueError("csp_mindegree failed (%d)" % rc)
+    return out
+
+
+class Symbolic:
+    """Clique tree + block storage layout of a chordal (embedded) sparsity pattern."""
+
+    def __init__(self, A, p=None):
+        n, cp, ri = _lower_csc(A)
+        self._cp, self._ri = cp, ri
+        perm = None if p is None else np.ascontiguousarray(p, dtype=np.int64)
+        info = ctypes.c_int64(0)
+        L = _lib.lib()
+        self._h = L.csp_symbolic_create(n, _ptr(cp), _ptr(ri), _ptr(perm), ctypes.byref(info))
+        if not self._h:
+            raise ValueError("csp_symbolic_create failed (%d)" % info.value)
+        sc = self._query("scalars")
+        (self.n, self.nnz, self.Nsn, self.fill, self.blklen, self.updlen, self.nlev, self.max_nn,
+         self.max_na, self.max_front) = [int(v) for v in sc]
+        self._cache = {}
+        self._device = None
+        self._max_rhs = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().csp_symbolic_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _query(self, what):
+        L = _lib.lib()
+        cnt = L.csp_symbolic_query(self._h, _Q[what], None)
+        out = np.empty(cnt, dtype=np.int64)
+        L.csp_symbolic_query(self._h, _Q[what], _ptr(out))
+        return out
+
+    def __getattr__(self, name):
+        if name in _Q and name != "scalars":
+            c = self.__dict__.setdefault("_cache", {})
+            if name not in c:
+                c[name] = self._query(name)
+            return c[name]
+        raise AttributeError(name)
+
+    # ---- chompack-like accessors -------------------------------------------------------
+    @property
+    def handle(self):
+        return self._h
+
+    def is_chordal_input(self):
+        return self.fill == 0
+
+    def supernodes(self):
+        sp = self.snptr
+        return [np.arange(sp[k], sp[k + 1]) for k in range(self.Nsn)]
+
+    def cliques(self):
+        rp, ri = self.rowptr, self.rowidx
+        return [ri[rp[k]:rp[k + 1]] for k in range(self.Nsn)]
+
+    def separators(self):
+        rp, ri, sp = self.rowptr, self.rowidx, self.snptr
+        return [ri[rp[k] + (sp[k + 1] - sp[k]):rp[k + 1]] for k in range(self.Nsn)]
+
+    def clique_sizes(self):
+        nn = np.diff(self.snptr)
+        nf = np.diff(self.rowptr)
+        return nn, nf - nn
+
+    def sparsity_pattern(self):
+        """Filled lower pattern in PERMUTED coordinates as (colptr, rowind)."""
+        cp = self.ccsptr
+        ri = np.empty(self.nnz, dtype=np.int64)
+        rp, rows, sp = self.rowptr, self.rowidx, self.snptr
+        for k in range(self.Nsn):
+            r = rows[rp[k]:rp[k + 1]]
+            for t in range(sp[k + 1] - sp[k]):
+                j = sp[k] + t
+                ri[cp[j]:cp[j + 1]] = r[t:]
+        return cp, ri
+
+    def ccs_to_blk(self):
+        """blkval position of every nonzero of sparsity_pattern(), in CCS order."""
+        if "ccs2blk" not in self._cache:
+            out = np.empty(self.nnz, dtype=np.int64)
+            cp, rp, sp, bp = self.ccsptr, self.rowptr, self.snptr, self.blkptr
+            for k in range(self.Nsn):
+                nf = rp[k + 1] - rp[k]
+                for t in range(sp[k + 1] - sp[k]):
+                    j = sp[k] + t
+                    out[cp[j]:cp[j + 1]] = bp[k] + t * nf + np.arange(t, nf)
+            self._cache["ccs2blk"] = out
+        return self._cache["ccs2blk"]
+
+    def index_map(self, I, J):
+        """blkval positions of original-coordinate entries (I, J); -1 where outside V."""
+        I = np.ascontiguousarray(I, dtype=np.int64)
+        J = np.ascontiguousarray(J, dtype=np.int64)
+        out = np.empty(I.shape[0], dtype=np.int64)
+        rc = _lib.lib().csp_index_map(self._h, I.shape[0], _ptr(I), _ptr(J), _ptr(out))
+        if rc:
+            raise ValueError("csp_index_map failed (%d)" % rc)
+        return out
+
+    def flops(self):
+        """Algorithmic flop / byte counts per SURVEY.md 8(d)."""
+        nn, na = self.clique_sizes()
+        nn = nn.astype(np.float64)
+        na = na.astype(np.float64)
+        f_chol = np.sum(nn ** 3 / 3 + na * nn ** 2 + na ** 2 * nn)
+        f_pinv = np.sum(2 * nn ** 3 / 3 + 2 * na * nn ** 2 + 2 * na ** 2 * nn)
+        f_compl = np.sum(na ** 3 / 3 + 2 * na ** 2 * nn + 2 * na * nn ** 2 + 2 * nn ** 3 / 3)
+        f_sweep = np.sum(nn ** 3 + 3 * na * nn ** 2 + 2 * na ** 2 * nn)
+        f_h = 2 * f_sweep + np.sum(2 * na ** 2 * nn)
+        return dict(chol=f_chol, pinv=f_pinv, completion=f_compl, sweep=f_sweep, hessian=f_h,
+                    B=float(self.blklen), U=float(self.updlen))
+
+    # ---- device ------------------------------------------------------------------------
+    def device_init(self, device=0, max_rhs=1):
+        rc = _lib.lib().csp_device_init(self._h, int(device), int(max_rhs))
+        if rc:
+            raise RuntimeError("csp_device_init failed (%d): no MI355X visible or out of memory; "
+                               "this package has no CPU fallback" % rc)
+        self._device = device
+        self._max_rhs = max(self._max_rhs, int(max_rhs))
+        return self
+
+    def device_bytes(self):
+        return int(_lib.lib().csp_device_bytes(self._h))
+
+
+def symbolic(A, p=None):
+    return Symbolic(A, p)
