@@ -1,0 +1,175 @@
+"""GPU parity: every C-ABI kernel against the CPU oracle on the same seeded inputs.
+
+Tolerance: fp64, relative 1e-10 on well-conditioned inputs (the north star's "stated fp64
+tolerance"); the factorisations differ from the oracle only in summation order.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from smcp_amd import chordal, problems
+from smcp_amd.cspmatrix import cspmatrix
+from smcp_amd.kkt import KKTSystem
+from smcp_amd.symbolic import Symbolic
+from tests.helpers import PATTERNS, proj, random_spd_on_V
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(1.0, np.linalg.norm(b))
+
+
+def dev(symb, x):
+    return cspmatrix(symb, torch.from_numpy(np.ascontiguousarray(x)).cuda())
+
+
+def host(X):
+    return X.blkval.cpu().numpy()
+
+
+def lowmask(symb):
+    m = np.zeros(symb.blklen, dtype=bool)
+    m[symb.ccs_to_blk()] = True
+    return m
+
+
+GPU_PATTERNS = dict(PATTERNS)
+GPU_PATTERNS["arrow_big"] = lambda: problems.block_arrow_pattern(12, 64, 128)
+GPU_PATTERNS["nested_mid"] = lambda: problems.nested_block_arrow_pattern(nsub=2, nmid=6, nleaf_per_mid=8, seed=3)
+GPU_PATTERNS["dense200"] = lambda: problems.band_pattern(200, 199)
+
+
+def setup(name, seed):
+    symb = Symbolic(GPU_PATTERNS[name]())
+    symb.device_init(0, 4)
+    S = orc.Sym(symb)
+    Lh = problems.random_factor_blkval(symb, seed)
+    A = Lh.copy()
+    orc.llt(S, A)              # S = L L^T on V (oracle used only to manufacture inputs / check)
+    return symb, S, A, lowmask(symb)
+
+
+@pytest.mark.parametrize("name", sorted(GPU_PATTERNS))
+def test_cholesky_llt_pinv_completion(name):
+    symb, S, A, msk = setup(name, 1)
+    X = dev(symb, A)
+    chordal.cholesky(X)
+    ref = A.copy()
+    orc.cholesky(S, ref)
+    assert rel(host(X)[msk], ref[msk]) < TOL
+    assert abs(chordal.logdiagsum(X) - orc.logdiagsum(S, ref)) < 1e-9 * max(1, abs(orc.logdiagsum(S, ref)))
+    Lfac = X.copy()
+    # llt round trip
+    chordal.llt(X)
+    assert rel(host(X)[msk], A[msk]) < TOL
+    # projected inverse
+    Y = Lfac.copy()
+    chordal.projected_inverse(Y)
+    yref = ref.copy()
+    orc.projected_inverse(S, yref)
+    assert rel(host(Y)[msk], yref[msk]) < TOL
+    # completion: round trip back to the factor, and against the oracle
+    C = Y.copy()
+    chordal.completion(C)
+    cref = yref.copy()
+    orc.completion(S, cref)
+    assert rel(host(C)[msk], cref[msk]) < 1e-8
+    assert rel(host(C)[msk], ref[msk]) < 1e-8
+    # dot
+    assert abs(chordal.dot(Y, dev(symb, A)) - orc.dot(S, yref, A)) < 1e-9 * max(1, abs(orc.dot(S, yref, A)))
+
+
+@pytest.mark.parametrize("name", ["band", "arrow", "rand2"])
+def test_failure_is_arithmetic_error(name):
+    symb, S, A, msk = setup(name, 2)
+    nn, na = symb.clique_sizes()
+    k = symb.Nsn // 2
+    bad = A.copy()
+    bad[symb.blkptr[k]] = -1.0                 # a diagonal entry
+    with pytest.raises(ArithmeticError):
+        chordal.cholesky(dev(symb, bad))
+    with pytest.raises(ArithmeticError):
+        chordal.completion(dev(symb, bad))
+    # and the context stays usable afterwards
+    X = dev(symb, A)
+    chordal.cholesky(X)
+
+
+@pytest.mark.parametrize("name", sorted(GPU_PATTERNS))
+@pytest.mark.parametrize("adj,inv", [(None, False), (None, True), (False, False), (True, False),
+                                     (False, True), (True, True)])
+def test_hessian(name, adj, inv):
+    symb, S, A, msk = setup(name, 3)
+    rng = np.random.default_rng(4)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    nr = 3
+    U = rng.standard_normal((nr, symb.blklen)) * msk
+    ref = U.copy()
+    for r in range(nr):
+        orc.hessian(S, L, Yh, ref[r], adj=adj, inv=inv)
+    Ud = torch.from_numpy(U).cuda()
+    chordal.hessian(dev(symb, L), dev(symb, Yh), Ud, adj=adj, inv=inv)
+    got = Ud.cpu().numpy()
+    for r in range(nr):
+        assert rel(got[r][msk], ref[r][msk]) < 1e-9
+    # single-matrix and list forms agree with the batched form
+    one = dev(symb, U[0])
+    chordal.hessian(dev(symb, L), dev(symb, Yh), [one], adj=adj, inv=inv)
+    assert rel(host(one)[msk], ref[0][msk]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["band", "arrow", "rand2", "nested"])
+def test_trsm(name):
+    symb, S, A, msk = setup(name, 5)
+    rng = np.random.default_rng(6)
+    L = A.copy()
+    orc.cholesky(S, L)
+    for trans in ("N", "T"):
+        B = rng.standard_normal((4, symb.n))
+        ref = B.copy()
+        orc.trsm(S, L, ref, trans)
+        Bd = torch.from_numpy(B).cuda()
+        chordal.trsm(dev(symb, L), Bd, trans)
+        assert rel(Bd.cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("name", ["arrow", "rand2", "nested_mid"])
+def test_kkt_factor_and_solve(name):
+    symb, S, A, msk = setup(name, 7)
+    rng = np.random.default_rng(8)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    m = 7
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.05, seed=9)
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=3)       # forces chunking over the constraints
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    # Amap / Aadj
+    x = rng.standard_normal(symb.blklen) * msk
+    assert rel(sys.amap(dev(symb, x)).cpu().numpy(), K.amap(x)) < TOL
+    y = rng.standard_normal(m)
+    assert rel(host(sys.aadj(torch.from_numpy(y).cuda()))[msk], K.aadj(y)[msk]) < TOL
+    solve = sys.factor(Ld, Yd)
+    Hg = np.tril(sys.H.cpu().numpy().T)          # device H is column-major m x m
+    assert rel(Hg, np.tril(Href)) < 1e-9
+    bx = rng.standard_normal(symb.blklen) * msk
+    by = rng.standard_normal(m)
+    for kk in (1.0, 0.25):
+        xr, yr = K.solve(L, Yh, Href, bx, by, kk)
+        bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+        solve(bxd, byd, kk)
+        assert rel(host(bxd)[msk], xr[msk]) < 1e-9
+        assert rel(byd.cpu().numpy(), yr) < 1e-9
+        # reference's own DEBUG residual check (solvers.py:534-538) on the GPU result
+        r, rr = K.residual(L, Yh, host(bxd) * msk, byd.cpu().numpy(), bx, by, kk)
+        assert np.sqrt(orc.dot(S, r, r)) / max(1, np.sqrt(orc.dot(S, bx, bx))) < 1e-10
+        assert np.linalg.norm(rr) / max(1, np.linalg.norm(by)) < 1e-10
