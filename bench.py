@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Newton-KKT solve benchmark (BASELINE.json metric) on MI355X.
+
+One "step" = one Newton-KKT solve at a new scaling point: cholesky(S) +
+projected_inverse (dual scaling, solvers.py:881-891) -> Schur complement build over the m
+constraints (solvers.py:479-497) -> potrf(H) (501) -> one solve_ call (506-541).
+Inputs are synthetic (seeded numpy) and resident in HBM before the timed region.
+
+N = 1 workload: the configuration the metric is quoted on, "synth50k" (config 5: nested
+block-arrow chordal SDP, n = 50000, 8073 cliques, m = 100), which fits one GPU.
+N > 1: the Schur build -- the data-parallel part, m independent constraint sweeps -- is sharded
+by constraint columns over the ranks (strong scaling of ONE solve); the only collective is one
+RCCL all-reduce of the m x m matrix H per step.  Factorisation and solve_ are replicated.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the
+dominant kernel (HIP-event timing inside the timed region) and `cpu_baseline` (the CPU
+oracle timed on a bounded sample on this host).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+FP64_PEAK_TFLOPS = 78.6   # vendor fp64 vector = matrix peak
+
+
+def build_workload(name, seed=0):
+    from smcp_amd import problems
+    if name == "synth50k":
+        pat = problems.nested_block_arrow_pattern(seed=seed)
+        m, density, label = 100, 0.005, "synth50k nested block-arrow SDP n=50000, 8073 cliques, m=100"
+    elif name == "synth6k":   # reduced copy for quick checks only (NOT the benchmark)
+        pat = problems.nested_block_arrow_pattern(nsub=2, nmid=56, seed=seed)
+        m, density, label = 100, 0.005, "synth6k (reduced, check only)"
+    elif name == "arrow":
+        pat = problems.block_arrow_pattern(2000, 64, 128)
+        m, density, label = 100, 0.005, "block-arrow 2000x64+128, m=100"
+    elif name == "dense4096":
+        pat = problems.band_pattern(4096, 4095)
+        m, density, label = 16, 0.005, "single dense clique n=4096, m=16"
+    else:
+        raise SystemExit("unknown workload " + name)
+    return pat, m, density, label
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="synth50k")
+    ap.add_argument("--m", type=int, default=None)
+    ap.add_argument("--max-rhs", type=int, default=None)
+    ap.add_argument("--cpu-cols", type=int, default=8, help="Schur columns timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from smcp_amd import _lib, chordal, problems
+    from smcp_amd.cspmatrix import cspmatrix
+    from smcp_amd.kkt import KKTSystem
+    from smcp_amd.symbolic import Symbolic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lib = _lib.lib()
+
+    # ---------------- problem (untimed) ----------------
+    pat, m, density, label = build_workload(args.workload)
+    if args.m:
+        m = args.m
+    t0 = time.time()
+    symb = Symbolic(pat)
+    t_sym = time.time() - t0
+    fl = symb.flops()
+    B, U = fl["B"], fl["U"]
+    per_rhs = 8 * (U + 3 * B)
+    max_rhs = args.max_rhs or int(max(1, min(m, (48 << 30) // per_rhs)))
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=1)
+    kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs)
+    Lh = problems.random_factor_blkval(symb, seed=0)
+    S = cspmatrix(symb, torch.from_numpy(Lh).to(dev))
+    chordal.llt(S)                       # S = L0 L0^T on V: positive definite by construction
+    msk = np.zeros(symb.blklen, dtype=bool)
+    msk[symb.ccs_to_blk()] = True
+    rng = np.random.default_rng(2)
+    bx0 = torch.from_numpy(rng.standard_normal(symb.blklen) * msk).to(dev)
+    by0 = torch.from_numpy(rng.standard_normal(m)).to(dev)
+    L = S.copy()
+    Y = S.copy()
+    bx = cspmatrix(symb, bx0.clone())
+    by = by0.clone()
+    H = kkt.H
+    j0 = (m * rank) // world
+    j1 = (m * (rank + 1)) // world
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    h = symb.handle
+
+    def chk(rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed rc=%d" % (what, rc))
+
+    def step():
+        L.blkval.copy_(S.blkval)
+        chk(lib.csp_cholesky(h, L.blkval.data_ptr(), st()), "cholesky")
+        Y.blkval.copy_(L.blkval)
+        chk(lib.csp_projected_inverse(h, Y.blkval.data_ptr(), st()), "projected_inverse")
+        if world > 1:
+            H.zero_()
+        chk(lib.kkt_schur_columns(h, L.blkval.data_ptr(), Y.blkval.data_ptr(), H.data_ptr(), m, j0, j1, st()),
+            "schur")
+        if world > 1:
+            dist.all_reduce(H)
+        chk(lib.dense_potrf(h, H.data_ptr(), m, m, st()), "potrf")
+        bx.blkval.copy_(bx0)
+        by.copy_(by0)
+        chk(lib.kkt_solve(h, L.blkval.data_ptr(), Y.blkval.data_ptr(), H.data_ptr(), m, 1.0,
+                          bx.blkval.data_ptr(), by.data_ptr(), st()), "solve")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    prof = not args.no_profile
+    if prof:
+        lib.csp_profile_enable(h, 1)
+        lib.csp_profile_read(h, None, None)  # clear
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---------------- roofline of the dominant kernel (HIP events, same timed region) --------
+    roofline = None
+    breakdown = {}
+    if prof:
+        nk = 64
+        ms = (ctypes.c_double * nk)()
+        cnt = (ctypes.c_int64 * nk)()
+        nk = int(lib.csp_profile_read(h, ms, cnt))   # events recorded during the timed steps above
+        lib.csp_profile_enable(h, 0)
+        for i in range(nk):
+            if cnt[i]:
+                breakdown[lib.csp_profile_kernel_name(i).decode()] = (ms[i] / args.steps, cnt[i] // args.steps)
+        dom = max(breakdown, key=lambda k: breakdown[k][0])
+        dom_ms, dom_launches = breakdown[dom]
+        # algorithmic bytes of all launches of the dominant kernel in one step:
+        # one Hessian half-sweep over r right-hand sides touches 8*(r*(2B+2U)+B) bytes
+        # (U panels read+written, update matrices written once + read once, L read once).
+        mloc = j1 - j0
+        chunks = [min(max_rhs, mloc - c) for c in range(0, mloc, max_rhs)] + [1, 1]
+        sweep_bytes = sum(8.0 * (r * (2 * B + 2 * U) + B) for r in chunks)
+        alg = {"k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
+               "k_chol_level": 8.0 * (2 * B + 2 * U), "k_pinv_level": 8.0 * (2 * B + 2 * U)}.get(dom)
+        if alg is not None:
+            per_launch = alg / dom_launches
+            avg_s = 1e-3 * dom_ms / dom_launches
+            achieved = per_launch / avg_s / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "bytes_per_launch": per_launch, "avg_launch_us": round(1e6 * avg_s, 2),
+                        "launches_per_step": dom_launches}
+        if args.verbose and rank == 0:
+            for k, (t, c) in sorted(breakdown.items(), key=lambda kv: -kv[1][0]):
+                print("  %-26s %9.3f ms/step  %5d launches" % (k, t, c), file=sys.stderr)
+
+    # ---------------- CPU baseline: the oracle on a bounded sample (rank 0, N = 1 only) --------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle as orc
+        So = orc.Sym(symb)
+        K = orc.KKT(So, cptr, cidx, cval)
+        Sh = S.blkval.cpu().numpy()
+        t0 = time.perf_counter()
+        Lo = Sh.copy()
+        orc.cholesky(So, Lo)
+        Yo = Lo.copy()
+        orc.projected_inverse(So, Yo)
+        t_fact = time.perf_counter() - t0
+        ncols = min(args.cpu_cols, m)
+        t0 = time.perf_counter()
+        K.schur_factor(Lo, Yo, ncols=ncols)
+        t_cols = time.perf_counter() - t0
+        Hh = np.asfortranarray(np.tril(H.cpu().numpy().T))   # factored H from the GPU (only to time solve_)
+        t0 = time.perf_counter()
+        xo, yo = K.solve(Lo, Yo, Hh, bx0.cpu().numpy(), by0.cpu().numpy(), 1.0)
+        t_solve = time.perf_counter() - t0
+        t_unit = t_fact + t_cols * (m / ncols) + (m ** 3 / 3.0) / 1e9 + t_solve
+        cpu = {"value": round(1.0 / t_unit, 5), "unit": "KKT solves/s", "cores": 1, "kind": "port",
+               "sample": "cholesky+projected_inverse (%.2fs) + %d of %d Schur columns (%.2fs, scaled x%.1f) + "
+                         "1 solve_ (%.2fs); oracle/chordal_oracle.c, single thread, host has %d cores"
+                         % (t_fact, ncols, m, t_cols, m / ncols, t_solve, os.cpu_count())}
+        # the same run doubles as a full-size check of the GPU search direction
+        ex = np.linalg.norm((bx.blkval.cpu().numpy() - xo)[msk]) / max(1e-300, np.linalg.norm(xo[msk]))
+        ey = np.linalg.norm(by.cpu().numpy() - yo) / max(1e-300, np.linalg.norm(yo))
+        cpu["gpu_vs_oracle_relerr"] = [float("%.2e" % ex), float("%.2e" % ey)]
+
+    if rank == 0:
+        out = {
+            "metric": "Newton KKT solves/sec", "value": round(args.steps / elapsed, 4), "unit": "KKT solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": label, "n": symb.n, "cliques": symb.Nsn, "m": m, "blkval_doubles": int(B),
+                       "update_doubles": int(U), "rhs_per_sweep": max_rhs,
+                       "parallelism": "schur-columns/%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "symbolic_s": round(t_sym, 3),
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

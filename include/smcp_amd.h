@@ -109,6 +109,10 @@ int kkt_aadj(csp_ctx* ctx, const double* y, double* X, void* stream);
  * in place (lapack.potrf, solvers.py:501). */
 int kkt_schur_factor(csp_ctx* ctx, const double* L, const double* Y, double* H, int64_t ldh,
                      void* stream);
+/* Columns j0..j1-1 of the (unfactored) Schur complement only: the unit that is sharded over
+ * GPUs (each rank builds its column range, then one RCCL all-gather of H). */
+int kkt_schur_columns(csp_ctx* ctx, const double* L, const double* Y, double* H, int64_t ldh,
+                      int64_t j0, int64_t j1, void* stream);
 /* lapack.potrf / potrs on a dense device matrix (solvers.py:501,526). */
 int dense_potrf(csp_ctx* ctx, double* A, int64_t n, int64_t lda, void* stream);
 int dense_potrs(csp_ctx* ctx, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs,
@@ -117,6 +121,14 @@ int dense_potrs(csp_ctx* ctx, const double* A, int64_t n, int64_t lda, double* B
  * and by (length m) with y for  [-kk*W^-1  A^adj; A 0][x;y] = [bx;by]. */
 int kkt_solve(csp_ctx* ctx, const double* L, const double* Y, const double* H, int64_t ldh,
               double kk, double* bx, double* by, void* stream);
+
+/* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */
+/* When enabled every kernel launch is bracketed by HIP events on its own stream. */
+int csp_profile_enable(csp_ctx* ctx, int on);
+/* Synchronises, then writes per-kernel accumulated milliseconds and launch counts (arrays of
+ * the returned length, host) and clears the record. */
+int64_t csp_profile_read(csp_ctx* ctx, double* ms, int64_t* count);
+const char* csp_profile_kernel_name(int kid);
 
 #ifdef __cplusplus
 }

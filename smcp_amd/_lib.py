@@ -37,6 +37,10 @@ SIGNATURES = {
     "kkt_amap": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "kkt_aadj": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "kkt_schur_factor": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kkt_schur_columns": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "csp_profile_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "csp_profile_read": (c_i64, [c_vp, c_vp, c_vp]),
+    "csp_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
     "dense_potrf": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "dense_potrs": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "kkt_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, c_vp, c_vp, c_vp]),

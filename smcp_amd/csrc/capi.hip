@@ -26,6 +26,31 @@ using namespace smcp;
 
 namespace {
 
+// ---- kernel ids + optional per-kernel HIP-event timing (csp_profile_*) ------------------
+enum {
+  KID_chol_level = 0, KID_llt_level, KID_pinv_level, KID_gather_level, KID_completion_all,
+  KID_hess_up_level, KID_hess_down_level, KID_hess_down_inv_all, KID_hess_up_inv_level, KID_scale_an,
+  KID_factor_yaa, KID_trsm_fwd_level, KID_trsm_bwd_level, KID_amap, KID_aadj, KID_scatter_constraints,
+  KID_dense_potrf, KID_dense_potrs, KID_vec_axpby, KID_axpby, KID_reduce_cliques, KID_reduce_final,
+  KID_COUNT
+};
+const char* const KID_NAMES[KID_COUNT] = {
+  "k_chol_level", "k_llt_level", "k_pinv_level", "k_gather_level", "k_completion_all",
+  "k_hess_up_level", "k_hess_down_level", "k_hess_down_inv_all", "k_hess_up_inv_level", "k_scale_an",
+  "k_factor_yaa", "k_trsm_fwd_level", "k_trsm_bwd_level", "k_amap", "k_aadj", "k_scatter_constraints",
+  "k_dense_potrf", "k_dense_potrs", "k_vec_axpby", "k_axpby", "k_reduce_cliques", "k_reduce_final"};
+
+template <class K, class... A>
+inline void launch(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, hipStream_t st, A... args) {
+  Profiler& P = c->prof;
+  if (P.on) (void)hipEventRecord(P.next(), st);
+  hipLaunchKernelGGL(kern, grid, block, 0, st, args...);
+  if (P.on) {
+    (void)hipEventRecord(P.next(), st);
+    P.kids.push_back(kid);
+  }
+}
+
 template <class T>
 int dev_upload(T** dst, const std::vector<T>& src, int64_t& bytes) {
   size_t n = std::max<size_t>(src.size(), 1) * sizeof(T);
@@ -93,7 +118,7 @@ void gather_all(csp_ctx* c, const double* x, int64_t ldx, int nrhs, double* updb
   TreeArgs a = tree_args(c);
   for_levels_down(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
-    hipLaunchKernelGGL(k_gather_level, dim3(cnt, nrhs), dim3(NT), 0, st, a, x, ldx, updbase);
+    launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs), dim3(NT), st, a, x, ldx, updbase);
   });
 }
 
@@ -101,7 +126,7 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st) {
   TreeArgs a = tree_args(c);
   gather_all(c, Y, 0, 1, c->D.yaa, st);
   if (need_fac) {
-    hipLaunchKernelGGL(k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), 0, st, a, c->D.yaa, c->D.fac);
+    launch(c, KID_factor_yaa, k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), st, a, c->D.yaa, c->D.fac);
   }
   return 0;
 }
@@ -113,27 +138,27 @@ int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t l
   auto up = [&]() {
     for_levels_up(c, [&](const int32_t* lev, int cnt) {
       a.lev = lev;
-      hipLaunchKernelGGL(k_hess_up_level, dim3(cnt, (int)nrhs), dim3(NT), 0, st, a, L, U, ldu);
+      launch(c, KID_hess_up_level, k_hess_up_level, dim3(cnt, (int)nrhs), dim3(NT), st, a, L, U, ldu);
     });
   };
   auto down = [&]() {
     for_levels_down(c, [&](const int32_t* lev, int cnt) {
       a.lev = lev;
-      hipLaunchKernelGGL(k_hess_down_level, dim3(cnt, (int)nrhs), dim3(NT), 0, st, a, L, U, ldu);
+      launch(c, KID_hess_down_level, k_hess_down_level, dim3(cnt, (int)nrhs), dim3(NT), st, a, L, U, ldu);
     });
   };
   auto up_inv = [&]() {
     for_levels_up(c, [&](const int32_t* lev, int cnt) {
       a.lev = lev;
-      hipLaunchKernelGGL(k_hess_up_inv_level, dim3(cnt, (int)nrhs), dim3(NT), 0, st, a, L, U, ldu);
+      launch(c, KID_hess_up_inv_level, k_hess_up_inv_level, dim3(cnt, (int)nrhs), dim3(NT), st, a, L, U, ldu);
     });
   };
   auto down_inv = [&]() {
     gather_all(c, U, ldu, (int)nrhs, c->D.upd, st);
-    hipLaunchKernelGGL(k_hess_down_inv_all, dim3(nsn, (int)nrhs), dim3(NT), 0, st, a, L, U, ldu);
+    launch(c, KID_hess_down_inv_all, k_hess_down_inv_all, dim3(nsn, (int)nrhs), dim3(NT), st, a, L, U, ldu);
   };
   auto scale = [&](int mode) {
-    hipLaunchKernelGGL(k_scale_an, dim3(nsn, (int)nrhs), dim3(NT), 0, st, a, c->D.yaa, c->D.fac, U, ldu, mode);
+    launch(c, KID_scale_an, k_scale_an, dim3(nsn, (int)nrhs), dim3(NT), st, a, c->D.yaa, c->D.fac, U, ldu, mode);
   };
   if (!inv) {
     if (adj == 0) { up(); scale(0); }
@@ -284,7 +309,7 @@ int csp_cholesky(csp_ctx* c, double* x, void* stream) {
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
   for_levels_up(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
-    hipLaunchKernelGGL(k_chol_level, dim3(cnt), dim3(NT), 0, st, a, x);
+    launch(c, KID_chol_level, k_chol_level, dim3(cnt), dim3(NT), st, a, x);
   });
   HIPCHK(hipGetLastError());
   return fetch_info(c, st);
@@ -296,7 +321,7 @@ int csp_llt(csp_ctx* c, double* x, void* stream) {
   TreeArgs a = tree_args(c);
   for_levels_up(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
-    hipLaunchKernelGGL(k_llt_level, dim3(cnt), dim3(NT), 0, st, a, x);
+    launch(c, KID_llt_level, k_llt_level, dim3(cnt), dim3(NT), st, a, x);
   });
   HIPCHK(hipGetLastError());
   return 0;
@@ -308,7 +333,7 @@ int csp_projected_inverse(csp_ctx* c, double* x, void* stream) {
   TreeArgs a = tree_args(c);
   for_levels_down(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
-    hipLaunchKernelGGL(k_pinv_level, dim3(cnt), dim3(NT), 0, st, a, x);
+    launch(c, KID_pinv_level, k_pinv_level, dim3(cnt), dim3(NT), st, a, x);
   });
   HIPCHK(hipGetLastError());
   return 0;
@@ -320,7 +345,7 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
   TreeArgs a = tree_args(c);
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
   gather_all(c, x, 0, 1, c->D.upd, st);
-  hipLaunchKernelGGL(k_completion_all, dim3((int)c->S.nsn), dim3(NT), 0, st, a, x);
+  launch(c, KID_completion_all, k_completion_all, dim3((int)c->S.nsn), dim3(NT), st, a, x);
   HIPCHK(hipGetLastError());
   return fetch_info(c, st);
 }
@@ -351,12 +376,12 @@ int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, 
   if (!trans) {
     for_levels_up(c, [&](const int32_t* lev, int cnt) {
       a.lev = lev;
-      hipLaunchKernelGGL(k_trsm_fwd_level, dim3(cnt), dim3(NT), 0, st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
+      launch(c, KID_trsm_fwd_level, k_trsm_fwd_level, dim3(cnt), dim3(NT), st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
     });
   } else {
     for_levels_down(c, [&](const int32_t* lev, int cnt) {
       a.lev = lev;
-      hipLaunchKernelGGL(k_trsm_bwd_level, dim3(cnt), dim3(NT), 0, st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
+      launch(c, KID_trsm_bwd_level, k_trsm_bwd_level, dim3(cnt), dim3(NT), st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
     });
   }
   HIPCHK(hipGetLastError());
@@ -365,8 +390,8 @@ int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, 
 
 static int reduce_impl(csp_ctx* c, const double* X, const double* Y, int mode, double* out, hipStream_t st) {
   int nb = (int)std::min<int64_t>(c->S.nsn, 512);
-  hipLaunchKernelGGL(k_reduce_cliques, dim3(nb), dim3(NT), 0, st, c->D.cl, (int)c->S.nsn, X, Y, mode, c->D.red);
-  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(NT), 0, st, c->D.red, nb, c->D.red + 512);
+  launch(c, KID_reduce_cliques, k_reduce_cliques, dim3(nb), dim3(NT), st, c->D.cl, (int)c->S.nsn, X, Y, mode, c->D.red);
+  launch(c, KID_reduce_final, k_reduce_final, dim3(1), dim3(NT), st, c->D.red, nb, c->D.red + 512);
   HIPCHK(hipGetLastError());
   double* h = (double*)(c->D.info_host + 2);
   HIPCHK(hipMemcpyAsync(h, c->D.red + 512, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -391,6 +416,32 @@ int csp_axpby(int64_t len, double a, const double* x, double b, double* y, void*
   HIPCHK(hipGetLastError());
   return 0;
 }
+
+
+int csp_profile_enable(csp_ctx* c, int on) {
+  if (!c) return SMCP_EINVAL;
+  c->prof.on = on != 0;
+  return 0;
+}
+
+int64_t csp_profile_read(csp_ctx* c, double* ms, int64_t* count) {
+  if (int rc = ready(c)) return rc;
+  Profiler& P = c->prof;
+  HIPCHK(hipDeviceSynchronize());
+  if (ms) for (int i = 0; i < KID_COUNT; ++i) ms[i] = 0.0;
+  if (count) for (int i = 0; i < KID_COUNT; ++i) count[i] = 0;
+  for (size_t i = 0; i < P.kids.size(); ++i) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, P.ev[2 * i], P.ev[2 * i + 1]));
+    if (ms) ms[P.kids[i]] += t;
+    if (count) count[P.kids[i]]++;
+  }
+  P.kids.clear();
+  P.used = 0;
+  return KID_COUNT;
+}
+
+const char* csp_profile_kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? KID_NAMES[kid] : nullptr; }
 
 }  // extern "C"
 

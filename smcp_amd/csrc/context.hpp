@@ -58,9 +58,28 @@ struct DeviceCtx {
 
 }  // namespace smcp
 
+namespace smcp {
+// optional per-kernel timing with HIP events on the launch stream
+struct Profiler {
+  bool on = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> kids;
+  size_t used = 0;
+  hipEvent_t next() {
+    if (used == ev.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      ev.push_back(e);
+    }
+    return ev[used++];
+  }
+};
+}  // namespace smcp
+
 struct csp_ctx {
   smcp::Symbolic S;
   smcp::DeviceCtx D;
+  smcp::Profiler prof;
   std::vector<int64_t> h_tmpptr;
   std::vector<uint8_t> is_diag_cache;
 };

@@ -58,7 +58,7 @@ __global__ void k_vec_axpby(int64_t m, double a, const double* x, double b, doub
 int amap_impl(csp_ctx* c, const double* X, int64_t ldx, int nrhs, double* y, int64_t ldy, hipStream_t st) {
   const DeviceCtx& D = c->D;
   int wpb = 4;
-  hipLaunchKernelGGL(k_amap, dim3((unsigned)((D.m + wpb - 1) / wpb), nrhs), dim3(64 * wpb), 0, st, D.m,
+  launch(c, KID_amap, k_amap, dim3((unsigned)((D.m + wpb - 1) / wpb), nrhs), dim3(64 * wpb), st, D.m,
                      D.cptr, D.cidx, D.cwval, X, ldx, y, ldy);
   return 0;
 }
@@ -66,7 +66,7 @@ int aadj_impl(csp_ctx* c, const double* y, double* X, hipStream_t st) {
   const DeviceCtx& D = c->D;
   if (hipMemsetAsync(X, 0, sizeof(double) * c->S.blklen(), st) != hipSuccess) return SMCP_EHIP;
   if (D.rnnz)
-    hipLaunchKernelGGL(k_aadj, dim3((unsigned)((D.rnnz + 255) / 256)), dim3(256), 0, st, D.rnnz, D.rpos,
+    launch(c, KID_aadj, k_aadj, dim3((unsigned)((D.rnnz + 255) / 256)), dim3(256), st, D.rnnz, D.rpos,
                        D.rptr, D.rcon, D.rval, y, X);
   return 0;
 }
@@ -155,36 +155,42 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
   if (int rc = ready(c)) return rc;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_dense_potrf, dim3(1), dim3(1024), 0, st, A, (int)n, lda, c->D.info);
+  launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
   HIPCHK(hipGetLastError());
   return fetch_info(c, st);
 }
 int dense_potrs(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs, int64_t ldb,
                 void* stream) {
   if (int rc = ready(c)) return rc;
-  hipLaunchKernelGGL(k_dense_potrs, dim3(1), dim3(1024), 0, (hipStream_t)stream, A, (int)n, lda, B, (int)nrhs, ldb);
+  launch(c, KID_dense_potrs, k_dense_potrs, dim3(1), dim3(1024), (hipStream_t)stream, A, (int)n, lda, B, (int)nrhs, ldb);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, int64_t j0,
+                      int64_t j1, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  const int64_t m = D.m, bl = c->S.blklen();
+  if (!m || ldh < m || j0 < 0 || j1 > m || j0 > j1) return SMCP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  prepare_yaa(c, Y, false, st);
+  for (int64_t jb = j0; jb < j1; jb += D.max_rhs) {
+    int nr = (int)std::min(D.max_rhs, j1 - jb);
+    HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * nr * bl, st));
+    launch(c, KID_scatter_constraints, k_scatter_constraints, dim3(8, nr), dim3(256), st, jb, D.cptr, D.cidx,
+           D.cval, D.ustack, bl);
+    hessian_impl(c, L, D.ustack, nr, bl, 2, 0, st);
+    // H[:, jb+r] = Amap(W(A_{jb+r}))  (full column; H is symmetric)
+    amap_impl(c, D.ustack, bl, nr, H + jb * ldh, ldh, st);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 int kkt_schur_factor(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, void* stream) {
-  if (int rc = ready(c)) return rc;
-  DeviceCtx& D = c->D;
-  const int64_t m = D.m, bl = c->S.blklen();
-  if (!m || ldh < m) return SMCP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  prepare_yaa(c, Y, false, st);
-  for (int64_t j0 = 0; j0 < m; j0 += D.max_rhs) {
-    int nr = (int)std::min(D.max_rhs, m - j0);
-    HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * nr * bl, st));
-    hipLaunchKernelGGL(k_scatter_constraints, dim3(8, nr), dim3(256), 0, st, j0, D.cptr, D.cidx, D.cval,
-                       D.ustack, bl);
-    hessian_impl(c, L, D.ustack, nr, bl, 2, 0, st);
-    // H[:, j0+r] = Amap(W(A_{j0+r}))  (full column; H is symmetric)
-    amap_impl(c, D.ustack, bl, nr, H + j0 * ldh, ldh, st);
-  }
-  HIPCHK(hipGetLastError());
-  return dense_potrf(c, H, m, ldh, stream);
+  if (int rc = kkt_schur_columns(c, L, Y, H, ldh, 0, c ? c->D.m : 0, stream)) return rc;
+  return dense_potrf(c, H, c->D.m, ldh, stream);
 }
 
 int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int64_t ldh, double kk,
@@ -205,12 +211,12 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
   hessian_impl(c, L, r1, 1, bl, 2, 0, st);                      // r1 = W(bx)
   amap_impl(c, r1, 0, 1, ytmp, 0, st);                          // Amap(r1)
-  hipLaunchKernelGGL(k_vec_axpby, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, 1.0, ytmp, kk, by);  // y = kk*by + Amap(r1)
-  hipLaunchKernelGGL(k_dense_potrs, dim3(1), dim3(1024), 0, st, H, (int)m, ldh, by, 1, m);
+  launch(c, KID_vec_axpby, k_vec_axpby, dim3((unsigned)((m + 255) / 256)), dim3(256), st, m, 1.0, ytmp, kk, by);  // y = kk*by + Amap(r1)
+  launch(c, KID_dense_potrs, k_dense_potrs, dim3(1), dim3(1024), st, H, (int)m, ldh, by, 1, m);
   if (int rc = aadj_impl(c, by, r1, st)) return rc;             // r1 = Aadj(y)
-  hipLaunchKernelGGL(k_axpby, dim3(1024), dim3(256), 0, st, bl, 1.0, (const double*)r1, -1.0, bx);  // bx = Aadj(y) - bx
+  launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 1.0, (const double*)r1, -1.0, bx);  // bx = Aadj(y) - bx
   hessian_impl(c, L, bx, 1, bl, 2, 0, st);
-  hipLaunchKernelGGL(k_axpby, dim3(1024), dim3(256), 0, st, bl, 0.0, (const double*)nullptr, 1.0 / kk, bx);
+  launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 0.0, (const double*)nullptr, 1.0 / kk, bx);
   HIPCHK(hipGetLastError());
   return 0;
 }
