@@ -12,6 +12,7 @@
 #include "../../include/smcp_amd.h"
 #include "context.hpp"
 #include "front_generic.hip"
+#include "front_mfma.hip"
 
 using namespace smcp;
 
@@ -32,14 +33,26 @@ enum {
   KID_hess_up_level, KID_hess_down_level, KID_hess_down_inv_all, KID_hess_up_inv_level, KID_scale_an,
   KID_factor_yaa, KID_trsm_fwd_level, KID_trsm_bwd_level, KID_amap, KID_aadj, KID_scatter_constraints,
   KID_dense_potrf, KID_dense_potrs, KID_vec_axpby, KID_axpby, KID_reduce_cliques, KID_reduce_final,
+  KID_hess_up_mfma, KID_hess_down_mfma, KID_chol_mfma, KID_pinv_mfma, KID_prep_lk,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
   "k_chol_level", "k_llt_level", "k_pinv_level", "k_gather_level", "k_completion_all",
   "k_hess_up_level", "k_hess_down_level", "k_hess_down_inv_all", "k_hess_up_inv_level", "k_scale_an",
   "k_factor_yaa", "k_trsm_fwd_level", "k_trsm_bwd_level", "k_amap", "k_aadj", "k_scatter_constraints",
-  "k_dense_potrf", "k_dense_potrs", "k_vec_axpby", "k_axpby", "k_reduce_cliques", "k_reduce_final"};
+  "k_dense_potrf", "k_dense_potrs", "k_vec_axpby", "k_axpby", "k_reduce_cliques", "k_reduce_final",
+  "k_hess_up_mfma", "k_hess_down_mfma", "k_chol_mfma", "k_pinv_mfma", "k_prep_lk"};
 
+template <class K, class... A>
+inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+  Profiler& P = c->prof;
+  if (P.on) (void)hipEventRecord(P.next(), st);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
+  if (P.on) {
+    (void)hipEventRecord(P.next(), st);
+    P.kids.push_back(kid);
+  }
+}
 template <class K, class... A>
 inline void launch(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, hipStream_t st, A... args) {
   Profiler& P = c->prof;
@@ -131,6 +144,75 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st) {
   return 0;
 }
 
+
+// ---- fast path (front_mfma.hip): per level, LDS-class cliques then HBM-class cliques ----------
+constexpr size_t LDS_LIMIT = 160 * 1024 - 256;
+
+bool use_generic() {
+  static int g = -1;
+  if (g < 0) { const char* e = getenv("SMCP_GENERIC"); g = (e && e[0] == '1') ? 1 : 0; }
+  return g == 1;
+}
+
+MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
+  MfmaArgs a;
+  a.t = tree_args(c);
+  a.t.lev = c->D.lev2idx;
+  a.LK = c->D.lk;
+  a.ysc = ysc;
+  a.ymode = ymode;
+  a.nnmax = a.namax = 0;
+  a.nrhs = nrhs;
+  return a;
+}
+
+int rhs_groups(int ncl, int nrhs, int target) {
+  int g = (target + ncl - 1) / ncl;
+  return std::max(1, std::min(g, nrhs));
+}
+
+// f(lds_mode, MfmaArgs-with-lev-set, count, lds_bytes, threads) for the two classes of level l
+template <class F>
+void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f) {
+  const LevelClass& L = c->lvl[l];
+  int64_t b = c->S.levptr[l];
+  if (L.nI) {
+    a.t.lev = c->D.lev2idx + b;
+    a.nnmax = L.nnmaxI;
+    a.namax = L.namaxI;
+    size_t lds = (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double);
+    f(true, a, (int)L.nI, lds, lds > 48 * 1024 ? 512 : 256);
+  }
+  if (L.nII) {
+    a.t.lev = c->D.lev2idx + b + L.nI;
+    f(false, a, (int)L.nII, (size_t)0, 1024);
+  }
+}
+
+void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
+  TreeArgs t = tree_args(c);
+  launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->S.nsn), dim3(NT), st, t, L, c->D.lk);
+}
+
+void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {
+  MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
+  for (int64_t l = 0; l < c->S.nlev; ++l)
+    for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
+      int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
+      if (lds) launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+      else launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+    });
+}
+void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {
+  MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
+  for (int64_t l = c->S.nlev - 1; l >= 0; --l)
+    for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
+      int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
+      if (lds) launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+      else launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+    });
+}
+
 int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t ldu, int adj, int inv,
                  hipStream_t st) {
   TreeArgs a = tree_args(c);
@@ -160,7 +242,12 @@ int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t l
   auto scale = [&](int mode) {
     launch(c, KID_scale_an, k_scale_an, dim3(nsn, (int)nrhs), dim3(NT), st, a, c->D.yaa, c->D.fac, U, ldu, mode);
   };
-  if (!inv) {
+  if (!inv && !use_generic()) {
+    // LK must have been prepared for this L (prep_lk) by the caller
+    if (adj == 0) hess_up_fast(c, U, (int)nrhs, ldu, c->D.fac, 2, st);
+    else if (adj == 1) hess_down_fast(c, U, (int)nrhs, ldu, c->D.fac, 3, st);
+    else { hess_up_fast(c, U, (int)nrhs, ldu, c->D.yaa, 1, st); hess_down_fast(c, U, (int)nrhs, ldu, nullptr, 0, st); }
+  } else if (!inv) {
     if (adj == 0) { up(); scale(0); }
     else if (adj == 1) { scale(1); down(); }
     else { up(); scale(4); down(); }
@@ -191,7 +278,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
     for (void* p : ptrs) if (p) hipFree(p);
     if (D.info_host) hipHostFree(D.info_host);
@@ -273,14 +360,48 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     }
     std::vector<int32_t> ch(S.chidx.begin(), S.chidx.end()), lev(S.levidx.begin(), S.levidx.end());
     c->h_tmpptr.resize(S.nsn + 1);
-    for (int64_t k = 0; k <= S.nsn; ++k) c->h_tmpptr[k] = 2 * S.blkptr[k];
-    D.tmplen = 2 * S.blklen();
+    for (int64_t k = 0; k <= S.nsn; ++k) c->h_tmpptr[k] = 2 * S.blkptr[k] + 256 * k;
+    D.tmplen = 2 * S.blklen() + 256 * S.nsn;
+    // per level: LDS-class cliques first, HBM-class cliques after
+    std::vector<int32_t> lev2(S.nsn);
+    c->lvl.assign(S.nlev, LevelClass());
+    for (int64_t l = 0; l < S.nlev; ++l) {
+      LevelClass& L = c->lvl[l];
+      int64_t b = S.levptr[l], e = S.levptr[l + 1], w = b;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int64_t q = b; q < e; ++q) {
+          int64_t k = S.levidx[q];
+          bool small = (size_t)mfma_lds_doubles((int)S.nn(k), (int)S.na(k)) * sizeof(double) <= LDS_LIMIT;
+          if (small == (pass == 0)) {
+            lev2[w++] = (int32_t)k;
+            if (small) {
+              L.nI++;
+              L.nnmaxI = std::max<int>(L.nnmaxI, (int)S.nn(k));
+              L.namaxI = std::max<int>(L.namaxI, (int)S.na(k));
+            } else L.nII++;
+          }
+        }
+      // the joint maxima may not fit even if every clique does: demote the level's LDS class then
+      if (L.nI && (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double) > LDS_LIMIT) {
+        L.nII += L.nI; L.nI = 0; L.nnmaxI = L.namaxI = 0;
+      }
+    }
     int rc = 0;
     if ((rc = dev_upload(&D.cl, cl, D.bytes))) return rc;
     if ((rc = dev_upload(&D.rowidx, S.rowidx, D.bytes))) return rc;
     if ((rc = dev_upload(&D.relidx, S.relidx, D.bytes))) return rc;
     if ((rc = dev_upload(&D.chidx, ch, D.bytes))) return rc;
     if ((rc = dev_upload(&D.levidx, lev, D.bytes))) return rc;
+    if ((rc = dev_upload(&D.lev2idx, lev2, D.bytes))) return rc;
+    if ((rc = dev_alloc(&D.lk, S.blklen(), D.bytes))) return rc;
+    HIPCHK(hipMemset(D.lk, 0, sizeof(double) * std::max<int64_t>(S.blklen(), 1)));
+    {
+      const int mx = 160 * 1024;
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_chol_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_pinv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    }
     if ((rc = dev_upload(&D.tmpptr, c->h_tmpptr, D.bytes))) return rc;
     if ((rc = dev_alloc(&D.yaa, S.updlen(), D.bytes))) return rc;
     if ((rc = dev_alloc(&D.fac, S.updlen(), D.bytes))) return rc;
@@ -307,6 +428,15 @@ int csp_cholesky(csp_ctx* c, double* x, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
+  if (!use_generic()) {
+    MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+    a0.LK = nullptr;
+    for (int64_t l = 0; l < c->S.nlev; ++l)
+      for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
+        if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
+        else launch_lds(c, KID_chol_mfma, k_chol_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
+      });
+  } else
   for_levels_up(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
     launch(c, KID_chol_level, k_chol_level, dim3(cnt), dim3(NT), st, a, x);
@@ -331,6 +461,15 @@ int csp_projected_inverse(csp_ctx* c, double* x, void* stream) {
   if (int rc = ready(c)) return rc;
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
+  if (!use_generic()) {
+    prep_lk(c, x, st);
+    MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+    for (int64_t l = c->S.nlev - 1; l >= 0; --l)
+      for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
+        if (lds) launch_lds(c, KID_pinv_mfma, k_pinv_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
+        else launch_lds(c, KID_pinv_mfma, k_pinv_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
+      });
+  } else
   for_levels_down(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
     launch(c, KID_pinv_level, k_pinv_level, dim3(cnt), dim3(NT), st, a, x);
@@ -358,6 +497,7 @@ int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t
   bool need_fac = !(adj == 2 && inv == 0);
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
   prepare_yaa(c, Y, need_fac, st);
+  if (!inv && !use_generic()) prep_lk(c, L, st);
   for (int64_t r0 = 0; r0 < nrhs; r0 += c->D.max_rhs) {
     int64_t nr = std::min(c->D.max_rhs, nrhs - r0);
     hessian_impl(c, L, U + r0 * ldu, nr, ldu, adj, inv, st);

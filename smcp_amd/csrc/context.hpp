@@ -31,6 +31,8 @@ struct DeviceCtx {
   int32_t* relidx = nullptr;
   int32_t* chidx = nullptr;
   int32_t* levidx = nullptr;  // cliques sorted by level
+  int32_t* lev2idx = nullptr; // per level: LDS-class cliques first, then HBM-class
+  double* lk = nullptr;       // inverse-form factor [L_NN^-1; L_AN L_NN^-1] of the most recent prep
   // workspaces
   double* upd = nullptr;   // max_rhs * updlen : update matrices
   double* yaa = nullptr;   // updlen : Y[A_k,A_k] cache (Hessian)
@@ -76,8 +78,16 @@ struct Profiler {
 };
 }  // namespace smcp
 
+namespace smcp {
+struct LevelClass {
+  int64_t nI = 0, nII = 0;     // cliques whose working set fits LDS / does not
+  int nnmaxI = 0, namaxI = 0;  // LDS layout sizing for the LDS class
+};
+}  // namespace smcp
+
 struct csp_ctx {
   smcp::Symbolic S;
+  std::vector<smcp::LevelClass> lvl;
   smcp::DeviceCtx D;
   smcp::Profiler prof;
   std::vector<int64_t> h_tmpptr;

@@ -1,0 +1,541 @@
+// LDS-resident / MFMA clique kernels (the fast path).
+//
+// Formulation: after a factorisation the "inverse-form" factor LK = [Li; K] with
+// Li = L_NN^-1 (explicit, lower, zeros above) and K = L_AN Li is prepared once per clique.
+// With it every per-right-hand-side step of the Hessian sweeps is a plain
+// matrix product -- no triangular solves, no sequential dependency chains:
+//   up   : E = F_AN - K F_NN/2 ; Upd = F_AA - K E^T - E K^T ; G_AN = (2E - F_AN) Li^T ;
+//          G_NN = Li F_NN Li^T ; (fused scale) Q = Y_AA G_AN
+//   down : QL = Q Li ; D = QL - Z_AA K/2 ; Z_AN = 2D - QL ; Z_NN = Li^T G_NN Li - K^T D - D^T K
+// All products run on v_mfma_f64_16x16x4_f64 through wg_mma() below, with the working set of a
+// (clique, rhs) pair staged in LDS when it fits (template LDS = true) or left in HBM/L2 scratch
+// for big fronts (LDS = false; same code through flat pointers).  One workgroup owns one clique
+// and loops over a group of right-hand sides so the clique constants are loaded once.
+#include <hip/hip_runtime.h>
+
+namespace smcp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// C(m,n) = sum_k A(m,k) B(k,n) on 16x16 MFMA tiles; all waves of the workgroup share the tiles.
+// A(m,k) / B(k,n) are element functors (any memory), store(m,n,acc) consumes the result.
+// MFMA operand map (v_mfma_f64_16x16x4_f64): the instruction's A operand holds [i=lane&15][k=lane>>4],
+// its B operand [k=lane>>4][j=lane&15], D register r holds [i=(lane>>4)+4r][j=lane&15].  We feed
+// B_my as the instruction's A and A_my as its B so that j (= lane&15) runs along the contiguous
+// row index m of our column-major matrices.
+template <class FA, class FB, class FC>
+__device__ inline void wg_mma(int M, int N, int Kd, FA A, FB B, FC store, bool lower_only = false) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int mt = (M + 15) >> 4, nt = (N + 15) >> 4;
+  const int l15 = lane & 15, kq = lane >> 4;
+  for (int t = wave; t < mt * nt; t += nw) {
+    const int tm = t % mt, tn = t / mt;
+    if (lower_only && tm < tn) continue;
+    const int m = tm * 16 + l15, nb = tn * 16 + l15;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < Kd; k0 += 4) {
+      const int k = k0 + kq;
+      const bool kin = k < Kd;
+      double av = (kin && m < M) ? A(m, k) : 0.0;
+      double bv = (kin && nb < N) ? B(k, nb) : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = tn * 16 + kq + 4 * r;
+      if (m < M && n < N) store(m, n, acc[r]);
+    }
+  }
+}
+
+struct MfmaArgs {
+  TreeArgs t;
+  const double* LK;   // inverse-form factor, blkval layout: rows 0..nn-1 = Li (zeros above diag), rows nn.. = K
+  const double* ysc;  // scaling operand in update-matrix layout (yaa or its Cholesky factor) or null
+  int ymode;          // 0 none, 1 symmetric (Y_AA), 2 R^T, 3 R
+  int nnmax, namax;   // LDS layout sizing (max over the cliques of this launch)
+  int nrhs;
+};
+
+__device__ __host__ inline int padld(int x) { return x | 1; }
+
+// doubles of LDS needed by the largest kernel (hess_up with scaling) for a front (nn, na)
+__host__ __device__ inline int64_t mfma_lds_doubles(int nn, int na) {
+  int64_t lk = padld(na), ll = padld(nn), lf = padld(nn + na);
+  int64_t nnc = nn;
+  //        K        Li        Y              F         Fnn       E         G         T        Upd
+  return lk * nnc + ll * nnc + lk * (int64_t)na + lf * nnc + ll * nnc + lk * nnc + lk * nnc + ll * nnc + lk * (int64_t)na + 16 * 16 + 8;
+}
+
+struct Work {  // working-set pointers of one (clique, rhs) pair
+  const double* K; int ldk;
+  const double* Li; int ldl;
+  const double* Y; int ldy;
+  double* F; int ldf;     // panel nf x nn
+  double* Fnn; int ldn;   // nn x nn full symmetric copy
+  double* E; int lde;     // na x nn
+  double* G; int ldg;     // na x nn
+  double* T; int ldt;     // nn x nn
+  double* U; int ldu;     // na x na update / separator matrix (lower)
+  double* D16;            // 16 x 16 scratch
+};
+
+template <bool LDS>
+__device__ inline Work make_work(const MfmaArgs& a, const CliqueDesc& d, double* smem, int k, int r) {
+  Work w;
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  if (LDS) {
+    const int lk = padld(a.namax), ll = padld(a.nnmax), lf = padld(a.nnmax + a.namax);
+    double* p = smem;
+    w.K = p; w.ldk = lk; p += (int64_t)lk * a.nnmax;
+    w.Li = p; w.ldl = ll; p += (int64_t)ll * a.nnmax;
+    w.Y = p; w.ldy = lk; p += (int64_t)lk * a.namax;
+    w.F = p; w.ldf = lf; p += (int64_t)lf * a.nnmax;
+    w.Fnn = p; w.ldn = ll; p += (int64_t)ll * a.nnmax;
+    w.E = p; w.lde = lk; p += (int64_t)lk * a.nnmax;
+    w.G = p; w.ldg = lk; p += (int64_t)lk * a.nnmax;
+    w.T = p; w.ldt = ll; p += (int64_t)ll * a.nnmax;
+    w.U = p; w.ldu = lk; p += (int64_t)lk * a.namax;
+    w.D16 = p;
+  } else {
+    w.Li = a.LK ? a.LK + d.blk : nullptr; w.ldl = nf;
+    w.K = a.LK ? a.LK + d.blk + nn : nullptr; w.ldk = nf;
+    w.Y = a.ysc ? a.ysc + d.upd : nullptr; w.ldy = na;
+    double* s = a.t.tmp + (int64_t)r * a.t.tmplen + a.t.tmpptr[k];  // 2*nf*nn doubles
+    w.Fnn = s; w.ldn = nn; s += (int64_t)nn * nn;
+    w.T = s; w.ldt = nn; s += (int64_t)nn * nn;
+    w.E = s; w.lde = na; s += (int64_t)na * nn;
+    w.G = s; w.ldg = na; s += (int64_t)na * nn;
+    w.D16 = s;                   // 256 doubles reserved per clique behind the 2*nf*nn scratch
+    w.F = nullptr; w.ldf = nf;   // set per rhs (in place)
+    w.U = nullptr; w.ldu = na;   // set per rhs (in place)
+  }
+  return w;
+}
+
+// load clique constants into LDS (LDS mode only)
+__device__ inline void load_consts(const MfmaArgs& a, const CliqueDesc& d, const Work& w, bool needY) {
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  if (a.LK) {
+    const double* src = a.LK + d.blk;
+    double* Li = const_cast<double*>(w.Li);
+    double* K = const_cast<double*>(w.K);
+    for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
+      int i = e % nf, j = e / nf;
+      double v = src[e];
+      if (i < nn) Li[i + j * w.ldl] = v; else K[(i - nn) + j * w.ldk] = v;
+    }
+  }
+  if (needY && a.ysc) {
+    const double* src = a.ysc + d.upd;
+    double* Y = const_cast<double*>(w.Y);
+    for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
+      int i = e % na, j = e / na;
+      if (i >= j) Y[i + j * w.ldy] = src[e];
+    }
+  }
+}
+
+__device__ inline double yacc(const double* Y, int ld, int mode, int m, int k) {
+  if (mode == 1) return m >= k ? Y[m + k * ld] : Y[k + m * ld];
+  if (mode == 2) return k >= m ? Y[k + m * ld] : 0.0;   // R^T
+  return m >= k ? Y[m + k * ld] : 0.0;                    // R
+}
+
+// children's update matrices (global, lower) scatter-added into the front [F | U]
+__device__ inline void add_children_front(const TreeArgs& t, const CliqueDesc& d, const double* updbase,
+                                          double* F, int ldf, double* U, int ldu, double sp, double su) {
+  const int nn = d.nn;
+  for (int q = d.chbeg; q < d.chend; ++q) {
+    const CliqueDesc c = t.cl[t.chidx[q]];
+    const int nac = c.na;
+    const int32_t* rel = t.relidx + c.rel;
+    const double* Uc = updbase + c.upd;
+    for (int e = threadIdx.x; e < nac * nac; e += blockDim.x) {
+      int i = e % nac, j = e / nac;
+      if (i < j) continue;
+      int ri = rel[i], rj = rel[j];
+      double v = Uc[e];
+      if (rj < nn) F[ri + rj * ldf] += sp * v;
+      else U[(ri - nn) + (rj - nn) * ldu] += su * v;
+    }
+    __syncthreads();
+  }
+}
+// separator block of the parent's front (global) gathered into U (lower); optionally mirrored to global
+__device__ inline void gather_front(const TreeArgs& t, const CliqueDesc& d, const double* xbase,
+                                    const double* updbase, double* U, int ldu, double* mirror) {
+  if (d.parent < 0 || d.na == 0) return;
+  const CliqueDesc p = t.cl[d.parent];
+  const int na = d.na, nnp = p.nn, nfp = p.nn + p.na, nap = p.na;
+  const int32_t* rel = t.relidx + d.rel;
+  const double* Pp = xbase + p.blk;
+  const double* Up = updbase + p.upd;
+  for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
+    int i = e % na, j = e / na;
+    if (i < j) continue;
+    int ri = rel[i], rj = rel[j];
+    double v = (rj < nnp) ? Pp[ri + (int64_t)rj * nfp] : Up[(ri - nnp) + (int64_t)(rj - nnp) * nap];
+    U[i + j * ldu] = v;
+    if (mirror) mirror[e] = v;
+  }
+}
+
+// in-place Cholesky of a w x w (w <= 16) block + its inverse (Dinv 16x16, ld 16, zeros elsewhere).
+// Uniform control flow, every thread calls it.  Returns 0 or j+1.
+__device__ inline int potrf_inv16(double* D, int ld, int w, double* Dinv) {
+  const int tid = threadIdx.x;
+  for (int j = 0; j < w; ++j) {
+    __syncthreads();
+    double dd = D[j + j * ld];
+    if (!(dd > 0.0)) return j + 1;
+    double sd = sqrt(dd);
+    __syncthreads();
+    if (tid < w - j) D[(j + tid) + j * ld] = (tid == 0) ? sd : D[(j + tid) + j * ld] / sd;
+    __syncthreads();
+    const int rem = w - j - 1;
+    if (tid < rem * rem) {
+      int i = tid % rem, c = tid / rem;
+      if (i >= c) D[(j + 1 + i) + (j + 1 + c) * ld] -= D[(j + 1 + i) + j * ld] * D[(j + 1 + c) + j * ld];
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int c = tid;
+    for (int i = 0; i < 16; ++i) {
+      double s = 0.0;
+      if (i >= c && i < w && c < w) {
+        s = (i == c) ? 1.0 : 0.0;
+        for (int k = c; k < i; ++k) s -= D[i + k * ld] * Dinv[k + c * 16];
+        s /= D[i + i * ld];
+      }
+      Dinv[i + c * 16] = s;
+    }
+  }
+  __syncthreads();
+  return 0;
+}
+// inverse only (block already a Cholesky factor / lower triangular)
+__device__ inline void tri_inv16(const double* D, int ld, int w, double* Dinv) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid < 16) {
+    const int c = tid;
+    for (int i = 0; i < 16; ++i) {
+      double s = 0.0;
+      if (i >= c && i < w && c < w) {
+        s = (i == c) ? 1.0 : 0.0;
+        for (int k = c; k < i; ++k) s -= D[i + k * ld] * Dinv[k + c * 16];
+        s /= D[i + i * ld];
+      }
+      Dinv[i + c * 16] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ Hessian, leaves -> root
+template <bool LDS>
+__global__ void k_hess_up_mfma(MfmaArgs a, double* u, int64_t ldu) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  Work w = make_work<LDS>(a, d, smem, k, blockIdx.y);
+  if (LDS) { load_consts(a, d, w, a.ymode != 0); }
+  const int ymode = a.ymode;
+  for (int r = blockIdx.y; r < a.nrhs; r += gridDim.y) {
+    double* P = u + (int64_t)r * ldu + d.blk;
+    const double* ub = a.t.upd + (int64_t)r * a.t.updlen;
+    double* UkG = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+    if (LDS) {
+      for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) w.F[(e % nf) + (e / nf) * w.ldf] = P[e];
+      for (int e = threadIdx.x; e < na * na; e += blockDim.x) w.U[(e % na) + (e / na) * w.ldu] = 0.0;
+    } else {
+      w.F = P;
+      w.U = UkG;
+      for (int e = threadIdx.x; e < na * na; e += blockDim.x) UkG[e] = 0.0;
+    }
+    __syncthreads();
+    add_children_front(a.t, d, ub, w.F, w.ldf, w.U, w.ldu, 1.0, 1.0);
+    for (int e = threadIdx.x; e < nn * nn; e += blockDim.x) {
+      int i = e % nn, j = e / nn;
+      w.Fnn[i + j * w.ldn] = i >= j ? w.F[i + j * w.ldf] : w.F[j + i * w.ldf];
+    }
+    __syncthreads();
+    const Work v = w;
+    // phase 1: E = F_AN - K Fnn / 2 ; T = Li Fnn
+    wg_mma(na, nn, nn, [=](int m, int kk) { return v.K[m + kk * v.ldk]; },
+           [=](int kk, int n) { return v.Fnn[kk + n * v.ldn]; },
+           [=](int m, int n, double acc) { v.E[m + n * v.lde] = v.F[nn + m + n * v.ldf] - 0.5 * acc; });
+    wg_mma(nn, nn, nn, [=](int m, int kk) { return v.Li[m + kk * v.ldl]; },
+           [=](int kk, int n) { return v.Fnn[kk + n * v.ldn]; },
+           [=](int m, int n, double acc) { v.T[m + n * v.ldt] = acc; });
+    __syncthreads();
+    // phase 2: U -= K E^T + E K^T (lower) ; G = (2E - F_AN) Li^T ; G_NN = T Li^T (lower, into the panel)
+    wg_mma(na, na, 2 * nn,
+           [=](int m, int kk) { return kk < nn ? v.K[m + kk * v.ldk] : v.E[m + (kk - nn) * v.lde]; },
+           [=](int kk, int n) { return kk < nn ? v.E[n + kk * v.lde] : v.K[n + (kk - nn) * v.ldk]; },
+           [=](int m, int n, double acc) { if (m >= n) v.U[m + n * v.ldu] -= acc; }, true);
+    wg_mma(na, nn, nn, [=](int m, int kk) { return 2.0 * v.E[m + kk * v.lde] - v.F[nn + m + kk * v.ldf]; },
+           [=](int kk, int n) { return v.Li[n + kk * v.ldl]; },
+           [=](int m, int n, double acc) { v.G[m + n * v.ldg] = acc; });
+    __syncthreads();  // all reads of F_AN by the G product are done before the panel is overwritten below
+    wg_mma(nn, nn, nn, [=](int m, int kk) { return v.T[m + kk * v.ldt]; },
+           [=](int kk, int n) { return v.Li[n + kk * v.ldl]; },
+           [=](int m, int n, double acc) { if (m >= n) v.F[m + n * v.ldf] = acc; });
+    // phase 3: Q = Ysc G (or G) into the AN rows of the panel
+    if (ymode) {
+      wg_mma(na, nn, na, [=](int m, int kk) { return yacc(v.Y, v.ldy, ymode, m, kk); },
+             [=](int kk, int n) { return v.G[kk + n * v.ldg]; },
+             [=](int m, int n, double acc) { v.F[nn + m + n * v.ldf] = acc; });
+    } else {
+      for (int e = threadIdx.x; e < na * nn; e += blockDim.x) {
+        int i = e % na, j = e / na;
+        v.F[nn + i + j * v.ldf] = v.G[i + j * v.ldg];
+      }
+    }
+    __syncthreads();
+    if (LDS) {
+      for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
+        int i = e % nf, j = e / nf;
+        if (i >= j) P[e] = v.F[i + j * v.ldf];
+      }
+      for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
+        int i = e % na, j = e / na;
+        if (i >= j) UkG[e] = v.U[i + j * v.ldu];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Hessian, root -> leaves
+template <bool LDS>
+__global__ void k_hess_down_mfma(MfmaArgs a, double* u, int64_t ldu) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  Work w = make_work<LDS>(a, d, smem, k, blockIdx.y);
+  if (LDS) { load_consts(a, d, w, a.ymode != 0); }
+  const int ymode = a.ymode;
+  for (int r = blockIdx.y; r < a.nrhs; r += gridDim.y) {
+    double* ur = u + (int64_t)r * ldu;
+    double* P = ur + d.blk;
+    double* ub = a.t.upd + (int64_t)r * a.t.updlen;
+    double* UkG = ub + d.upd;
+    if (LDS) {
+      for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) w.F[(e % nf) + (e / nf) * w.ldf] = P[e];
+      gather_front(a.t, d, ur, ub, w.U, w.ldu, UkG);
+    } else {
+      w.F = P;
+      w.U = UkG;
+      gather_front(a.t, d, ur, ub, UkG, na, nullptr);
+    }
+    __syncthreads();
+    const Work v = w;
+    for (int e = threadIdx.x; e < nn * nn; e += blockDim.x) {
+      int i = e % nn, j = e / nn;
+      v.Fnn[i + j * v.ldn] = i >= j ? v.F[i + j * v.ldf] : v.F[j + i * v.ldf];
+    }
+    // phase 0: Q (into G): either R * Ghat_AN or a plain copy
+    if (ymode) {
+      wg_mma(na, nn, na, [=](int m, int kk) { return yacc(v.Y, v.ldy, ymode, m, kk); },
+             [=](int kk, int n) { return v.F[nn + kk + n * v.ldf]; },
+             [=](int m, int n, double acc) { v.G[m + n * v.ldg] = acc; });
+    } else {
+      for (int e = threadIdx.x; e < na * nn; e += blockDim.x) {
+        int i = e % na, j = e / na;
+        v.G[i + j * v.ldg] = v.F[nn + i + j * v.ldf];
+      }
+    }
+    __syncthreads();
+    // phase 1: QL = Q Li (into E) ; T = G_NN Li
+    wg_mma(na, nn, nn, [=](int m, int kk) { return v.G[m + kk * v.ldg]; },
+           [=](int kk, int n) { return v.Li[kk + n * v.ldl]; },
+           [=](int m, int n, double acc) { v.E[m + n * v.lde] = acc; });
+    wg_mma(nn, nn, nn, [=](int m, int kk) { return v.Fnn[m + kk * v.ldn]; },
+           [=](int kk, int n) { return v.Li[kk + n * v.ldl]; },
+           [=](int m, int n, double acc) { v.T[m + n * v.ldt] = acc; });
+    __syncthreads();
+    // phase 2: D = QL - Z_AA K / 2 (into G; Q is dead)
+    wg_mma(na, nn, na, [=](int m, int kk) { return m >= kk ? v.U[m + kk * v.ldu] : v.U[kk + m * v.ldu]; },
+           [=](int kk, int n) { return v.K[kk + n * v.ldk]; },
+           [=](int m, int n, double acc) { v.G[m + n * v.ldg] = v.E[m + n * v.lde] - 0.5 * acc; });
+    __syncthreads();
+    // phase 3: Z_AN = 2D - QL ; Z_NN = Li^T T - K^T D - D^T K (lower)
+    for (int e = threadIdx.x; e < na * nn; e += blockDim.x) {
+      int i = e % na, j = e / na;
+      v.F[nn + i + j * v.ldf] = 2.0 * v.G[i + j * v.ldg] - v.E[i + j * v.lde];
+    }
+    wg_mma(nn, nn, nn + 2 * na,
+           [=](int m, int kk) {
+             return kk < nn ? v.Li[kk + m * v.ldl]
+                            : (kk < nn + na ? -v.K[(kk - nn) + m * v.ldk] : -v.G[(kk - nn - na) + m * v.ldg]);
+           },
+           [=](int kk, int n) {
+             return kk < nn ? v.T[kk + n * v.ldt]
+                            : (kk < nn + na ? v.G[(kk - nn) + n * v.ldg] : v.K[(kk - nn - na) + n * v.ldk]);
+           },
+           [=](int m, int n, double acc) { if (m >= n) v.F[m + n * v.ldf] = acc; });
+    __syncthreads();
+    if (LDS) {
+      for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
+        int i = e % nf, j = e / nf;
+        if (i >= j) P[e] = v.F[i + j * v.ldf];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Cholesky
+template <bool LDS>
+__global__ void k_chol_mfma(MfmaArgs a, double* x) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (*a.t.info) return;
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  Work w = make_work<LDS>(a, d, smem, k, 0);
+  double* P = x + d.blk;
+  double* UkG = a.t.upd + d.upd;
+  if (LDS) {
+    for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) w.F[(e % nf) + (e / nf) * w.ldf] = P[e];
+    for (int e = threadIdx.x; e < na * na; e += blockDim.x) w.U[(e % na) + (e / na) * w.ldu] = 0.0;
+  } else {
+    w.F = P;
+    w.U = UkG;
+    for (int e = threadIdx.x; e < na * na; e += blockDim.x) UkG[e] = 0.0;
+  }
+  __syncthreads();
+  add_children_front(a.t, d, a.t.upd, w.F, w.ldf, w.U, w.ldu, 1.0, 1.0);
+  const Work v = w;
+  for (int jb = 0; jb < nn; jb += 16) {
+    const int bw = min(16, nn - jb);
+    int f = potrf_inv16(v.F + jb + jb * v.ldf, v.ldf, bw, v.D16);
+    if (f) { if (threadIdx.x == 0) atomicCAS(a.t.info, 0, k + 1); return; }
+    const int mrem = nf - jb - bw, ncr = nn - jb - bw;
+    const double* Pj = v.F + (jb + bw) + jb * v.ldf;  // rows below the diagonal block, block column jb
+    double* Pw = v.F + (jb + bw) + jb * v.ldf;
+    // rows below <- rows below * Dinv^T  (single column tile: in place is safe)
+    wg_mma(mrem, bw, bw, [=](int m, int kk) { return Pj[m + kk * v.ldf]; },
+           [=](int kk, int n) { return v.D16[n + kk * 16]; },
+           [=](int m, int n, double acc) { Pw[m + n * v.ldf] = acc; });
+    __syncthreads();
+    if (ncr > 0) {
+      double* Tr = v.F + (jb + bw) + (jb + bw) * v.ldf;
+      wg_mma(mrem, ncr, bw, [=](int m, int kk) { return Pj[m + kk * v.ldf]; },
+             [=](int kk, int n) { return Pj[n + kk * v.ldf]; },
+             [=](int m, int n, double acc) { if (m >= n) Tr[m + n * v.ldf] -= acc; }, true);
+      __syncthreads();
+    }
+  }
+  if (na) {
+    const double* La = v.F + nn;
+    wg_mma(na, na, nn, [=](int m, int kk) { return La[m + kk * v.ldf]; },
+           [=](int kk, int n) { return La[n + kk * v.ldf]; },
+           [=](int m, int n, double acc) { if (m >= n) v.U[m + n * v.ldu] -= acc; }, true);
+  }
+  __syncthreads();
+  if (LDS) {
+    for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
+      int i = e % nf, j = e / nf;
+      if (i >= j) P[e] = v.F[i + j * v.ldf];
+    }
+    for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
+      int i = e % na, j = e / na;
+      if (i >= j) UkG[e] = v.U[i + j * v.ldu];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ inverse-form factor LK = [L_NN^-1 ; L_AN L_NN^-1]
+// One workgroup per clique, operands in HBM/L2 (runs once per factorisation).
+__global__ void k_prep_lk(TreeArgs t, const double* L, double* LK) {
+  const int k = blockIdx.x;
+  const CliqueDesc d = t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  const double* Lk = L + d.blk;
+  double* Li = LK + d.blk;
+  double* Kk = Li + nn;
+  __shared__ double Dinv[256];
+  __shared__ double S[16 * 16 * 16];  // 16 x (up to 256) row-block scratch; larger nn handled in column chunks
+  // zero the upper triangle of Li
+  for (int e = threadIdx.x; e < nn * nn; e += blockDim.x) {
+    int i = e % nn, j = e / nn;
+    if (i < j) Li[i + (int64_t)j * nf] = 0.0;
+  }
+  for (int ib = 0; ib < nn; ib += 16) {
+    const int bw = min(16, nn - ib);
+    tri_inv16(Lk + ib + (int64_t)ib * nf, nf, bw, Dinv);
+    // diagonal block of Li
+    for (int e = threadIdx.x; e < bw * bw; e += blockDim.x) {
+      int i = e % bw, j = e / bw;
+      if (i >= j) Li[(ib + i) + (int64_t)(ib + j) * nf] = Dinv[i + j * 16];
+    }
+    // off-diagonal blocks: Li[ib, 0:ib] = -Dinv * (L[ib, 0:ib] * Li[0:ib, 0:ib]), in column chunks of 256
+    for (int c0 = 0; c0 < ib; c0 += 256) {
+      const int cw = min(256, ib - c0);
+      __syncthreads();
+      wg_mma(bw, cw, ib - c0, [=](int m, int kk) { return Lk[(ib + m) + (int64_t)(c0 + kk) * nf]; },
+             [=](int kk, int n) { return (c0 + kk >= c0 + n) ? Li[(c0 + kk) + (int64_t)(c0 + n) * nf] : 0.0; },
+             [=](int m, int n, double acc) { S[m + n * 16] = acc; });
+      __syncthreads();
+      wg_mma(bw, cw, bw, [=](int m, int kk) { return Dinv[m + kk * 16]; },
+             [=](int kk, int n) { return S[kk + n * 16]; },
+             [=](int m, int n, double acc) { Li[(ib + m) + (int64_t)(c0 + n) * nf] = -acc; });
+    }
+    __syncthreads();
+  }
+  // K = L_AN Li
+  if (na) {
+    wg_mma(na, nn, nn, [=](int m, int kk) { return Lk[(nn + m) + (int64_t)kk * nf]; },
+           [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; },
+           [=](int m, int n, double acc) { Kk[m + (int64_t)n * nf] = acc; });
+  }
+}
+
+// ------------------------------------------------------------------ projected inverse (needs LK of the factor)
+template <bool LDS>
+__global__ void k_pinv_mfma(MfmaArgs a, double* x) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  Work w = make_work<LDS>(a, d, smem, k, 0);
+  double* P = x + d.blk;
+  double* UkG = a.t.upd + d.upd;
+  if (LDS) {
+    load_consts(a, d, w, false);
+    gather_front(a.t, d, x, a.t.upd, w.U, w.ldu, UkG);
+  } else {
+    w.U = UkG;
+    gather_front(a.t, d, x, a.t.upd, UkG, na, nullptr);
+  }
+  __syncthreads();
+  const Work v = w;
+  // E = Y_AA K
+  wg_mma(na, nn, na, [=](int m, int kk) { return m >= kk ? v.U[m + kk * v.ldu] : v.U[kk + m * v.ldu]; },
+         [=](int kk, int n) { return v.K[kk + n * v.ldk]; },
+         [=](int m, int n, double acc) { v.E[m + n * v.lde] = acc; });
+  __syncthreads();
+  // Y_NN = Li^T Li + K^T E (lower) ; Y_AN = -E   (written straight to the global panel)
+  wg_mma(nn, nn, nn + na,
+         [=](int m, int kk) { return kk < nn ? v.Li[kk + m * v.ldl] : v.K[(kk - nn) + m * v.ldk]; },
+         [=](int kk, int n) { return kk < nn ? v.Li[kk + n * v.ldl] : v.E[(kk - nn) + n * v.lde]; },
+         [=](int m, int n, double acc) { if (m >= n) P[m + (int64_t)n * nf] = acc; });
+  for (int e = threadIdx.x; e < na * nn; e += blockDim.x) {
+    int i = e % na, j = e / na;
+    P[nn + i + (int64_t)j * nf] = -v.E[i + j * v.lde];
+  }
+}
+
+// self-test of the MFMA operand map: C (M x N) = A (M x Kd) * B (Kd x N), column-major, one workgroup
+__global__ void k_selftest_mma(int M, int N, int Kd, const double* A, const double* B, double* C) {
+  wg_mma(M, N, Kd, [=](int m, int kk) { return A[m + kk * M]; }, [=](int kk, int n) { return B[kk + n * Kd]; },
+         [=](int m, int n, double acc) { C[m + n * M] = acc; });
+}
+
+}  // namespace smcp

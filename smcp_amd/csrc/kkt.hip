@@ -175,6 +175,7 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
   if (!m || ldh < m || j0 < 0 || j1 > m || j0 > j1) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   prepare_yaa(c, Y, false, st);
+  if (!use_generic()) prep_lk(c, L, st);
   for (int64_t jb = j0; jb < j1; jb += D.max_rhs) {
     int nr = (int)std::min(D.max_rhs, j1 - jb);
     HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * nr * bl, st));
@@ -208,6 +209,7 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   }
   // the Y_AA cache must correspond to (L, Y): recompute (cheap, one gather sweep)
   prepare_yaa(c, Y, false, st);
+  if (!use_generic()) prep_lk(c, L, st);
   HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
   hessian_impl(c, L, r1, 1, bl, 2, 0, st);                      // r1 = W(bx)
   amap_impl(c, r1, 0, 1, ytmp, 0, st);                          // Amap(r1)
