@@ -182,7 +182,9 @@ def main():
         chunks = [min(max_rhs, mloc - c) for c in range(0, mloc, max_rhs)] + [1, 1]
         sweep_bytes = sum(8.0 * (r * (2 * B + 2 * U) + B) for r in chunks)
         alg = {"k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
-               "k_chol_level": 8.0 * (2 * B + 2 * U), "k_pinv_level": 8.0 * (2 * B + 2 * U)}.get(dom)
+               "k_hess_up_mfma": sweep_bytes, "k_hess_down_mfma": sweep_bytes,
+               "k_chol_level": 8.0 * (2 * B + 2 * U), "k_pinv_level": 8.0 * (2 * B + 2 * U),
+               "k_chol_mfma": 8.0 * (2 * B + 2 * U), "k_pinv_mfma": 8.0 * (2 * B + 2 * U)}.get(dom)
         if alg is not None:
             per_launch = alg / dom_launches
             avg_s = 1e-3 * dom_ms / dom_launches

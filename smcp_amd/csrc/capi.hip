@@ -163,6 +163,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.ymode = ymode;
   a.nnmax = a.namax = 0;
   a.nrhs = nrhs;
+  { static int sk = -1; if (sk < 0) { const char* e = getenv("SMCP_SKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
   return a;
 }
 

@@ -24,8 +24,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // B_my as the instruction's A and A_my as its B so that j (= lane&15) runs along the contiguous
 // row index m of our column-major matrices.
 template <class FA, class FB, class FC>
-__device__ inline void wg_mma(int M, int N, int Kd, FA A, FB B, FC store, bool lower_only = false) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+__device__ inline void wg_mma(int M, int N, int Kd, FA A, FB B, FC store, bool lower_only = false, int rot = 0) {
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = ((threadIdx.x >> 6) + nw - (rot % nw)) % nw;  // rot shifts which wave takes tile 0
   const int mt = (M + 15) >> 4, nt = (N + 15) >> 4;
   const int l15 = lane & 15, kq = lane >> 4;
   for (int t = wave; t < mt * nt; t += nw) {
@@ -33,6 +34,7 @@ __device__ inline void wg_mma(int M, int N, int Kd, FA A, FB B, FC store, bool l
     if (lower_only && tm < tn) continue;
     const int m = tm * 16 + l15, nb = tn * 16 + l15;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
     for (int k0 = 0; k0 < Kd; k0 += 4) {
       const int k = k0 + kq;
       const bool kin = k < Kd;
@@ -48,6 +50,25 @@ __device__ inline void wg_mma(int M, int N, int Kd, FA A, FB B, FC store, bool l
   }
 }
 
+// Loop e = begin, begin+step, ... < end in batches of UNR: all loads of a batch are issued before
+// any use, so a thread keeps UNR independent memory requests in flight instead of one.
+template <int UNR, class LoadF, class UseF>
+__device__ inline void batched_loop(int begin, int end, int step, LoadF load, UseF use) {
+  for (int e0 = begin; e0 < end; e0 += step * UNR) {
+    decltype(load(0)) v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int e = e0 + u * step;
+      if (e < end) v[u] = load(e);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int e = e0 + u * step;
+      if (e < end) use(e, v[u]);
+    }
+  }
+}
+
 struct MfmaArgs {
   TreeArgs t;
   const double* LK;   // inverse-form factor, blkval layout: rows 0..nn-1 = Li (zeros above diag), rows nn.. = K
@@ -55,6 +76,7 @@ struct MfmaArgs {
   int ymode;          // 0 none, 1 symmetric (Y_AA), 2 R^T, 3 R
   int nnmax, namax;   // LDS layout sizing (max over the cliques of this launch)
   int nrhs;
+  int skip;  // debug-only phase mask (SMCP_SKIP env), 0 in production
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }
@@ -64,7 +86,7 @@ __host__ __device__ inline int64_t mfma_lds_doubles(int nn, int na) {
   int64_t lk = padld(na), ll = padld(nn), lf = padld(nn + na);
   int64_t nnc = nn;
   //        K        Li        Y              F         Fnn       E         G         T        Upd
-  return lk * nnc + ll * nnc + lk * (int64_t)na + lf * nnc + ll * nnc + lk * nnc + lk * nnc + ll * nnc + lk * (int64_t)na + 16 * 16 + 8;
+  return lk * nnc + ll * nnc + lk * (int64_t)na + lf * nnc + ll * nnc + lk * nnc + lk * nnc + ll * nnc + lk * (int64_t)na + 16 * 16 + 8 + (na + 2) / 2;
 }
 
 struct Work {  // working-set pointers of one (clique, rhs) pair
@@ -120,19 +142,20 @@ __device__ inline void load_consts(const MfmaArgs& a, const CliqueDesc& d, const
     const double* src = a.LK + d.blk;
     double* Li = const_cast<double*>(w.Li);
     double* K = const_cast<double*>(w.K);
-    for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
-      int i = e % nf, j = e / nf;
-      double v = src[e];
-      if (i < nn) Li[i + j * w.ldl] = v; else K[(i - nn) + j * w.ldk] = v;
-    }
+    const int ldl = w.ldl, ldk = w.ldk;
+    batched_loop<8>(threadIdx.x, nf * nn, blockDim.x, [=](int e) { return src[e]; },
+                    [=](int e, double v) {
+                      int i = e % nf, j = e / nf;
+                      if (i < nn) Li[i + j * ldl] = v; else K[(i - nn) + j * ldk] = v;
+                    });
   }
   if (needY && a.ysc) {
     const double* src = a.ysc + d.upd;
     double* Y = const_cast<double*>(w.Y);
-    for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
-      int i = e % na, j = e / na;
-      if (i >= j) Y[i + j * w.ldy] = src[e];
-    }
+    const int ldy = w.ldy;
+    batched_loop<8>(threadIdx.x, na * na, blockDim.x,
+                    [=](int e) { return (e % na) >= (e / na) ? src[e] : 0.0; },
+                    [=](int e, double v) { if ((e % na) >= (e / na)) Y[(e % na) + (e / na) * ldy] = v; });
   }
 }
 
@@ -142,43 +165,68 @@ __device__ inline double yacc(const double* Y, int ld, int mode, int m, int k) {
   return m >= k ? Y[m + k * ld] : 0.0;                    // R
 }
 
-// children's update matrices (global, lower) scatter-added into the front [F | U]
+// children's update matrices (global, lower) scatter-added into the front [F | U].
+// One wave per child, all children in flight at once; collisions between children are resolved
+// by hardware fp64 atomic adds (ds_add_f64 / global_atomic_add_f64), so the summation order --
+// and with it the last bit -- may differ between runs.  One barrier at the end.
+struct ChildEntry { double v; int ri, rj; };
 __device__ inline void add_children_front(const TreeArgs& t, const CliqueDesc& d, const double* updbase,
                                           double* F, int ldf, double* U, int ldu, double sp, double su) {
   const int nn = d.nn;
-  for (int q = d.chbeg; q < d.chend; ++q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int q = d.chbeg + wave; q < d.chend; q += nw) {
     const CliqueDesc c = t.cl[t.chidx[q]];
     const int nac = c.na;
     const int32_t* rel = t.relidx + c.rel;
     const double* Uc = updbase + c.upd;
-    for (int e = threadIdx.x; e < nac * nac; e += blockDim.x) {
-      int i = e % nac, j = e / nac;
-      if (i < j) continue;
-      int ri = rel[i], rj = rel[j];
-      double v = Uc[e];
-      if (rj < nn) F[ri + rj * ldf] += sp * v;
-      else U[(ri - nn) + (rj - nn) * ldu] += su * v;
-    }
-    __syncthreads();
+    batched_loop<16>(lane, nac * nac, 64,
+      [=](int e) {
+        ChildEntry x;
+        int i = e % nac, j = e / nac;
+        x.ri = -1; x.rj = 0; x.v = 0.0;
+        if (i >= j) { x.ri = rel[i]; x.rj = rel[j]; x.v = Uc[e]; }
+        return x;
+      },
+      [=](int e, const ChildEntry& x) {
+        if (x.ri < 0) return;
+        if (x.rj < nn) unsafeAtomicAdd(&F[x.ri + x.rj * ldf], sp * x.v);
+        else unsafeAtomicAdd(&U[(x.ri - nn) + (x.rj - nn) * ldu], su * x.v);
+      });
   }
+  __syncthreads();
 }
-// separator block of the parent's front (global) gathered into U (lower); optionally mirrored to global
-__device__ inline void gather_front(const TreeArgs& t, const CliqueDesc& d, const double* xbase,
-                                    const double* updbase, double* U, int ldu, double* mirror) {
+// separator block of the parent's front (global) gathered into U (lower); optionally mirrored to
+// global.  `p` (parent descriptor) and `rel` (relative indices, LDS or global) are loop invariants
+// hoisted by the caller so that the per-right-hand-side loads are all independent.
+__device__ inline void gather_front(const CliqueDesc& d, const CliqueDesc& p, const int32_t* rel,
+                                    const double* xbase, const double* updbase, double* U, int ldu,
+                                    double* mirror) {
   if (d.parent < 0 || d.na == 0) return;
-  const CliqueDesc p = t.cl[d.parent];
   const int na = d.na, nnp = p.nn, nfp = p.nn + p.na, nap = p.na;
-  const int32_t* rel = t.relidx + d.rel;
   const double* Pp = xbase + p.blk;
   const double* Up = updbase + p.upd;
-  for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
-    int i = e % na, j = e / na;
-    if (i < j) continue;
-    int ri = rel[i], rj = rel[j];
-    double v = (rj < nnp) ? Pp[ri + (int64_t)rj * nfp] : Up[(ri - nnp) + (int64_t)(rj - nnp) * nap];
-    U[i + j * ldu] = v;
-    if (mirror) mirror[e] = v;
-  }
+  batched_loop<8>(threadIdx.x, na * na, blockDim.x,
+    [=](int e) {
+      int i = e % na, j = e / na;
+      if (i < j) return 0.0;
+      int ri = rel[i], rj = rel[j];
+      return (rj < nnp) ? Pp[ri + (int64_t)rj * nfp] : Up[(ri - nnp) + (int64_t)(rj - nnp) * nap];
+    },
+    [=](int e, double v) {
+      int i = e % na, j = e / na;
+      if (i < j) return;
+      U[i + j * ldu] = v;
+      if (mirror) mirror[e] = v;
+    });
+}
+// hoisted invariants for gather_front
+template <bool LDS>
+__device__ inline const int32_t* hoist_rel(const TreeArgs& t, const CliqueDesc& d, double* lds_tail) {
+  const int32_t* g = t.relidx + d.rel;
+  if (!LDS) return g;
+  int32_t* r = reinterpret_cast<int32_t*>(lds_tail);
+  for (int i = threadIdx.x; i < d.na; i += blockDim.x) r[i] = g[i];
+  return r;
 }
 
 // in-place Cholesky of a w x w (w <= 16) block + its inverse (Dinv 16x16, ld 16, zeros elsewhere).
@@ -249,7 +297,11 @@ __global__ void k_hess_up_mfma(MfmaArgs a, double* u, int64_t ldu) {
     const double* ub = a.t.upd + (int64_t)r * a.t.updlen;
     double* UkG = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
     if (LDS) {
-      for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) w.F[(e % nf) + (e / nf) * w.ldf] = P[e];
+      {
+        double* Fl = w.F; const int ldfl = w.ldf;
+        batched_loop<8>(threadIdx.x, nf * nn, blockDim.x, [=](int e) { return P[e]; },
+                        [=](int e, double v) { Fl[(e % nf) + (e / nf) * ldfl] = v; });
+      }
       for (int e = threadIdx.x; e < na * na; e += blockDim.x) w.U[(e % na) + (e / na) * w.ldu] = 0.0;
     } else {
       w.F = P;
@@ -257,20 +309,16 @@ __global__ void k_hess_up_mfma(MfmaArgs a, double* u, int64_t ldu) {
       for (int e = threadIdx.x; e < na * na; e += blockDim.x) UkG[e] = 0.0;
     }
     __syncthreads();
-    add_children_front(a.t, d, ub, w.F, w.ldf, w.U, w.ldu, 1.0, 1.0);
-    for (int e = threadIdx.x; e < nn * nn; e += blockDim.x) {
-      int i = e % nn, j = e / nn;
-      w.Fnn[i + j * w.ldn] = i >= j ? w.F[i + j * w.ldf] : w.F[j + i * w.ldf];
-    }
-    __syncthreads();
+    if (!(a.skip & 1)) add_children_front(a.t, d, ub, w.F, w.ldf, w.U, w.ldu, 1.0, 1.0);
     const Work v = w;
+    if (!(a.skip & 2)) {
     // phase 1: E = F_AN - K Fnn / 2 ; T = Li Fnn
     wg_mma(na, nn, nn, [=](int m, int kk) { return v.K[m + kk * v.ldk]; },
-           [=](int kk, int n) { return v.Fnn[kk + n * v.ldn]; },
+           [=](int kk, int n) { return kk >= n ? v.F[kk + n * v.ldf] : v.F[n + kk * v.ldf]; },
            [=](int m, int n, double acc) { v.E[m + n * v.lde] = v.F[nn + m + n * v.ldf] - 0.5 * acc; });
     wg_mma(nn, nn, nn, [=](int m, int kk) { return v.Li[m + kk * v.ldl]; },
-           [=](int kk, int n) { return v.Fnn[kk + n * v.ldn]; },
-           [=](int m, int n, double acc) { v.T[m + n * v.ldt] = acc; });
+           [=](int kk, int n) { return kk >= n ? v.F[kk + n * v.ldf] : v.F[n + kk * v.ldf]; },
+           [=](int m, int n, double acc) { v.T[m + n * v.ldt] = acc; }, false, (na + 15) >> 4);
     __syncthreads();
     // phase 2: U -= K E^T + E K^T (lower) ; G = (2E - F_AN) Li^T ; G_NN = T Li^T (lower, into the panel)
     wg_mma(na, na, 2 * nn,
@@ -279,11 +327,11 @@ __global__ void k_hess_up_mfma(MfmaArgs a, double* u, int64_t ldu) {
            [=](int m, int n, double acc) { if (m >= n) v.U[m + n * v.ldu] -= acc; }, true);
     wg_mma(na, nn, nn, [=](int m, int kk) { return 2.0 * v.E[m + kk * v.lde] - v.F[nn + m + kk * v.ldf]; },
            [=](int kk, int n) { return v.Li[n + kk * v.ldl]; },
-           [=](int m, int n, double acc) { v.G[m + n * v.ldg] = acc; });
+           [=](int m, int n, double acc) { v.G[m + n * v.ldg] = acc; }, false, 3);
     __syncthreads();  // all reads of F_AN by the G product are done before the panel is overwritten below
     wg_mma(nn, nn, nn, [=](int m, int kk) { return v.T[m + kk * v.ldt]; },
            [=](int kk, int n) { return v.Li[n + kk * v.ldl]; },
-           [=](int m, int n, double acc) { if (m >= n) v.F[m + n * v.ldf] = acc; });
+           [=](int m, int n, double acc) { if (m >= n) v.F[m + n * v.ldf] = acc; }, false, (na + 15) >> 4);
     // phase 3: Q = Ysc G (or G) into the AN rows of the panel
     if (ymode) {
       wg_mma(na, nn, na, [=](int m, int kk) { return yacc(v.Y, v.ldy, ymode, m, kk); },
@@ -295,8 +343,9 @@ __global__ void k_hess_up_mfma(MfmaArgs a, double* u, int64_t ldu) {
         v.F[nn + i + j * v.ldf] = v.G[i + j * v.ldg];
       }
     }
+    }
     __syncthreads();
-    if (LDS) {
+    if (LDS && !(a.skip & 4)) {
       for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
         int i = e % nf, j = e / nf;
         if (i >= j) P[e] = v.F[i + j * v.ldf];
@@ -320,25 +369,28 @@ __global__ void k_hess_down_mfma(MfmaArgs a, double* u, int64_t ldu) {
   Work w = make_work<LDS>(a, d, smem, k, blockIdx.y);
   if (LDS) { load_consts(a, d, w, a.ymode != 0); }
   const int ymode = a.ymode;
+  const CliqueDesc par = a.t.cl[d.parent < 0 ? k : d.parent];
+  const int32_t* rel = hoist_rel<LDS>(a.t, d, w.D16 + 256);
+  __syncthreads();
   for (int r = blockIdx.y; r < a.nrhs; r += gridDim.y) {
     double* ur = u + (int64_t)r * ldu;
     double* P = ur + d.blk;
     double* ub = a.t.upd + (int64_t)r * a.t.updlen;
     double* UkG = ub + d.upd;
     if (LDS) {
-      for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) w.F[(e % nf) + (e / nf) * w.ldf] = P[e];
-      gather_front(a.t, d, ur, ub, w.U, w.ldu, UkG);
+      {
+        double* Fl = w.F; const int ldfl = w.ldf;
+        batched_loop<8>(threadIdx.x, nf * nn, blockDim.x, [=](int e) { return P[e]; },
+                        [=](int e, double v) { Fl[(e % nf) + (e / nf) * ldfl] = v; });
+      }
+      gather_front(d, par, rel, ur, ub, w.U, w.ldu, UkG);
     } else {
       w.F = P;
       w.U = UkG;
-      gather_front(a.t, d, ur, ub, UkG, na, nullptr);
+      gather_front(d, par, rel, ur, ub, UkG, na, nullptr);
     }
     __syncthreads();
     const Work v = w;
-    for (int e = threadIdx.x; e < nn * nn; e += blockDim.x) {
-      int i = e % nn, j = e / nn;
-      v.Fnn[i + j * v.ldn] = i >= j ? v.F[i + j * v.ldf] : v.F[j + i * v.ldf];
-    }
     // phase 0: Q (into G): either R * Ghat_AN or a plain copy
     if (ymode) {
       wg_mma(na, nn, na, [=](int m, int kk) { return yacc(v.Y, v.ldy, ymode, m, kk); },
@@ -355,9 +407,9 @@ __global__ void k_hess_down_mfma(MfmaArgs a, double* u, int64_t ldu) {
     wg_mma(na, nn, nn, [=](int m, int kk) { return v.G[m + kk * v.ldg]; },
            [=](int kk, int n) { return v.Li[kk + n * v.ldl]; },
            [=](int m, int n, double acc) { v.E[m + n * v.lde] = acc; });
-    wg_mma(nn, nn, nn, [=](int m, int kk) { return v.Fnn[m + kk * v.ldn]; },
+    wg_mma(nn, nn, nn, [=](int m, int kk) { return m >= kk ? v.F[m + kk * v.ldf] : v.F[kk + m * v.ldf]; },
            [=](int kk, int n) { return v.Li[kk + n * v.ldl]; },
-           [=](int m, int n, double acc) { v.T[m + n * v.ldt] = acc; });
+           [=](int m, int n, double acc) { v.T[m + n * v.ldt] = acc; }, false, (na + 15) >> 4);
     __syncthreads();
     // phase 2: D = QL - Z_AA K / 2 (into G; Q is dead)
     wg_mma(na, nn, na, [=](int m, int kk) { return m >= kk ? v.U[m + kk * v.ldu] : v.U[kk + m * v.ldu]; },
@@ -402,7 +454,11 @@ __global__ void k_chol_mfma(MfmaArgs a, double* x) {
   double* P = x + d.blk;
   double* UkG = a.t.upd + d.upd;
   if (LDS) {
-    for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) w.F[(e % nf) + (e / nf) * w.ldf] = P[e];
+    {
+      double* Fl = w.F; const int ldfl = w.ldf;
+      batched_loop<8>(threadIdx.x, nf * nn, blockDim.x, [=](int e) { return P[e]; },
+                      [=](int e, double v) { Fl[(e % nf) + (e / nf) * ldfl] = v; });
+    }
     for (int e = threadIdx.x; e < na * na; e += blockDim.x) w.U[(e % na) + (e / na) * w.ldu] = 0.0;
   } else {
     w.F = P;
@@ -507,12 +563,14 @@ __global__ void k_pinv_mfma(MfmaArgs a, double* x) {
   Work w = make_work<LDS>(a, d, smem, k, 0);
   double* P = x + d.blk;
   double* UkG = a.t.upd + d.upd;
+  const CliqueDesc par = a.t.cl[d.parent < 0 ? k : d.parent];
+  const int32_t* rel = a.t.relidx + d.rel;
   if (LDS) {
     load_consts(a, d, w, false);
-    gather_front(a.t, d, x, a.t.upd, w.U, w.ldu, UkG);
+    gather_front(d, par, rel, x, a.t.upd, w.U, w.ldu, UkG);
   } else {
     w.U = UkG;
-    gather_front(a.t, d, x, a.t.upd, UkG, na, nullptr);
+    gather_front(d, par, rel, x, a.t.upd, UkG, na, nullptr);
   }
   __syncthreads();
   const Work v = w;
