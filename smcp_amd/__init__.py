@@ -6,6 +6,8 @@ the KKT/Schur-complement layer around them.  The interior-point drivers stay in 
 """
 from .symbolic import Symbolic, symbolic, maxcardsearch, mindegree  # noqa: F401
 from .cspmatrix import cspmatrix  # noqa: F401
+from . import base, solvers  # noqa: F401
+from .base import SDP, band_SDP  # noqa: F401
 from .chordal import (cholesky, completion, projected_inverse, hessian, llt, trsm, dot,  # noqa: F401
                       logdiagsum)
 

@@ -1,0 +1,233 @@
+"""Problem container + generators + SDPA-sparse I/O (host side).
+
+Counterparts of the reference's ``SDP`` (src/python/base.py:35-511), ``band_SDP`` (563-636) and the
+SDPA reader/writer in src/C/misc.c:139-365 (format: comment lines, m, nBlocks, block sizes with
+negative = diagonal block, b, then ``matno blkno i j val`` 1-based upper-triangular entries).
+The reference draws random data from cvxopt's RNG; these generators use numpy ``default_rng``.
+"""
+import math
+
+import numpy as np
+import scipy.sparse as sp
+
+
+class SDP:
+    """minimize <C,X> s.t. <A_i,X> = b_i, X psd-completable; data as an n^2 x (m+1) sparse matrix
+    with columns vec(C), vec(A_1)... (lower triangles), exactly the reference's layout."""
+
+    def __init__(self, filename=None):
+        self._A = None
+        self._b = None
+        self._blockstruct = None
+        self._pname = None
+        self._X0 = self._y0 = self._S0 = None
+        if filename is not None:
+            self._A, self._b, self._blockstruct = sdpa_read(filename)
+            self._pname = str(filename)
+
+    # ---- properties (base.py:92-314) ---------------------------------------------------
+    @property
+    def n(self):
+        return int(round(math.sqrt(self._A.shape[0])))
+
+    @property
+    def m(self):
+        return self._A.shape[1] - 1
+
+    @property
+    def A(self):
+        return self._A
+
+    @property
+    def b(self):
+        return self._b
+
+    @property
+    def blockstruct(self):
+        return self._blockstruct
+
+    @property
+    def nnz(self):
+        """Number of nonzeros in the lower triangle of the aggregate sparsity pattern."""
+        return len(np.unique(sp.csc_matrix(self._A).indices))
+
+    @property
+    def V(self):
+        """Aggregate sparsity pattern (lower triangle) as a scipy matrix of ones."""
+        n = self.n
+        idx = np.unique(sp.csc_matrix(self._A).indices)
+        return sp.csc_matrix((np.ones(len(idx)), (idx % n, idx // n)), shape=(n, n))
+
+    @property
+    def nnzs(self):
+        return np.diff(sp.csc_matrix(self._A).indptr)
+
+    @property
+    def ischordal(self):
+        from .symbolic import Symbolic, maxcardsearch
+        V = self.V + sp.identity(self.n)
+        return Symbolic(V, maxcardsearch(V)).fill == 0
+
+    def get_A(self, i):
+        """A_i (i = 0 is C) as a symmetric scipy matrix."""
+        n = self.n
+        col = sp.csc_matrix(self._A[:, i]).tocoo()
+        L = sp.csc_matrix((col.data, (col.row % n, col.row // n)), shape=(n, n))
+        return L + sp.tril(L, -1).T
+
+    # ---- solvers (base.py:316-368) -----------------------------------------------------
+    def solve_esd(self, kktsolver="chol", scaling="primal", primalstart=None, dualstart=None):
+        from . import solvers
+        return solvers.chordalsolver_esd(self._A, self._b, primalstart, dualstart, scaling=scaling,
+                                         kktsolver=kktsolver)
+
+    def solve_feas(self, kktsolver="chol", scaling="primal", primalstart=None, dualstart=None):
+        from . import solvers
+        return solvers.chordalsolver_feas(self._A, self._b, primalstart, dualstart, scaling=scaling,
+                                          kktsolver=kktsolver)
+
+    def write_sdpa(self, filename):
+        sdpa_write(filename, self._A, self._b, self._blockstruct or [self.n])
+
+
+def _band_entries(n, bw):
+    J = np.repeat(np.arange(n), np.minimum(bw + 1, n - np.arange(n)))
+    I = np.concatenate([np.arange(j, min(j + bw + 1, n)) for j in range(n)])
+    return I.astype(np.int64), J.astype(np.int64)
+
+
+def _band_posdef(n, bw, rng):
+    """Random positive definite band matrix (dense storage): diagonally dominant."""
+    M = np.zeros((n, n))
+    for d in range(1, bw + 1):
+        v = rng.standard_normal(n - d) / math.sqrt(n)
+        M[np.arange(d, n), np.arange(n - d)] = v
+    M = M + M.T
+    M[np.diag_indices(n)] = np.abs(M).sum(axis=1) + 0.1 + rng.random(n)
+    return M
+
+
+class band_SDP(SDP):
+    """Random SDP with band structure: P = band_SDP(n, m, bw, seed) (bw = half bandwidth).
+    Same construction as the reference (base.py:600-636): strictly feasible X0 / (y0, S0) by
+    construction, A_i dense on the band with std 1/|V|, C = sum_i y0_i A_i + S0, b = A(X0)."""
+
+    def __init__(self, n, m, bw, seed=0):
+        super().__init__()
+        rng = np.random.default_rng(seed)
+        I, J = _band_entries(n, bw)
+        nv = len(I)
+        y0 = rng.standard_normal(m)
+        y0 /= np.linalg.norm(y0)
+        S0 = _band_posdef(n, bw, rng)
+        X0 = _band_posdef(n, bw, rng)        # a positive definite band matrix is trivially completable
+        Av = rng.standard_normal((nv, m)) / nv
+        c = S0[I, J] + Av @ y0
+        w = np.where(I == J, 1.0, 2.0)
+        b = Av.T @ (w * X0[I, J])
+        rows = I + n * J
+        data = np.concatenate([c[:, None], Av], axis=1)
+        self._A = sp.csc_matrix((data.reshape(-1, order="F"),
+                                 (np.tile(rows, m + 1), np.repeat(np.arange(m + 1), nv))),
+                                shape=(n * n, m + 1))
+        self._b = b
+        self._bw = bw
+        self._blockstruct = [n]
+        self._pname = "band_n%i_m%i_bw%i" % (n, m, bw)
+        self._X0, self._y0, self._S0 = X0, y0, S0
+
+    @property
+    def bw(self):
+        return self._bw
+
+
+def maxcut_SDP(n=1000, nedges=5909, seed=0):
+    """Max-cut relaxation on a random graph with the size of SDPLIB maxG51 (config 4):
+    minimize <C,X>, diag(X) = 1, C = -(Diag(W1) - W)/4."""
+    from .problems import maxcut_graph_pattern
+    _, e = maxcut_graph_pattern(n, nedges, seed)
+    P = SDP()
+    W = sp.coo_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(n, n))
+    W = W + W.T
+    deg = np.asarray(W.sum(axis=1)).reshape(-1)
+    Cm = sp.tril(-(sp.diags(deg) - W) / 4.0).tocoo()
+    rows = [Cm.row + n * Cm.col]
+    cols = [np.zeros(len(Cm.row), dtype=np.int64)]
+    vals = [Cm.data]
+    rows.append(np.arange(n) * (n + 1))
+    cols.append(np.arange(1, n + 1))
+    vals.append(np.ones(n))
+    P._A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n * n, n + 1))
+    P._b = np.ones(n)
+    P._blockstruct = [n]
+    P._pname = "maxcut_n%d_e%d" % (n, nedges)
+    return P
+
+
+# ---- SDPA sparse format (misc.c:139-365) ----------------------------------------------------
+def sdpa_readhead(filename):
+    """(n, m, blockstruct) from the header (misc.c:56-137)."""
+    with open(filename) as f:
+        toks = _sdpa_tokens(f)
+        m = int(next(toks))
+        nb = int(next(toks))
+        bs = [int(float(next(toks))) for _ in range(nb)]
+    return sum(abs(x) for x in bs), m, bs
+
+
+def _sdpa_tokens(f):
+    for line in f:
+        s = line.strip()
+        if not s or s[0] in '*"':
+            continue
+        for ch in "{}(),":
+            s = s.replace(ch, " ")
+        for t in s.split():
+            yield t
+
+
+def sdpa_read(filename, neg=False):
+    """Returns (A, b, blockstruct): A is n^2 x (m+1) CSC with columns vec(lower triangles); the
+    SDPA entry (i, j) of block k lands at row (off+j-1) + n*(off+i-1)... i.e. the lower-triangular
+    position of the symmetric entry (misc.c:205-237).  neg=True negates b and A (misc.c:192-193,223-224)."""
+    with open(filename) as f:
+        toks = _sdpa_tokens(f)
+        m = int(next(toks))
+        nb = int(next(toks))
+        bs = [int(float(next(toks))) for _ in range(nb)]
+        offs = np.concatenate([[0], np.cumsum([abs(x) for x in bs])])
+        n = int(offs[-1])
+        b = np.array([float(next(toks)) for _ in range(m)])
+        rows, cols, vals = [], [], []
+        rest = list(toks)
+    for q in range(0, len(rest) - 4, 5):
+        mat, blk, i, j, v = int(rest[q]), int(rest[q + 1]), int(rest[q + 2]), int(rest[q + 3]), float(rest[q + 4])
+        a, c = offs[blk - 1] + i - 1, offs[blk - 1] + j - 1
+        lo, hi = min(a, c), max(a, c)
+        rows.append(hi + n * lo)
+        cols.append(mat)
+        vals.append(v)
+    sgn = -1.0 if neg else 1.0
+    A = sp.csc_matrix((sgn * np.asarray(vals), (np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64))),
+                      shape=(n * n, m + 1))
+    return A, sgn * b, bs
+
+
+def sdpa_write(filename, A, b, blockstruct, neg=False):
+    """Write the problem in SDPA sparse format (the reference opens the file with mode "r",
+    misc.c:299 -- a bug this writer does not share)."""
+    A = sp.csc_matrix(A)
+    n = int(round(math.sqrt(A.shape[0])))
+    m = A.shape[1] - 1
+    offs = np.concatenate([[0], np.cumsum([abs(x) for x in blockstruct])])
+    sgn = -1.0 if neg else 1.0
+    with open(filename, "w") as f:
+        f.write("%d\n%d\n%s\n" % (m, len(blockstruct), " ".join(str(x) for x in blockstruct)))
+        f.write(" ".join(repr(float(sgn * v)) for v in np.asarray(b).reshape(-1)) + "\n")
+        for k in range(m + 1):
+            col = A[:, k].tocoo()
+            order = np.argsort(col.row, kind="stable")
+            for r, v in zip(col.row[order], col.data[order]):
+                i, j = r % n, r // n            # i >= j (lower); SDPA wants upper: (j, i)
+                blk = int(np.searchsorted(offs, j, side="right"))
+                f.write("%d %d %d %d %r\n" % (k, blk, j - offs[blk - 1] + 1, i - offs[blk - 1] + 1, float(sgn * v)))

@@ -1,0 +1,960 @@
+"""Interior-point drivers for sparse matrix cone programs on top of the HIP chordal kernels.
+
+Host-side (Python) counterparts of the reference's drivers; the loop stays in Python and every
+chordal operation goes through the C-ABI (include/smcp_amd.h):
+
+  chordalsolver_esd   extended self-dual embedding      (reference: src/python/solvers.py:1330-2467)
+  chordalsolver_feas  feasible-start barrier method      (reference: src/python/solvers.py:49-1327)
+  conelp / lp / socp / sdp   CVXOPT-style front ends     (reference: src/python/solvers.py:2470-2699)
+
+Problem format (solvers.py:54-62 docstring): ``A`` is an n^2 x (m+1) sparse matrix whose columns
+are vec(C), vec(A_1), ..., vec(A_m), lower triangles only; ``b`` has length m.
+cvxopt is not a dependency here: sparse inputs/outputs are scipy.sparse, dense ones numpy.
+"""
+import copy as _copy
+import math
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import chordal
+from .cspmatrix import cspmatrix
+from .kkt import KKTSystem
+from .symbolic import Symbolic, maxcardsearch, mindegree
+
+# same keys / defaults as the reference (solvers.py:22-44)
+options = {
+    "debug": False, "maxiters": 100, "abstol": 1e-6, "reltol": 1e-6, "feastol": 1e-8, "refinement": 2,
+    "cholmod": False, "order": "AMD", "tnzcols": 0.1, "show_progress": True, "dimacs": True, "eta": None,
+    "delta": 0.9, "alpha": 1e-1, "beta": 0.7, "minstep": 1e-8, "lifting": True, "t0": 1e-1,
+    "equalsteps": True, "prediction": True, "step": 0.98,
+}
+_defaults = _copy.deepcopy(options)
+
+
+def _opt(name, kind, lo=None, hi=None, strict_lo=False):
+    v = options.get(name, _defaults[name])
+    if kind is bool:
+        if not isinstance(v, bool):
+            raise TypeError("options['%s'] must be a bool" % name)
+        return v
+    if kind is int:
+        if not isinstance(v, (int, np.integer)) or isinstance(v, bool):
+            raise TypeError("options['%s'] must be an integer" % name)
+    else:
+        if not isinstance(v, (int, float, np.floating, np.integer)) or isinstance(v, bool):
+            raise TypeError("options['%s'] must be a scalar" % name)
+    if lo is not None and (v < lo or (strict_lo and v <= lo)):
+        raise ValueError("options['%s'] out of range" % name)
+    if hi is not None and v > hi:
+        raise ValueError("options['%s'] out of range" % name)
+    return v
+
+
+class _Problem:
+    """Index algebra of solvers.py:234-367 on the C-ABI symbolic layer: aggregate sparsity,
+    ordering (perfect elimination order if chordal, else a fill-reducing embedding), C and the
+    constraints in blkval coordinates, Amap / Aadj on the device."""
+
+    def __init__(self, A, b, p=None, device=None):
+        A = sp.csc_matrix(A)
+        self.m = A.shape[1] - 1
+        self.n = int(round(math.sqrt(A.shape[0])))
+        if self.n * self.n != A.shape[0]:
+            raise ValueError("A must have n^2 rows")
+        n, m = self.n, self.m
+        b = np.asarray(b, dtype=np.float64).reshape(-1)
+        if b.shape[0] != m:
+            raise ValueError("b must have length m")
+        A.sum_duplicates()
+        rows = A.indices.astype(np.int64)
+        I, J = rows % n, rows // n
+        if (I < J).any():
+            raise ValueError("only lower-triangular entries (i >= j) are allowed in A")
+        # aggregate sparsity pattern + diagonal
+        key = np.unique(np.concatenate([J * n + I, np.arange(n, dtype=np.int64) * (n + 1)]))
+        pj, pi = key // n, key % n
+        cp = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(cp, pj + 1, 1)
+        pat = (n, np.cumsum(cp), pi)
+        if p is None:
+            p = maxcardsearch(pat)
+            symb = Symbolic(pat, p)
+            if symb.fill > 0:                      # not chordal: embed (solvers.py:278-279, 305-308)
+                p = mindegree(pat)
+                symb = Symbolic(pat, p)
+        else:
+            symb = Symbolic(pat, np.asarray(p, dtype=np.int64))
+        self.symb = symb
+        self.ischordal = symb.fill == 0
+        if torch.cuda.is_available():
+            self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        else:
+            self.dev = torch.device("cpu")   # storage only: every kernel call fails without a GPU
+        colptr = A.indptr.astype(np.int64)
+        pos = symb.index_map(I, J)
+        vals = A.data.astype(np.float64)
+        # C
+        h = np.zeros(symb.blklen)
+        sl = slice(colptr[0], colptr[1])
+        np.add.at(h, pos[sl], vals[sl])
+        cptr = colptr[1:] - colptr[1]
+        self.kkt = KKTSystem(symb, cptr, pos[colptr[1]:], vals[colptr[1]:])
+        self.C = cspmatrix(symb, torch.from_numpy(h).to(self.dev))
+        self.b = torch.from_numpy(b.copy()).to(self.dev)
+        self.bh = b
+        self.cmaxabs = float(np.abs(vals[sl]).max()) if sl.stop > sl.start else 0.0
+        self._diag_idx = None
+
+    def identity(self):
+        s = self.symb
+        X = cspmatrix(s, torch.zeros(s.blklen, dtype=torch.float64, device=self.dev))
+        if self._diag_idx is None:
+            nn, na = s.clique_sizes()
+            nf = nn + na
+            idx = np.concatenate([s.blkptr[k] + np.arange(nn[k]) * (nf[k] + 1) for k in range(s.Nsn)])
+            self._diag_idx = torch.as_tensor(idx, device=self.dev)
+        X.blkval[self._diag_idx] = 1.0
+        return X
+
+    def from_sym(self, M):
+        """cspmatrix of a symmetric scipy/numpy matrix given in ORIGINAL coordinates (start points)."""
+        M = sp.tril(sp.coo_matrix(M)).tocoo()
+        return cspmatrix.from_entries(self.symb, M.row, M.col, M.data, device=self.dev)
+
+    def Amap(self, X):
+        return self.kkt.amap(X)
+
+    def Aadj(self, y):
+        return self.kkt.aadj(y)
+
+    def to_scipy(self, X):
+        """Symmetric scipy matrix in original coordinates (perm(symmetrize(X), ip), solvers.py:2437)."""
+        return X.spmatrix(reordered=False, symmetric=True)
+
+
+def _dot(a, b):
+    return float(torch.dot(a, b).item())
+
+
+def _nrm2(a):
+    return float(torch.linalg.vector_norm(a).item())
+
+
+def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", kktsolver="chol", p=None):
+    """Extended self-dual embedding solver for
+
+         minimize   <C, X>            maximize   b'y
+         subject to <A_i, X> = b_i    subject to sum_i y_i A_i + S = C
+                    X in C_V                      S in K_V
+
+    (C_V: PSD-completable matrices with pattern V, K_V: PSD matrices with pattern V).
+    Returns the reference's result dictionary (solvers.py:2451-2467) with scipy/numpy values.
+    """
+    BETA, EXPON, STEP, MINSTEP = 0.7, 3.0, 0.99, 1e-12   # hard-coded in the reference (solvers.py:1384-1387)
+    T0w, T0 = time.perf_counter(), time.process_time()
+    DEBUG = _opt("debug", bool)
+    MAXITERS = _opt("maxiters", int, 1)
+    ABSTOL = _opt("abstol", float, 0.0)
+    RELTOL = _opt("reltol", float, 0.0)
+    FEASTOL = _opt("feastol", float, 0.0, strict_lo=True)
+    REFINEMENT = _opt("refinement", int, 0)
+    show_progress = _opt("show_progress", bool)
+    DIMACS = _opt("dimacs", bool)
+    if scaling not in ("primal", "dual"):
+        raise ValueError("scaling must be 'primal' or 'dual'")
+    if kktsolver != "chol":
+        raise NotImplementedError("kktsolver='qr' (solvers.py:413-475) is out of scope of this build; use 'chol'")
+
+    P = A if isinstance(A, _Problem) else _Problem(A, b, p)
+    n, m, C, bv = P.n, P.m, P.C, P.b
+    Amap, Aadj = P.Amap, P.Aadj
+    dot = chordal.dot
+    bmax = float(np.abs(P.bh).max()) if m else 0.0
+    ii = int(np.abs(P.bh).argmax()) if m else 0
+
+    X = P.from_sym(primalstart["x"]) if primalstart is not None else P.identity()
+    if dualstart is not None:
+        y = torch.as_tensor(np.asarray(dualstart["y"], dtype=np.float64).reshape(-1), device=P.dev).clone()
+        S = P.from_sym(dualstart["s"])
+    else:
+        S = P.identity()
+        y = torch.zeros(m, dtype=torch.float64, device=P.dev)
+    tau, kappa = 1.0, 1.0
+    resy0 = max(1.0, _nrm2(bv))
+    resx0 = max(1.0, math.sqrt(dot(C, C)))
+    status, step = "unknown", None
+    pcost = dcost = gap = relgap = pres = dres = pinfres = dinfres = None
+    st = {}   # per-iteration state shared by the closures below
+
+    def hess(U, inv):
+        chordal.hessian(st["L"], st["Y"], U, adj=None, inv=inv)
+
+    def bres(sigma, dz=None):
+        t = st["t"]
+        rby = (1 - sigma) * st["ry"]
+        rbx = st["rx"] * (1 - sigma)
+        rbt = (1 - sigma) * st["rt"]
+        if scaling == "primal":
+            rbs = st["L"].copy()
+            chordal.llt(rbs)
+            rbs *= sigma / t
+            rbs -= S
+            rbk = -kappa + sigma / (t * tau)
+        else:
+            rbs = st["Y"] * (sigma / t)
+            rbs -= X
+            rbk = -tau + sigma / (t * kappa)
+        if dz is not None:
+            ddy, ddX, ddtau, ddS, ddkappa = dz
+            rby = rby + bv * ddtau - Amap(ddX)
+            rbx += Aadj(ddy)
+            rbx += ddS
+            rbx -= C * ddtau
+            rbt += dot(C, ddX) - _dot(bv, ddy) + ddkappa
+            if scaling == "primal":
+                rbs -= ddS
+                u = ddX.copy()
+                hess(u, True)
+                rbs -= u * (1.0 / t)
+                rbk -= ddkappa + ddtau / (t * tau ** 2)
+            else:
+                rbs -= ddX
+                u = ddS.copy()
+                hess(u, False)
+                rbs -= u * (1.0 / t)
+                rbk -= ddtau + ddkappa / (t * kappa ** 2)
+        return rby, rbx, rbt, rbs, rbk
+
+    def tres(rbz):
+        t = st["t"]
+        if scaling == "primal":
+            a = tau ** 2 * t * (rbz[2] + rbz[4])
+            rtx = C * a
+            rtx -= rbz[1]
+            rtx -= rbz[3]
+        else:
+            a = rbz[4] + rbz[2] / (t * kappa ** 2)
+            rtx = rbz[3].copy()
+            hess(rtx, True)
+            rtx *= -t
+            rtx += C * a
+            rtx -= rbz[1]
+        return rtx, rbz[0] + a * bv
+
+    def solve(bx, by):
+        x, yy = bx.copy(), by.clone()
+        st["f"](x, yy, st["kk"])
+        return x, yy
+
+    def newton_once(sigma, dz):
+        t = st["t"]
+        rbz = bres(sigma, dz)
+        rtx, rty = tres(rbz)
+        u1, u2 = solve(rtx, rty)
+        den = (1.0 / (t * tau ** 2) if scaling == "primal" else t * kappa ** 2)
+        gamma = (-_dot(bv, u2) + dot(C, u1)) / (den + _dot(bv, st["v2"]) - dot(C, st["v1"]))
+        dy = u2 + gamma * st["v2"]
+        dX = u1 + st["v1"] * gamma
+        dkappa = -rbz[2] + _dot(bv, dy) - dot(C, dX)
+        if bmax > 1e-5:
+            dtau = (float(Amap(dX)[ii].item()) - float(rbz[0][ii].item())) / P.bh[ii]
+        elif scaling == "primal":
+            dtau = (rbz[4] - dkappa) * t * tau ** 2
+        else:
+            dtau = rbz[4] - dkappa / (t * kappa ** 2)
+        if scaling == "primal":
+            dS = dX * (-1.0 / t)
+            hess(dS, True)
+            dS += rbz[3]
+        else:
+            dS = rbz[3] - dX
+            dS *= t
+            hess(dS, True)
+        return dy, dX, dtau, dS, dkappa
+
+    def newton(sigma):
+        dy, dX, dtau, dS, dkappa = newton_once(sigma, None)
+        for _ in range(REFINEMENT):
+            e = newton_once(sigma, (dy, dX, dtau, dS, dkappa))
+            dy = dy + e[0]
+            dX += e[1]
+            dtau += e[2]
+            dS += e[3]
+            dkappa += e[4]
+        return dy, dX, dtau, dS, dkappa
+
+    def newton_res(sigma, dy, dX, dtau, dS, dkappa):
+        """Residuals of the 5-block Newton system (reference DEBUG check, solvers.py:1813-1841)."""
+        t = st["t"]
+        rbz = bres(sigma)
+        r1 = _nrm2(Amap(dX) - dtau * bv - rbz[0])
+        r2 = Aadj(-dy)
+        r2 += C * dtau
+        r2 -= dS
+        r2 -= rbz[1]
+        r2 = math.sqrt(max(dot(r2, r2), 0.0))
+        r3 = abs(_dot(bv, dy) - dot(C, dX) - dkappa - rbz[2])
+        if scaling == "primal":
+            r4 = dX.copy()
+            hess(r4, True)
+            r4 *= 1.0 / t
+            r4 += dS
+            r4 -= rbz[3]
+            r5 = abs(dtau / (t * tau ** 2) + dkappa - rbz[4])
+        else:
+            r4 = dS.copy()
+            hess(r4, False)
+            r4 *= 1.0 / t
+            r4 += dX
+            r4 -= rbz[3]
+            r5 = abs(dkappa / (t * kappa ** 2) + dtau - rbz[4])
+        r4 = math.sqrt(max(dot(r4, r4), 0.0))
+        print("   Newton residuals: %.2e %.2e %.2e %.2e %.2e" % (r1, r2, r3, r4, r5))
+
+    def linesearch(dX, dS, dtau, dkappa):
+        s = 1.0
+        while kappa + s * dkappa <= 0 or tau + s * dtau <= 0:
+            s *= BETA
+            if s < MINSTEP:
+                return None
+        while True:
+            Lt = X + dX * s
+            try:
+                chordal.completion(Lt)
+                break
+            except ArithmeticError:
+                s *= BETA
+                if s < MINSTEP:
+                    return None
+        while True:
+            Lt = S + dS * s
+            try:
+                chordal.cholesky(Lt)
+                break
+            except ArithmeticError:
+                s *= BETA
+                if s < MINSTEP:
+                    return None
+        return s
+
+    if show_progress:
+        print("smcp_amd: extended self-dual embedding, %s scaling (Cholesky), n=%d m=%d cliques=%d%s"
+              % (scaling, n, m, P.symb.Nsn, "" if P.ischordal else " (chordal embedding)"))
+        print("%3s %12s %12s %8s %8s %8s %8s %8s" % ("it", "pcost", "dcost", "gap", "pres", "dres", "k/t", "step"))
+
+    it = 0
+    for it in range(MAXITERS + 1):
+        hry = Amap(X)
+        ry = bv * tau - hry
+        hrx = Aadj(y)
+        hrx += S
+        rx = hrx - C * tau
+        cx = dot(C, X)
+        by = _dot(bv, y)
+        rt = kappa - by + cx
+        resy = _nrm2(ry) / tau
+        resx = math.sqrt(max(dot(rx, rx), 0.0)) / tau
+        pres, dres = resy / resy0, resx / resx0
+        pcost, dcost = cx / tau, by / tau
+        gap = dot(X, S) / tau ** 2
+        relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
+        pinfres = math.sqrt(max(dot(hrx, hrx), 0.0)) / resx0 / by if by > 0.0 else None
+        dinfres = _nrm2(hry) / resy0 / (-cx) if cx < 0.0 else None
+        if show_progress:
+            print("%3d % .4e % .4e %.1e %.1e %.1e %.1e %s" % (it, pcost, dcost, gap, pres, dres, kappa / tau,
+                                                               "" if step is None else "%.1e" % step))
+        if dres <= FEASTOL and pres <= FEASTOL and (gap <= ABSTOL or (relgap is not None and relgap <= RELTOL)):
+            status = "optimal"
+            break
+        if pinfres is not None and pinfres <= FEASTOL:
+            status = "primal infeasibility"
+            X = None
+            pcost, dcost, gap, relgap, pres, dres, dinfres = None, 1, None, None, None, None, None
+            break
+        if dinfres is not None and dinfres <= FEASTOL:
+            status = "dual infeasibility"
+            y = S = None
+            pcost, dcost, gap, relgap, pres, dres, pinfres = -1, None, None, None, None, None, None
+            break
+        if it == MAXITERS:
+            status = "unknown"
+            break
+        t = (n + 1) / (gap * tau ** 2 + kappa * tau)
+        try:
+            if scaling == "primal":
+                L = X.copy()
+                chordal.completion(L)
+                Y = X
+            else:
+                L = S.copy()
+                chordal.cholesky(L)
+                Y = L.copy()
+                chordal.projected_inverse(Y)
+        except ArithmeticError:
+            status = "unknown"
+            break
+        try:
+            f = P.kkt.factor(L, Y)
+        except ArithmeticError:
+            status = "unknown"
+            break
+        st.update(L=L, Y=Y, t=t, f=f, kk=(1.0 / t if scaling == "primal" else t), ry=ry, rx=rx, rt=rt)
+        st["v1"], st["v2"] = solve(C, bv)
+        dy, dX, dtau, dS, dkappa = newton(0.0)
+        if DEBUG:
+            newton_res(0.0, dy, dX, dtau, dS, dkappa)
+        step = linesearch(dX, dS, dtau, dkappa)
+        if not step:
+            status = "unknown"
+            break
+        Xt, St = X + dX * step, S + dS * step
+        taut, kappat = tau + step * dtau, kappa + step * dkappa
+        sigma = ((dot(Xt, St) + taut * kappat) / (gap * tau ** 2 + kappa * tau)) ** EXPON
+        dy, dX, dtau, dS, dkappa = newton(sigma)
+        if DEBUG:
+            newton_res(sigma, dy, dX, dtau, dS, dkappa)
+        step = linesearch(dX, dS, dtau, dkappa)
+        if not step:
+            status = "unknown"
+            break
+        X += dX * (STEP * step)
+        y = y + (STEP * step) * dy
+        S += dS * (STEP * step)
+        tau += STEP * step * dtau
+        kappa += STEP * step * dkappa
+        if DEBUG:
+            print("   mu=%.2e tau=%.2e kappa=%.2e sigma=%.2e" % (1.0 / t, tau, kappa, sigma))
+
+    dimacs = None
+    if DIMACS and X is not None and y is not None and S is not None:
+        R = Aadj(y)
+        R += S
+        R *= 1.0 / tau
+        R -= C
+        dimacs = [_nrm2(Amap(X) / tau - bv) / (1 + bmax), 0.0,
+                  math.sqrt(max(dot(R, R), 0.0)) / (1 + P.cmaxabs), 0.0,
+                  (pcost - dcost) / (1 + abs(pcost) + abs(dcost)), gap / (1 + abs(pcost) + abs(dcost))]
+    xs = ys = ss = None
+    if X is not None:
+        X *= 1.0 / tau
+        xs = P.to_scipy(X)
+    if y is not None:
+        ys = (y / tau).cpu().numpy()
+    if S is not None:
+        S *= 1.0 / tau
+        ss = P.to_scipy(S)
+    if show_progress:
+        print("status: %s, %d iterations, %.2f s" % (status, it, time.perf_counter() - T0w))
+    return {"status": status, "x": xs, "y": ys, "s": ss, "primal objective": pcost, "dual objective": dcost,
+            "gap": gap, "relative gap": relgap, "primal infeasibility": pres, "dual infeasibility": dres,
+            "residual as primal infeasibility certificate": pinfres,
+            "residual as dual infeasibility certificate": dinfres, "iterations": it,
+            "cputime": time.process_time() - T0, "time": time.perf_counter() - T0w, "dimacs": dimacs}
+
+
+def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal", kktsolver="chol", p=None):
+    """Feasible-start barrier method (reference: solvers.py:49-1327; behaviour summarised in
+    SURVEY.md App. D.1).  Either a strictly feasible primal start {'x': X0} (primal scaling), a dual
+    start {'y': y0[, 's': S0]} (dual scaling), both, or neither (start heuristics, solvers.py:722-814).
+    Each pass: scaling point -> kkt_chol factor -> centering step (with `refinement` rounds of
+    kkt_res + solve) until the Newton decrement is below `delta`, then lifting + approximate
+    tangent step with 8-step bisection line search, optional prediction/corrector, gap update."""
+    T0w, T0 = time.perf_counter(), time.process_time()
+    DEBUG = _opt("debug", bool)
+    MAXITERS = _opt("maxiters", int, 1)
+    ABSTOL = _opt("abstol", float, 0.0)
+    RELTOL = _opt("reltol", float, 0.0)
+    FEASTOL = _opt("feastol", float, 0.0, strict_lo=True)
+    REFINEMENT = _opt("refinement", int, 0)
+    show_progress = _opt("show_progress", bool)
+    DIMACS = _opt("dimacs", bool)
+    DELTA = _opt("delta", float, 0.0, 1.0, strict_lo=True)
+    ALPHA = _opt("alpha", float, 0.0, 0.5, strict_lo=True)
+    BETA = _opt("beta", float, 0.0, 1.0, strict_lo=True)
+    MINSTEP = _opt("minstep", float, 0.0, strict_lo=True)
+    LIFTING = _opt("lifting", bool)
+    EQUALSTEPS = _opt("equalsteps", bool)
+    PREDICTION = _opt("prediction", bool)
+    STEP = _opt("step", float, 0.0, 1.0, strict_lo=True)
+    t = float(_opt("t0", float, 0.0, strict_lo=True))
+    if options.get("eta") is not None:
+        raise NotImplementedError("options['eta'] (Omega-neighbourhood line search, solvers.py:665-689) is not built")
+    if scaling not in ("primal", "dual"):
+        raise ValueError("scaling must be 'primal' or 'dual'")
+    if kktsolver != "chol":
+        raise NotImplementedError("kktsolver='qr' (solvers.py:413-475) is out of scope of this build; use 'chol'")
+
+    P = A if isinstance(A, _Problem) else _Problem(A, b, p)
+    n, m, C, bv = P.n, P.m, P.C, P.b
+    Amap, Aadj, dot = P.Amap, P.Aadj, chordal.dot
+    resy0 = max(1.0, _nrm2(bv))
+    resx0 = max(1.0, math.sqrt(dot(C, C)))
+    st = {}
+
+    def S_of(y):
+        S = Aadj(-y)
+        S += C
+        return S
+
+    def in_cone(M, which):
+        Lt = M.copy()
+        (chordal.completion if which == "p" else chordal.cholesky)(Lt)
+        return Lt
+
+    def factor(L, Y):
+        st.update(L=L, Y=Y, f=P.kkt.factor(L, Y))
+
+    def kk_of(tt):
+        return 1.0 / tt if st["scaling"] == "primal" else tt
+
+    def solve(bx, by, tt):
+        x, yy = bx.copy(), by.clone()
+        st["f"](x, yy, kk_of(tt))
+        return x, yy
+
+    def kkt_res(x, yy, bx, by, tt):
+        r = x.copy()
+        chordal.hessian(st["L"], st["Y"], r, adj=None, inv=True)
+        r *= -kk_of(tt)
+        r += Aadj(yy)
+        r -= bx
+        return r, Amap(x) - by
+
+    def solve_refined(bx, by, tt):
+        x, yy = solve(bx, by, tt)
+        for _ in range(REFINEMENT):
+            r1, r2 = kkt_res(x, yy, bx, by, tt)
+            dx_, dy_ = solve(r1, r2, tt)
+            x -= dx_
+            yy = yy - dy_
+        return x, yy
+
+    def ntdecr_primal(dx):
+        du = dx.copy()
+        chordal.hessian(st["L"], st["Y"], du, adj=True, inv=True)
+        return math.sqrt(max(dot(du, du), 0.0))
+
+    def ntdecr_dual(dy):
+        du = Aadj(dy)
+        chordal.hessian(st["L"], st["Y"], du, adj=False, inv=False)
+        return math.sqrt(max(dot(du, du), 0.0))
+
+    def bisect(base_, d, which, a):
+        lo, hi, g_ = MINSTEP, 1.0, MINSTEP
+        for _ in range(8):
+            g = 0.5 * (lo + hi)
+            try:
+                in_cone(base_ + d * g, which)
+                lo = g_ = g
+            except ArithmeticError:
+                hi = g
+                g_ = lo
+        return a * g_
+
+    def backtrack_primal(X, dx, tt, ntd):
+        """Damped centering step on X (solvers.py:928-939)."""
+        gam, logdetL, tdcdx = 1.0, chordal.logdiagsum(st["L"]), tt * dot(C, dx)
+        Xt = X
+        while gam > MINSTEP:
+            Xt = X + dx * gam
+            val = tdcdx + gam * ALPHA * ntd ** 2
+            try:
+                Lt = in_cone(Xt, "p")
+                if gam * val < 2 * (logdetL - chordal.logdiagsum(Lt)):
+                    break
+            except ArithmeticError:
+                pass
+            gam *= BETA
+        return Xt, gam
+
+    def backtrack_dual(y, dy, tt, ntd):
+        gam, logdetL, ddyb = 1.0, chordal.logdiagsum(st["L"]), -tt * _dot(dy, bv)
+        yt, St = y, None
+        while gam > MINSTEP:
+            yt = y + gam * dy
+            St = S_of(yt)
+            val = ddyb + gam * ALPHA * ntd ** 2
+            try:
+                Lt = in_cone(St, "d")
+                if gam * val < 2 * (chordal.logdiagsum(Lt) - logdetL):
+                    break
+            except ArithmeticError:
+                pass
+            gam *= BETA
+        return yt, St, gam
+
+    # ---- starting points (solvers.py:691-814) ---------------------------------------------
+    X = y = S = None
+    if primalstart is not None:
+        X = P.from_sym(primalstart["x"])
+        if _nrm2(bv - Amap(X)) / resy0 > 1e-8:
+            raise ValueError("infeasible primal starting point")
+        try:
+            in_cone(X, "p")
+        except ArithmeticError:
+            raise ValueError("infeasible primal starting point")
+    if dualstart is not None:
+        y = torch.as_tensor(np.asarray(dualstart["y"], dtype=np.float64).reshape(-1), device=P.dev).clone()
+        if "s" in dualstart and dualstart["s"] is not None:
+            S = P.from_sym(dualstart["s"])
+            r = S_of(y) - S
+            if math.sqrt(max(dot(r, r), 0.0)) / resx0 > 1e-8:
+                raise ValueError("infeasible dual starting point")
+        else:
+            S = S_of(y)
+        try:
+            in_cone(S, "d")
+        except ArithmeticError:
+            raise ValueError("infeasible dual starting point")
+    if primalstart is None and dualstart is None:
+        st["scaling"] = "primal"
+        Xt = P.identity()
+        factor(in_cone(Xt, "p"), Xt)
+        zero = cspmatrix(P.symb, torch.zeros_like(C.blkval))
+        X0, _ = solve(zero, bv, 1.0)
+        try:
+            in_cone(X0, "p")
+            X = X0
+        except ArithmeticError:
+            trA = Amap(Xt)
+            Xb, _ = solve(zero, trA, 1.0)
+            Xb -= Xt
+            for sgn in (1.0, -1.0):
+                try:
+                    D = Xb * sgn
+                    in_cone(D, "p")
+                    gam = 2.0
+                    while gam < 1e12:
+                        try:
+                            cand = X0 + D * gam
+                            in_cone(cand, "p")
+                            X = cand
+                            break
+                        except ArithmeticError:
+                            gam *= 2
+                    if X is not None:
+                        break
+                except ArithmeticError:
+                    continue
+        _, y0 = solve(C, torch.zeros_like(bv), 1.0)
+        S0 = S_of(y0)
+        try:
+            in_cone(S0, "d")
+            y, S = y0, S0
+        except ArithmeticError:
+            _, yh = solve(P.identity() * -1.0, torch.zeros_like(bv), 1.0)
+            try:
+                in_cone(Aadj(-yh), "d")
+                for _ in range(200):
+                    S0 = S_of(yh)
+                    try:
+                        in_cone(S0, "d")
+                        y, S = yh, S0
+                        break
+                    except ArithmeticError:
+                        yh = yh * 1.4
+            except ArithmeticError:
+                pass
+    if X is None and y is None:
+        raise ValueError("could not find a feasible starting point (solve Phase I problem instead)")
+    if X is None and scaling == "primal":
+        scaling = "dual"
+    elif S is None and scaling == "dual":
+        scaling = "primal"
+    st["scaling"] = scaling
+
+    if show_progress:
+        print("smcp_amd: feasible-start barrier method, %s scaling (Cholesky), n=%d m=%d cliques=%d"
+              % (scaling, n, m, P.symb.Nsn))
+    gap = n / t
+    pres = dres = pcost = dcost = relgap = None
+    CENTER, status, it = True, "unknown", 0
+    dxL = dyL = Shat = None
+    for it in range(1, MAXITERS + 2):
+        if scaling == "primal":
+            pres = _nrm2(bv - Amap(X)) / resy0
+            pcost = dot(C, X)
+        else:
+            r = S_of(y) - S
+            dres = math.sqrt(max(dot(r, r), 0.0)) / resx0
+            dcost = _dot(bv, y)
+        relgap = (gap / -pcost if pcost is not None and pcost < 0.0 else
+                  (gap / dcost if dcost is not None and dcost > 0.0 else None))
+        if it == MAXITERS + 1:
+            status = "unknown"
+            break
+        if dres is not None and pres is not None and pres < FEASTOL and dres < FEASTOL and \
+                (gap < ABSTOL or (relgap is not None and relgap < RELTOL)):
+            status = "optimal"
+            break
+        try:
+            if scaling == "primal":
+                L = in_cone(X, "p")
+                Y = X.copy()
+            else:
+                L = in_cone(S, "d")
+                Y = L.copy()
+                chordal.projected_inverse(Y)
+            factor(L, Y)
+        except ArithmeticError:
+            status = "unknown"
+            break
+        stype = "c"
+        if CENTER:
+            if scaling == "primal":
+                Shat = L.copy()
+                chordal.llt(Shat)
+                bx = C - Shat * (1.0 / t)
+                dx, lam = solve_refined(bx, bv - Amap(X), t)
+                ntd = ntdecr_primal(dx)
+                if ntd > DELTA:
+                    if ntd >= 1.0:
+                        X, _g = backtrack_primal(X, dx, t, ntd)
+                    else:
+                        X += dx
+                else:
+                    if LIFTING:
+                        X -= dx
+                        dxL = dx
+                    else:
+                        X += dx
+                    y = lam
+                    S = S_of(y)
+                    CENTER = False
+            else:
+                nu, dy = solve_refined(S * -1.0, bv, t)
+                ntd = ntdecr_dual(dy)
+                if ntd > DELTA:
+                    if ntd >= 1.0:
+                        y, S, _g = backtrack_dual(y, dy, t, ntd)
+                    else:
+                        y = y + dy
+                        S = S_of(y)
+                else:
+                    if LIFTING:
+                        y = y - dy
+                        dyL = dy
+                    else:
+                        y = y + dy
+                    S = S_of(y)
+                    X = nu
+                    CENTER = False
+        if not CENTER:
+            stype = "a"
+            dx, dy = solve_refined(S, bv - Amap(X), t)
+            ds = Aadj(-dy)
+            pstep, dstep = bisect(X, dx, "p", STEP), bisect(S, ds, "d", STEP)
+            if EQUALSTEPS:
+                pstep = dstep = min(pstep, dstep)
+            Xt = X + dx * pstep
+            yt = y + dstep * dy
+            St = S_of(yt)
+            if not PREDICTION:
+                X, y, S = Xt, yt, St
+            else:
+                gapt = dot(Xt, St)
+                if LIFTING:
+                    if scaling == "primal":
+                        X += dxL
+                    else:
+                        y = y + dyL
+                        S = S_of(y)
+                t = n / gapt
+                if scaling == "primal":
+                    bx = S - Shat * (1.0 / t)
+                else:
+                    bx = X.copy()
+                    chordal.hessian(L, Y, bx, adj=None, inv=True)
+                    bx *= t
+                    bx -= S
+                dx, dy = solve_refined(bx, bv - Amap(X), t)
+                if scaling == "primal":
+                    ntd = ntdecr_primal(dx)
+                    if ntd >= 1.0:
+                        X, _g = backtrack_primal(X, dx, t, ntd)
+                    else:
+                        X += dx
+                    gam = 1.0
+                    while True:
+                        yt = y + gam * dy
+                        St = S_of(yt)
+                        try:
+                            in_cone(St, "d")
+                            break
+                        except ArithmeticError:
+                            gam *= BETA
+                            if gam < 1e-14:
+                                break
+                    y, S = yt, St
+                else:
+                    ntd = ntdecr_dual(dy)
+                    if ntd >= 1.0:
+                        y, S, _g = backtrack_dual(y, dy, t, ntd)
+                    else:
+                        y = y + dy
+                        S = S_of(y)
+                    gam = 1.0
+                    while True:
+                        Xt = X + dx * gam
+                        try:
+                            in_cone(Xt, "p")
+                            break
+                        except ArithmeticError:
+                            gam *= BETA
+                            if gam < 1e-14:
+                                break
+                    X = Xt
+            try:
+                in_cone(X, "p")
+                in_cone(S, "d")
+            except ArithmeticError:
+                status = "unknown"
+                break
+            gapt = dot(X, S)
+            gap = min(n / t, gapt)
+            t = n / gap
+            pres = _nrm2(Amap(X) - bv) / resy0
+            r = Aadj(y)
+            r += S
+            r -= C
+            dres = math.sqrt(max(dot(r, r), 0.0)) / resx0
+            pcost, dcost = dot(C, X), _dot(bv, y)
+            CENTER = True
+        if show_progress:
+            print("%3d %s %s %s gap %.1e pres %s dres %s" % (
+                it, stype, "% .4e" % pcost if pcost is not None else "      -     ",
+                "% .4e" % dcost if dcost is not None else "      -     ", gap if gap is not None else n / t,
+                "%.1e" % pres if pres is not None else "-", "%.1e" % dres if dres is not None else "-"))
+
+    dimacs = None
+    bmax = float(np.abs(P.bh).max()) if m else 0.0
+    if DIMACS and X is not None and y is not None and S is not None and pcost is not None and dcost is not None:
+        R = Aadj(y)
+        R += S
+        R -= C
+        dimacs = [_nrm2(Amap(X) - bv) / (1 + bmax), 0.0, math.sqrt(max(dot(R, R), 0.0)) / (1 + P.cmaxabs), 0.0,
+                  (pcost - dcost) / (1 + abs(pcost) + abs(dcost)), dot(X, S) / (1 + abs(pcost) + abs(dcost))]
+    if show_progress:
+        print("status: %s, %d iterations, %.2f s" % (status, it - 1, time.perf_counter() - T0w))
+    return {"status": status, "x": P.to_scipy(X) if X is not None else None,
+            "y": y.cpu().numpy() if y is not None else None, "s": P.to_scipy(S) if S is not None else None,
+            "primal objective": pcost, "dual objective": dcost, "gap": gap, "relative gap": relgap,
+            "primal infeasibility": pres, "dual infeasibility": dres, "iterations": it - 1,
+            "cputime": time.process_time() - T0, "time": time.perf_counter() - T0w, "dimacs": dimacs}
+
+
+# ---------------------------------------------------------------------------------------------
+# CVXOPT-style front ends (solvers.py:2470-2699)
+# ---------------------------------------------------------------------------------------------
+def _embed_columns(cols, dims):
+    """Map each column v (length Nl + sum(Nq) + sum(Ns^2)) of [h G] to vec of the block-diagonal
+    matrix: LP part -> diagonal, SOC part -> arrow with the head in the LAST row (solvers.py:2512-2520),
+    's' part -> lower triangle of the ns x ns block (2523-2529)."""
+    Nl = int(dims.get("l", 0) or 0)
+    Nq = [int(q) for q in dims.get("q", [])]
+    Ns = [int(s) for s in dims.get("s", [])]
+    n = Nl + sum(Nq) + sum(Ns)
+    R, Cc, V = [], [], []
+    cols = sp.csc_matrix(cols)
+    for k in range(cols.shape[1]):
+        v = np.asarray(cols[:, k].todense()).reshape(-1)
+        I, J, W = [], [], []
+        ptr, off = 0, 0
+        for i in range(Nl):
+            if v[i] != 0.0:
+                I.append(i); J.append(i); W.append(v[i])
+        ptr, off = Nl, Nl
+        for nq in Nq:
+            u0, u1 = v[ptr], v[ptr + 1:ptr + nq]
+            if u0 != 0.0:
+                for d in range(nq):
+                    I.append(off + d); J.append(off + d); W.append(u0)
+            for j in np.nonzero(u1)[0]:
+                I.append(off + nq - 1); J.append(off + j); W.append(u1[j])
+            ptr += nq
+            off += nq
+        for ns in Ns:
+            blk = v[ptr:ptr + ns * ns].reshape((ns, ns), order="F")
+            ii, jj = np.nonzero(np.tril(blk))
+            for a, c in zip(ii, jj):
+                I.append(off + a); J.append(off + c); W.append(blk[a, c])
+            ptr += ns * ns
+            off += ns
+        I, J, W = np.asarray(I, dtype=np.int64), np.asarray(J, dtype=np.int64), np.asarray(W, dtype=np.float64)
+        R.append(I + n * J)
+        Cc.append(np.full(len(I), k, dtype=np.int64))
+        V.append(W)
+    A = sp.csc_matrix((np.concatenate(V), (np.concatenate(R), np.concatenate(Cc))), shape=(n * n, cols.shape[1]))
+    return A, n, Nl, Nq, Ns
+
+
+def conelp(c, G, h, dims=None, kktsolver="chol"):
+    """minimize c'x s.t. Gx + s = h, s in K (cone given by dims = {'l','q','s'}); solved as the dual
+    of a block-diagonal SDP through chordalsolver_esd (solvers.py:2470-2535).  Returns the reference's
+    dictionary with 'x' (primal), 's' (slack) and 'z' (dual) as dense numpy vectors."""
+    c = np.asarray(c, dtype=np.float64).reshape(-1)
+    hh = np.asarray(h, dtype=np.float64).reshape(-1, 1)
+    G = sp.csc_matrix(G)
+    if dims is None:
+        dims = {"l": G.shape[0], "q": [], "s": []}
+    A, n, Nl, Nq, Ns = _embed_columns(sp.hstack([sp.csc_matrix(hh), G]), dims)
+    sol = chordalsolver_esd(A, -c, kktsolver=kktsolver)
+    X, S = sol["x"], sol["s"]
+
+    def unpack(M, dual):
+        if M is None:
+            return None
+        M = np.asarray(M.todense())
+        out = [np.diag(M)[:Nl]]
+        N = Nl
+        for q in Nq:
+            B = M[N:N + q, N:N + q]
+            if dual:   # z0 = trace, z1 = 2 * last row (solvers.py:2551-2560)
+                out.append(np.concatenate([[np.trace(B)], 2.0 * B[q - 1, :q - 1]]))
+            else:      # s0 = corner, s1 = last row (solvers.py:2581-2583)
+                out.append(np.concatenate([[B[q - 1, q - 1]], B[q - 1, :q - 1]]))
+            N += q
+        for s_ in Ns:
+            out.append(M[N:N + s_, N:N + s_].reshape(-1, order="F"))
+            N += s_
+        return np.concatenate(out)
+
+    sol["x"] = sol.pop("y")
+    sol["z"] = unpack(X, True)
+    sol["s"] = unpack(S, False)
+    return sol
+
+
+def lp(c, G, h, kktsolver="chol"):
+    """minimize c'x s.t. Gx <= h (solvers.py:2600-2607)."""
+    G = sp.csc_matrix(G)
+    return conelp(c, G, h, {"l": G.shape[0], "q": [], "s": []}, kktsolver=kktsolver)
+
+
+def socp(c, Gl=None, hl=None, Gq=None, hq=None, kktsolver="chol"):
+    """Second-order cone program front end (solvers.py:2608-2650; the reference's dims['l'].append bug,
+    SURVEY App. C, is not reproduced)."""
+    Gs, hs, dims = [], [], {"l": 0, "q": [], "s": []}
+    if Gl is not None:
+        Gl = sp.csc_matrix(Gl)
+        Gs.append(Gl); hs.append(np.asarray(hl, dtype=np.float64).reshape(-1)); dims["l"] = Gl.shape[0]
+    for Gk, hk in zip(Gq or [], hq or []):
+        Gk = sp.csc_matrix(Gk)
+        Gs.append(Gk); hs.append(np.asarray(hk, dtype=np.float64).reshape(-1)); dims["q"].append(Gk.shape[0])
+    return conelp(c, sp.vstack(Gs), np.concatenate(hs), dims, kktsolver=kktsolver)
+
+
+def sdp(c, Gl=None, hl=None, Gs=None, hs=None, kktsolver="chol"):
+    """SDP front end: Gs[k] has ns^2 rows (column-major vec), hs[k] is ns x ns (solvers.py:2651-2699)."""
+    Gall, hall, dims = [], [], {"l": 0, "q": [], "s": []}
+    if Gl is not None:
+        Gl = sp.csc_matrix(Gl)
+        Gall.append(Gl); hall.append(np.asarray(hl, dtype=np.float64).reshape(-1)); dims["l"] = Gl.shape[0]
+    for Gk, hk in zip(Gs or [], hs or []):
+        Gk = sp.csc_matrix(Gk)
+        ns = int(round(math.sqrt(Gk.shape[0])))
+        Gall.append(Gk); hall.append(np.asarray(hk, dtype=np.float64).reshape(-1, order="F")); dims["s"].append(ns)
+    return conelp(c, sp.vstack(Gall), np.concatenate(hall), dims, kktsolver=kktsolver)

@@ -1,0 +1,132 @@
+"""End-to-end interior-point runs on the GPU path (config 1 plumbing + the reference's own test problem).
+
+The reference's test (tests/test_basic.py:6-22) asserts nothing, so optimality is certified here
+independently: primal/dual feasibility and duality gap recomputed in dense numpy from the returned
+solution (DIMACS-style errors, doc benchmarks index.rst:113-122)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _certify(P, sol, tol=1e-6):
+    n, m = P.n, P.m
+    X = np.asarray(sol["x"].todense())
+    S = np.asarray(sol["s"].todense())
+    y = sol["y"]
+    C = np.asarray(P.get_A(0).todense())
+    Ai = [np.asarray(P.get_A(i + 1).todense()) for i in range(m)]
+    pres = np.linalg.norm(np.array([np.sum(a * X) for a in Ai]) - P.b) / (1 + np.abs(P.b).max())
+    dres = np.linalg.norm(sum(yi * a for yi, a in zip(y, Ai)) + S - C) / (1 + np.abs(C).max())
+    assert pres < tol and dres < tol
+    assert np.linalg.eigvalsh(S).min() > -1e-8                     # S in the PSD cone
+    pc, dc = np.sum(C * X), float(P.b @ y)
+    assert abs(pc - dc) / (1 + abs(pc) + abs(dc)) < 1e-5
+    assert abs(np.sum(X * S)) / (1 + abs(pc)) < 1e-5                # complementarity
+    return pc, dc
+
+
+def _starts(P):
+    return ({"x": sp.csc_matrix(np.tril(P._X0))}, {"y": P._y0, "s": sp.csc_matrix(np.tril(P._S0))})
+
+
+def test_band_sdp_config1_feas_primal_and_dual_scaling():
+    """BASELINE config 1: band SDP n=200, half-bandwidth 3, m=100 through the feasible-start
+    driver (the reference's benchmark method M1: 36-38 iterations, DIMACS feasibility errors
+    ~1e-16, doc band_ex1_*.html)."""
+    from smcp_amd import base, solvers
+    solvers.options.update(show_progress=False, maxiters=100)
+    P = base.band_SDP(200, 100, 3, seed=0)
+    assert P.nnz == 794
+    ps, ds = _starts(P)
+    sol_p = P.solve_feas(scaling="primal", primalstart=ps, dualstart=ds)
+    assert sol_p["status"] == "optimal" and sol_p["iterations"] <= 60
+    pc, dc = _certify(P, sol_p)
+    assert max(abs(sol_p["dimacs"][0]), abs(sol_p["dimacs"][2])) < 1e-12     # feasible-start stays feasible
+    # X is PSD-completable: its maximal cliques are PSD
+    X = np.asarray(sol_p["x"].todense())
+    for j in range(0, 196, 17):
+        assert np.linalg.eigvalsh(X[j:j + 4, j:j + 4]).min() > -1e-8
+    sol_d = P.solve_feas(scaling="dual", primalstart=ps, dualstart=ds)
+    assert sol_d["status"] == "optimal"
+    pc2, dc2 = _certify(P, sol_d)
+    assert abs(pc - pc2) < 1e-5 * (1 + abs(pc))
+    assert pc <= np.sum(np.asarray(P.get_A(0).todense()) * P._X0) + 1e-6    # the start bounds the optimum
+
+
+def test_band_sdp_config1_via_conelp():
+    """Config 1 "via smcp.solvers.conelp": the same band SDP in CVXOPT cone-LP form (dims s=[n]),
+    which runs the self-dual-embedding driver.  The embedding has to drive infeasibility to zero
+    together with the gap; on these band problems it plateaus around 1e-6 (also with the CPU oracle
+    as backend), so the tolerances are relaxed here and stated: feastol 1e-6, abs/reltol 1e-5."""
+    from smcp_amd import base, solvers
+    solvers.options.update(show_progress=False, maxiters=60, feastol=1e-6, abstol=1e-5, reltol=1e-5)
+    try:
+        P = base.band_SDP(200, 100, 3, seed=0)
+        n, m = P.n, P.m
+        G = sp.hstack([sp.csc_matrix(P.get_A(i + 1).reshape((n * n, 1), order="F")) for i in range(m)]).tocsc()
+        h = np.asarray(P.get_A(0).todense()).reshape(-1, order="F")
+        sol = solvers.conelp(-P.b, G, h, {"l": 0, "q": [], "s": [n]})
+        assert sol["status"] == "optimal"
+        ref = P.solve_feas(scaling="dual", primalstart=_starts(P)[0], dualstart=_starts(P)[1])
+        assert abs(sol["dual objective"] - ref["dual objective"]) < 1e-3 * (1 + abs(ref["dual objective"]))
+    finally:
+        solvers.options.update(feastol=1e-8, abstol=1e-6, reltol=1e-6, maxiters=100)
+
+
+def test_reference_conelp_example():
+    """The problem of the reference's tests/test_basic.py (CVXOPT manual example, l=2, q=[4,4], s=[3])."""
+    from smcp_amd import solvers
+    solvers.options["show_progress"] = False
+    solvers.options["maxiters"] = 100
+    c = np.array([-6., -4., -5.])
+    G = np.array([[16., 7., 24., -8., 8., -1., 0., -1., 0., 0., 7., -5., 1., -5., 1., -7., 1., -7., -4.],
+                  [-14., 2., 7., -13., -18., 3., 0., 0., -1., 0., 3., 13., -6., 13., 12., -10., -6., -10., -28.],
+                  [5., 0., -15., 12., -6., 17., 0., 0., 0., -1., 9., 6., -6., 6., -7., -7., -6., -7., -11.]]).T
+    h = np.array([-3., 5., 12., -2., -14., -13., 10., 0., 0., 0., 68., -30., -19., -30., 99., 23., -19., 23., 10.])
+    dims = {"l": 2, "q": [4, 4], "s": [3]}
+    sol = solvers.conelp(c, G, h, dims)
+    assert sol["status"] == "optimal"
+    x, s, z = sol["x"], sol["s"], sol["z"]
+    assert np.linalg.norm(G @ x + s - h) < 1e-6 * (1 + np.linalg.norm(h))      # primal feasibility
+    assert np.linalg.norm(G.T @ z + c) < 1e-6 * (1 + np.linalg.norm(c))        # dual feasibility
+    assert abs(c @ x + h @ z) < 1e-5 * (1 + abs(c @ x))                        # zero duality gap
+    # cone membership of the slack and of the multiplier
+    for v in (s, z):
+        assert (v[:2] > -1e-8).all()
+        assert v[2] >= np.linalg.norm(v[3:6]) - 1e-7 and v[6] >= np.linalg.norm(v[7:10]) - 1e-7
+        M = v[10:].reshape(3, 3)
+        assert np.linalg.eigvalsh((M + M.T) / 2).min() > -1e-7
+    # CVXOPT manual's optimum for this example
+    assert np.allclose(x, [-1.22, 0.0966, 3.58], atol=5e-3)
+
+
+def test_lp_against_scipy():
+    """LP through the LP -> diagonal-SDP mapping (solvers.py:2505-2509) against scipy.optimize.linprog."""
+    from scipy.optimize import linprog
+    from smcp_amd import solvers
+    solvers.options["show_progress"] = False
+    rng = np.random.default_rng(0)
+    nvar, ncon = 6, 15
+    G = rng.standard_normal((ncon, nvar))
+    x0 = rng.standard_normal(nvar)
+    h = G @ x0 + rng.random(ncon) + 0.1
+    z0 = rng.random(ncon) + 0.1
+    c = -G.T @ z0
+    sol = solvers.lp(c, G, h)
+    ref = linprog(c, A_ub=G, b_ub=h, bounds=[(None, None)] * nvar, method="highs")
+    assert sol["status"] == "optimal" and ref.status == 0
+    assert abs(c @ sol["x"] - ref.fun) < 1e-5 * (1 + abs(ref.fun))
+
+
+def test_sdpa_roundtrip(tmp_path):
+    from smcp_amd import base
+    P = base.band_SDP(12, 4, 2, seed=3)
+    fn = tmp_path / "p.dat-s"
+    P.write_sdpa(str(fn))
+    Q = base.SDP(str(fn))
+    assert Q.n == P.n and Q.m == P.m
+    assert abs(sp.csc_matrix(Q.A) - sp.csc_matrix(P.A)).max() < 1e-14
+    assert np.allclose(Q.b, P.b)
+    assert base.sdpa_readhead(str(fn)) == (12, 4, [12])

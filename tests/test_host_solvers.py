@@ -1,0 +1,107 @@
+"""Host logic of the interior-point drivers and front ends with the CPU oracle as the compute
+backend (tests/oracle_backend.py), so that it runs in the ``-m "not gpu"`` suite.  The same
+problems run on the HIP path in tests/test_gpu_solvers.py."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from smcp_amd import base, solvers
+from tests.oracle_backend import oracle_backend
+
+
+@pytest.fixture(autouse=True)
+def _quiet():
+    saved = dict(solvers.options)
+    solvers.options.update(show_progress=False, maxiters=100)
+    yield
+    solvers.options.clear()
+    solvers.options.update(saved)
+
+
+def test_feas_band_matches_reference_behaviour():
+    P = base.band_SDP(60, 20, 3, seed=1)
+    ps = {"x": sp.csc_matrix(np.tril(P._X0))}
+    ds = {"y": P._y0, "s": sp.csc_matrix(np.tril(P._S0))}
+    with oracle_backend():
+        sp_ = P.solve_feas(scaling="primal", primalstart=ps, dualstart=ds)
+        sd_ = P.solve_feas(scaling="dual", primalstart=ps, dualstart=ds)
+        sn_ = P.solve_feas(scaling="primal")            # start heuristics (solvers.py:722-814)
+    for sol in (sp_, sd_, sn_):
+        assert sol["status"] == "optimal"
+        assert abs(sol["dimacs"][0]) < 1e-12 and abs(sol["dimacs"][2]) < 1e-12 and abs(sol["dimacs"][5]) < 1e-5
+    assert abs(sp_["primal objective"] - sd_["primal objective"]) < 1e-5 * (1 + abs(sp_["primal objective"]))
+    assert abs(sp_["primal objective"] - sn_["primal objective"]) < 1e-5 * (1 + abs(sp_["primal objective"]))
+    # result-dict keys of the reference (solvers.py:1313-1327)
+    for k in ("status", "x", "y", "s", "primal objective", "dual objective", "gap", "relative gap",
+              "primal infeasibility", "dual infeasibility", "iterations", "cputime", "time"):
+        assert k in sp_
+
+
+def test_feas_rejects_infeasible_start():
+    P = base.band_SDP(20, 5, 2, seed=2)
+    with oracle_backend():
+        with pytest.raises(ValueError):
+            P.solve_feas(primalstart={"x": sp.identity(20, format="csc") * -1.0})
+
+
+def test_conelp_reference_example_and_lp():
+    c = np.array([-6., -4., -5.])
+    G = np.array([[16., 7., 24., -8., 8., -1., 0., -1., 0., 0., 7., -5., 1., -5., 1., -7., 1., -7., -4.],
+                  [-14., 2., 7., -13., -18., 3., 0., 0., -1., 0., 3., 13., -6., 13., 12., -10., -6., -10., -28.],
+                  [5., 0., -15., 12., -6., 17., 0., 0., 0., -1., 9., 6., -6., 6., -7., -7., -6., -7., -11.]]).T
+    h = np.array([-3., 5., 12., -2., -14., -13., 10., 0., 0., 0., 68., -30., -19., -30., 99., 23., -19., 23., 10.])
+    with oracle_backend():
+        sol = solvers.conelp(c, G, h, {"l": 2, "q": [4, 4], "s": [3]})
+    assert sol["status"] == "optimal"
+    assert np.allclose(sol["x"], [-1.22, 0.0966, 3.58], atol=5e-3)   # CVXOPT manual optimum
+    assert np.linalg.norm(G @ sol["x"] + sol["s"] - h) < 1e-6 * (1 + np.linalg.norm(h))
+    assert np.linalg.norm(G.T @ sol["z"] + c) < 1e-6 * (1 + np.linalg.norm(c))
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(0)
+    Gl = rng.standard_normal((15, 6))
+    hl = Gl @ rng.standard_normal(6) + rng.random(15) + 0.1
+    cl = -Gl.T @ (rng.random(15) + 0.1)
+    with oracle_backend():
+        sol = solvers.lp(cl, Gl, hl)
+    ref = linprog(cl, A_ub=Gl, b_ub=hl, bounds=[(None, None)] * 6, method="highs")
+    assert sol["status"] == "optimal" and abs(cl @ sol["x"] - ref.fun) < 1e-5 * (1 + abs(ref.fun))
+
+
+def test_infeasibility_certificates():
+    """esd returns certificates (solvers.py:2299-2327).  As in the reference, conelp maps the cone LP
+    onto the DUAL of the SDP pair and does not rename the status (solvers.py:2535-2597), so an
+    infeasible cone LP reports 'dual infeasibility' and an unbounded one 'primal infeasibility'."""
+    with oracle_backend():
+        sol = solvers.lp(np.array([1.0]), np.array([[-1.0], [1.0]]), np.array([-1.0, 0.0]))
+    assert sol["status"] == "dual infeasibility"
+    with oracle_backend():
+        sol = solvers.lp(np.array([-1.0]), np.array([[-1.0]]), np.array([0.0]))   # minimize -x, x >= 0: unbounded
+    assert sol["status"] == "primal infeasibility"
+
+
+def test_options_validation():
+    solvers.options["maxiters"] = 0
+    with oracle_backend():
+        with pytest.raises(ValueError):
+            base.band_SDP(10, 3, 1).solve_esd()
+    solvers.options["maxiters"] = "many"
+    with oracle_backend():
+        with pytest.raises(TypeError):
+            base.band_SDP(10, 3, 1).solve_esd()
+
+
+def test_nonchordal_embedding_maxcut_small():
+    """Config-4-shaped problem at test size: max-cut SDP on a random (non-chordal) graph; the
+    symbolic layer embeds it, the solution is checked by its optimality conditions in dense numpy."""
+    P = base.maxcut_SDP(30, 70, seed=1)
+    assert not P.ischordal
+    with oracle_backend():
+        sol = P.solve_feas(scaling="dual", dualstart={"y": -np.ones(30) * 20.0})
+    assert sol["status"] == "optimal"
+    X = np.asarray(sol["x"].todense())
+    S = np.asarray(sol["s"].todense())
+    C = np.asarray(P.get_A(0).todense())
+    assert np.allclose(np.diag(X), 1.0, atol=1e-7)
+    assert np.linalg.norm(np.diag(sol["y"]) + S - C) < 1e-7 * (1 + np.abs(C).max())
+    assert np.linalg.eigvalsh(S).min() > -1e-8
+    assert abs(np.sum(C * X) - sol["y"].sum()) < 1e-5 * (1 + abs(sol["y"].sum()))
