@@ -265,14 +265,23 @@ def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", 
             dtau = (rbz[4] - dkappa) * t * tau ** 2
         else:
             dtau = rbz[4] - dkappa / (t * kappa ** 2)
-        if scaling == "primal":
-            dS = dX * (-1.0 / t)
-            hess(dS, True)
-            dS += rbz[3]
+        if options.get("esd_ds_from_hessian", True):
+            # the reference's choice (solvers.py:2017-2022, 2082-2086): dS through the inverse Hessian
+            if scaling == "primal":
+                dS = dX * (-1.0 / t)
+                hess(dS, True)
+                dS += rbz[3]
+            else:
+                dS = rbz[3] - dX
+                dS *= t
+                hess(dS, True)
         else:
-            dS = rbz[3] - dX
-            dS *= t
-            hess(dS, True)
+            # dS from the dual-feasibility row of the Newton system (the variant the reference keeps as a
+            # comment at solvers.py:2014-2016): algebraically identical, but it keeps the dual residual
+            # exact to rounding instead of amplifying the error of dX by cond(W) ~ 1/mu^2 near the optimum
+            dS = Aadj(-dy)
+            dS += C * dtau
+            dS -= rbz[1]
         return dy, dX, dtau, dS, dkappa
 
     def newton(sigma):

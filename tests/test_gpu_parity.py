@@ -40,6 +40,7 @@ GPU_PATTERNS = dict(PATTERNS)
 GPU_PATTERNS["arrow_big"] = lambda: problems.block_arrow_pattern(12, 64, 128)
 GPU_PATTERNS["nested_mid"] = lambda: problems.nested_block_arrow_pattern(nsub=2, nmid=6, nleaf_per_mid=8, seed=3)
 GPU_PATTERNS["dense200"] = lambda: problems.band_pattern(200, 199)
+GPU_PATTERNS["diag"] = lambda: problems.band_pattern(15, 0)          # LP case: every clique is 1 x 1
 
 
 def setup(name, seed):
@@ -139,7 +140,7 @@ def test_trsm(name):
         assert rel(Bd.cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("name", ["arrow", "rand2", "nested_mid"])
+@pytest.mark.parametrize("name", ["arrow", "rand2", "nested_mid", "diag"])
 def test_kkt_factor_and_solve(name):
     symb, S, A, msk = setup(name, 7)
     rng = np.random.default_rng(8)
