@@ -51,6 +51,14 @@ def build_workload(name, seed=0):
     return pat, m, density, label
 
 
+def lds_fits(nn, na):
+    """Mirror of mfma_lds_doubles() in csrc/front_mfma.hip: does the working set of a front fit 160 KB of LDS?"""
+    pad = lambda x: x | 1
+    lk, ll, lf = pad(na), pad(nn), pad(nn + na)
+    d = lk * nn + ll * nn + lk * na + lf * nn + ll * nn + lk * nn + lk * nn + ll * nn + lk * na + 256 + 8 + (na + 2) // 2
+    return d * 8 <= 160 * 1024 - 256
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,13 +134,9 @@ def main():
         chk(lib.csp_cholesky(h, L.blkval.data_ptr(), st()), "cholesky")
         Y.blkval.copy_(L.blkval)
         chk(lib.csp_projected_inverse(h, Y.blkval.data_ptr(), st()), "projected_inverse")
-        if world > 1:
-            H.zero_()
-        chk(lib.kkt_schur_columns(h, L.blkval.data_ptr(), Y.blkval.data_ptr(), H.data_ptr(), m, j0, j1, st()),
-            "schur")
-        if world > 1:
-            dist.all_reduce(H)
-        chk(lib.dense_potrf(h, H.data_ptr(), m, m, st()), "potrf")
+        # Schur complement: this rank's columns + one RCCL all-reduce (smcp_amd.kkt.ShardedSchur), then potrf
+        kkt.build_schur(L, Y, dist.group.WORLD if world > 1 else None)
+        kkt._potrf()
         bx.blkval.copy_(bx0)
         by.copy_(by0)
         chk(lib.kkt_solve(h, L.blkval.data_ptr(), Y.blkval.data_ptr(), H.data_ptr(), m, 1.0,
@@ -181,10 +185,25 @@ def main():
         mloc = j1 - j0
         chunks = [min(max_rhs, mloc - c) for c in range(0, mloc, max_rhs)] + [1, 1]
         sweep_bytes = sum(8.0 * (r * (2 * B + 2 * U) + B) for r in chunks)
+        # the LDS-class / HBM-class instantiations of a sweep kernel split the cliques of every level
+        # between them: the bytes of a sweep are apportioned by the cliques each instantiation owns
+        nn_, na_ = symb.clique_sizes()
+        from smcp_amd.symbolic import Symbolic as _S  # noqa: F401
+        lds_ok = np.array([lds_fits(int(a), int(b)) for a, b in zip(nn_, na_)])
+        Bk = ((nn_ + na_) * nn_).astype(np.float64)
+        Uk = (na_ * na_).astype(np.float64)
+        par = symb.snpar
+        Uch = np.zeros(symb.Nsn)
+        np.add.at(Uch, par[par >= 0], Uk[par >= 0])   # update volume a clique reads from its children
+
+        def cls_bytes(mask):
+            return sum(8.0 * (r * (2 * Bk[mask].sum() + Uk[mask].sum() + Uch[mask].sum()) + Bk[mask].sum())
+                       for r in chunks)
+
         alg = {"k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
-               "k_hess_up_mfma": sweep_bytes, "k_hess_down_mfma": sweep_bytes,
-               "k_chol_level": 8.0 * (2 * B + 2 * U), "k_pinv_level": 8.0 * (2 * B + 2 * U),
-               "k_chol_mfma": 8.0 * (2 * B + 2 * U), "k_pinv_mfma": 8.0 * (2 * B + 2 * U)}.get(dom)
+               "k_hess_up_mfma<true>": cls_bytes(lds_ok), "k_hess_down_mfma<true>": cls_bytes(lds_ok),
+               "k_hess_up_mfma<false>": cls_bytes(~lds_ok), "k_hess_down_mfma<false>": cls_bytes(~lds_ok),
+               "k_chol_level": 8.0 * (2 * B + 2 * U), "k_pinv_level": 8.0 * (2 * B + 2 * U)}.get(dom)
         if alg is not None:
             per_launch = alg / dom_launches
             avg_s = 1e-3 * dom_ms / dom_launches

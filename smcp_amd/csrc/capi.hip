@@ -34,6 +34,7 @@ enum {
   KID_factor_yaa, KID_trsm_fwd_level, KID_trsm_bwd_level, KID_amap, KID_aadj, KID_scatter_constraints,
   KID_dense_potrf, KID_dense_potrs, KID_vec_axpby, KID_axpby, KID_reduce_cliques, KID_reduce_final,
   KID_hess_up_mfma, KID_hess_down_mfma, KID_chol_mfma, KID_pinv_mfma, KID_prep_lk,
+  KID_hess_up_mfma_hbm, KID_hess_down_mfma_hbm, KID_chol_mfma_hbm, KID_pinv_mfma_hbm,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -41,7 +42,8 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_level", "k_hess_down_level", "k_hess_down_inv_all", "k_hess_up_inv_level", "k_scale_an",
   "k_factor_yaa", "k_trsm_fwd_level", "k_trsm_bwd_level", "k_amap", "k_aadj", "k_scatter_constraints",
   "k_dense_potrf", "k_dense_potrs", "k_vec_axpby", "k_axpby", "k_reduce_cliques", "k_reduce_final",
-  "k_hess_up_mfma", "k_hess_down_mfma", "k_chol_mfma", "k_pinv_mfma", "k_prep_lk"};
+  "k_hess_up_mfma<true>", "k_hess_down_mfma<true>", "k_chol_mfma<true>", "k_pinv_mfma<true>", "k_prep_lk",
+  "k_hess_up_mfma<false>", "k_hess_down_mfma<false>", "k_chol_mfma<false>", "k_pinv_mfma<false>"};
 
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -201,7 +203,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
       if (lds) launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
-      else launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+      else launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
     });
 }
 void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {
@@ -210,7 +212,7 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
       if (lds) launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
-      else launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+      else launch_lds(c, KID_hess_down_mfma_hbm, k_hess_down_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
     });
 }
 
@@ -435,7 +437,7 @@ int csp_cholesky(csp_ctx* c, double* x, void* stream) {
     for (int64_t l = 0; l < c->S.nlev; ++l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
         if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
-        else launch_lds(c, KID_chol_mfma, k_chol_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
+        else launch_lds(c, KID_chol_mfma_hbm, k_chol_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
       });
   } else
   for_levels_up(c, [&](const int32_t* lev, int cnt) {
@@ -468,7 +470,7 @@ int csp_projected_inverse(csp_ctx* c, double* x, void* stream) {
     for (int64_t l = c->S.nlev - 1; l >= 0; --l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
         if (lds) launch_lds(c, KID_pinv_mfma, k_pinv_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
-        else launch_lds(c, KID_pinv_mfma, k_pinv_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
+        else launch_lds(c, KID_pinv_mfma_hbm, k_pinv_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
       });
   } else
   for_levels_down(c, [&](const int32_t* lev, int cnt) {

@@ -20,13 +20,15 @@ def _np(X):
     return X.blkval.numpy()
 
 
-class OracleKKT:
+class OracleKKT(kkt.ShardedSchur):
+    """Same host-side sharding logic as the product's KKTSystem, compute by the CPU oracle."""
+
     def __init__(self, symb, cptr, cidx, cval, max_rhs=None):
         self.symb = symb
         self.m = len(cptr) - 1
         self.K = orc.KKT(_S(symb), np.asarray(cptr), np.asarray(cidx), np.asarray(cval))
         self.dev = torch.device("cpu")
-        self.H = None
+        self.H = torch.zeros((self.m, self.m), dtype=torch.float64)   # H.T is the column-major matrix
 
     def amap(self, X):
         return torch.from_numpy(self.K.amap(_np(X)))
@@ -34,9 +36,21 @@ class OracleKKT:
     def aadj(self, y):
         return cspmatrix(self.symb, torch.from_numpy(self.K.aadj(y.numpy())))
 
-    def factor(self, L, Y):
-        H = self.K.schur_factor(_np(L), _np(Y))
-        self.H = H
+    def _columns(self, L, Y, j0, j1):
+        for j in range(j0, j1):
+            u = self.K.constraint(j)
+            orc.hessian(self.K.S, _np(L), _np(Y), u, adj=None, inv=False)
+            self.H[j, :] = torch.from_numpy(self.K.amap(u))
+
+    def _potrf(self):
+        Hf = np.asfortranarray(self.H.numpy().T)
+        orc.dense_potrf(Hf)
+        self.H.copy_(torch.from_numpy(np.ascontiguousarray(Hf.T)))
+
+    def factor(self, L, Y, group=None):
+        self.build_schur(L, Y, group)
+        self._potrf()
+        H = np.asfortranarray(self.H.numpy().T)
 
         def solve_(bx, by, kk):
             x, y = self.K.solve(_np(L), _np(Y), H, _np(bx).copy(), by.numpy().copy(), kk)
