@@ -35,6 +35,7 @@ enum {
   KID_dense_potrf, KID_dense_potrs, KID_vec_axpby, KID_axpby, KID_reduce_cliques, KID_reduce_final,
   KID_hess_up_mfma, KID_hess_down_mfma, KID_chol_mfma, KID_pinv_mfma, KID_prep_lk,
   KID_hess_up_mfma_hbm, KID_hess_down_mfma_hbm, KID_chol_mfma_hbm, KID_pinv_mfma_hbm,
+  KID_gram_partial, KID_gram_reduce, KID_hess_up_pad,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -43,7 +44,8 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_factor_yaa", "k_trsm_fwd_level", "k_trsm_bwd_level", "k_amap", "k_aadj", "k_scatter_constraints",
   "k_dense_potrf", "k_dense_potrs", "k_vec_axpby", "k_axpby", "k_reduce_cliques", "k_reduce_final",
   "k_hess_up_mfma<true>", "k_hess_down_mfma<true>", "k_chol_mfma<true>", "k_pinv_mfma<true>", "k_prep_lk",
-  "k_hess_up_mfma<false>", "k_hess_down_mfma<false>", "k_chol_mfma<false>", "k_pinv_mfma<false>"};
+  "k_hess_up_mfma<false>", "k_hess_down_mfma<false>", "k_chol_mfma<false>", "k_pinv_mfma<false>",
+  "k_gram_partial", "k_gram_reduce", "k_hess_up_pad"};
 
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -95,6 +97,10 @@ TreeArgs tree_args(csp_ctx* c) {
   a.upd = c->D.upd;
   a.tmp = c->D.tmp;
   a.info = c->D.info;
+  a.gp_tptr = c->D.gp_tptr;
+  a.gp_tgt = c->D.gp_tgt;
+  a.gp_cptr = c->D.gp_cptr;
+  a.gp_src = c->D.gp_src;
   return a;
 }
 
@@ -202,8 +208,15 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
   for (int64_t l = 0; l < c->S.nlev; ++l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
-      if (lds) launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
-      else launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+      if (lds) {
+        static int oldk = -1;
+        if (oldk < 0) { const char* e = getenv("SMCP_OLDLDS"); oldk = (e && e[0] == '1') ? 1 : 0; }
+        size_t pbytes = (size_t)pad_layout(a.nnmax, a.namax).total * sizeof(double);
+        if (!oldk && pbytes <= LDS_LIMIT)
+          launch_lds(c, KID_hess_up_pad, k_hess_up_pad, dim3(cnt, g), dim3(pbytes > 48 * 1024 ? 512 : 256), pbytes, st, a, U, ldu);
+        else
+          launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+      } else launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
     });
 }
 void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {
@@ -281,7 +294,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
     for (void* p : ptrs) if (p) hipFree(p);
     if (D.info_host) hipHostFree(D.info_host);
@@ -396,11 +409,48 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     if ((rc = dev_upload(&D.chidx, ch, D.bytes))) return rc;
     if ((rc = dev_upload(&D.levidx, lev, D.bytes))) return rc;
     if ((rc = dev_upload(&D.lev2idx, lev2, D.bytes))) return rc;
+    // ---- gather plans for the extend-add
+    if (S.updlen() < (int64_t)1 << 31) {
+      std::vector<int64_t> tptr(S.nsn + 1, 0), cptr;
+      std::vector<int32_t> tgt, src;
+      cptr.push_back(0);
+      std::vector<std::pair<int32_t, int32_t>> pr;  // (target code, src offset)
+      for (int64_t k = 0; k < S.nsn; ++k) {
+        pr.clear();
+        const int64_t nnp = S.nn(k);
+        for (int64_t q = S.chptr[k]; q < S.chptr[k + 1]; ++q) {
+          const int64_t cc = S.chidx[q], nac = S.na(cc);
+          const int32_t* rel = &S.relidx[S.sepptr[cc]];
+          for (int64_t j = 0; j < nac; ++j)
+            for (int64_t i = j; i < nac; ++i) {
+              int32_t ri = rel[i], rj = rel[j];
+              int32_t code = rj < nnp ? (ri | (rj << 15)) : ((1 << 30) | (ri - (int32_t)nnp) | ((rj - (int32_t)nnp) << 15));
+              pr.emplace_back(code, (int32_t)(S.updptr[cc] + i + j * nac));
+            }
+        }
+        std::sort(pr.begin(), pr.end());
+        for (size_t e = 0; e < pr.size(); ++e) {
+          if (e == 0 || pr[e].first != pr[e - 1].first) {
+            if (e) cptr.push_back((int64_t)src.size());
+            tgt.push_back(pr[e].first);
+          }
+          src.push_back(pr[e].second);
+        }
+        if (!pr.empty()) cptr.push_back((int64_t)src.size());
+        tptr[k + 1] = (int64_t)tgt.size();
+      }
+      // cptr has one entry per target plus the leading 0: make it ntargets+1 long
+      if ((rc = dev_upload(&D.gp_tptr, tptr, D.bytes))) return rc;
+      if ((rc = dev_upload(&D.gp_tgt, tgt, D.bytes))) return rc;
+      if ((rc = dev_upload(&D.gp_cptr, cptr, D.bytes))) return rc;
+      if ((rc = dev_upload(&D.gp_src, src, D.bytes))) return rc;
+    }
     if ((rc = dev_alloc(&D.lk, S.blklen(), D.bytes))) return rc;
     HIPCHK(hipMemset(D.lk, 0, sizeof(double) * std::max<int64_t>(S.blklen(), 1)));
     {
       const int mx = 160 * 1024;
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_pad, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_chol_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_pinv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));

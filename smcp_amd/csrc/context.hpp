@@ -32,6 +32,13 @@ struct DeviceCtx {
   int32_t* chidx = nullptr;
   int32_t* levidx = nullptr;  // cliques sorted by level
   int32_t* lev2idx = nullptr; // per level: LDS-class cliques first, then HBM-class
+  // extend-add gather plans (deterministic, atomic-free): per clique with children, the list of
+  // front positions that receive contributions and, per position, the update-workspace offsets
+  // of the children's entries that map onto it
+  int64_t* gp_tptr = nullptr;  // nsn+1 : first target of clique k
+  int32_t* gp_tgt = nullptr;   // target code: bit 30 = update-matrix block, i | j << 15
+  int64_t* gp_cptr = nullptr;  // ntargets+1 : first contribution of target t
+  int32_t* gp_src = nullptr;   // offset of the contributing entry in the (per right-hand side) update workspace
   double* lk = nullptr;       // inverse-form factor [L_NN^-1; L_AN L_NN^-1] of the most recent prep
   // workspaces
   double* upd = nullptr;   // max_rhs * updlen : update matrices
@@ -54,7 +61,11 @@ struct DeviceCtx {
   int64_t* rptr = nullptr;   // rnnz+1
   int32_t* rcon = nullptr;   // constraint index per entry
   double* rval = nullptr;
-  double* ustack = nullptr;  // m * blklen : constraint matrices swept by the Hessian
+  double* ustack = nullptr;  // max(m, max_rhs) * blklen : constraint matrices swept by the Hessian
+  int64_t ustack_cols = 0;
+  double* sw = nullptr;      // blklen : sqrt of the inner-product weights (Gram path)
+  double* gpart = nullptr;   // partial Gram tiles
+  int64_t gpart_len = 0;
   int64_t bytes = 0;
 };
 

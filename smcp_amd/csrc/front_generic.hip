@@ -25,6 +25,11 @@ struct TreeArgs {
   double* upd;
   double* tmp;
   int* info;
+  // extend-add gather plan (null = not available)
+  const int64_t* gp_tptr;
+  const int32_t* gp_tgt;
+  const int64_t* gp_cptr;
+  const int32_t* gp_src;
 };
 
 // ---- extend-add / gather -------------------------------------------------------------

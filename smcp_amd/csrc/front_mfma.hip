@@ -34,13 +34,21 @@ __device__ inline void wg_mma(int M, int N, int Kd, FA A, FB B, FC store, bool l
     if (lower_only && tm < tn) continue;
     const int m = tm * 16 + l15, nb = tn * 16 + l15;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int k0 = 0; k0 < Kd; k0 += 4) {
-      const int k = k0 + kq;
-      const bool kin = k < Kd;
-      double av = (kin && m < M) ? A(m, k) : 0.0;
-      double bv = (kin && nb < N) ? B(k, nb) : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);
+    // operands of KU k-steps are fetched before the KU MFMAs are issued, so the loads of a batch
+    // overlap instead of each MFMA waiting for its own pair of loads
+    constexpr int KU = 2;
+    for (int k0 = 0; k0 < Kd; k0 += 4 * KU) {
+      double av[KU], bv[KU];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int k = k0 + 4 * u + kq;
+        const bool kin = k < Kd;
+        av[u] = (kin && m < M) ? A(m, k) : 0.0;
+        bv[u] = (kin && nb < N) ? B(k, nb) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u)
+        if (k0 + 4 * u < Kd) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[u], av[u], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -169,11 +177,43 @@ __device__ inline double yacc(const double* Y, int ld, int mode, int m, int k) {
 // One wave per child, all children in flight at once; collisions between children are resolved
 // by hardware fp64 atomic adds (ds_add_f64 / global_atomic_add_f64), so the summation order --
 // and with it the last bit -- may differ between runs.  One barrier at the end.
+
+// Atomic-free, deterministic extend-add: every front position that receives contributions is owned
+// by one thread, which sums the children's entries in a fixed order (plan built at device_init).
+// add(code, value) applies the sum to the front (code: bit 30 = update block, i | j << 15).
+template <class AddF>
+__device__ inline void gather_children_plan(const TreeArgs& t, int k, const double* updbase, AddF add) {
+  const int64_t t0 = t.gp_tptr[k], t1 = t.gp_tptr[k + 1];
+  for (int64_t tt = t0 + threadIdx.x; tt < t1; tt += blockDim.x) {
+    const int32_t code = t.gp_tgt[tt];
+    const int64_t c0 = t.gp_cptr[tt], c1 = t.gp_cptr[tt + 1];
+    double acc = 0.0;
+    int64_t cc = c0;
+    for (; cc + 4 <= c1; cc += 4) {
+      const int32_t s0 = t.gp_src[cc], s1 = t.gp_src[cc + 1], s2 = t.gp_src[cc + 2], s3 = t.gp_src[cc + 3];
+      const double v0 = updbase[s0], v1 = updbase[s1], v2 = updbase[s2], v3 = updbase[s3];
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; cc < c1; ++cc) acc += updbase[t.gp_src[cc]];
+    add(code, acc);
+  }
+}
+
 struct ChildEntry { double v; int ri, rj; };
 __device__ inline void add_children_front(const TreeArgs& t, const CliqueDesc& d, const double* updbase,
-                                          double* F, int ldf, double* U, int ldu, double sp, double su) {
+                                          double* F, int ldf, double* U, int ldu, double sp, double su,
+                                          int dbg = 0) {
   const int nn = d.nn;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (t.gp_tptr && d.chend > d.chbeg) {
+    const int kk = t.cl[t.chidx[d.chbeg]].parent;   // this clique's own id
+    gather_children_plan(t, kk, updbase, [=](int32_t code, double v) {
+      const int i = code & 0x7fff, j = (code >> 15) & 0x7fff;
+      if (code & (1 << 30)) U[i + j * ldu] += su * v; else F[i + j * ldf] += sp * v;
+    });
+    __syncthreads();
+    return;
+  }
   for (int q = d.chbeg + wave; q < d.chend; q += nw) {
     const CliqueDesc c = t.cl[t.chidx[q]];
     const int nac = c.na;
@@ -184,11 +224,12 @@ __device__ inline void add_children_front(const TreeArgs& t, const CliqueDesc& d
         ChildEntry x;
         int i = e % nac, j = e / nac;
         x.ri = -1; x.rj = 0; x.v = 0.0;
-        if (i >= j) { x.ri = rel[i]; x.rj = rel[j]; x.v = Uc[e]; }
+        if (i >= j) { x.ri = rel[i]; x.rj = rel[j]; x.v = (dbg & 16) ? 1.0 : Uc[e]; }
         return x;
       },
       [=](int e, const ChildEntry& x) {
         if (x.ri < 0) return;
+        if (dbg & 8) { if (x.v == 123.456) F[0] = x.v; return; }
         if (x.rj < nn) unsafeAtomicAdd(&F[x.ri + x.rj * ldf], sp * x.v);
         else unsafeAtomicAdd(&U[(x.ri - nn) + (x.rj - nn) * ldu], su * x.v);
       });
@@ -309,7 +350,7 @@ __global__ void k_hess_up_mfma(MfmaArgs a, double* u, int64_t ldu) {
       for (int e = threadIdx.x; e < na * na; e += blockDim.x) UkG[e] = 0.0;
     }
     __syncthreads();
-    if (!(a.skip & 1)) add_children_front(a.t, d, ub, w.F, w.ldf, w.U, w.ldu, 1.0, 1.0);
+    if (!(a.skip & 1)) add_children_front(a.t, d, ub, w.F, w.ldf, w.U, w.ldu, 1.0, 1.0, a.skip);
     const Work v = w;
     if (!(a.skip & 2)) {
     // phase 1: E = F_AN - K Fnn / 2 ; T = Li Fnn
@@ -587,6 +628,341 @@ __global__ void k_pinv_mfma(MfmaArgs a, double* x) {
   for (int e = threadIdx.x; e < na * nn; e += blockDim.x) {
     int i = e % na, j = e / na;
     P[nn + i + (int64_t)j * nf] = -v.E[i + j * v.lde];
+  }
+}
+
+
+
+// ------------------------------------------------------------------ padded-LDS fast kernels
+// Every LDS matrix is padded to multiples of 16 rows / columns with zero fill, so the MFMA loops
+// need no bounds checks or branches: each k-step is two ds_read_b64, two pointer bumps, one MFMA.
+struct PadL {
+  int NN, NA, ldn, lda;
+  int oK, oLi, oY, oFnn, oFan, oE, oG, oT, oU, oInt, total;
+};
+__host__ __device__ inline PadL pad_layout(int nnmax, int namax) {
+  PadL L;
+  L.NN = (nnmax + 15) & ~15;
+  L.NA = (namax + 15) & ~15;
+  L.ldn = L.NN + 1;
+  L.lda = L.NA + 1;
+  int o = 0;
+  L.oK = o; o += L.lda * L.NN;
+  L.oLi = o; o += L.ldn * L.NN;
+  L.oY = o; o += L.lda * L.NA;
+  L.oFnn = o; o += L.ldn * L.NN;
+  L.oFan = o; o += L.lda * L.NN;
+  L.oE = o; o += L.lda * L.NN;
+  L.oG = o; o += L.lda * L.NN;
+  L.oT = o; o += L.ldn * L.NN;
+  L.oU = o; o += L.lda * L.NA;
+  L.oInt = o; o += (namax + 2) / 2;
+  L.total = o + 2;
+  return L;
+}
+
+// acc += sum over ks k-steps; pa / pb: this lane's operand addresses for k-step 0, sa / sb: bump per k-step
+__device__ inline void mma_run(d4& acc, const double* pa, int sa, const double* pb, int sb, int ks) {
+#pragma unroll 4
+  for (int s = 0; s < ks; ++s) {
+    const double av = *pa, bv = *pb;
+    pa += sa;
+    pb += sb;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);
+  }
+}
+
+__global__ void k_hess_up_pad(MfmaArgs a, double* u, int64_t ldu) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  const PadL L = pad_layout(a.nnmax, a.namax);
+  double* const sK = smem + L.oK;
+  double* const sLi = smem + L.oLi;
+  double* const sY = smem + L.oY;
+  double* const sFnn = smem + L.oFnn;
+  double* const sFan = smem + L.oFan;
+  double* const sE = smem + L.oE;
+  double* const sG = smem + L.oG;
+  double* const sT = smem + L.oT;
+  double* const sU = smem + L.oU;
+  const int ldn = L.ldn, lda = L.lda;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int ymode = a.ymode;
+  // zero everything once (pads must stay zero), then load the clique constants
+  for (int e = tid; e < L.total; e += nthr) smem[e] = 0.0;
+  __syncthreads();
+  {
+    const double* src = a.LK + d.blk;
+    batched_loop<8>(tid, nf * nn, nthr, [=](int e) { return src[e]; },
+                    [=](int e, double v) {
+                      int i = e % nf, j = e / nf;
+                      if (i < nn) sLi[i + j * ldn] = v; else sK[(i - nn) + j * lda] = v;
+                    });
+    if (ymode) {
+      const double* ys = a.ysc + d.upd;
+      batched_loop<8>(tid, na * na, nthr, [=](int e) { return (e % na) >= (e / na) ? ys[e] : 0.0; },
+                      [=](int e, double v) {
+                        int i = e % na, j = e / na;
+                        if (i < j) return;
+                        if (ymode == 1) { sY[i + j * lda] = v; sY[j + i * lda] = v; }
+                        else if (ymode == 2) sY[j + i * lda] = v;     // R^T
+                        else sY[i + j * lda] = v;                       // R
+                      });
+    }
+  }
+  const int NAt = L.NA >> 4, NNt = L.NN >> 4;
+  const int ksn = (nn + 3) >> 2, ksa = (na + 3) >> 2;
+  for (int r = blockIdx.y; r < a.nrhs; r += gridDim.y) {
+    double* P = u + (int64_t)r * ldu + d.blk;
+    const double* ub = a.t.upd + (int64_t)r * a.t.updlen;
+    double* UkG = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+    __syncthreads();
+    // ---- assemble the front: panel (NN block mirrored to full symmetric) + children
+    batched_loop<8>(tid, nf * nn, nthr, [=](int e) { return P[e]; },
+                    [=](int e, double v) {
+                      int i = e % nf, j = e / nf;
+                      if (i >= nn) sFan[(i - nn) + j * lda] = v;
+                      else if (i >= j) { sFnn[i + j * ldn] = v; sFnn[j + i * ldn] = v; }
+                    });
+    for (int e = tid; e < na * na; e += nthr) sU[(e % na) + (e / na) * lda] = 0.0;
+    __syncthreads();
+    if (a.t.gp_tptr && (a.skip & 32)) {   // LDS class: the per-child atomic version is faster (plan loads are latency-bound)
+      gather_children_plan(a.t, k, ub, [=](int32_t code, double v) {
+        const int i = code & 0x7fff, j = (code >> 15) & 0x7fff;
+        if (code & (1 << 30)) sU[i + j * lda] += v;
+        else if (i >= nn) sFan[(i - nn) + j * lda] += v;
+        else { sFnn[i + j * ldn] += v; if (i != j) sFnn[j + i * ldn] += v; }
+      });
+    } else
+    for (int q = d.chbeg + wave; q < d.chend; q += nw) {
+      const CliqueDesc c = a.t.cl[a.t.chidx[q]];
+      const int nac = c.na;
+      const int32_t* rel = a.t.relidx + c.rel;
+      const double* Uc = ub + c.upd;
+      batched_loop<16>(lane, nac * nac, 64,
+        [=](int e) {
+          ChildEntry x;
+          int i = e % nac, j = e / nac;
+          x.ri = -1; x.rj = 0; x.v = 0.0;
+          if (i >= j) { x.ri = rel[i]; x.rj = rel[j]; x.v = Uc[e]; }
+          return x;
+        },
+        [=](int e, const ChildEntry& x) {
+          if (x.ri < 0) return;
+          if (x.rj >= nn) unsafeAtomicAdd(&sU[(x.ri - nn) + (x.rj - nn) * lda], x.v);
+          else if (x.ri >= nn) unsafeAtomicAdd(&sFan[(x.ri - nn) + x.rj * lda], x.v);
+          else {
+            unsafeAtomicAdd(&sFnn[x.ri + x.rj * ldn], x.v);
+            if (x.ri != x.rj) unsafeAtomicAdd(&sFnn[x.rj + x.ri * ldn], x.v);
+          }
+        });
+    }
+    __syncthreads();
+    // ---- phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place of F_AN) ; T = Li F_NN
+    {
+      const int nE = NAt * NNt, nT = NNt * NNt;
+      for (int t = wave; t < nE + nT; t += nw) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (t < nE) {
+          const int tm = t % NAt, tn = t / NAt;
+          mma_run(acc, sK + tm * 16 + l15 + kq * lda, 4 * lda, sFnn + kq + (tn * 16 + l15) * ldn, 4, ksn);
+          const int m = tm * 16 + l15;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int n = tn * 16 + kq + 4 * rr;
+            const double f = sFan[m + n * lda];
+            sE[m + n * lda] = f - 0.5 * acc[rr];
+            sFan[m + n * lda] = f - acc[rr];
+          }
+        } else {
+          const int tt = t - nE, tm = tt % NNt, tn = tt / NNt;
+          mma_run(acc, sLi + tm * 16 + l15 + kq * ldn, 4 * ldn, sFnn + kq + (tn * 16 + l15) * ldn, 4, ksn);
+          const int m = tm * 16 + l15;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) sT[m + (tn * 16 + kq + 4 * rr) * ldn] = acc[rr];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: U -= K E^T + E K^T (lower tiles) ; G = X Li^T ; G_NN = T Li^T (into sFnn)
+    {
+      const int nU = NAt * (NAt + 1) / 2, nG = NAt * NNt, nN = NNt * NNt;
+      for (int t = wave; t < nU + nG + nN; t += nw) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (t < nU) {
+          int tm = 0, rem = t;
+          while (rem > tm) { rem -= tm + 1; ++tm; }
+          const int tn = rem;
+          mma_run(acc, sK + tm * 16 + l15 + kq * lda, 4 * lda, sE + tn * 16 + l15 + kq * lda, 4 * lda, ksn);
+          mma_run(acc, sE + tm * 16 + l15 + kq * lda, 4 * lda, sK + tn * 16 + l15 + kq * lda, 4 * lda, ksn);
+          const int m = tm * 16 + l15;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int n = tn * 16 + kq + 4 * rr;
+            if (m >= n) sU[m + n * lda] -= acc[rr];
+          }
+        } else if (t < nU + nG) {
+          const int tt = t - nU, tm = tt % NAt, tn = tt / NAt;
+          mma_run(acc, sFan + tm * 16 + l15 + kq * lda, 4 * lda, sLi + tn * 16 + l15 + kq * ldn, 4 * ldn, ksn);
+          const int m = tm * 16 + l15;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) sG[m + (tn * 16 + kq + 4 * rr) * lda] = acc[rr];
+        } else {
+          const int tt = t - nU - nG, tm = tt % NNt, tn = tt / NNt;
+          mma_run(acc, sT + tm * 16 + l15 + kq * ldn, 4 * ldn, sLi + tn * 16 + l15 + kq * ldn, 4 * ldn, ksn);
+          const int m = tm * 16 + l15;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) sFnn[m + (tn * 16 + kq + 4 * rr) * ldn] = acc[rr];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: Q = Ysc G into the F_AN buffer (X is dead), or plain G
+    {
+      const int nQ = NAt * NNt;
+      for (int t = wave; t < nQ; t += nw) {
+        const int tm = t % NAt, tn = t / NAt;
+        const int m = tm * 16 + l15;
+        if (ymode) {
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+          mma_run(acc, sY + m + kq * lda, 4 * lda, sG + kq + (tn * 16 + l15) * lda, 4, ksa);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) sFan[m + (tn * 16 + kq + 4 * rr) * lda] = acc[rr];
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int n = tn * 16 + kq + 4 * rr;
+            sFan[m + n * lda] = sG[m + n * lda];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- write out: panel (lower of NN + AN) and the update matrix (lower)
+    for (int e = tid; e < nf * nn; e += nthr) {
+      int i = e % nf, j = e / nf;
+      if (i >= nn) P[e] = sFan[(i - nn) + j * lda];
+      else if (i >= j) P[e] = sFnn[i + j * ldn];
+    }
+    for (int e = tid; e < na * na; e += nthr) {
+      int i = e % na, j = e / na;
+      if (i >= j) UkG[e] = sU[i + j * lda];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Gram matrix  H = G^T W G
+// G: the m swept constraint matrices (column r at G + r*ldg, length len), W = diag(w) with the
+// cspmatrix inner-product weights (1 diagonal, 2 off-diagonal lower, 0 unused upper entries),
+// passed as sw = sqrt(w) so that both MFMA operands are the same LDS image sqrt(w) * G.
+// Grid: (chunks of the long dimension, lower 128x128 blocks of H).  Each workgroup streams its
+// chunk through LDS in slices of 64 entries (coalesced along the contiguous dimension) and keeps
+// its 16x16 output tiles in registers; partial sums go to `partial` and are reduced in a fixed
+// order by k_gram_reduce (deterministic).
+constexpr int GRAM_BLK = 128;   // columns of H per block
+constexpr int GRAM_KS = 64;     // slice of the long dimension staged per step
+constexpr int GRAM_LD = GRAM_BLK + 1;
+
+__global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t ldg, int m, int64_t len,
+                                                      const double* sw, int64_t chunk, double* partial) {
+  __shared__ double sA[GRAM_KS * GRAM_LD];
+  __shared__ double sB[GRAM_KS * GRAM_LD];
+  // block (bi, bj), bi >= bj, from the linear index blockIdx.y
+  int bi = 0, rem = blockIdx.y;
+  while (rem > bi) { rem -= bi + 1; ++bi; }
+  const int bj = rem;
+  const bool diag = bi == bj;
+  const int ci0 = bi * GRAM_BLK, cj0 = bj * GRAM_BLK;
+  const int ni = min(GRAM_BLK, m - ci0), nj = min(GRAM_BLK, m - cj0);
+  const int mti = (ni + 15) >> 4, mtj = (nj + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  // tiles of this block owned by this wave (lower tiles only on diagonal blocks): up to 16 per wave
+  constexpr int MAXT = 16;
+  d4 acc[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+  const int64_t e_begin = (int64_t)blockIdx.x * chunk, e_end = min(len, e_begin + chunk);
+  for (int64_t e0 = e_begin; e0 < e_end; e0 += GRAM_KS) {
+    __syncthreads();
+    // stage sqrt(w) * G[e0 .. e0+64) for the columns of both blocks: one wave instruction = one column
+    {
+      const int64_t e = e0 + lane;
+      const bool ein = e < e_end;
+      const double swe = ein ? sw[e] : 0.0;
+      batched_loop<16>(wave, ni, 4, [=](int c) { return ein ? G[(int64_t)(ci0 + c) * ldg + e] : 0.0; },
+                       [=](int c, double v) { sA[lane * GRAM_LD + c] = v * swe; });
+      if (!diag)
+        batched_loop<16>(wave, nj, 4, [=](int c) { return ein ? G[(int64_t)(cj0 + c) * ldg + e] : 0.0; },
+                         [=](int c, double v) { sB[lane * GRAM_LD + c] = v * swe; });
+    }
+    __syncthreads();
+    const double* pB = diag ? sA : sB;
+    int slot = 0;
+    for (int t = wave; t < mti * mtj; t += 4) {
+      const int tm = t % mti, tn = t / mti;
+      if (diag && tm < tn) continue;
+      const int ia = tm * 16 + l15, jb = tn * 16 + l15;
+      d4 a = acc[slot];
+#pragma unroll
+      for (int k0 = 0; k0 < GRAM_KS; k0 += 4) {
+        double av = (ia < ni) ? sA[(k0 + kq) * GRAM_LD + ia] : 0.0;
+        double bv = (jb < nj) ? pB[(k0 + kq) * GRAM_LD + jb] : 0.0;
+        a = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, a, 0, 0, 0);
+      }
+      acc[slot] = a;
+      ++slot;
+    }
+  }
+  // write partial tiles: layout [blockIdx.y][blockIdx.x][tile][256], tile elements column-major
+  const int ntile = mti * mtj;
+  double* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(64 * 256);
+  int slot = 0;
+  for (int t = wave; t < ntile; t += 4) {
+    const int tm = t % mti, tn = t / mti;
+    if (diag && tm < tn) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(int64_t)t * 256 + (kq + 4 * r) * 16 + l15] = acc[slot][r];
+    ++slot;
+  }
+}
+
+// H (m x m, ld ldh, both triangles) <- sum over chunks of the partial tiles
+__global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* H, int64_t ldh) {
+  int bi = 0, rem = blockIdx.y;
+  while (rem > bi) { rem -= bi + 1; ++bi; }
+  const int bj = rem;
+  const bool diag = bi == bj;
+  const int ci0 = bi * GRAM_BLK, cj0 = bj * GRAM_BLK;
+  const int ni = min(GRAM_BLK, m - ci0), nj = min(GRAM_BLK, m - cj0);
+  const int mti = (ni + 15) >> 4;
+  const int t = blockIdx.x;             // tile within the block
+  const int tm = t % mti, tn = t / mti;
+  if (tn * 16 >= nj || (diag && tm < tn)) return;
+  const int idx = threadIdx.x;          // element within the tile (column-major 16 x 16)
+  const double* p = partial + (int64_t)blockIdx.y * nchunk * (int64_t)(64 * 256) + (int64_t)t * 256 + idx;
+  double s = 0.0;
+  for (int c = 0; c < nchunk; ++c) s += p[(int64_t)c * (64 * 256)];
+  const int i = ci0 + tm * 16 + (idx & 15), j = cj0 + tn * 16 + (idx >> 4);
+  if (i < ci0 + ni && j < cj0 + nj) {
+    H[i + (int64_t)j * ldh] = s;
+    H[j + (int64_t)i * ldh] = s;
+  }
+}
+
+// sw[e] = sqrt(weight of blkval position e) : 1 on the diagonal, sqrt(2) below it, 0 above it
+__global__ void k_fill_sqrt_weights(const CliqueDesc* cl, int nsn, double* sw) {
+  for (int k = blockIdx.x; k < nsn; k += gridDim.x) {
+    const CliqueDesc d = cl[k];
+    const int nn = d.nn, nf = d.nn + d.na;
+    for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
+      int i = e % nf, j = e / nf;
+      sw[d.blk + e] = (i == j) ? 1.0 : (i > j ? 1.4142135623730951 : 0.0);
+    }
   }
 }
 

@@ -128,7 +128,13 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   if ((rc = dev_upload(&D.rptr, rptr, D.bytes))) return rc;
   if ((rc = dev_upload(&D.rcon, rcon, D.bytes))) return rc;
   if ((rc = dev_upload(&D.rval, rval, D.bytes))) return rc;
-  if ((rc = dev_alloc(&D.ustack, D.max_rhs * S.blklen(), D.bytes))) return rc;
+  D.ustack_cols = std::max(D.max_rhs, m);
+  if ((rc = dev_alloc(&D.ustack, D.ustack_cols * S.blklen(), D.bytes))) return rc;
+  if (!D.sw) {
+    if ((rc = dev_alloc(&D.sw, S.blklen(), D.bytes))) return rc;
+    hipLaunchKernelGGL(k_fill_sqrt_weights, dim3((unsigned)std::min<int64_t>(S.nsn, 4096)), dim3(256), 0, 0, D.cl, (int)S.nsn, D.sw);
+    HIPCHK(hipDeviceSynchronize());
+  }
   D.m = m;
   D.cnnz = nnz;
   D.rnnz = (int64_t)rpos.size();
@@ -167,6 +173,47 @@ int dense_potrs(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, 
   return 0;
 }
 
+static bool use_gram() {
+  static int g = -1;
+  if (g < 0) { const char* e = getenv("SMCP_GRAM"); g = (e && e[0] == '0') ? 0 : 1; }
+  return g == 1 && !use_generic();
+}
+
+// Gram formulation of the whole Schur complement (what kkt_qr implies, solvers.py:414-420):
+// H = G(A)^T G(A) with ONE leaves->root sweep per constraint, then one tall-skinny SYRK.
+static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  const int64_t m = D.m, bl = c->S.blklen();
+  prepare_yaa(c, Y, true, st);
+  prep_lk(c, L, st);
+  HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * m * bl, st));
+  for (int64_t jb = 0; jb < m; jb += 65535)
+    launch(c, KID_scatter_constraints, k_scatter_constraints, dim3(8, (unsigned)std::min<int64_t>(65535, m - jb)),
+           dim3(256), st, jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
+  for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
+    int nr = (int)std::min(D.max_rhs, m - jb);
+    hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st);     // G(A_j) = (G_NN, R^T G_AN)
+  }
+  // chunking of the long dimension: ~1.5k workgroups per block column
+  int64_t chunk = std::max<int64_t>(2048, ((bl / 1536 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS);
+  int nchunk = (int)((bl + chunk - 1) / chunk);
+  int nb = (int)((m + GRAM_BLK - 1) / GRAM_BLK);
+  int nblk = nb * (nb + 1) / 2;
+  int64_t need = (int64_t)nblk * nchunk * 64 * 256;
+  if (D.gpart_len < need) {
+    if (D.gpart) { HIPCHK(hipFree(D.gpart)); D.bytes -= D.gpart_len * 8; }
+    D.gpart = nullptr;
+    if (int rc = dev_alloc(&D.gpart, need, D.bytes)) return rc;
+    D.gpart_len = need;
+  }
+  launch(c, KID_gram_partial, k_gram_partial, dim3(nchunk, nblk), dim3(256), st, (const double*)D.ustack, bl, (int)m, bl,
+         (const double*)D.sw, chunk, D.gpart);
+  launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
+  HIPCHK(hipGetLastError());
+  if (int f = fetch_info(c, st)) return f;   // chol(Y_AA) failure
+  return 0;
+}
+
 int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, int64_t j0,
                       int64_t j1, void* stream) {
   if (int rc = ready(c)) return rc;
@@ -174,6 +221,7 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
   const int64_t m = D.m, bl = c->S.blklen();
   if (!m || ldh < m || j0 < 0 || j1 > m || j0 > j1) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (j0 == 0 && j1 == m && use_gram()) return schur_gram(c, L, Y, H, ldh, st);
   prepare_yaa(c, Y, false, st);
   if (!use_generic()) prep_lk(c, L, st);
   for (int64_t jb = j0; jb < j1; jb += D.max_rhs) {
