@@ -13,6 +13,7 @@
 #include "context.hpp"
 #include "front_generic.hip"
 #include "front_mfma.hip"
+#include "front_large.hip"
 
 using namespace smcp;
 
@@ -36,6 +37,8 @@ enum {
   KID_hess_up_mfma, KID_hess_down_mfma, KID_chol_mfma, KID_pinv_mfma, KID_prep_lk,
   KID_hess_up_mfma_hbm, KID_hess_down_mfma_hbm, KID_chol_mfma_hbm, KID_pinv_mfma_hbm,
   KID_gram_partial, KID_gram_reduce, KID_hess_up_pad,
+  KID_lf_assemble, KID_lf_clear_upd, KID_lf_up1, KID_lf_up2, KID_lf_up3, KID_lf_down1, KID_lf_down2, KID_lf_down3,
+  KID_lf_pinv1, KID_lf_pinv2,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -45,7 +48,9 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_dense_potrf", "k_dense_potrs", "k_vec_axpby", "k_axpby", "k_reduce_cliques", "k_reduce_final",
   "k_hess_up_mfma<true>", "k_hess_down_mfma<true>", "k_chol_mfma<true>", "k_pinv_mfma<true>", "k_prep_lk",
   "k_hess_up_mfma<false>", "k_hess_down_mfma<false>", "k_chol_mfma<false>", "k_pinv_mfma<false>",
-  "k_gram_partial", "k_gram_reduce", "k_hess_up_pad"};
+  "k_gram_partial", "k_gram_reduce", "k_hess_up_pad",
+  "k_lf_assemble", "k_lf_clear_upd", "k_lf_up1", "k_lf_up2", "k_lf_up3", "k_lf_down1", "k_lf_down2", "k_lf_down3",
+  "k_lf_pinv1", "k_lf_pinv2"};
 
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -194,8 +199,45 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f) {
   }
   if (L.nII) {
     a.t.lev = c->D.lev2idx + b + L.nI;
+    a.nnmax = L.nnmaxII;
+    a.namax = L.namaxII;
     f(false, a, (int)L.nII, (size_t)0, 1024);
   }
+}
+
+
+bool use_large() {
+  static int g = -1;
+  if (g < 0) { const char* e = getenv("SMCP_LARGE"); g = (e && e[0] == '0') ? 0 : 1; }
+  return g == 1;
+}
+inline unsigned umax1(int x) { return (unsigned)std::max(1, x); }
+
+void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
+  dim3 blk(256);
+  launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), blk, st, a);
+  if (a.t.gp_tptr) launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), blk, st, a, U, ldu);
+  launch(c, KID_lf_up1, k_lf_up1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
+  launch(c, KID_lf_up2, k_lf_up2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
+  if (a.namax) launch(c, KID_lf_up3, k_lf_up3, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
+}
+void lf_down(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
+  dim3 blk(256);
+  if (a.namax) launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs), dim3(NT), st, a.t, (const double*)U, ldu, a.t.upd);
+  launch(c, KID_lf_down1, k_lf_down1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
+  if (a.namax) launch(c, KID_lf_down2, k_lf_down2, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
+  launch(c, KID_lf_down3, k_lf_down3, dim3(umax1(ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
+}
+void lf_pinv(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) {
+  const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
+  dim3 blk(256);
+  if (a.namax) {
+    launch(c, KID_gather_level, k_gather_level, dim3(cnt, 1), dim3(NT), st, a.t, (const double*)x, (int64_t)0, a.t.upd);
+    launch(c, KID_lf_pinv1, k_lf_pinv1, dim3(umax1(mtA * ntN), cnt, 1), blk, st, a, x);
+  }
+  launch(c, KID_lf_pinv2, k_lf_pinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, 1), blk, st, a, x);
 }
 
 void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
@@ -216,7 +258,8 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
           launch_lds(c, KID_hess_up_pad, k_hess_up_pad, dim3(cnt, g), dim3(pbytes > 48 * 1024 ? 512 : 256), pbytes, st, a, U, ldu);
         else
           launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
-      } else launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+      } else if (use_large() && c->D.gp_tptr) lf_up(c, a, cnt, nrhs, U, ldu, st);
+      else launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
     });
 }
 void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {
@@ -225,6 +268,7 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
       if (lds) launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+      else if (use_large() && ymode == 0) lf_down(c, a, cnt, nrhs, U, ldu, st);
       else launch_lds(c, KID_hess_down_mfma_hbm, k_hess_down_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
     });
 }
@@ -394,12 +438,18 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
               L.nI++;
               L.nnmaxI = std::max<int>(L.nnmaxI, (int)S.nn(k));
               L.namaxI = std::max<int>(L.namaxI, (int)S.na(k));
-            } else L.nII++;
+            } else {
+              L.nII++;
+              L.nnmaxII = std::max<int>(L.nnmaxII, (int)S.nn(k));
+              L.namaxII = std::max<int>(L.namaxII, (int)S.na(k));
+            }
           }
         }
       // the joint maxima may not fit even if every clique does: demote the level's LDS class then
       if (L.nI && (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double) > LDS_LIMIT) {
-        L.nII += L.nI; L.nI = 0; L.nnmaxI = L.namaxI = 0;
+        L.nII += L.nI; L.nI = 0;
+        L.nnmaxII = std::max(L.nnmaxII, L.nnmaxI); L.namaxII = std::max(L.namaxII, L.namaxI);
+        L.nnmaxI = L.namaxI = 0;
       }
     }
     int rc = 0;
@@ -520,6 +570,7 @@ int csp_projected_inverse(csp_ctx* c, double* x, void* stream) {
     for (int64_t l = c->S.nlev - 1; l >= 0; --l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
         if (lds) launch_lds(c, KID_pinv_mfma, k_pinv_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
+        else if (use_large()) lf_pinv(c, am, cnt, x, st);
         else launch_lds(c, KID_pinv_mfma_hbm, k_pinv_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
       });
   } else

@@ -93,6 +93,7 @@ namespace smcp {
 struct LevelClass {
   int64_t nI = 0, nII = 0;     // cliques whose working set fits LDS / does not
   int nnmaxI = 0, namaxI = 0;  // LDS layout sizing for the LDS class
+  int nnmaxII = 0, namaxII = 0;  // tile-grid sizing for the large-front (HBM) class
 };
 }  // namespace smcp
 

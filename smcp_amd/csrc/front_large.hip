@@ -1,0 +1,358 @@
+// Large-front path: fronts whose working set does not fit LDS are processed by PHASE kernels whose
+// grid covers (output tile, clique, right-hand side).  Each workgroup computes one 64x64 output tile
+// with operands staged through LDS in 16-deep slices (coalesced global -> LDS, MFMA from LDS) -- the
+// classic tiled GEMM -- so a single big front (config 2: one 4096 front) spreads over the whole
+// chip and the 192-fronts of config 3 run as batched GEMMs.  Intermediates (E, G, T) live in the
+// per-(clique, rhs) scratch, which stays L2 / Infinity-Cache resident between phases.
+#include <hip/hip_runtime.h>
+
+namespace smcp {
+
+constexpr int LT = 64;    // output tile edge
+constexpr int LKC = 16;   // k slice
+constexpr int LSA = LT + 1, LSB = LKC + 1;
+
+// acc (2x2 MFMA tiles per wave, waves arranged 2x2 over the 64x64 tile) += A[m0.., :] * B[:, n0..]
+// la(m, k) / lb(k, n): element loaders (global memory, any layout / symmetry); out-of-range -> 0.
+template <class LA, class LB>
+__device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0, int n0, LA la, LB lb,
+                                   double* sA, double* sB) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4, wm = wave & 1, wn = wave >> 1;
+  for (int k0 = 0; k0 < Kd; k0 += LKC) {
+    double va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      const int i = e & 63, kk = e >> 6;
+      va[u] = (m0 + i < M && k0 + kk < Kd) ? la(m0 + i, k0 + kk) : 0.0;
+      const int kb = e & 15, j = e >> 4;
+      vb[u] = (n0 + j < N && k0 + kb < Kd) ? lb(k0 + kb, n0 + j) : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      sA[(e & 63) + (e >> 6) * LSA] = va[u];
+      sB[(e & 15) + (e >> 4) * LSB] = vb[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < LKC / 4; ++ks) {
+      const int kk = 4 * ks + kq;
+      const double a0 = sA[(32 * wm + l15) + kk * LSA], a1 = sA[(32 * wm + 16 + l15) + kk * LSA];
+      const double b0 = sB[kk + (32 * wn + l15) * LSB], b1 = sB[kk + (32 * wn + 16 + l15) * LSB];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+    }
+  }
+}
+// visit the accumulator elements of this lane: f(m, n, value)
+template <class F>
+__device__ inline void tile64_foreach(const d4 (&acc)[2][2], int m0, int n0, int M, int N, F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kq = lane >> 4, wm = wave & 1, wn = wave >> 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 32 * wm + 16 * a + l15, n = n0 + 32 * wn + 16 * b + kq + 4 * r;
+        if (m < M && n < N) f(m, n, acc[a][b][r]);
+      }
+}
+__device__ inline void tile64_zero(d4 (&acc)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+}
+__host__ __device__ inline int tiles64(int x) { return (x + LT - 1) / LT; }
+// linear index -> (tm >= tn) lower tile pair
+__device__ inline void lower_pair(int t, int& tm, int& tn) {
+  tm = 0;
+  while (t > tm) { t -= tm + 1; ++tm; }
+  tn = t;
+}
+
+struct LfCtx {   // per-workgroup view of one (clique, rhs) pair
+  int k, nn, na, nf;
+  const double* Li; const double* K;   // ld nf
+  const double* Ys;                    // ld na (lower stored) or null
+  double* P;                           // panel of this rhs (ld nf)
+  double* U;                           // update / separator matrix of this rhs (ld na)
+  double* T; double* E; double* G;     // scratch: nn x nn, na x nn, na x nn
+};
+__device__ inline LfCtx lf_ctx(const MfmaArgs& a, double* u, int64_t ldu) {
+  LfCtx c;
+  c.k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[c.k];
+  const int r = blockIdx.z;
+  c.nn = d.nn; c.na = d.na; c.nf = d.nn + d.na;
+  c.Li = a.LK ? a.LK + d.blk : nullptr;
+  c.K = a.LK ? a.LK + d.blk + d.nn : nullptr;
+  c.Ys = a.ysc ? a.ysc + d.upd : nullptr;
+  c.P = u + (int64_t)r * ldu + d.blk;
+  c.U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+  double* s = a.t.tmp + (int64_t)r * a.t.tmplen + a.t.tmpptr[c.k];
+  c.T = s; s += (int64_t)d.nn * d.nn;
+  c.E = s; s += (int64_t)d.na * d.nn;
+  c.G = s;
+  return c;
+}
+
+// ---- phase 0: zero the update block and add the children (gather plan: one owner per position)
+__global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu) {
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  const int r = blockIdx.z;
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  double* P = u + (int64_t)r * ldu + d.blk;
+  double* ubase = a.t.upd + (int64_t)r * a.t.updlen;
+  double* U = ubase + d.upd;
+  const int64_t t0 = a.t.gp_tptr[k], t1 = a.t.gp_tptr[k + 1];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // positions of U that receive no contribution must read as zero: clear the lower triangle first
+  // (phase-0 launches for one level are preceded by this kernel's own clear pass: see host code)
+  for (int64_t tt = t0 + gid; tt < t1; tt += stride) {
+    const int32_t code = a.t.gp_tgt[tt];
+    const int64_t c0 = a.t.gp_cptr[tt], c1 = a.t.gp_cptr[tt + 1];
+    double acc = 0.0;
+    int64_t cc = c0;
+    for (; cc + 4 <= c1; cc += 4) {
+      const int32_t s0 = a.t.gp_src[cc], s1 = a.t.gp_src[cc + 1], s2 = a.t.gp_src[cc + 2], s3 = a.t.gp_src[cc + 3];
+      const double v0 = ubase[s0], v1 = ubase[s1], v2 = ubase[s2], v3 = ubase[s3];
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; cc < c1; ++cc) acc += ubase[a.t.gp_src[cc]];
+    const int i = code & 0x7fff, j = (code >> 15) & 0x7fff;
+    if (code & (1 << 30)) U[i + (int64_t)j * na] = acc;     // U was cleared: plain store
+    else P[i + (int64_t)j * nf] += acc;
+  }
+}
+__global__ void k_lf_clear_upd(MfmaArgs a) {
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  double* U = a.t.upd + (int64_t)blockIdx.z * a.t.updlen + d.upd;
+  const int64_t len = (int64_t)d.na * d.na;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += (int64_t)gridDim.x * blockDim.x) U[e] = 0.0;
+}
+
+// ---- up-sweep phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place) ; T = Li F_NN
+__global__ void __launch_bounds__(256) k_lf_up1(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int nE = mtA * ntN, nT = ntN * ntN;
+  const int t = blockIdx.x;
+  if (t >= nE + nT) return;
+  const double* P = c.P;
+  auto fsym = [=](int kk, int n) { return kk >= n ? P[kk + (int64_t)n * nf] : P[n + (int64_t)kk * nf]; };
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (t < nE) {
+    const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+    const double* K = c.K;
+    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return K[m + (int64_t)kk * nf]; }, fsym, sA, sB);
+    double* E = c.E; double* Pw = c.P;
+    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) {
+      const double f = Pw[nn + m + (int64_t)n * nf];
+      E[m + (int64_t)n * na] = f - 0.5 * v;
+      Pw[nn + m + (int64_t)n * nf] = f - v;
+    });
+  } else {
+    const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
+    const double* Li = c.Li;
+    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; }, fsym, sA, sB);
+    double* T = c.T;
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
+  }
+}
+// ---- up-sweep phase 2: U -= K E^T + E K^T (lower tiles) ; G = X Li^T ; G_NN = T Li^T (lower, in place)
+__global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int nU = mtA * (mtA + 1) / 2, nG = mtA * ntN, nN = ntN * (ntN + 1) / 2;
+  const int t = blockIdx.x;
+  if (t >= nU + nG + nN) return;
+  const double* K = c.K; const double* E = c.E; const double* Li = c.Li; const double* T = c.T; const double* P = c.P;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (t < nU) {
+    int tm, tn;
+    lower_pair(t, tm, tn);
+    const int m0 = tm * LT, n0 = tn * LT;
+    gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return K[m + (int64_t)kk * nf]; },
+                [=](int kk, int n) { return E[n + (int64_t)kk * na]; }, sA, sB);
+    gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return E[m + (int64_t)kk * na]; },
+                [=](int kk, int n) { return K[n + (int64_t)kk * nf]; }, sA, sB);
+    double* U = c.U;
+    tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) { if (m >= n) U[m + (int64_t)n * na] -= v; });
+  } else if (t < nU + nG) {
+    const int tt = t - nU, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
+    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; },
+                [=](int kk, int n) { return Li[n + (int64_t)kk * nf]; }, sA, sB);
+    double* G = c.G;
+    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { G[m + (int64_t)n * na] = v; });
+  } else {
+    int tm, tn;
+    lower_pair(t - nU - nG, tm, tn);
+    const int m0 = tm * LT, n0 = tn * LT;
+    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return T[m + (int64_t)kk * nn]; },
+                [=](int kk, int n) { return Li[n + (int64_t)kk * nf]; }, sA, sB);
+    double* Pw = c.P;
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
+  }
+}
+// ---- up-sweep phase 3: Q = Ysc G into the AN rows of the panel (X is dead)
+__global__ void __launch_bounds__(256) k_lf_up3(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int t = blockIdx.x;
+  if (t >= mtA * ntN) return;
+  const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+  const double* G = c.G; const double* Y = c.Ys;
+  double* Pw = c.P;
+  const int ymode = a.ymode;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (ymode) {
+    gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return yacc(Y, na, ymode, m, kk); },
+                [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB);
+    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = v; });
+  } else {
+    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = G[m + (int64_t)n * na]; });
+  }
+}
+
+// ---- down-sweep phase 1: QL = Q Li (into E) ; T = G_NN Li        (Q = AN rows of the panel)
+__global__ void __launch_bounds__(256) k_lf_down1(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int nE = mtA * ntN, nT = ntN * ntN;
+  const int t = blockIdx.x;
+  if (t >= nE + nT) return;
+  const double* P = c.P; const double* Li = c.Li;
+  auto li = [=](int kk, int n) { return Li[kk + (int64_t)n * nf]; };
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (t < nE) {
+    const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, li, sA, sB);
+    double* E = c.E;
+    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = v; });
+  } else {
+    const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
+    gemm_tile64(acc, nn, nn, nn, m0, n0,
+                [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : P[kk + (int64_t)m * nf]; }, li, sA, sB);
+    double* T = c.T;
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
+  }
+}
+// ---- down-sweep phase 2: D = QL - Z_AA K / 2 (into G) ; Z_AN = 2D - QL (into the panel)
+__global__ void __launch_bounds__(256) k_lf_down2(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int t = blockIdx.x;
+  if (t >= mtA * ntN) return;
+  const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+  const double* Z = c.U; const double* K = c.K; const double* E = c.E;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64(acc, na, nn, na, m0, n0,
+              [=](int m, int kk) { return m >= kk ? Z[m + (int64_t)kk * na] : Z[kk + (int64_t)m * na]; },
+              [=](int kk, int n) { return K[kk + (int64_t)n * nf]; }, sA, sB);
+  double* G = c.G; double* Pw = c.P;
+  tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) {
+    const double ql = E[m + (int64_t)n * na];
+    const double dd = ql - 0.5 * v;
+    G[m + (int64_t)n * na] = dd;
+    Pw[nn + m + (int64_t)n * nf] = 2.0 * dd - ql;
+  });
+}
+// ---- down-sweep phase 3: Z_NN = Li^T T - K^T D - D^T K (lower tiles, into the panel)
+__global__ void __launch_bounds__(256) k_lf_down3(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int ntN = tiles64(nn);
+  const int t = blockIdx.x;
+  if (t >= ntN * (ntN + 1) / 2) return;
+  int tm, tn;
+  lower_pair(t, tm, tn);
+  const int m0 = tm * LT, n0 = tn * LT;
+  const double* Li = c.Li; const double* K = c.K; const double* T = c.T; const double* D = c.G;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
+              [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB);
+  gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -K[kk + (int64_t)m * nf]; },
+              [=](int kk, int n) { return D[kk + (int64_t)n * na]; }, sA, sB);
+  gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -D[kk + (int64_t)m * na]; },
+              [=](int kk, int n) { return K[kk + (int64_t)n * nf]; }, sA, sB);
+  double* Pw = c.P;
+  tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
+}
+
+// ---- projected inverse, large fronts: E = Y_AA K ; Y_NN = Li^T Li + K^T E (lower) ; Y_AN = -E
+__global__ void __launch_bounds__(256) k_lf_pinv1(MfmaArgs a, double* x) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, x, 0);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int t = blockIdx.x;
+  if (t >= mtA * ntN) return;
+  const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+  const double* Y = c.U; const double* K = c.K;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64(acc, na, nn, na, m0, n0,
+              [=](int m, int kk) { return m >= kk ? Y[m + (int64_t)kk * na] : Y[kk + (int64_t)m * na]; },
+              [=](int kk, int n) { return K[kk + (int64_t)n * nf]; }, sA, sB);
+  double* E = c.E;
+  tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = v; });
+}
+__global__ void __launch_bounds__(256) k_lf_pinv2(MfmaArgs a, double* x) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, x, 0);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int nN = ntN * (ntN + 1) / 2, nA = mtA * ntN;
+  const int t = blockIdx.x;
+  if (t >= nN + nA) return;
+  double* Pw = c.P;
+  const double* E = c.E;
+  if (t < nN) {
+    int tm, tn;
+    lower_pair(t, tm, tn);
+    const int m0 = tm * LT, n0 = tn * LT;
+    const double* Li = c.Li; const double* K = c.K;
+    d4 acc[2][2];
+    tile64_zero(acc);
+    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
+                [=](int kk, int n) { return Li[kk + (int64_t)n * nf]; }, sA, sB);
+    gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return K[kk + (int64_t)m * nf]; },
+                [=](int kk, int n) { return E[kk + (int64_t)n * na]; }, sA, sB);
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
+  } else {
+    const int tt = t - nN, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
+    for (int e = threadIdx.x; e < LT * LT; e += blockDim.x) {
+      const int m = m0 + (e & 63), n = n0 + (e >> 6);
+      if (m < na && n < nn) Pw[nn + m + (int64_t)n * nf] = -E[m + (int64_t)n * na];
+    }
+  }
+}
+
+}  // namespace smcp
