@@ -150,6 +150,7 @@ void gather_all(csp_ctx* c, const double* x, int64_t ldx, int nrhs, double* updb
 
 int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st) {
   TreeArgs a = tree_args(c);
+  c->D.yaa_tag = Y;
   gather_all(c, Y, 0, 1, c->D.yaa, st);
   if (need_fac) {
     launch(c, KID_factor_yaa, k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), st, a, c->D.yaa, c->D.fac);
@@ -175,6 +176,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.ysc = ysc;
   a.ymode = ymode;
   a.nnmax = a.namax = 0;
+  a.nchmax = a.relsum = 0;
   a.nrhs = nrhs;
   { static int sk = -1; if (sk < 0) { const char* e = getenv("SMCP_SKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
   return a;
@@ -194,6 +196,8 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f) {
     a.t.lev = c->D.lev2idx + b;
     a.nnmax = L.nnmaxI;
     a.namax = L.namaxI;
+    a.nchmax = L.nchmaxI;
+    a.relsum = L.relsumI;
     size_t lds = (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double);
     f(true, a, (int)L.nI, lds, lds > 48 * 1024 ? 512 : 256);
   }
@@ -243,6 +247,23 @@ void lf_pinv(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
 void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
   TreeArgs t = tree_args(c);
   launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->S.nsn), dim3(NT), st, t, L, c->D.lk);
+  c->D.lk_tag_L = L;
+  c->D.lk_tag_Y = nullptr;
+}
+// The KKT entry points are called with (L, Y) where either LK was just prepared from this very L,
+// or Y = projected_inverse(L) was produced by csp_projected_inverse (which prepares LK from L
+// before overwriting it).  In both cases the cached LK is still the inverse form of L.
+void prep_lk_cached(csp_ctx* c, const double* L, const double* Y, hipStream_t st) {
+  static int nocache = -1;
+  if (nocache < 0) { const char* e = getenv("SMCP_NOCACHE"); nocache = (e && e[0] == '1') ? 1 : 0; }
+  if (!nocache && ((c->D.lk_tag_L && c->D.lk_tag_L == L) || (c->D.lk_tag_Y && c->D.lk_tag_Y == Y))) return;
+  prep_lk(c, L, st);
+}
+// an in-place operation is about to change the matrix stored at p: forget what was derived from it
+void invalidate_tags(csp_ctx* c, const void* p) {
+  if (c->D.lk_tag_L == p) c->D.lk_tag_L = nullptr;
+  if (c->D.lk_tag_Y == p) c->D.lk_tag_Y = nullptr;
+  if (c->D.yaa_tag == p) c->D.yaa_tag = nullptr;
 }
 
 void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {
@@ -253,7 +274,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
       if (lds) {
         static int oldk = -1;
         if (oldk < 0) { const char* e = getenv("SMCP_OLDLDS"); oldk = (e && e[0] == '1') ? 1 : 0; }
-        size_t pbytes = (size_t)pad_layout(a.nnmax, a.namax).total * sizeof(double);
+        size_t pbytes = (size_t)pad_layout(a.nnmax, a.namax, a.nchmax, a.relsum).total * sizeof(double);
         if (!oldk && pbytes <= LDS_LIMIT)
           launch_lds(c, KID_hess_up_pad, k_hess_up_pad, dim3(cnt, g), dim3(pbytes > 48 * 1024 ? 512 : 256), pbytes, st, a, U, ldu);
         else
@@ -438,6 +459,10 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
               L.nI++;
               L.nnmaxI = std::max<int>(L.nnmaxI, (int)S.nn(k));
               L.namaxI = std::max<int>(L.namaxI, (int)S.na(k));
+              int rs = 0;
+              for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) rs += (int)S.na(S.chidx[q2]);
+              L.relsumI = std::max(L.relsumI, rs);
+              L.nchmaxI = std::max<int>(L.nchmaxI, (int)(S.chptr[k + 1] - S.chptr[k]));
             } else {
               L.nII++;
               L.nnmaxII = std::max<int>(L.nnmaxII, (int)S.nn(k));
@@ -501,6 +526,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       const int mx = 160 * 1024;
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_pad, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_partial, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_chol_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_pinv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
@@ -528,6 +554,7 @@ int64_t csp_device_bytes(const csp_ctx* c) { return c ? c->D.bytes : 0; }
 
 int csp_cholesky(csp_ctx* c, double* x, void* stream) {
   if (int rc = ready(c)) return rc;
+  invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
@@ -550,6 +577,7 @@ int csp_cholesky(csp_ctx* c, double* x, void* stream) {
 
 int csp_llt(csp_ctx* c, double* x, void* stream) {
   if (int rc = ready(c)) return rc;
+  invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
   for_levels_up(c, [&](const int32_t* lev, int cnt) {
@@ -562,10 +590,13 @@ int csp_llt(csp_ctx* c, double* x, void* stream) {
 
 int csp_projected_inverse(csp_ctx* c, double* x, void* stream) {
   if (int rc = ready(c)) return rc;
+  invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
   if (!use_generic()) {
     prep_lk(c, x, st);
+    c->D.lk_tag_L = nullptr;   // x is about to be overwritten by Y: LK stays valid for the pair (L, Y = x)
+    c->D.lk_tag_Y = x;
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
     for (int64_t l = c->S.nlev - 1; l >= 0; --l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
@@ -584,6 +615,7 @@ int csp_projected_inverse(csp_ctx* c, double* x, void* stream) {
 
 int csp_completion(csp_ctx* c, double* x, void* stream) {
   if (int rc = ready(c)) return rc;
+  invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
@@ -599,9 +631,10 @@ int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t
   if (nrhs < 1 || adj < 0 || adj > 2 || (nrhs > 1 && ldu < c->S.blklen())) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   bool need_fac = !(adj == 2 && inv == 0);
+  invalidate_tags(c, U);
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
   prepare_yaa(c, Y, need_fac, st);
-  if (!inv && !use_generic()) prep_lk(c, L, st);
+  if (!inv && !use_generic()) prep_lk_cached(c, L, Y, st);
   for (int64_t r0 = 0; r0 < nrhs; r0 += c->D.max_rhs) {
     int64_t nr = std::min(c->D.max_rhs, nrhs - r0);
     hessian_impl(c, L, U + r0 * ldu, nr, ldu, adj, inv, st);

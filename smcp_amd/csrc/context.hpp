@@ -39,6 +39,11 @@ struct DeviceCtx {
   int32_t* gp_tgt = nullptr;   // target code: bit 30 = update-matrix block, i | j << 15
   int64_t* gp_cptr = nullptr;  // ntargets+1 : first contribution of target t
   int32_t* gp_src = nullptr;   // offset of the contributing entry in the (per right-hand side) update workspace
+  // validity tags of the cached inverse-form factor / Y_AA blocks: the buffers they were derived
+  // from.  Every in-place factor operation on a buffer clears the tags that mention it.
+  const void* lk_tag_L = nullptr;   // LK was prepared from the factor stored at this address ...
+  const void* lk_tag_Y = nullptr;   // ... or from the factor whose projected inverse now lives here
+  const void* yaa_tag = nullptr;    // yaa holds the separator blocks of the matrix at this address
   double* lk = nullptr;       // inverse-form factor [L_NN^-1; L_AN L_NN^-1] of the most recent prep
   // workspaces
   double* upd = nullptr;   // max_rhs * updlen : update matrices
@@ -93,6 +98,7 @@ namespace smcp {
 struct LevelClass {
   int64_t nI = 0, nII = 0;     // cliques whose working set fits LDS / does not
   int nnmaxI = 0, namaxI = 0;  // LDS layout sizing for the LDS class
+  int nchmaxI = 0, relsumI = 0;  // children metadata hoisted into LDS (max #children, max sum of child separator sizes)
   int nnmaxII = 0, namaxII = 0;  // tile-grid sizing for the large-front (HBM) class
 };
 }  // namespace smcp

@@ -84,6 +84,7 @@ struct MfmaArgs {
   int ymode;          // 0 none, 1 symmetric (Y_AA), 2 R^T, 3 R
   int nnmax, namax;   // LDS layout sizing (max over the cliques of this launch)
   int nrhs;
+  int nchmax, relsum;  // LDS sizing for the hoisted children metadata (padded kernels)
   int skip;  // debug-only phase mask (SMCP_SKIP env), 0 in production
 };
 
@@ -640,7 +641,7 @@ struct PadL {
   int NN, NA, ldn, lda;
   int oK, oLi, oY, oFnn, oFan, oE, oG, oT, oU, oInt, total;
 };
-__host__ __device__ inline PadL pad_layout(int nnmax, int namax) {
+__host__ __device__ inline PadL pad_layout(int nnmax, int namax, int nchmax = 0, int relsum = 0) {
   PadL L;
   L.NN = (nnmax + 15) & ~15;
   L.NA = (namax + 15) & ~15;
@@ -656,7 +657,7 @@ __host__ __device__ inline PadL pad_layout(int nnmax, int namax) {
   L.oG = o; o += L.lda * L.NN;
   L.oT = o; o += L.ldn * L.NN;
   L.oU = o; o += L.lda * L.NA;
-  L.oInt = o; o += (namax + 2) / 2;
+  L.oInt = o; o += (4 * nchmax + relsum + 3) / 2;   // children metadata: (upd lo, upd hi, na, rel offset) per child + rel lists
   L.total = o + 2;
   return L;
 }
@@ -672,12 +673,13 @@ __device__ inline void mma_run(d4& acc, const double* pa, int sa, const double* 
   }
 }
 
-__global__ void k_hess_up_pad(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int64_t ldu) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int k = a.t.lev[blockIdx.x];
   const CliqueDesc d = a.t.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
-  const PadL L = pad_layout(a.nnmax, a.namax);
+  const PadL L = pad_layout(a.nnmax, a.namax, a.nchmax, a.relsum);
+  int* const sCh = reinterpret_cast<int*>(smem + L.oInt);
   double* const sK = smem + L.oK;
   double* const sLi = smem + L.oLi;
   double* const sY = smem + L.oY;
@@ -693,8 +695,29 @@ __global__ void k_hess_up_pad(MfmaArgs a, double* u, int64_t ldu) {
   const int l15 = lane & 15, kq = lane >> 4;
   const int ymode = a.ymode;
   // zero everything once (pads must stay zero), then load the clique constants
-  for (int e = tid; e < L.total; e += nthr) smem[e] = 0.0;
+  for (int e = tid; e < L.oInt; e += nthr) smem[e] = 0.0;
+  // children metadata (offset of the child's update block, its size, its relative indices) is the
+  // same for every right-hand side: fetch it once so the per-rhs loop only loads values
+  const int nch = d.chend - d.chbeg;
+  int* const sRel = sCh + 4 * nch;
+  for (int q = tid; q < nch; q += nthr) {
+    const CliqueDesc c = a.t.cl[a.t.chidx[d.chbeg + q]];
+    sCh[4 * q] = (int)(c.upd & 0xffffffff);
+    sCh[4 * q + 1] = (int)(c.upd >> 32);
+    sCh[4 * q + 2] = c.na;
+    sCh[4 * q + 3] = (int)(c.rel - a.t.cl[a.t.chidx[d.chbeg]].rel);   // children are consecutive in relidx? not guaranteed: see below
+  }
   __syncthreads();
+  {
+    // rel offsets: prefix sums of the children's separator sizes (serial, tiny)
+    if (tid == 0) { int off = 0; for (int q = 0; q < nch; ++q) { int n_ = sCh[4 * q + 2]; sCh[4 * q + 3] = off; off += n_; } }
+  }
+  __syncthreads();
+  for (int q = wave; q < nch; q += nw) {
+    const int32_t* rel = a.t.relidx + a.t.cl[a.t.chidx[d.chbeg + q]].rel;
+    const int nac = sCh[4 * q + 2], off = sCh[4 * q + 3];
+    for (int i = lane; i < nac; i += 64) sRel[off + i] = rel[i];
+  }
   {
     const double* src = a.LK + d.blk;
     batched_loop<8>(tid, nf * nn, nthr, [=](int e) { return src[e]; },
@@ -738,26 +761,21 @@ __global__ void k_hess_up_pad(MfmaArgs a, double* u, int64_t ldu) {
         else { sFnn[i + j * ldn] += v; if (i != j) sFnn[j + i * ldn] += v; }
       });
     } else
-    for (int q = d.chbeg + wave; q < d.chend; q += nw) {
-      const CliqueDesc c = a.t.cl[a.t.chidx[q]];
-      const int nac = c.na;
-      const int32_t* rel = a.t.relidx + c.rel;
-      const double* Uc = ub + c.upd;
+    for (int q = wave; q < nch; q += nw) {
+      const int nac = sCh[4 * q + 2];
+      const int* rel = sRel + sCh[4 * q + 3];
+      const double* Uc = ub + (((int64_t)sCh[4 * q + 1] << 32) | (uint32_t)sCh[4 * q]);
       batched_loop<16>(lane, nac * nac, 64,
-        [=](int e) {
-          ChildEntry x;
-          int i = e % nac, j = e / nac;
-          x.ri = -1; x.rj = 0; x.v = 0.0;
-          if (i >= j) { x.ri = rel[i]; x.rj = rel[j]; x.v = Uc[e]; }
-          return x;
-        },
-        [=](int e, const ChildEntry& x) {
-          if (x.ri < 0) return;
-          if (x.rj >= nn) unsafeAtomicAdd(&sU[(x.ri - nn) + (x.rj - nn) * lda], x.v);
-          else if (x.ri >= nn) unsafeAtomicAdd(&sFan[(x.ri - nn) + x.rj * lda], x.v);
+        [=](int e) { return (e % nac) >= (e / nac) ? Uc[e] : 0.0; },
+        [=](int e, double vv) {
+          const int i = e % nac, j = e / nac;
+          if (i < j) return;
+          const int ri = rel[i], rj = rel[j];
+          if (rj >= nn) unsafeAtomicAdd(&sU[(ri - nn) + (rj - nn) * lda], vv);
+          else if (ri >= nn) unsafeAtomicAdd(&sFan[(ri - nn) + rj * lda], vv);
           else {
-            unsafeAtomicAdd(&sFnn[x.ri + x.rj * ldn], x.v);
-            if (x.ri != x.rj) unsafeAtomicAdd(&sFnn[x.rj + x.ri * ldn], x.v);
+            unsafeAtomicAdd(&sFnn[ri + rj * ldn], vv);
+            if (ri != rj) unsafeAtomicAdd(&sFnn[rj + ri * ldn], vv);
           }
         });
     }
@@ -869,8 +887,9 @@ constexpr int GRAM_LD = GRAM_BLK + 1;
 
 __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t ldg, int m, int64_t len,
                                                       const double* sw, int64_t chunk, double* partial) {
-  __shared__ double sA[GRAM_KS * GRAM_LD];
-  __shared__ double sB[GRAM_KS * GRAM_LD];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const sA = smem;
+  double* const sB = smem + GRAM_KS * GRAM_LD;   // only allocated when the launch has off-diagonal blocks
   // block (bi, bj), bi >= bj, from the linear index blockIdx.y
   int bi = 0, rem = blockIdx.y;
   while (rem > bi) { rem -= bi + 1; ++bi; }

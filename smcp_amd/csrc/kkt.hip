@@ -185,7 +185,7 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
   prepare_yaa(c, Y, true, st);
-  prep_lk(c, L, st);
+  prep_lk_cached(c, L, Y, st);
   HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * m * bl, st));
   for (int64_t jb = 0; jb < m; jb += 65535)
     launch(c, KID_scatter_constraints, k_scatter_constraints, dim3(8, (unsigned)std::min<int64_t>(65535, m - jb)),
@@ -195,7 +195,8 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st);     // G(A_j) = (G_NN, R^T G_AN)
   }
   // chunking of the long dimension: ~1.5k workgroups per block column
-  int64_t chunk = std::max<int64_t>(2048, ((bl / 1536 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS);
+  // one resident wave of workgroups (2 per CU) per block column: fewer partial tiles to reduce
+  int64_t chunk = std::max<int64_t>(2048, ((bl / 512 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS);
   int nchunk = (int)((bl + chunk - 1) / chunk);
   int nb = (int)((m + GRAM_BLK - 1) / GRAM_BLK);
   int nblk = nb * (nb + 1) / 2;
@@ -206,8 +207,9 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     if (int rc = dev_alloc(&D.gpart, need, D.bytes)) return rc;
     D.gpart_len = need;
   }
-  launch(c, KID_gram_partial, k_gram_partial, dim3(nchunk, nblk), dim3(256), st, (const double*)D.ustack, bl, (int)m, bl,
-         (const double*)D.sw, chunk, D.gpart);
+  launch_lds(c, KID_gram_partial, k_gram_partial, dim3(nchunk, nblk), dim3(256),
+             (size_t)(nblk > 1 ? 2 : 1) * GRAM_KS * GRAM_LD * sizeof(double), st, (const double*)D.ustack, bl, (int)m, bl,
+             (const double*)D.sw, chunk, D.gpart);
   launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
   HIPCHK(hipGetLastError());
   if (int f = fetch_info(c, st)) return f;   // chol(Y_AA) failure
@@ -223,7 +225,7 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
   hipStream_t st = (hipStream_t)stream;
   if (j0 == 0 && j1 == m && use_gram()) return schur_gram(c, L, Y, H, ldh, st);
   prepare_yaa(c, Y, false, st);
-  if (!use_generic()) prep_lk(c, L, st);
+  if (!use_generic()) prep_lk_cached(c, L, Y, st);
   for (int64_t jb = j0; jb < j1; jb += D.max_rhs) {
     int nr = (int)std::min(D.max_rhs, j1 - jb);
     HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * nr * bl, st));
@@ -256,8 +258,8 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
     ytmp = D.ustack + bl;
   }
   // the Y_AA cache must correspond to (L, Y): recompute (cheap, one gather sweep)
-  prepare_yaa(c, Y, false, st);
-  if (!use_generic()) prep_lk(c, L, st);
+  if (!(c->D.yaa_tag == Y && c->D.yaa_tag)) prepare_yaa(c, Y, false, st);
+  if (!use_generic()) prep_lk_cached(c, L, Y, st);
   HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
   hessian_impl(c, L, r1, 1, bl, 2, 0, st);                      // r1 = W(bx)
   amap_impl(c, r1, 0, 1, ytmp, 0, st);                          // Amap(r1)
