@@ -100,6 +100,8 @@ TreeArgs tree_args(csp_ctx* c) {
   a.tmplen = c->D.tmplen;
   a.tmpptr = c->D.tmpptr;
   a.upd = c->D.upd;
+  a.updp = c->D.updp;
+  a.updplen = c->S.updplen();
   a.tmp = c->D.tmp;
   a.info = c->D.info;
   a.gp_tptr = c->D.gp_tptr;
@@ -176,7 +178,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.ysc = ysc;
   a.ymode = ymode;
   a.nnmax = a.namax = 0;
-  a.nchmax = a.relsum = 0;
+  a.nchmax = a.panmax = a.pkmax = a.plansum = 0;
   a.nrhs = nrhs;
   { static int sk = -1; if (sk < 0) { const char* e = getenv("SMCP_SKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
   return a;
@@ -197,7 +199,9 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f) {
     a.nnmax = L.nnmaxI;
     a.namax = L.namaxI;
     a.nchmax = L.nchmaxI;
-    a.relsum = L.relsumI;
+    a.panmax = L.panmaxI;
+    a.pkmax = L.pkmaxI;
+    a.plansum = L.plansumI;
     size_t lds = (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double);
     f(true, a, (int)L.nI, lds, lds > 48 * 1024 ? 512 : 256);
   }
@@ -274,7 +278,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
       if (lds) {
         static int oldk = -1;
         if (oldk < 0) { const char* e = getenv("SMCP_OLDLDS"); oldk = (e && e[0] == '1') ? 1 : 0; }
-        size_t pbytes = (size_t)pad_layout(a.nnmax, a.namax, a.nchmax, a.relsum).total * sizeof(double);
+        size_t pbytes = (size_t)pad_layout(a.nnmax, a.namax, a.nchmax, a.panmax, a.pkmax, a.plansum).total * sizeof(double);
         if (!oldk && pbytes <= LDS_LIMIT)
           launch_lds(c, KID_hess_up_pad, k_hess_up_pad, dim3(cnt, g), dim3(pbytes > 48 * 1024 ? 512 : 256), pbytes, st, a, U, ldu);
         else
@@ -359,7 +363,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
     for (void* p : ptrs) if (p) hipFree(p);
     if (D.info_host) hipHostFree(D.info_host);
@@ -429,6 +433,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       CliqueDesc& d = cl[k];
       d.blk = S.blkptr[k];
       d.upd = S.updptr[k];
+      d.updp = S.updpptr[k];
       d.rows = S.rowptr[k];
       d.rel = S.sepptr[k];
       d.nn = (int32_t)S.nn(k);
@@ -459,10 +464,12 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
               L.nI++;
               L.nnmaxI = std::max<int>(L.nnmaxI, (int)S.nn(k));
               L.namaxI = std::max<int>(L.namaxI, (int)S.na(k));
-              int rs = 0;
-              for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) rs += (int)S.na(S.chidx[q2]);
-              L.relsumI = std::max(L.relsumI, rs);
+              int64_t rs = 0;
+              for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) rs += S.na(S.chidx[q2]) * (S.na(S.chidx[q2]) + 1) / 2;
+              L.plansumI = (int)std::max<int64_t>(L.plansumI, rs);
               L.nchmaxI = std::max<int>(L.nchmaxI, (int)(S.chptr[k + 1] - S.chptr[k]));
+              L.panmaxI = std::max<int>(L.panmaxI, (int)(S.nf(k) * S.nn(k)));
+              L.pkmaxI = std::max<int>(L.pkmaxI, (int)(S.na(k) * (S.na(k) + 1) / 2));
             } else {
               L.nII++;
               L.nnmaxII = std::max<int>(L.nnmaxII, (int)S.nn(k));
@@ -485,7 +492,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     if ((rc = dev_upload(&D.levidx, lev, D.bytes))) return rc;
     if ((rc = dev_upload(&D.lev2idx, lev2, D.bytes))) return rc;
     // ---- gather plans for the extend-add
-    if (S.updlen() < (int64_t)1 << 31) {
+    if (S.updplen() < (int64_t)1 << 31) {
       std::vector<int64_t> tptr(S.nsn + 1, 0), cptr;
       std::vector<int32_t> tgt, src;
       cptr.push_back(0);
@@ -500,7 +507,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
             for (int64_t i = j; i < nac; ++i) {
               int32_t ri = rel[i], rj = rel[j];
               int32_t code = rj < nnp ? (ri | (rj << 15)) : ((1 << 30) | (ri - (int32_t)nnp) | ((rj - (int32_t)nnp) << 15));
-              pr.emplace_back(code, (int32_t)(S.updptr[cc] + i + j * nac));
+              pr.emplace_back(code, (int32_t)(S.updpptr[cc] + j * nac - j * (j - 1) / 2 + (i - j)));
             }
         }
         std::sort(pr.begin(), pr.end());
@@ -541,10 +548,12 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     D.device = device;
   } else {
     if (D.upd) { hipFree(D.upd); D.bytes -= D.max_rhs * S.updlen() * 8; D.upd = nullptr; }
+    if (D.updp) { hipFree(D.updp); D.bytes -= D.max_rhs * S.updplen() * 8; D.updp = nullptr; }
     if (D.tmp) { hipFree(D.tmp); D.bytes -= D.max_rhs * D.tmplen * 8; D.tmp = nullptr; }
   }
   int rc = 0;
   if ((rc = dev_alloc(&D.upd, max_rhs * S.updlen(), D.bytes))) return rc;
+  if ((rc = dev_alloc(&D.updp, max_rhs * S.updplen(), D.bytes))) return rc;
   if ((rc = dev_alloc(&D.tmp, max_rhs * D.tmplen, D.bytes))) return rc;
   D.max_rhs = max_rhs;
   return 0;

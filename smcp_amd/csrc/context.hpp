@@ -13,6 +13,7 @@ namespace smcp {
 struct CliqueDesc {
   int64_t blk;     // offset of the (nf x nn) panel in blkval
   int64_t upd;     // offset of the (na x na) update matrix in the update workspace
+  int64_t updp;    // offset of its packed lower triangle in the child->parent exchange buffer
   int64_t rows;    // offset into rowidx (nf entries)
   int64_t rel;     // offset into relidx (na entries)
   int32_t nn, na;  // supernode / separator size
@@ -47,6 +48,7 @@ struct DeviceCtx {
   double* lk = nullptr;       // inverse-form factor [L_NN^-1; L_AN L_NN^-1] of the most recent prep
   // workspaces
   double* upd = nullptr;   // max_rhs * updlen : update matrices
+  double* updp = nullptr;  // max_rhs * updplen : packed lower triangles handed from children to parents (fast up-sweeps, cholesky)
   double* yaa = nullptr;   // updlen : Y[A_k,A_k] cache (Hessian)
   double* fac = nullptr;   // updlen : chol(Y_AA) cache
   double* tmp = nullptr;   // max_rhs * tmplen : per-clique scratch (tmpptr)
@@ -98,7 +100,7 @@ namespace smcp {
 struct LevelClass {
   int64_t nI = 0, nII = 0;     // cliques whose working set fits LDS / does not
   int nnmaxI = 0, namaxI = 0;  // LDS layout sizing for the LDS class
-  int nchmaxI = 0, relsumI = 0;  // children metadata hoisted into LDS (max #children, max sum of child separator sizes)
+  int nchmaxI = 0, panmaxI = 0, pkmaxI = 0, plansumI = 0;  // index tables of the padded kernels (see pad_layout)
   int nnmaxII = 0, namaxII = 0;  // tile-grid sizing for the large-front (HBM) class
 };
 }  // namespace smcp

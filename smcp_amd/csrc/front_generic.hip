@@ -23,6 +23,8 @@ struct TreeArgs {
   int64_t tmplen;      // stride between right-hand sides in the scratch workspace
   const int64_t* tmpptr;
   double* upd;
+  double* updp;        // packed child->parent exchange buffer (fast kernels)
+  int64_t updplen;
   double* tmp;
   int* info;
   // extend-add gather plan (null = not available)

@@ -84,6 +84,7 @@ struct LfCtx {   // per-workgroup view of one (clique, rhs) pair
   const double* Ys;                    // ld na (lower stored) or null
   double* P;                           // panel of this rhs (ld nf)
   double* U;                           // update / separator matrix of this rhs (ld na)
+  double* UP;                          // its packed lower triangle in the exchange buffer
   double* T; double* E; double* G;     // scratch: nn x nn, na x nn, na x nn
 };
 __device__ inline LfCtx lf_ctx(const MfmaArgs& a, double* u, int64_t ldu) {
@@ -97,6 +98,7 @@ __device__ inline LfCtx lf_ctx(const MfmaArgs& a, double* u, int64_t ldu) {
   c.Ys = a.ysc ? a.ysc + d.upd : nullptr;
   c.P = u + (int64_t)r * ldu + d.blk;
   c.U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+  c.UP = a.t.updp + (int64_t)r * a.t.updplen + d.updp;
   double* s = a.t.tmp + (int64_t)r * a.t.tmplen + a.t.tmpptr[c.k];
   c.T = s; s += (int64_t)d.nn * d.nn;
   c.E = s; s += (int64_t)d.na * d.nn;
@@ -111,8 +113,8 @@ __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu) {
   const int r = blockIdx.z;
   const int nn = d.nn, na = d.na, nf = nn + na;
   double* P = u + (int64_t)r * ldu + d.blk;
-  double* ubase = a.t.upd + (int64_t)r * a.t.updlen;
-  double* U = ubase + d.upd;
+  const double* ubase = a.t.updp + (int64_t)r * a.t.updplen;   // children: packed exchange buffer
+  double* U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
   const int64_t t0 = a.t.gp_tptr[k], t1 = a.t.gp_tptr[k + 1];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // positions of U that receive no contribution must read as zero: clear the lower triangle first
@@ -192,8 +194,10 @@ __global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t l
                 [=](int kk, int n) { return E[n + (int64_t)kk * na]; }, sA, sB);
     gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return E[m + (int64_t)kk * na]; },
                 [=](int kk, int n) { return K[n + (int64_t)kk * nf]; }, sA, sB);
-    double* U = c.U;
-    tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) { if (m >= n) U[m + (int64_t)n * na] -= v; });
+    double* U = c.U; double* UP = c.UP;
+    tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) {
+      if (m >= n) { const double w = U[m + (int64_t)n * na] - v; U[m + (int64_t)n * na] = w; UP[pk_idx(m, n, na)] = w; }
+    });
   } else if (t < nU + nG) {
     const int tt = t - nU, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
     gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; },

@@ -84,7 +84,7 @@ struct MfmaArgs {
   int ymode;          // 0 none, 1 symmetric (Y_AA), 2 R^T, 3 R
   int nnmax, namax;   // LDS layout sizing (max over the cliques of this launch)
   int nrhs;
-  int nchmax, relsum;  // LDS sizing for the hoisted children metadata (padded kernels)
+  int nchmax, panmax, pkmax, plansum;  // LDS sizing of the index tables of the padded kernels
   int skip;  // debug-only phase mask (SMCP_SKIP env), 0 in production
 };
 
@@ -200,6 +200,21 @@ __device__ inline void gather_children_plan(const TreeArgs& t, int k, const doub
   }
 }
 
+
+// packed lower-triangular (column-major) storage of the exchanged update matrices
+__device__ __host__ inline int pk_col(int j, int n) { return j * n - (j * (j - 1)) / 2; }
+__device__ __host__ inline int pk_idx(int i, int j, int n) { return pk_col(j, n) + (i - j); }
+// inverse map: packed position e -> (i, j), i >= j
+__device__ inline void pk_unpack(int e, int n, int& i, int& j) {
+  const float t = (float)(2 * n + 1);
+  j = (int)((t - sqrtf(t * t - 8.0f * (float)e)) * 0.5f);
+  if (j < 0) j = 0;
+  if (j > n - 1) j = n - 1;
+  while (j + 1 < n && pk_col(j + 1, n) <= e) ++j;
+  while (j > 0 && pk_col(j, n) > e) --j;
+  i = j + (e - pk_col(j, n));
+}
+
 struct ChildEntry { double v; int ri, rj; };
 __device__ inline void add_children_front(const TreeArgs& t, const CliqueDesc& d, const double* updbase,
                                           double* F, int ldf, double* U, int ldu, double sp, double su,
@@ -219,13 +234,13 @@ __device__ inline void add_children_front(const TreeArgs& t, const CliqueDesc& d
     const CliqueDesc c = t.cl[t.chidx[q]];
     const int nac = c.na;
     const int32_t* rel = t.relidx + c.rel;
-    const double* Uc = updbase + c.upd;
-    batched_loop<16>(lane, nac * nac, 64,
+    const double* Uc = updbase + c.updp;
+    batched_loop<16>(lane, nac * (nac + 1) / 2, 64,
       [=](int e) {
         ChildEntry x;
-        int i = e % nac, j = e / nac;
-        x.ri = -1; x.rj = 0; x.v = 0.0;
-        if (i >= j) { x.ri = rel[i]; x.rj = rel[j]; x.v = (dbg & 16) ? 1.0 : Uc[e]; }
+        int i, j;
+        pk_unpack(e, nac, i, j);
+        x.ri = rel[i]; x.rj = rel[j]; x.v = (dbg & 16) ? 1.0 : Uc[e];
         return x;
       },
       [=](int e, const ChildEntry& x) {
@@ -336,8 +351,9 @@ __global__ void k_hess_up_mfma(MfmaArgs a, double* u, int64_t ldu) {
   const int ymode = a.ymode;
   for (int r = blockIdx.y; r < a.nrhs; r += gridDim.y) {
     double* P = u + (int64_t)r * ldu + d.blk;
-    const double* ub = a.t.upd + (int64_t)r * a.t.updlen;
+    const double* ub = a.t.updp + (int64_t)r * a.t.updplen;          // children: packed exchange buffer
     double* UkG = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+    double* UkP = a.t.updp + (int64_t)r * a.t.updplen + d.updp;
     if (LDS) {
       {
         double* Fl = w.F; const int ldfl = w.ldf;
@@ -394,7 +410,13 @@ __global__ void k_hess_up_mfma(MfmaArgs a, double* u, int64_t ldu) {
       }
       for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
         int i = e % na, j = e / na;
-        if (i >= j) UkG[e] = v.U[i + j * v.ldu];
+        if (i >= j) UkP[pk_idx(i, j, na)] = v.U[i + j * v.ldu];
+      }
+      __syncthreads();
+    } else {
+      for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
+        int i = e % na, j = e / na;
+        if (i >= j) UkP[pk_idx(i, j, na)] = UkG[e];
       }
       __syncthreads();
     }
@@ -495,6 +517,7 @@ __global__ void k_chol_mfma(MfmaArgs a, double* x) {
   Work w = make_work<LDS>(a, d, smem, k, 0);
   double* P = x + d.blk;
   double* UkG = a.t.upd + d.upd;
+  double* UkP = a.t.updp + d.updp;
   if (LDS) {
     {
       double* Fl = w.F; const int ldfl = w.ldf;
@@ -508,7 +531,7 @@ __global__ void k_chol_mfma(MfmaArgs a, double* x) {
     for (int e = threadIdx.x; e < na * na; e += blockDim.x) UkG[e] = 0.0;
   }
   __syncthreads();
-  add_children_front(a.t, d, a.t.upd, w.F, w.ldf, w.U, w.ldu, 1.0, 1.0);
+  add_children_front(a.t, d, a.t.updp, w.F, w.ldf, w.U, w.ldu, 1.0, 1.0);
   const Work v = w;
   for (int jb = 0; jb < nn; jb += 16) {
     const int bw = min(16, nn - jb);
@@ -544,7 +567,12 @@ __global__ void k_chol_mfma(MfmaArgs a, double* x) {
     }
     for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
       int i = e % na, j = e / na;
-      if (i >= j) UkG[e] = v.U[i + j * v.ldu];
+      if (i >= j) UkP[pk_idx(i, j, na)] = v.U[i + j * v.ldu];
+    }
+  } else {
+    for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
+      int i = e % na, j = e / na;
+      if (i >= j) UkP[pk_idx(i, j, na)] = UkG[e];
     }
   }
 }
@@ -640,8 +668,11 @@ __global__ void k_pinv_mfma(MfmaArgs a, double* x) {
 struct PadL {
   int NN, NA, ldn, lda;
   int oK, oLi, oY, oFnn, oFan, oE, oG, oT, oU, oInt, total;
+  int iCh, iPan, iOut, iTgt;   // int-table offsets (in ints, relative to the int region)
 };
-__host__ __device__ inline PadL pad_layout(int nnmax, int namax, int nchmax = 0, int relsum = 0) {
+// nchmax: max #children, panmax: max nf*nn, pkmax: max na(na+1)/2, plansum: max sum of the children's packed sizes
+__host__ __device__ inline PadL pad_layout(int nnmax, int namax, int nchmax = 0, int panmax = 0, int pkmax = 0,
+                                           int plansum = 0) {
   PadL L;
   L.NN = (nnmax + 15) & ~15;
   L.NA = (namax + 15) & ~15;
@@ -657,7 +688,15 @@ __host__ __device__ inline PadL pad_layout(int nnmax, int namax, int nchmax = 0,
   L.oG = o; o += L.lda * L.NN;
   L.oT = o; o += L.ldn * L.NN;
   L.oU = o; o += L.lda * L.NA;
-  L.oInt = o; o += (4 * nchmax + relsum + 3) / 2;   // children metadata: (upd lo, upd hi, na, rel offset) per child + rel lists
+  L.oInt = o;
+  // RHS-invariant index tables, built once per workgroup, so the per-rhs loop has no index arithmetic:
+  //   child metadata (4 ints per child), panel position -> LDS offset, packed own-update position ->
+  //   LDS offset, packed child-update position -> LDS offset of its target in the front
+  L.iCh = 0;
+  L.iPan = 4 * nchmax;
+  L.iOut = L.iPan + panmax;
+  L.iTgt = L.iOut + pkmax;
+  o += (L.iTgt + plansum + 3) / 2;
   L.total = o + 2;
   return L;
 }
@@ -678,8 +717,12 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
   const int k = a.t.lev[blockIdx.x];
   const CliqueDesc d = a.t.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
-  const PadL L = pad_layout(a.nnmax, a.namax, a.nchmax, a.relsum);
-  int* const sCh = reinterpret_cast<int*>(smem + L.oInt);
+  const PadL L = pad_layout(a.nnmax, a.namax, a.nchmax, a.panmax, a.pkmax, a.plansum);
+  int* const sInt = reinterpret_cast<int*>(smem + L.oInt);
+  int* const sCh = sInt + L.iCh;
+  int* const sPan = sInt + L.iPan;
+  int* const sOut = sInt + L.iOut;
+  int* const sTgt = sInt + L.iTgt;
   double* const sK = smem + L.oK;
   double* const sLi = smem + L.oLi;
   double* const sY = smem + L.oY;
@@ -694,33 +737,46 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
   const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
   const int ymode = a.ymode;
-  // zero everything once (pads must stay zero), then load the clique constants
+  const int npan = nf * nn, npk = na * (na + 1) / 2;
+  // zero everything once (pads must stay zero)
   for (int e = tid; e < L.oInt; e += nthr) smem[e] = 0.0;
-  // children metadata (offset of the child's update block, its size, its relative indices) is the
-  // same for every right-hand side: fetch it once so the per-rhs loop only loads values
+  // ---- RHS-invariant index tables
   const int nch = d.chend - d.chbeg;
-  int* const sRel = sCh + 4 * nch;
   for (int q = tid; q < nch; q += nthr) {
     const CliqueDesc c = a.t.cl[a.t.chidx[d.chbeg + q]];
-    sCh[4 * q] = (int)(c.upd & 0xffffffff);
-    sCh[4 * q + 1] = (int)(c.upd >> 32);
+    sCh[4 * q] = (int)(c.updp & 0xffffffff);
+    sCh[4 * q + 1] = (int)(c.updp >> 32);
     sCh[4 * q + 2] = c.na;
-    sCh[4 * q + 3] = (int)(c.rel - a.t.cl[a.t.chidx[d.chbeg]].rel);   // children are consecutive in relidx? not guaranteed: see below
+  }
+  for (int e = tid; e < npan; e += nthr) {       // panel entry -> LDS offset (-1: unused upper triangle)
+    const int i = e % nf, j = e / nf;
+    sPan[e] = (i >= nn) ? L.oFan + (i - nn) + j * lda : (i >= j ? L.oFnn + i + j * ldn : -1);
+  }
+  for (int e = tid; e < npk; e += nthr) {        // packed own update entry -> LDS offset
+    int i, j;
+    pk_unpack(e, na, i, j);
+    sOut[e] = L.oU + i + j * lda;
   }
   __syncthreads();
-  {
-    // rel offsets: prefix sums of the children's separator sizes (serial, tiny)
-    if (tid == 0) { int off = 0; for (int q = 0; q < nch; ++q) { int n_ = sCh[4 * q + 2]; sCh[4 * q + 3] = off; off += n_; } }
+  if (tid == 0) {                                // table offsets of the children (serial prefix sum, tiny)
+    int off = 0;
+    for (int q = 0; q < nch; ++q) { sCh[4 * q + 3] = off; off += sCh[4 * q + 2] * (sCh[4 * q + 2] + 1) / 2; }
   }
   __syncthreads();
-  for (int q = wave; q < nch; q += nw) {
+  for (int q = wave; q < nch; q += nw) {         // packed child entry -> LDS offset of its target
     const int32_t* rel = a.t.relidx + a.t.cl[a.t.chidx[d.chbeg + q]].rel;
-    const int nac = sCh[4 * q + 2], off = sCh[4 * q + 3];
-    for (int i = lane; i < nac; i += 64) sRel[off + i] = rel[i];
+    const int nac = sCh[4 * q + 2], tb = sCh[4 * q + 3];
+    for (int e = lane; e < nac * (nac + 1) / 2; e += 64) {
+      int i, j;
+      pk_unpack(e, nac, i, j);
+      const int ri = rel[i], rj = rel[j];
+      sTgt[tb + e] = (rj >= nn) ? L.oU + (ri - nn) + (rj - nn) * lda
+                                : (ri >= nn ? L.oFan + (ri - nn) + rj * lda : L.oFnn + ri + rj * ldn);
+    }
   }
   {
     const double* src = a.LK + d.blk;
-    batched_loop<8>(tid, nf * nn, nthr, [=](int e) { return src[e]; },
+    batched_loop<8>(tid, npan, nthr, [=](int e) { return src[e]; },
                     [=](int e, double v) {
                       int i = e % nf, j = e / nf;
                       if (i < nn) sLi[i + j * ldn] = v; else sK[(i - nn) + j * lda] = v;
@@ -741,44 +797,24 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
   const int ksn = (nn + 3) >> 2, ksa = (na + 3) >> 2;
   for (int r = blockIdx.y; r < a.nrhs; r += gridDim.y) {
     double* P = u + (int64_t)r * ldu + d.blk;
-    const double* ub = a.t.upd + (int64_t)r * a.t.updlen;
-    double* UkG = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+    const double* ub = a.t.updp + (int64_t)r * a.t.updplen;          // children: packed exchange buffer
+    double* UkP = a.t.updp + (int64_t)r * a.t.updplen + d.updp;
     __syncthreads();
-    // ---- assemble the front: panel (NN block mirrored to full symmetric) + children
-    batched_loop<8>(tid, nf * nn, nthr, [=](int e) { return P[e]; },
-                    [=](int e, double v) {
-                      int i = e % nf, j = e / nf;
-                      if (i >= nn) sFan[(i - nn) + j * lda] = v;
-                      else if (i >= j) { sFnn[i + j * ldn] = v; sFnn[j + i * ldn] = v; }
-                    });
-    for (int e = tid; e < na * na; e += nthr) sU[(e % na) + (e / na) * lda] = 0.0;
+    // ---- assemble the front: panel + children (lower triangles), then mirror F_NN
+    batched_loop<8>(tid, npan, nthr, [=](int e) { return P[e]; },
+                    [=](int e, double v) { const int o = sPan[e]; if (o >= 0) smem[o] = v; });
+    for (int e = tid; e < npk; e += nthr) smem[sOut[e]] = 0.0;
     __syncthreads();
-    if (a.t.gp_tptr && (a.skip & 32)) {   // LDS class: the per-child atomic version is faster (plan loads are latency-bound)
-      gather_children_plan(a.t, k, ub, [=](int32_t code, double v) {
-        const int i = code & 0x7fff, j = (code >> 15) & 0x7fff;
-        if (code & (1 << 30)) sU[i + j * lda] += v;
-        else if (i >= nn) sFan[(i - nn) + j * lda] += v;
-        else { sFnn[i + j * ldn] += v; if (i != j) sFnn[j + i * ldn] += v; }
-      });
-    } else
     for (int q = wave; q < nch; q += nw) {
       const int nac = sCh[4 * q + 2];
-      const int* rel = sRel + sCh[4 * q + 3];
+      const int* tg = sTgt + sCh[4 * q + 3];
       const double* Uc = ub + (((int64_t)sCh[4 * q + 1] << 32) | (uint32_t)sCh[4 * q]);
-      batched_loop<16>(lane, nac * nac, 64,
-        [=](int e) { return (e % nac) >= (e / nac) ? Uc[e] : 0.0; },
-        [=](int e, double vv) {
-          const int i = e % nac, j = e / nac;
-          if (i < j) return;
-          const int ri = rel[i], rj = rel[j];
-          if (rj >= nn) unsafeAtomicAdd(&sU[(ri - nn) + (rj - nn) * lda], vv);
-          else if (ri >= nn) unsafeAtomicAdd(&sFan[(ri - nn) + rj * lda], vv);
-          else {
-            unsafeAtomicAdd(&sFnn[ri + rj * ldn], vv);
-            if (ri != rj) unsafeAtomicAdd(&sFnn[rj + ri * ldn], vv);
-          }
-        });
+      batched_loop<8>(lane, nac * (nac + 1) / 2, 64, [=](int e) { return Uc[e]; },
+                      [=](int e, double vv) { unsafeAtomicAdd(&smem[tg[e]], vv); });
     }
+    __syncthreads();
+    for (int j = wave; j < nn; j += nw)
+      for (int i = j + 1 + lane; i < nn; i += 64) sFnn[j + i * ldn] = sFnn[i + j * ldn];
     __syncthreads();
     // ---- phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place of F_AN) ; T = Li F_NN
     {
@@ -861,15 +897,11 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
     }
     __syncthreads();
     // ---- write out: panel (lower of NN + AN) and the update matrix (lower)
-    for (int e = tid; e < nf * nn; e += nthr) {
-      int i = e % nf, j = e / nf;
-      if (i >= nn) P[e] = sFan[(i - nn) + j * lda];
-      else if (i >= j) P[e] = sFnn[i + j * ldn];
+    for (int e = tid; e < npan; e += nthr) {
+      const int o = sPan[e];
+      if (o >= 0) P[e] = smem[o];
     }
-    for (int e = tid; e < na * na; e += nthr) {
-      int i = e % na, j = e / na;
-      if (i >= j) UkG[e] = sU[i + j * lda];
-    }
+    for (int e = tid; e < npk; e += nthr) UkP[e] = smem[sOut[e]];
   }
 }
 

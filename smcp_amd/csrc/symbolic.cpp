@@ -288,11 +288,13 @@ int symbolic_build(int64_t n, const int64_t* colptr, const int64_t* rowind, cons
   S.sepptr.assign(nsn + 1, 0);
   S.blkptr.assign(nsn + 1, 0);
   S.updptr.assign(nsn + 1, 0);
+  S.updpptr.assign(nsn + 1, 0);
   for (int64_t k = 0; k < nsn; ++k) {
     int64_t nn = S.nn(k), nf = S.nf(k), na = nf - nn;
     S.sepptr[k + 1] = S.sepptr[k] + na;
     S.blkptr[k + 1] = S.blkptr[k] + nf * nn;
     S.updptr[k + 1] = S.updptr[k] + na * na;
+    S.updpptr[k + 1] = S.updpptr[k] + na * (na + 1) / 2;
     S.max_nn = std::max(S.max_nn, nn);
     S.max_na = std::max(S.max_na, na);
     S.max_front = std::max(S.max_front, nf);

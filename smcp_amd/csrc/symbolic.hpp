@@ -31,6 +31,7 @@ struct Symbolic {
   std::vector<int32_t> relidx;  // |A_k| entries at sepptr[k]: position of each A_k row inside rows(parent(k))
   std::vector<int64_t> blkptr;  // nsn+1 : offset of the (nn+na) x nn column-major block of clique k in blkval
   std::vector<int64_t> updptr;  // nsn+1 : offset of the na x na update matrix of clique k in the update workspace
+  std::vector<int64_t> updpptr; // nsn+1 : offset of the PACKED lower triangle (na(na+1)/2) in the child->parent exchange buffer
   std::vector<int64_t> chptr;   // nsn+1 : children lists
   std::vector<int64_t> chidx;   // nsn-#roots
   std::vector<int64_t> level;   // nsn   : height-based level (leaves = 0, parent > all children)
@@ -45,6 +46,7 @@ struct Symbolic {
   int64_t na(int64_t k) const { return nf(k) - nn(k); }
   int64_t blklen() const { return blkptr[nsn]; }
   int64_t updlen() const { return updptr[nsn]; }
+  int64_t updplen() const { return updpptr[nsn]; }
 };
 
 // Build from the lower-triangular pattern (CCS, row indices need not be sorted, diagonal
