@@ -32,6 +32,8 @@ def build(force=False, verbose=True):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if os.environ.get("SMCP_STAMPS") == "1":      # diagnostic build with in-kernel cycle stamps
+        cmd.insert(1, "-DSMCP_STAMPS")
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -181,6 +181,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.nchmax = a.panmax = a.pkmax = a.plansum = 0;
   a.nrhs = nrhs;
   { static int sk = -1; if (sk < 0) { const char* e = getenv("SMCP_SKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
+  a.dbg = (a.skip & 64) ? (unsigned long long*)(c->D.red + 768) : nullptr;
   return a;
 }
 
@@ -725,6 +726,14 @@ int64_t csp_profile_read(csp_ctx* c, double* ms, int64_t* count) {
   P.kids.clear();
   P.used = 0;
   return KID_COUNT;
+}
+
+int csp_debug_stamps(csp_ctx* c, unsigned long long* out, int reset) {
+  if (int rc = ready(c)) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  if (out) HIPCHK(hipMemcpy(out, c->D.red + 768, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(c->D.red + 768, 0, 16 * sizeof(unsigned long long)));
+  return 0;
 }
 
 const char* csp_profile_kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? KID_NAMES[kid] : nullptr; }

@@ -86,6 +86,7 @@ struct MfmaArgs {
   int nrhs;
   int nchmax, panmax, pkmax, plansum;  // LDS sizing of the index tables of the padded kernels
   int skip;  // debug-only phase mask (SMCP_SKIP env), 0 in production
+  unsigned long long* dbg;  // diagnostic builds: cycle-stamp accumulator (null otherwise)
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }
@@ -795,16 +796,25 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
   }
   const int NAt = L.NA >> 4, NNt = L.NN >> 4;
   const int ksn = (nn + 3) >> 2, ksa = (na + 3) >> 2;
+#ifdef SMCP_STAMPS   // diagnostic build only (SMCP_STAMPS=1 python -m smcp_amd.build --force): cycle stamps of thread 0
+  const bool stamp = tid == 0 && a.dbg;
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamp ? clock64() : 0;
+#define STAMP(i) do { if (stamp) { unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
   for (int r = blockIdx.y; r < a.nrhs; r += gridDim.y) {
     double* P = u + (int64_t)r * ldu + d.blk;
     const double* ub = a.t.updp + (int64_t)r * a.t.updplen;          // children: packed exchange buffer
     double* UkP = a.t.updp + (int64_t)r * a.t.updplen + d.updp;
     __syncthreads();
+    STAMP(0);
     // ---- assemble the front: panel + children (lower triangles), then mirror F_NN
     batched_loop<8>(tid, npan, nthr, [=](int e) { return P[e]; },
                     [=](int e, double v) { const int o = sPan[e]; if (o >= 0) smem[o] = v; });
     for (int e = tid; e < npk; e += nthr) smem[sOut[e]] = 0.0;
     __syncthreads();
+    STAMP(1);
     for (int q = wave; q < nch; q += nw) {
       const int nac = sCh[4 * q + 2];
       const int* tg = sTgt + sCh[4 * q + 3];
@@ -816,6 +826,7 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
     for (int j = wave; j < nn; j += nw)
       for (int i = j + 1 + lane; i < nn; i += 64) sFnn[j + i * ldn] = sFnn[i + j * ldn];
     __syncthreads();
+    STAMP(2);
     // ---- phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place of F_AN) ; T = Li F_NN
     {
       const int nE = NAt * NNt, nT = NNt * NNt;
@@ -842,6 +853,7 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
       }
     }
     __syncthreads();
+    STAMP(3);
     // ---- phase 2: U -= K E^T + E K^T (lower tiles) ; G = X Li^T ; G_NN = T Li^T (into sFnn)
     {
       const int nU = NAt * (NAt + 1) / 2, nG = NAt * NNt, nN = NNt * NNt;
@@ -875,6 +887,7 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
       }
     }
     __syncthreads();
+    STAMP(4);
     // ---- phase 3: Q = Ysc G into the F_AN buffer (X is dead), or plain G
     {
       const int nQ = NAt * NNt;
@@ -896,13 +909,20 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
       }
     }
     __syncthreads();
+    STAMP(5);
     // ---- write out: panel (lower of NN + AN) and the update matrix (lower)
     for (int e = tid; e < npan; e += nthr) {
       const int o = sPan[e];
       if (o >= 0) P[e] = smem[o];
     }
     for (int e = tid; e < npk; e += nthr) UkP[e] = smem[sOut[e]];
+    STAMP(6);
   }
+#ifdef SMCP_STAMPS
+  if (stamp)
+    for (int i = 0; i < 7; ++i) atomicAdd(a.dbg + i + 8 * (d.na > 40), tph[i]);
+#endif
+#undef STAMP
 }
 
 // ------------------------------------------------------------------ Gram matrix  H = G^T W G
