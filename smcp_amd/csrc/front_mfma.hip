@@ -668,7 +668,7 @@ __global__ void k_pinv_mfma(MfmaArgs a, double* x) {
 // need no bounds checks or branches: each k-step is two ds_read_b64, two pointer bumps, one MFMA.
 struct PadL {
   int NN, NA, ldn, lda;
-  int oK, oLi, oY, oFnn, oFan, oE, oG, oT, oU, oInt, total;
+  int oK, oLi, oBD, oY, oFnn, oFan, oE, oG, oT, oU, oInt, total;
   int iCh, iPan, iOut, iTgt;   // int-table offsets (in ints, relative to the int region)
 };
 // nchmax: max #children, panmax: max nf*nn, pkmax: max na(na+1)/2, plansum: max sum of the children's packed sizes
@@ -682,6 +682,7 @@ __host__ __device__ inline PadL pad_layout(int nnmax, int namax, int nchmax = 0,
   int o = 0;
   L.oK = o; o += L.lda * L.NN;
   L.oLi = o; o += L.ldn * L.NN;
+  L.oBD = o; o += L.ldn * L.NN;   // kron(I_rb, Li^T): applies Li^T to every stacked right-hand side at once
   L.oY = o; o += L.lda * L.NA;
   L.oFnn = o; o += L.ldn * L.NN;
   L.oFan = o; o += L.lda * L.NN;
@@ -726,6 +727,7 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
   int* const sTgt = sInt + L.iTgt;
   double* const sK = smem + L.oK;
   double* const sLi = smem + L.oLi;
+  double* const sBD = smem + L.oBD;
   double* const sY = smem + L.oY;
   double* const sFnn = smem + L.oFnn;
   double* const sFan = smem + L.oFan;
@@ -739,19 +741,24 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
   const int l15 = lane & 15, kq = lane >> 4;
   const int ymode = a.ymode;
   const int npan = nf * nn, npk = na * (na + 1) / 2;
+  const int nch = d.chend - d.chbeg;
+  // Childless cliques with a narrow supernode stack several right-hand sides side by side in the
+  // 16-column tiles (column = q*nn + n): one tile pass serves rb right-hand sides, and their update
+  // matrices go from the accumulators straight to HBM.
+  const int rb = (nch == 0) ? max(1, min(4, L.NN / max(nn, 1))) : 1;
+  const int ncs = rb * nn;
   // zero everything once (pads must stay zero)
   for (int e = tid; e < L.oInt; e += nthr) smem[e] = 0.0;
   // ---- RHS-invariant index tables
-  const int nch = d.chend - d.chbeg;
   for (int q = tid; q < nch; q += nthr) {
     const CliqueDesc c = a.t.cl[a.t.chidx[d.chbeg + q]];
     sCh[4 * q] = (int)(c.updp & 0xffffffff);
     sCh[4 * q + 1] = (int)(c.updp >> 32);
     sCh[4 * q + 2] = c.na;
   }
-  for (int e = tid; e < npan; e += nthr) {       // panel entry -> LDS offset (-1: unused upper triangle)
+  for (int e = tid; e < npan; e += nthr) {       // panel entry -> LDS offset; bit 30: F_NN block; -1: unused
     const int i = e % nf, j = e / nf;
-    sPan[e] = (i >= nn) ? L.oFan + (i - nn) + j * lda : (i >= j ? L.oFnn + i + j * ldn : -1);
+    sPan[e] = (i >= nn) ? (i - nn) + j * lda : (i >= j ? ((1 << 30) | (i + j * ldn)) : -1);
   }
   for (int e = tid; e < npk; e += nthr) {        // packed own update entry -> LDS offset
     int i, j;
@@ -759,7 +766,7 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
     sOut[e] = L.oU + i + j * lda;
   }
   __syncthreads();
-  if (tid == 0) {                                // table offsets of the children (serial prefix sum, tiny)
+  if (tid == 0) {
     int off = 0;
     for (int q = 0; q < nch; ++q) { sCh[4 * q + 3] = off; off += sCh[4 * q + 2] * (sCh[4 * q + 2] + 1) / 2; }
   }
@@ -780,7 +787,11 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
     batched_loop<8>(tid, npan, nthr, [=](int e) { return src[e]; },
                     [=](int e, double v) {
                       int i = e % nf, j = e / nf;
-                      if (i < nn) sLi[i + j * ldn] = v; else sK[(i - nn) + j * lda] = v;
+                      if (i < nn) {
+                        sLi[i + j * ldn] = v;
+                        if (i >= j)                               // Li^T on the diagonal blocks of BD
+                          for (int q = 0; q < rb; ++q) sBD[(q * nn + j) + (q * nn + i) * ldn] = v;
+                      } else sK[(i - nn) + j * lda] = v;
                     });
     if (ymode) {
       const double* ys = a.ysc + d.upd;
@@ -795,7 +806,8 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
     }
   }
   const int NAt = L.NA >> 4, NNt = L.NN >> 4;
-  const int ksn = (nn + 3) >> 2, ksa = (na + 3) >> 2;
+  const int NCt = (ncs + 15) >> 4;                  // column tiles actually used
+  const int ksn = (nn + 3) >> 2, ksa = (na + 3) >> 2, ksc = (ncs + 3) >> 2;
 #ifdef SMCP_STAMPS   // diagnostic build only (SMCP_STAMPS=1 python -m smcp_amd.build --force): cycle stamps of thread 0
   const bool stamp = tid == 0 && a.dbg;
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamp ? clock64() : 0;
@@ -803,33 +815,45 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
 #else
 #define STAMP(i) do { } while (0)
 #endif
-  for (int r = blockIdx.y; r < a.nrhs; r += gridDim.y) {
-    double* P = u + (int64_t)r * ldu + d.blk;
-    const double* ub = a.t.updp + (int64_t)r * a.t.updplen;          // children: packed exchange buffer
-    double* UkP = a.t.updp + (int64_t)r * a.t.updplen + d.updp;
+  for (int r0 = blockIdx.y; r0 < a.nrhs; r0 += gridDim.y * rb) {
+    // this pass: right-hand sides r0, r0 + gridDim.y, ... (rbc of them)
+    const int rbc = min(rb, (a.nrhs - r0 + (int)gridDim.y - 1) / (int)gridDim.y);
     __syncthreads();
     STAMP(0);
-    // ---- assemble the front: panel + children (lower triangles), then mirror F_NN
-    batched_loop<8>(tid, npan, nthr, [=](int e) { return P[e]; },
-                    [=](int e, double v) { const int o = sPan[e]; if (o >= 0) smem[o] = v; });
-    for (int e = tid; e < npk; e += nthr) smem[sOut[e]] = 0.0;
+    // ---- assemble the front(s): panel + children (lower triangles), then mirror F_NN
+    for (int q = 0; q < rbc; ++q) {
+      const double* P = u + (int64_t)(r0 + q * gridDim.y) * ldu + d.blk;
+      const int oan = L.oFan + q * nn * lda, onn = L.oFnn + q * nn * ldn;
+      batched_loop<8>(tid, npan, nthr, [=](int e) { return P[e]; },
+                      [=](int e, double v) {
+                        const int o = sPan[e];
+                        if (o >= 0) smem[(o & (1 << 30)) ? onn + (o & 0x3fffffff) : oan + o] = v;
+                      });
+    }
+    if (nch) for (int e = tid; e < npk; e += nthr) smem[sOut[e]] = 0.0;
     __syncthreads();
     STAMP(1);
-    for (int q = wave; q < nch; q += nw) {
-      const int nac = sCh[4 * q + 2];
-      const int* tg = sTgt + sCh[4 * q + 3];
-      const double* Uc = ub + (((int64_t)sCh[4 * q + 1] << 32) | (uint32_t)sCh[4 * q]);
-      batched_loop<8>(lane, nac * (nac + 1) / 2, 64, [=](int e) { return Uc[e]; },
-                      [=](int e, double vv) { unsafeAtomicAdd(&smem[tg[e]], vv); });
+    if (nch) {
+      const double* ub = a.t.updp + (int64_t)r0 * a.t.updplen;      // children: packed exchange buffer
+      for (int q = wave; q < nch; q += nw) {
+        const int nac = sCh[4 * q + 2];
+        const int* tg = sTgt + sCh[4 * q + 3];
+        const double* Uc = ub + (((int64_t)sCh[4 * q + 1] << 32) | (uint32_t)sCh[4 * q]);
+        batched_loop<8>(lane, nac * (nac + 1) / 2, 64, [=](int e) { return Uc[e]; },
+                        [=](int e, double vv) { unsafeAtomicAdd(&smem[tg[e]], vv); });
+      }
+      __syncthreads();
+    }
+    for (int q = 0; q < rbc; ++q) {
+      double* Fq = sFnn + q * nn * ldn;
+      for (int j = wave; j < nn; j += nw)
+        for (int i = j + 1 + lane; i < nn; i += 64) Fq[j + i * ldn] = Fq[i + j * ldn];
     }
     __syncthreads();
-    for (int j = wave; j < nn; j += nw)
-      for (int i = j + 1 + lane; i < nn; i += 64) sFnn[j + i * ldn] = sFnn[i + j * ldn];
-    __syncthreads();
     STAMP(2);
-    // ---- phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place of F_AN) ; T = Li F_NN
+    // ---- phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place of F_AN) ; T = Li F_NN   (all stacked columns)
     {
-      const int nE = NAt * NNt, nT = NNt * NNt;
+      const int nE = NAt * NCt, nT = NNt * NCt;
       for (int t = wave; t < nE + nT; t += nw) {
         d4 acc = {0.0, 0.0, 0.0, 0.0};
         if (t < nE) {
@@ -854,32 +878,43 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
     }
     __syncthreads();
     STAMP(3);
-    // ---- phase 2: U -= K E^T + E K^T (lower tiles) ; G = X Li^T ; G_NN = T Li^T (into sFnn)
+    // ---- phase 2: U_q -= K E_q^T + E_q K^T (lower tiles, per stacked rhs) ; G = X BD ; G_NN = T BD (into sFnn)
     {
-      const int nU = NAt * (NAt + 1) / 2, nG = NAt * NNt, nN = NNt * NNt;
+      const int nUq = NAt * (NAt + 1) / 2, nU = nUq * rbc, nG = NAt * NCt, nN = NNt * NCt;
       for (int t = wave; t < nU + nG + nN; t += nw) {
         d4 acc = {0.0, 0.0, 0.0, 0.0};
         if (t < nU) {
-          int tm = 0, rem = t;
+          const int q = t / nUq;
+          int tm = 0, rem = t - q * nUq;
           while (rem > tm) { rem -= tm + 1; ++tm; }
           const int tn = rem;
-          mma_run(acc, sK + tm * 16 + l15 + kq * lda, 4 * lda, sE + tn * 16 + l15 + kq * lda, 4 * lda, ksn);
-          mma_run(acc, sE + tm * 16 + l15 + kq * lda, 4 * lda, sK + tn * 16 + l15 + kq * lda, 4 * lda, ksn);
+          const double* Eq = sE + q * nn * lda;
+          mma_run(acc, sK + tm * 16 + l15 + kq * lda, 4 * lda, Eq + tn * 16 + l15 + kq * lda, 4 * lda, ksn);
+          mma_run(acc, Eq + tm * 16 + l15 + kq * lda, 4 * lda, sK + tn * 16 + l15 + kq * lda, 4 * lda, ksn);
           const int m = tm * 16 + l15;
+          if (nch) {
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int n = tn * 16 + kq + 4 * rr;
-            if (m >= n) sU[m + n * lda] -= acc[rr];
+            for (int rr = 0; rr < 4; ++rr) {
+              const int n = tn * 16 + kq + 4 * rr;
+              if (m >= n) sU[m + n * lda] -= acc[rr];
+            }
+          } else {   // no children: the update matrix is exactly -acc, stored packed
+            double* UkP = a.t.updp + (int64_t)(r0 + q * gridDim.y) * a.t.updplen + d.updp;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int n = tn * 16 + kq + 4 * rr;
+              if (m >= n && m < na) UkP[n * na - (n * (n - 1)) / 2 + (m - n)] = -acc[rr];
+            }
           }
         } else if (t < nU + nG) {
           const int tt = t - nU, tm = tt % NAt, tn = tt / NAt;
-          mma_run(acc, sFan + tm * 16 + l15 + kq * lda, 4 * lda, sLi + tn * 16 + l15 + kq * ldn, 4 * ldn, ksn);
+          mma_run(acc, sFan + tm * 16 + l15 + kq * lda, 4 * lda, sBD + kq + (tn * 16 + l15) * ldn, 4, ksc);
           const int m = tm * 16 + l15;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) sG[m + (tn * 16 + kq + 4 * rr) * lda] = acc[rr];
         } else {
           const int tt = t - nU - nG, tm = tt % NNt, tn = tt / NNt;
-          mma_run(acc, sT + tm * 16 + l15 + kq * ldn, 4 * ldn, sLi + tn * 16 + l15 + kq * ldn, 4 * ldn, ksn);
+          mma_run(acc, sT + tm * 16 + l15 + kq * ldn, 4 * ldn, sBD + kq + (tn * 16 + l15) * ldn, 4, ksc);
           const int m = tm * 16 + l15;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) sFnn[m + (tn * 16 + kq + 4 * rr) * ldn] = acc[rr];
@@ -890,7 +925,7 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
     STAMP(4);
     // ---- phase 3: Q = Ysc G into the F_AN buffer (X is dead), or plain G
     {
-      const int nQ = NAt * NNt;
+      const int nQ = NAt * NCt;
       for (int t = wave; t < nQ; t += nw) {
         const int tm = t % NAt, tn = t / NAt;
         const int m = tm * 16 + l15;
@@ -910,12 +945,19 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
     }
     __syncthreads();
     STAMP(5);
-    // ---- write out: panel (lower of NN + AN) and the update matrix (lower)
-    for (int e = tid; e < npan; e += nthr) {
-      const int o = sPan[e];
-      if (o >= 0) P[e] = smem[o];
+    // ---- write out: panel(s) (lower of NN + AN) and, with children, the update matrix (lower, packed)
+    for (int q = 0; q < rbc; ++q) {
+      double* P = u + (int64_t)(r0 + q * gridDim.y) * ldu + d.blk;
+      const int oan = L.oFan + q * nn * lda, onn = L.oFnn + q * nn * ldn;
+      for (int e = tid; e < npan; e += nthr) {
+        const int o = sPan[e];
+        if (o >= 0) P[e] = smem[(o & (1 << 30)) ? onn + (o & 0x3fffffff) : oan + o];
+      }
     }
-    for (int e = tid; e < npk; e += nthr) UkP[e] = smem[sOut[e]];
+    if (nch) {
+      double* UkP = a.t.updp + (int64_t)r0 * a.t.updplen + d.updp;
+      for (int e = tid; e < npk; e += nthr) UkP[e] = smem[sOut[e]];
+    }
     STAMP(6);
   }
 #ifdef SMCP_STAMPS
