@@ -815,12 +815,42 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
 #else
 #define STAMP(i) do { } while (0)
 #endif
+  // Software pipeline (cliques with children, one rhs per pass): the panel and the children's values of
+  // the NEXT right-hand side are fetched into registers while the current one is being computed.
+  constexpr int PP = 4, PC = 8;
+  const bool pipe = nch > 0 && nch <= nw && npan <= PP * nthr && a.plansum > 0;
+  bool pipe_ok = pipe;
+  if (pipe) {
+    bool fits = true;
+    for (int q = 0; q < nch; ++q) fits = fits && (sCh[4 * q + 2] * (sCh[4 * q + 2] + 1) / 2 <= PC * 64);
+    pipe_ok = fits;
+  }
+  double pre_p[PP], pre_c[PC];
+  auto prefetch = [&](int rr) {
+    const double* P = u + (int64_t)rr * ldu + d.blk;
+#pragma unroll
+    for (int x = 0; x < PP; ++x) { const int e = tid + x * nthr; pre_p[x] = e < npan ? P[e] : 0.0; }
+    if (wave < nch) {
+      const int nac = sCh[4 * wave + 2], np_ = nac * (nac + 1) / 2;
+      const double* Uc = a.t.updp + (int64_t)rr * a.t.updplen + (((int64_t)sCh[4 * wave + 1] << 32) | (uint32_t)sCh[4 * wave]);
+#pragma unroll
+      for (int x = 0; x < PC; ++x) { const int e = lane + 64 * x; pre_c[x] = e < np_ ? Uc[e] : 0.0; }
+    }
+  };
+  if (pipe_ok && (int)blockIdx.y < a.nrhs) prefetch(blockIdx.y);
   for (int r0 = blockIdx.y; r0 < a.nrhs; r0 += gridDim.y * rb) {
     // this pass: right-hand sides r0, r0 + gridDim.y, ... (rbc of them)
     const int rbc = min(rb, (a.nrhs - r0 + (int)gridDim.y - 1) / (int)gridDim.y);
     __syncthreads();
     STAMP(0);
     // ---- assemble the front(s): panel + children (lower triangles), then mirror F_NN
+    if (pipe_ok) {
+#pragma unroll
+      for (int x = 0; x < PP; ++x) {
+        const int e = tid + x * nthr;
+        if (e < npan) { const int o = sPan[e]; if (o >= 0) smem[(o & (1 << 30)) ? L.oFnn + (o & 0x3fffffff) : L.oFan + o] = pre_p[x]; }
+      }
+    } else
     for (int q = 0; q < rbc; ++q) {
       const double* P = u + (int64_t)(r0 + q * gridDim.y) * ldu + d.blk;
       const int oan = L.oFan + q * nn * lda, onn = L.oFnn + q * nn * ldn;
@@ -833,7 +863,17 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
     if (nch) for (int e = tid; e < npk; e += nthr) smem[sOut[e]] = 0.0;
     __syncthreads();
     STAMP(1);
-    if (nch) {
+    if (pipe_ok) {
+      if (wave < nch) {
+        const int nac = sCh[4 * wave + 2], np_ = nac * (nac + 1) / 2;
+        const int* tg = sTgt + sCh[4 * wave + 3];
+#pragma unroll
+        for (int x = 0; x < PC; ++x) { const int e = lane + 64 * x; if (e < np_) unsafeAtomicAdd(&smem[tg[e]], pre_c[x]); }
+      }
+      __syncthreads();
+      const int rn = r0 + (int)gridDim.y;
+      if (rn < a.nrhs) prefetch(rn);          // in flight during the three compute phases below
+    } else if (nch) {
       const double* ub = a.t.updp + (int64_t)r0 * a.t.updplen;      // children: packed exchange buffer
       for (int q = wave; q < nch; q += nw) {
         const int nac = sCh[4 * q + 2];
