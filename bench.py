@@ -55,7 +55,7 @@ def lds_fits(nn, na):
     """Mirror of mfma_lds_doubles() in csrc/front_mfma.hip: does the working set of a front fit 160 KB of LDS?"""
     pad = lambda x: x | 1
     lk, ll, lf = pad(na), pad(nn), pad(nn + na)
-    d = lk * nn + ll * nn + lk * na + lf * nn + ll * nn + lk * nn + lk * nn + ll * nn + lk * na + 256 + 8 + (na + 2) // 2
+    d = lk * nn + ll * nn + lk * na + lf * nn + ll * nn + lk * nn + lk * nn + ll * nn + lk * na + 256 + 8
     return d * 8 <= 160 * 1024 - 256
 
 
@@ -200,7 +200,20 @@ def main():
             return sum(8.0 * (r * (2 * Bk[mask].sum() + Uk[mask].sum() + Uch[mask].sum()) + Bk[mask].sum())
                        for r in chunks)
 
+        # Gram formulation at N = 1: the m constraint sweeps are leaves->root only; the two Hessians of
+        # solve_ add one up- and one down-sweep each.  Update matrices are exchanged as packed lower
+        # triangles, so the algorithmic update volume of the fast up-sweep is Up = sum na(na+1)/2.
+        Upk = (na_ * (na_ + 1) // 2).astype(np.float64)
+        Upch = np.zeros(symb.Nsn)
+        np.add.at(Upch, par[par >= 0], Upk[par >= 0])
+        up_chunks = chunks if world == 1 else chunks
+
+        def up_bytes(mask):
+            return sum(8.0 * (r * (2 * Bk[mask].sum() + Upk[mask].sum() + Upch[mask].sum()) + Bk[mask].sum())
+                       for r in up_chunks)
+
         alg = {"k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
+               "k_hess_up_pad": up_bytes(lds_ok),
                "k_hess_up_mfma<true>": cls_bytes(lds_ok), "k_hess_down_mfma<true>": cls_bytes(lds_ok),
                "k_hess_up_mfma<false>": cls_bytes(~lds_ok), "k_hess_down_mfma<false>": cls_bytes(~lds_ok),
                "k_chol_level": 8.0 * (2 * B + 2 * U), "k_pinv_level": 8.0 * (2 * B + 2 * U)}.get(dom)
