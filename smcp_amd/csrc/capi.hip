@@ -38,7 +38,8 @@ enum {
   KID_hess_up_mfma_hbm, KID_hess_down_mfma_hbm, KID_chol_mfma_hbm, KID_pinv_mfma_hbm,
   KID_gram_partial, KID_gram_reduce, KID_hess_up_pad,
   KID_lf_assemble, KID_lf_clear_upd, KID_lf_up1, KID_lf_up2, KID_lf_up3, KID_lf_down1, KID_lf_down2, KID_lf_down3,
-  KID_lf_pinv1, KID_lf_pinv2,
+  KID_lf_pinv1, KID_lf_pinv2, KID_lf_diag, KID_lf_chol_panel, KID_lf_chol_trail, KID_lf_pack_upd,
+  KID_lf_prep_s, KID_lf_prep_row, KID_lf_prep_k, KID_factor_yaa_lds,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -50,7 +51,8 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_mfma<false>", "k_hess_down_mfma<false>", "k_chol_mfma<false>", "k_pinv_mfma<false>",
   "k_gram_partial", "k_gram_reduce", "k_hess_up_pad",
   "k_lf_assemble", "k_lf_clear_upd", "k_lf_up1", "k_lf_up2", "k_lf_up3", "k_lf_down1", "k_lf_down2", "k_lf_down3",
-  "k_lf_pinv1", "k_lf_pinv2"};
+  "k_lf_pinv1", "k_lf_pinv2", "k_lf_diag", "k_lf_chol_panel", "k_lf_chol_trail", "k_lf_pack_upd",
+  "k_lf_prep_s", "k_lf_prep_row", "k_lf_prep_k", "k_factor_yaa_lds"};
 
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -150,15 +152,7 @@ void gather_all(csp_ctx* c, const double* x, int64_t ldx, int nrhs, double* updb
   });
 }
 
-int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st) {
-  TreeArgs a = tree_args(c);
-  c->D.yaa_tag = Y;
-  gather_all(c, Y, 0, 1, c->D.yaa, st);
-  if (need_fac) {
-    launch(c, KID_factor_yaa, k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), st, a, c->D.yaa, c->D.fac);
-  }
-  return 0;
-}
+int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st);
 
 
 // ---- fast path (front_mfma.hip): per level, LDS-class cliques then HBM-class cliques ----------
@@ -182,6 +176,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.nrhs = nrhs;
   { static int sk = -1; if (sk < 0) { const char* e = getenv("SMCP_SKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
   a.dbg = (a.skip & 64) ? (unsigned long long*)(c->D.red + 768) : nullptr;
+  a.lfd = c->D.lfd;
   return a;
 }
 
@@ -249,9 +244,61 @@ void lf_pinv(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
   launch(c, KID_lf_pinv2, k_lf_pinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, 1), blk, st, a, x);
 }
 
+constexpr size_t LF_DIAG_LDS = (size_t)(2 * LB * LBD + 256 + 16 * LB) * sizeof(double);
+
+// blocked Cholesky of the large fronts of one level (children already factored): clear + assemble + steps
+void lf_chol(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) {
+  dim3 blk(256);
+  const int nfmax = a.nnmax + a.namax;
+  launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, 1), blk, st, a);
+  if (a.t.gp_tptr) launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, 1), blk, st, a, x, (int64_t)0);
+  const int mtA = tiles64(a.namax);
+  for (int jb = 0; jb < a.nnmax; jb += LB) {
+    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, x, (double*)nullptr, 0, jb, 1);
+    const int mrem = nfmax - jb - 1, ncr = std::max(0, a.nnmax - jb - 1);
+    if (mrem > 0) launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(umax1(tiles64(mrem)), cnt), blk, st, a, x, (double*)nullptr, 0, jb);
+    const int mt = tiles64(mrem), nt = tiles64(ncr);
+    const int ntask = nt * (nt + 1) / 2 + std::max(0, mt - nt) * nt + mtA * (mtA + 1) / 2;
+    if (ntask > 0) launch(c, KID_lf_chol_trail, k_lf_chol_trail, dim3(umax1(ntask), cnt), blk, st, a, x, (double*)nullptr, 0, jb);
+  }
+  if (a.namax) launch(c, KID_lf_pack_upd, k_lf_pack_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 255) / 256)), cnt), blk, st, a);
+}
+// chol(Y_AA) of the large fronts of one level, in place in fac (already a copy of yaa)
+void lf_factor_yaa(csp_ctx* c, const MfmaArgs& a, int cnt, double* fac, hipStream_t st) {
+  dim3 blk(256);
+  for (int jb = 0; jb < a.namax; jb += LB) {
+    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, (double*)nullptr, fac, 2, jb, 1);
+    const int mrem = a.namax - jb - 1;
+    if (mrem > 0) {
+      launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(umax1(tiles64(mrem)), cnt), blk, st, a, (double*)nullptr, fac, 2, jb);
+      const int mt = tiles64(mrem);
+      launch(c, KID_lf_chol_trail, k_lf_chol_trail, dim3(umax1(mt * (mt + 1) / 2), cnt), blk, st, a, (double*)nullptr, fac, 2, jb);
+    }
+  }
+}
+// inverse-form factor of the large fronts of one level
+void lf_prep(csp_ctx* c, const MfmaArgs& a, int cnt, const double* L, hipStream_t st) {
+  dim3 blk(256);
+  for (int ib = 0; ib < a.nnmax; ib += LB) {
+    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, const_cast<double*>(L), (double*)nullptr, 1, ib, 0);
+    if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, L, c->D.lk, ib);
+    launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, L, c->D.lk, ib);
+  }
+  if (a.namax) launch(c, KID_lf_prep_k, k_lf_prep_k, dim3(umax1(tiles64(a.namax) * tiles64(a.nnmax)), cnt), blk, st, a, L, c->D.lk);
+}
+
 void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
   TreeArgs t = tree_args(c);
-  launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->S.nsn), dim3(NT), st, t, L, c->D.lk);
+  if (use_large()) {
+    t.lev = c->D.lev3idx;
+    if (c->D.nI_total) launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->D.nI_total), dim3(NT), st, t, L, c->D.lk);
+    MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+    for (int64_t l = 0; l < c->S.nlev; ++l)
+      for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) { if (!lds) lf_prep(c, am, cnt, L, st); });
+  } else {
+    t.lev = nullptr;
+    launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->S.nsn), dim3(NT), st, t, L, c->D.lk);
+  }
   c->D.lk_tag_L = L;
   c->D.lk_tag_Y = nullptr;
 }
@@ -297,6 +344,25 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
       else if (use_large() && ymode == 0) lf_down(c, a, cnt, nrhs, U, ldu, st);
       else launch_lds(c, KID_hess_down_mfma_hbm, k_hess_down_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
     });
+}
+
+int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st) {
+  TreeArgs a = tree_args(c);
+  c->D.yaa_tag = Y;
+  gather_all(c, Y, 0, 1, c->D.yaa, st);
+  if (need_fac && !use_generic() && use_large()) {
+    (void)hipMemcpyAsync(c->D.fac, c->D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st);
+    MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+    for (int64_t l = 0; l < c->S.nlev; ++l)
+      for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
+        if (!lds) { lf_factor_yaa(c, am, cnt, c->D.fac, st); return; }
+        size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
+        if (am.namax) launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(256), bytes, st, am, (const double*)c->D.yaa, c->D.fac);
+      });
+  } else if (need_fac) {
+    launch(c, KID_factor_yaa, k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), st, a, c->D.yaa, c->D.fac);
+  }
+  return 0;
 }
 
 int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t ldu, int adj, int inv,
@@ -364,7 +430,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
     for (void* p : ptrs) if (p) hipFree(p);
     if (D.info_host) hipHostFree(D.info_host);
@@ -443,7 +509,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       d.chbeg = (int32_t)S.chptr[k];
       d.chend = (int32_t)S.chptr[k + 1];
       d.first = (int32_t)S.snptr[k];
-      d.pad = 0;
+      d.pad = -1;
     }
     std::vector<int32_t> ch(S.chidx.begin(), S.chidx.end()), lev(S.levidx.begin(), S.levidx.end());
     c->h_tmpptr.resize(S.nsn + 1);
@@ -486,6 +552,20 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       }
     }
     int rc = 0;
+    {
+      // slots of the large fronts (per-front 64 x 64 scratch) and the flat list of LDS-class cliques
+      int32_t slot = 0;
+      std::vector<int32_t> lev3;
+      for (int64_t l = 0; l < S.nlev; ++l) {
+        const LevelClass& L = c->lvl[l];
+        int64_t b = S.levptr[l];
+        for (int64_t q = 0; q < L.nI; ++q) lev3.push_back(lev2[b + q]);
+        for (int64_t q = L.nI; q < L.nI + L.nII; ++q) cl[lev2[b + q]].pad = slot++;
+      }
+      D.nI_total = (int64_t)lev3.size();
+      if ((rc = dev_upload(&D.lev3idx, lev3, D.bytes))) return rc;
+      if ((rc = dev_alloc(&D.lfd, (int64_t)std::max(slot, 1) * 64 * 64, D.bytes))) return rc;
+    }
     if ((rc = dev_upload(&D.cl, cl, D.bytes))) return rc;
     if ((rc = dev_upload(&D.rowidx, S.rowidx, D.bytes))) return rc;
     if ((rc = dev_upload(&D.relidx, S.relidx, D.bytes))) return rc;
@@ -535,6 +615,8 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_pad, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_gram_partial, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_lf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_factor_yaa_lds, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_chol_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_pinv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
@@ -574,6 +656,7 @@ int csp_cholesky(csp_ctx* c, double* x, void* stream) {
     for (int64_t l = 0; l < c->S.nlev; ++l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
         if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
+        else if (use_large() && c->D.gp_tptr) lf_chol(c, am, cnt, x, st);
         else launch_lds(c, KID_chol_mfma_hbm, k_chol_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
       });
   } else

@@ -20,7 +20,7 @@ struct CliqueDesc {
   int32_t parent;  // parent clique or -1
   int32_t chbeg, chend;  // children list range in chidx
   int32_t first;   // first permuted column (snptr[k])
-  int32_t pad;
+  int32_t pad;     // slot of this clique among the large (HBM-class) fronts, -1 otherwise
 };
 
 struct DeviceCtx {
@@ -45,6 +45,9 @@ struct DeviceCtx {
   const void* lk_tag_L = nullptr;   // LK was prepared from the factor stored at this address ...
   const void* lk_tag_Y = nullptr;   // ... or from the factor whose projected inverse now lives here
   const void* yaa_tag = nullptr;    // yaa holds the separator blocks of the matrix at this address
+  double* lfd = nullptr;      // 64 x 64 doubles per large front: inverse of the current diagonal block
+  int32_t* lev3idx = nullptr; // all LDS-class cliques (any level), then nothing: list for clique-local kernels
+  int64_t nI_total = 0;
   double* lk = nullptr;       // inverse-form factor [L_NN^-1; L_AN L_NN^-1] of the most recent prep
   // workspaces
   double* upd = nullptr;   // max_rhs * updlen : update matrices

@@ -360,3 +360,257 @@ __global__ void __launch_bounds__(256) k_lf_pinv2(MfmaArgs a, double* x) {
 }
 
 }  // namespace smcp
+
+namespace smcp {
+
+// ---------------------------------------------------------------------------------------------
+// Blocked Cholesky / triangular inversion of large fronts: 64-wide block columns, one launch
+// per step and phase (diag block in LDS by one workgroup per clique; panel and trailing updates
+// as 64x64 MFMA tiles over the whole chip).
+// ---------------------------------------------------------------------------------------------
+constexpr int LB = 64;          // block-column width
+constexpr int LBD = LB + 1;     // LDS leading dimension of the diagonal block
+
+// In-LDS Cholesky (do_potrf) and inverse of a w x w (w <= 64) lower block D (ld LBD); the inverse goes
+// to Di (ld LBD, zeros above the diagonal).  d16: 256 doubles, s16: 16 x 64 doubles of scratch.
+// Returns 0 or the 1-based failing pivot (uniform).
+__device__ inline int potrf_inv64(double* D, int w, double* Di, double* d16, double* s16, bool do_potrf) {
+  for (int e = threadIdx.x; e < LB * LBD; e += blockDim.x) Di[e] = 0.0;
+  __syncthreads();
+  for (int jb = 0; jb < w; jb += 16) {
+    const int bw = min(16, w - jb);
+    if (do_potrf) {
+      int f = potrf_inv16(D + jb + jb * LBD, LBD, bw, d16);
+      if (f) return jb + f;
+      const int mrem = w - jb - bw;
+      if (mrem > 0) {
+        double* Pj = D + (jb + bw) + jb * LBD;
+        wg_mma(mrem, bw, bw, [=](int m, int kk) { return Pj[m + kk * LBD]; },
+               [=](int kk, int n) { return d16[n + kk * 16]; },
+               [=](int m, int n, double acc) { Pj[m + n * LBD] = acc; });
+        __syncthreads();
+        double* Tr = D + (jb + bw) + (jb + bw) * LBD;
+        wg_mma(mrem, mrem, bw, [=](int m, int kk) { return Pj[m + kk * LBD]; },
+               [=](int kk, int n) { return Pj[n + kk * LBD]; },
+               [=](int m, int n, double acc) { if (m >= n) Tr[m + n * LBD] -= acc; }, true);
+        __syncthreads();
+      }
+    } else {
+      tri_inv16(D + jb + jb * LBD, LBD, bw, d16);
+    }
+    // block row jb of the inverse: diagonal block, then -Dinv16 * (D[jb, 0:jb] * Di[0:jb, 0:jb])
+    for (int e = threadIdx.x; e < bw * bw; e += blockDim.x) {
+      int i = e % bw, j = e / bw;
+      if (i >= j) Di[(jb + i) + (jb + j) * LBD] = d16[i + j * 16];
+    }
+    __syncthreads();
+    if (jb > 0) {
+      wg_mma(bw, jb, jb, [=](int m, int kk) { return D[(jb + m) + kk * LBD]; },
+             [=](int kk, int n) { return Di[kk + n * LBD]; },
+             [=](int m, int n, double acc) { s16[m + n * 16] = acc; });
+      __syncthreads();
+      wg_mma(bw, jb, bw, [=](int m, int kk) { return d16[m + kk * 16]; },
+             [=](int kk, int n) { return s16[kk + n * 16]; },
+             [=](int m, int n, double acc) { Di[(jb + m) + n * LBD] = -acc; });
+      __syncthreads();
+    }
+  }
+  return 0;
+}
+
+// A square or panel matrix view processed by the blocked kernels: M (rows) x N (cols) at ptr (ld), optional
+// trailing block `upd` (na x na, ld na) that receives -P_A P_A^T (Cholesky of a front), scratch for Dinv.
+struct LfMat {
+  double* A; int64_t ld; int nrow, ncol;   // factor the leading ncol x ncol block, nrow >= ncol
+  double* upd; int na;                     // rows ncol..nrow-1 update this (na = nrow - ncol) or null
+  double* dinv;                            // w x w inverse of the current diagonal block (ld = w)
+};
+// mode 0: panel of a front in x (Cholesky), 1: L -> LK preparation (triangular inverse), 2: Y_AA -> its Cholesky factor
+__device__ inline LfMat lf_mat(const MfmaArgs& a, int k, int mode, double* x, double* aux) {
+  const CliqueDesc d = a.t.cl[k];
+  LfMat m;
+  double* scratch = a.lfd + (int64_t)d.pad * (LB * LB);   // d.pad = slot of this clique among the large fronts
+  if (mode == 2) {
+    m.A = aux + d.upd; m.ld = d.na; m.nrow = d.na; m.ncol = d.na; m.upd = nullptr; m.na = 0;
+  } else {
+    m.A = x + d.blk; m.ld = d.nn + d.na; m.nrow = d.nn + d.na; m.ncol = d.nn;
+    m.upd = (mode == 0) ? a.t.upd + d.upd : nullptr; m.na = d.na;
+  }
+  m.dinv = scratch;
+  return m;
+}
+
+// diag step: factor (or only invert) the diagonal block at column jb; L block written back, inverse to scratch
+__global__ void __launch_bounds__(256) k_lf_diag(MfmaArgs a, double* x, double* aux, int mode, int jb, int do_potrf) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const D = smem;
+  double* const Di = D + LB * LBD;
+  double* const d16 = Di + LB * LBD;
+  double* const s16 = d16 + 256;
+  if (*a.t.info) return;
+  const int k = a.t.lev[blockIdx.x];
+  const LfMat M = lf_mat(a, k, mode, x, aux);
+  if (jb >= M.ncol) return;
+  const int w = min(LB, M.ncol - jb);
+  double* Ab = M.A + jb + (int64_t)jb * M.ld;
+  for (int e = threadIdx.x; e < w * w; e += blockDim.x) {
+    int i = e % w, j = e / w;
+    D[i + j * LBD] = (i >= j) ? Ab[i + (int64_t)j * M.ld] : 0.0;
+  }
+  __syncthreads();
+  int f = potrf_inv64(D, w, Di, d16, s16, do_potrf != 0);
+  if (f) { if (threadIdx.x == 0) atomicCAS(a.t.info, 0, k + 1); return; }
+  for (int e = threadIdx.x; e < w * w; e += blockDim.x) {
+    int i = e % w, j = e / w;
+    if (do_potrf && i >= j) Ab[i + (int64_t)j * M.ld] = D[i + j * LBD];
+    M.dinv[i + j * w] = Di[i + j * LBD];
+  }
+}
+// panel step: rows below the diagonal block <- rows * Dinv^T   (one 64x64 tile per workgroup, in place)
+__global__ void __launch_bounds__(256) k_lf_chol_panel(MfmaArgs a, double* x, double* aux, int mode, int jb) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  if (*a.t.info) return;
+  const int k = a.t.lev[blockIdx.y];
+  const LfMat M = lf_mat(a, k, mode, x, aux);
+  if (jb >= M.ncol) return;
+  const int w = min(LB, M.ncol - jb);
+  const int mrem = M.nrow - jb - w;
+  const int m0 = blockIdx.x * LT;
+  if (m0 >= mrem) return;
+  double* Pj = M.A + (jb + w) + (int64_t)jb * M.ld;
+  const double* Di = M.dinv;
+  const int64_t ld = M.ld;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64(acc, mrem, w, w, m0, 0, [=](int m, int kk) { return Pj[m + kk * ld]; },
+              [=](int kk, int n) { return Di[n + kk * w]; }, sA, sB);
+  __syncthreads();   // every thread has consumed its rows before they are overwritten
+  tile64_foreach(acc, m0, 0, mrem, w, [=](int m, int n, double v) { Pj[m + n * ld] = v; });
+}
+// trailing step: remaining columns of the panel and the update block -= P P^T (lower tiles)
+__global__ void __launch_bounds__(256) k_lf_chol_trail(MfmaArgs a, double* x, double* aux, int mode, int jb) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  if (*a.t.info) return;
+  const int k = a.t.lev[blockIdx.y];
+  const LfMat M = lf_mat(a, k, mode, x, aux);
+  if (jb >= M.ncol) return;
+  const int w = min(LB, M.ncol - jb);
+  const int mrem = M.nrow - jb - w;       // rows below the diagonal block
+  const int ncr = M.ncol - jb - w;        // remaining columns of the factored part
+  const int mt = tiles64(mrem), nt = tiles64(ncr);
+  // tasks: (a) tiles (tm, tn) with tn < nt, tm >= tn of the in-panel trailing block; (b) lower tiles of upd
+  const int mtA = tiles64(M.na);
+  const int nP = (ncr > 0) ? (nt * (nt + 1) / 2 + (mt - nt) * nt) : 0;
+  const int nU = M.upd ? mtA * (mtA + 1) / 2 : 0;
+  const int t = blockIdx.x;
+  if (t >= nP + nU) return;
+  const double* Pj = M.A + (jb + w) + (int64_t)jb * M.ld;
+  const int64_t ld = M.ld;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (t < nP) {
+    int tm, tn;
+    const int ntri = nt * (nt + 1) / 2;
+    if (t < ntri) lower_pair(t, tm, tn);
+    else { const int tt = t - ntri; tm = nt + tt / nt; tn = tt % nt; }
+    const int m0 = tm * LT, n0 = tn * LT;
+    gemm_tile64(acc, mrem, ncr, w, m0, n0, [=](int m, int kk) { return Pj[m + kk * ld]; },
+                [=](int kk, int n) { return Pj[n + kk * ld]; }, sA, sB);
+    double* Tr = M.A + (jb + w) + (int64_t)(jb + w) * M.ld;
+    tile64_foreach(acc, m0, n0, mrem, ncr, [=](int m, int n, double v) { if (m >= n) Tr[m + n * ld] -= v; });
+  } else {
+    int tm, tn;
+    lower_pair(t - nP, tm, tn);
+    const int m0 = tm * LT, n0 = tn * LT;
+    const double* Pa = M.A + M.ncol + (int64_t)jb * M.ld;   // separator rows of block column jb
+    const int na = M.na;
+    gemm_tile64(acc, na, na, w, m0, n0, [=](int m, int kk) { return Pa[m + kk * ld]; },
+                [=](int kk, int n) { return Pa[n + kk * ld]; }, sA, sB);
+    double* U = M.upd;
+    tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) { if (m >= n) U[m + (int64_t)n * na] -= v; });
+  }
+}
+// after the last step of a front's Cholesky: publish the update block as packed lower triangle
+__global__ void k_lf_pack_upd(MfmaArgs a) {
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  const int na = d.na;
+  const double* U = a.t.upd + d.upd;
+  double* UP = a.t.updp + d.updp;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < na * na; e += gridDim.x * blockDim.x) {
+    int i = e % na, j = e / na;
+    if (i >= j) UP[pk_idx(i, j, na)] = U[e];
+  }
+}
+
+// ---- inverse-form factor of large fronts: Li = L_NN^-1 by block rows, K = L_AN Li
+// step ib: (after k_lf_diag wrote Dinv of block ib) S = L[ib, 0:ib] Li[0:ib, 0:ib] ; Li[ib, 0:ib] = -Dinv S
+__global__ void __launch_bounds__(256) k_lf_prep_s(MfmaArgs a, const double* L, double* LK, int ib) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, nf = d.nn + d.na;
+  if (ib >= nn || ib == 0) return;
+  const int w = min(LB, nn - ib);
+  const int n0 = blockIdx.x * LT;
+  if (n0 >= ib) return;
+  const double* Lk = L + d.blk;
+  const double* Li = LK + d.blk;
+  double* S = a.t.tmp + a.t.tmpptr[k];   // w x ib (ld w)
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64(acc, w, ib, ib, 0, n0, [=](int m, int kk) { return Lk[(ib + m) + (int64_t)kk * nf]; },
+              [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB);
+  tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { S[m + (int64_t)n * w] = v; });
+}
+__global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L, double* LK, int ib) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, nf = d.nn + d.na;
+  if (ib >= nn) return;
+  const int w = min(LB, nn - ib);
+  const double* Di = a.lfd + (int64_t)d.pad * (LB * LB);       // w x w (ld w)
+  double* Li = LK + d.blk;
+  const int t = blockIdx.x;
+  const int ntS = tiles64(ib);
+  if (t == ntS) {   // diagonal block of Li (and zeros above it)
+    for (int e = threadIdx.x; e < w * w; e += blockDim.x) {
+      int i = e % w, j = e / w;
+      Li[(ib + i) + (int64_t)(ib + j) * nf] = (i >= j) ? Di[i + j * w] : 0.0;
+    }
+    for (int e = threadIdx.x; e < ib * w; e += blockDim.x) {   // upper part: rows < ib of these columns
+      int i = e % ib, j = e / ib;
+      Li[i + (int64_t)(ib + j) * nf] = 0.0;
+    }
+    return;
+  }
+  if (t > ntS) return;
+  const int n0 = t * LT;
+  const double* S = a.t.tmp + a.t.tmpptr[k];
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64(acc, w, ib, w, 0, n0, [=](int m, int kk) { return Di[m + kk * w]; },
+              [=](int kk, int n) { return S[kk + (int64_t)n * w]; }, sA, sB);
+  tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { Li[(ib + m) + (int64_t)n * nf] = -v; });
+}
+__global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, double* LK) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int t = blockIdx.x;
+  if (t >= mtA * ntN) return;
+  const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+  const double* Lk = L + d.blk;
+  const double* Li = LK + d.blk;
+  double* Kk = LK + d.blk + nn;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return Lk[(nn + m) + (int64_t)kk * nf]; },
+              [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB);
+  tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Kk[m + (int64_t)n * nf] = v; });
+}
+
+}  // namespace smcp

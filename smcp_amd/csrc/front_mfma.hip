@@ -87,6 +87,7 @@ struct MfmaArgs {
   int nchmax, panmax, pkmax, plansum;  // LDS sizing of the index tables of the padded kernels
   int skip;  // debug-only phase mask (SMCP_SKIP env), 0 in production
   unsigned long long* dbg;  // diagnostic builds: cycle-stamp accumulator (null otherwise)
+  double* lfd;              // 64 x 64 scratch per large front (inverse of the current diagonal block)
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }
@@ -581,7 +582,7 @@ __global__ void k_chol_mfma(MfmaArgs a, double* x) {
 // ------------------------------------------------------------------ inverse-form factor LK = [L_NN^-1 ; L_AN L_NN^-1]
 // One workgroup per clique, operands in HBM/L2 (runs once per factorisation).
 __global__ void k_prep_lk(TreeArgs t, const double* L, double* LK) {
-  const int k = blockIdx.x;
+  const int k = t.lev ? t.lev[blockIdx.x] : blockIdx.x;
   const CliqueDesc d = t.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
   const double* Lk = L + d.blk;
@@ -662,6 +663,45 @@ __global__ void k_pinv_mfma(MfmaArgs a, double* x) {
 }
 
 
+
+
+// fac[k] <- chol(yaa[k]) for cliques whose separator block fits LDS: blocked (16-wide) in LDS on MFMA
+__global__ void __launch_bounds__(256) k_factor_yaa_lds(MfmaArgs a, const double* yaa, double* fac) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int na = d.na;
+  if (!na) return;
+  const int ld = padld(a.namax);
+  double* const M = smem;
+  double* const D16 = smem + (int64_t)ld * a.namax;
+  const double* src = yaa + d.upd;
+  double* dst = fac + d.upd;
+  batched_loop<8>(threadIdx.x, na * na, blockDim.x, [=](int e) { return (e % na) >= (e / na) ? src[e] : 0.0; },
+                  [=](int e, double v) { M[(e % na) + (e / na) * ld] = v; });
+  for (int jb = 0; jb < na; jb += 16) {
+    const int bw = min(16, na - jb);
+    int f = potrf_inv16(M + jb + jb * ld, ld, bw, D16);
+    if (f) { if (threadIdx.x == 0) atomicCAS(a.t.info, 0, k + 1); return; }
+    const int mrem = na - jb - bw;
+    if (mrem > 0) {
+      double* Pj = M + (jb + bw) + jb * ld;
+      wg_mma(mrem, bw, bw, [=](int m, int kk) { return Pj[m + kk * ld]; },
+             [=](int kk, int n) { return D16[n + kk * 16]; },
+             [=](int m, int n, double acc) { Pj[m + n * ld] = acc; });
+      __syncthreads();
+      double* Tr = M + (jb + bw) + (jb + bw) * ld;
+      wg_mma(mrem, mrem, bw, [=](int m, int kk) { return Pj[m + kk * ld]; },
+             [=](int kk, int n) { return Pj[n + kk * ld]; },
+             [=](int m, int n, double acc) { if (m >= n) Tr[m + n * ld] -= acc; }, true);
+      __syncthreads();
+    }
+  }
+  for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
+    int i = e % na, j = e / na;
+    if (i >= j) dst[e] = M[i + j * ld];
+  }
+}
 
 // ------------------------------------------------------------------ padded-LDS fast kernels
 // Every LDS matrix is padded to multiples of 16 rows / columns with zero fill, so the MFMA loops
