@@ -8,9 +8,12 @@ Inputs are synthetic (seeded numpy) and resident in HBM before the timed region.
 
 N = 1 workload: the configuration the metric is quoted on, "synth50k" (config 5: nested
 block-arrow chordal SDP, n = 50000, 8073 cliques, m = 100), which fits one GPU.
-N > 1: the Schur build -- the data-parallel part, m independent constraint sweeps -- is sharded
-by constraint columns over the ranks (strong scaling of ONE solve); the only collective is one
-RCCL all-reduce of the m x m matrix H per step.  Factorisation and solve_ are replicated.
+N > 1 (strong scaling of ONE solve): the clique tree is cut into subtrees owned by single ranks plus a
+small replicated top (smcp_amd/shard.py).  Every rank sweeps all m constraints over its own subtrees,
+the packed update blocks of the subtree roots are exchanged with one RCCL all-gather, the top is swept
+redundantly, each rank forms the partial Gram matrix of its blkval ranges and one all-reduce of the
+m x m matrix H completes it.  Factorisation and solve_ are replicated.  (--shard columns selects the
+simpler column sharding of H.)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the
 dominant kernel (HIP-event timing inside the timed region) and `cpu_baseline` (the CPU
@@ -68,6 +71,8 @@ def main():
     ap.add_argument("--m", type=int, default=None)
     ap.add_argument("--max-rhs", type=int, default=None)
     ap.add_argument("--cpu-cols", type=int, default=8, help="Schur columns timed on the CPU oracle")
+    ap.add_argument("--shard", default="subtree", choices=["subtree", "columns"],
+                    help="N > 1: subtree sharding + boundary exchange (default) or column sharding of H")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing")
     ap.add_argument("--verbose", action="store_true")
@@ -86,8 +91,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("SMCP_BENCH_BACKEND", "nccl")   # "gloo": functional check with ranks sharing a GPU
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local % ndev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
@@ -107,6 +117,9 @@ def main():
     max_rhs = args.max_rhs or int(max(1, min(m, (48 << 30) // per_rhs)))
     cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=1)
     kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs)
+    part = None
+    if world > 1 and args.shard == "subtree":
+        part = kkt.set_partition(dist.group.WORLD)   # subtrees -> ranks, replicated top, boundary exchange lists
     Lh = problems.random_factor_blkval(symb, seed=0)
     S = cspmatrix(symb, torch.from_numpy(Lh).to(dev))
     chordal.llt(S)                       # S = L0 L0^T on V: positive definite by construction
@@ -160,7 +173,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -190,6 +203,9 @@ def main():
         nn_, na_ = symb.clique_sizes()
         from smcp_amd.symbolic import Symbolic as _S  # noqa: F401
         lds_ok = np.array([lds_fits(int(a), int(b)) for a, b in zip(nn_, na_)])
+        if part is not None:     # this rank sweeps only its own subtrees and the replicated top
+            lds_ok = lds_ok & ((part.owner == rank) | (part.owner == -1))
+            chunks = [min(max_rhs, m - c) for c in range(0, m, max_rhs)] + [1, 1]
         Bk = ((nn_ + na_) * nn_).astype(np.float64)
         Uk = (na_ * na_).astype(np.float64)
         par = symb.snpar
@@ -268,7 +284,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "n": symb.n, "cliques": symb.Nsn, "m": m, "blkval_doubles": int(B),
                        "update_doubles": int(U), "rhs_per_sweep": max_rhs,
-                       "parallelism": "schur-columns/%d" % world},
+                       "parallelism": ("single" if world == 1 else
+                                       ("subtree-sharded Gram + boundary exchange/%d" % world if part is not None
+                                        else "schur-columns/%d" % world))},
             "roofline": roofline, "cpu_baseline": cpu,
             "symbolic_s": round(t_sym, 3),
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},

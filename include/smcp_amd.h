@@ -122,6 +122,20 @@ int dense_potrs(csp_ctx* ctx, const double* A, int64_t n, int64_t lda, double* B
 int kkt_solve(csp_ctx* ctx, const double* L, const double* Y, const double* H, int64_t ldh,
               double kk, double* bx, double* by, void* stream);
 
+/* ---- subtree-sharded multi-GPU Schur complement (Gram formulation) ---------------------------
+ * The elimination tree is cut into subtrees owned by single ranks plus a replicated top
+ * (owner[k] = rank, or -1 for the top).  Per solve: kkt_gram_prepare; for every chunk of right-hand
+ * sides: kkt_gram_sweep(set 1 = owned) -> exchange of the subtree roots' packed update blocks
+ * (csp_exchange_copy + one collective) -> kkt_gram_sweep(set 2 = top); then kkt_gram_accumulate over
+ * the blkval ranges this rank owns and one all-reduce of H. */
+int csp_set_partition(csp_ctx* ctx, const int32_t* owner, int rank);
+int kkt_gram_prepare(csp_ctx* ctx, const double* L, const double* Y, void* stream);
+int kkt_gram_sweep(csp_ctx* ctx, int set, int64_t j0, int64_t j1, void* stream);
+int kkt_gram_accumulate(csp_ctx* ctx, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh,
+                        void* stream);
+int csp_exchange_copy(csp_ctx* ctx, int64_t nk, const int64_t* cliques, int64_t nrhs, double* buf,
+                      int unpack, void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on its own stream. */
 int csp_profile_enable(csp_ctx* ctx, int on);

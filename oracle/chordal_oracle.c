@@ -382,8 +382,9 @@ static int prepare_yaa(const orc_sym *s, const double *Y, double *yaa, double *f
 }
 
 /* leaves->root half of the Hessian: panel <- (G_NN, G_AN) */
-static void hess_up(const orc_sym *s, const double *L, double *u, double *upd) {
+static void hess_up_m(const orc_sym *s, const double *L, double *u, double *upd, const unsigned char *mask) {
   for (int64_t k = 0; k < s->nsn; ++k) {
+    if (mask && !mask[k]) continue;
     int64_t nn = NN(s, k), nf = NF(s, k), na = nf - nn;
     const double *Lk = L + s->blkptr[k];
     double *P = u + s->blkptr[k], *Uk = upd + s->updptr[k];
@@ -415,6 +416,8 @@ static void hess_up(const orc_sym *s, const double *L, double *u, double *upd) {
     free(T1);
   }
 }
+
+static void hess_up(const orc_sym *s, const double *L, double *u, double *upd) { hess_up_m(s, L, u, upd, 0); }
 
 /* root->leaves half: panel holds (G_NN, Q); result Z = 𝐋^-T [G_NN Q^T; Q Z_AA] 𝐋^-1 on V */
 static void hess_down(const orc_sym *s, const double *L, double *u, double *upd) {
@@ -529,8 +532,10 @@ static void hess_up_inv(const orc_sym *s, const double *L, double *u, double *up
 
 /* scale the AN block of every clique: mode 0: G_AN <- R^T G_AN ; 1: <- R G_AN ; 2: <- R^-T ; 3: <- R^-1;
  * 4: <- Y_AA G_AN (full symmetric, from yaa) ; 5: <- Y_AA^-1 G_AN (via fac) */
-static void scale_an(const orc_sym *s, double *u, const double *yaa, const double *fac, int mode) {
+static void scale_an_m(const orc_sym *s, double *u, const double *yaa, const double *fac, int mode,
+                       const unsigned char *mask) {
   for (int64_t k = 0; k < s->nsn; ++k) {
+    if (mask && !mask[k]) continue;
     int64_t nn = NN(s, k), nf = NF(s, k), na = nf - nn;
     if (!na) continue;
     double *B = u + s->blkptr[k] + nn;
@@ -555,6 +560,10 @@ static void scale_an(const orc_sym *s, double *u, const double *yaa, const doubl
   }
 }
 
+static void scale_an(const orc_sym *s, double *u, const double *yaa, const double *fac, int mode) {
+  scale_an_m(s, u, yaa, fac, mode, 0);
+}
+
 /* hessian(L, Y, U, adj, inv) for one matrix U (in place).
  * adj: 0 = G, 1 = G^adj, 2 = both (None in the reference).  work: 3*updptr[nsn] doubles. */
 int orc_hessian(const orc_sym *s, const double *L, const double *Y, double *u, int adj, int inv,
@@ -574,6 +583,17 @@ int orc_hessian(const orc_sym *s, const double *L, const double *Y, double *u, i
     else { hess_down_inv(s, L, u, upd); scale_an(s, u, yaa, fac, 5); hess_up_inv(s, L, u, upd); }
   }
   return 0;
+}
+
+/* Pieces of hessian(adj=False) exposed for the multi-GPU host-logic tests (tests/test_distributed.py):
+ * orc_prepare_fac: yaa <- Y[A_k,A_k], fac <- chol(yaa);  orc_hess_g_masked: the leaves->root G sweep
+ * (including the R^T scaling of the AN blocks) restricted to the cliques with mask[k] != 0.  Running it
+ * over a partition of the cliques in any order that respects the tree gives exactly orc_hessian(adj=0). */
+int orc_prepare_fac(const orc_sym *s, const double *Y, double *yaa, double *fac) { return prepare_yaa(s, Y, yaa, fac); }
+void orc_hess_g_masked(const orc_sym *s, const double *L, const double *fac, double *u, double *upd,
+                       const unsigned char *mask) {
+  hess_up_m(s, L, u, upd, mask);
+  scale_an_m(s, u, 0, fac, 0, mask);
 }
 
 /* supernodal triangular solve with a dense n x nrhs right-hand side in permuted row order.

@@ -54,6 +54,10 @@ def lib():
         L.orc_dense_potrf.argtypes = [ctypes.c_int64, P, ctypes.c_int64]
         L.orc_dense_potrs.restype = None
         L.orc_dense_potrs.argtypes = [ctypes.c_int64, ctypes.c_int64, P, ctypes.c_int64, P, ctypes.c_int64]
+        L.orc_prepare_fac.restype = ctypes.c_int
+        L.orc_prepare_fac.argtypes = [S, P, P, P]
+        L.orc_hess_g_masked.restype = None
+        L.orc_hess_g_masked.argtypes = [S, P, P, P, P, P]
         L.orc_scmcolumn2.restype = None
         L.orc_scmcolumn2.argtypes = [ctypes.c_int64, ctypes.c_int64, P, P, P, P, P, P, P, ctypes.c_int64]
         _lib = L
@@ -165,6 +169,18 @@ _ADJ = {False: 0, True: 1, None: 2}
 
 def hessian(S, L, Y, U, adj=False, inv=False):
     _chk(lib().orc_hessian(S.ref(), _p(L), _p(Y), _p(U), _ADJ[adj], 1 if inv else 0, _p(S.work())), "hessian")
+
+
+def prepare_fac(S, Y):
+    yaa, fac = np.zeros(max(1, S.updlen)), np.zeros(max(1, S.updlen))
+    _chk(lib().orc_prepare_fac(S.ref(), _p(Y), _p(yaa), _p(fac)), "prepare_fac")
+    return yaa, fac
+
+
+def hess_g_masked(S, L, fac, u, upd, mask):
+    """G sweep (adj=False) over the cliques with mask != 0; upd: this right-hand side's update workspace."""
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().orc_hess_g_masked(S.ref(), _p(L), _p(fac), _p(u), _p(upd), _p(mask))
 
 
 def trsm(S, L, B, trans="N"):

@@ -41,6 +41,11 @@ SIGNATURES = {
     "csp_profile_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "csp_profile_read": (c_i64, [c_vp, c_vp, c_vp]),
     "csp_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "csp_set_partition": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int]),
+    "kkt_gram_prepare": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "kkt_gram_sweep": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_i64, c_vp]),
+    "kkt_gram_accumulate": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "csp_exchange_copy": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, ctypes.c_int, c_vp]),
     "dense_potrf": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "dense_potrs": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "kkt_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, c_vp, c_vp, c_vp]),

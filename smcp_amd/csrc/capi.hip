@@ -187,11 +187,11 @@ int rhs_groups(int ncl, int nrhs, int target) {
 
 // f(lds_mode, MfmaArgs-with-lev-set, count, lds_bytes, threads) for the two classes of level l
 template <class F>
-void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f) {
-  const LevelClass& L = c->lvl[l];
-  int64_t b = c->S.levptr[l];
+void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f, int set = 0) {
+  const LevelClass& L = set ? c->sets[set].lvl[l] : c->lvl[l];
+  const int32_t* base = set ? c->sets[set].lev2 + c->sets[set].off[l] : c->D.lev2idx + c->S.levptr[l];
   if (L.nI) {
-    a.t.lev = c->D.lev2idx + b;
+    a.t.lev = base;
     a.nnmax = L.nnmaxI;
     a.namax = L.namaxI;
     a.nchmax = L.nchmaxI;
@@ -202,7 +202,7 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f) {
     f(true, a, (int)L.nI, lds, lds > 48 * 1024 ? 512 : 256);
   }
   if (L.nII) {
-    a.t.lev = c->D.lev2idx + b + L.nI;
+    a.t.lev = base + L.nI;
     a.nnmax = L.nnmaxII;
     a.namax = L.namaxII;
     f(false, a, (int)L.nII, (size_t)0, 1024);
@@ -318,7 +318,7 @@ void invalidate_tags(csp_ctx* c, const void* p) {
   if (c->D.yaa_tag == p) c->D.yaa_tag = nullptr;
 }
 
-void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {
+void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0) {
   MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
   for (int64_t l = 0; l < c->S.nlev; ++l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
@@ -333,7 +333,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
           launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
       } else if (use_large() && c->D.gp_tptr) lf_up(c, a, cnt, nrhs, U, ldu, st);
       else launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
-    });
+    }, set);
 }
 void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {
   MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
@@ -409,6 +409,53 @@ int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t l
     else { down_inv(); scale(5); up_inv(); }
   }
   return 0;
+}
+
+
+// Splits the cliques selected by `keep` into per-level lists (LDS-class first, large fronts after) and
+// records the sizing maxima of each class.  lev2 is the concatenation of the lists, off[l] its start.
+template <class Keep>
+void classify_levels(const Symbolic& S, Keep keep, std::vector<LevelClass>& lvl, std::vector<int32_t>& lev2,
+                     std::vector<int64_t>& off) {
+  lvl.assign(S.nlev, LevelClass());
+  lev2.clear();
+  off.assign(S.nlev + 1, 0);
+  for (int64_t l = 0; l < S.nlev; ++l) {
+    LevelClass& L = lvl[l];
+    off[l] = (int64_t)lev2.size();
+    int64_t b = S.levptr[l], e = S.levptr[l + 1];
+    for (int pass = 0; pass < 2; ++pass)
+      for (int64_t q = b; q < e; ++q) {
+        int64_t k = S.levidx[q];
+        if (!keep(k)) continue;
+        bool small = (size_t)mfma_lds_doubles((int)S.nn(k), (int)S.na(k)) * sizeof(double) <= LDS_LIMIT;
+        if (small == (pass == 0)) {
+          lev2.push_back((int32_t)k);
+          if (small) {
+            L.nI++;
+            L.nnmaxI = std::max<int>(L.nnmaxI, (int)S.nn(k));
+            L.namaxI = std::max<int>(L.namaxI, (int)S.na(k));
+            int64_t rs = 0;
+            for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) rs += S.na(S.chidx[q2]) * (S.na(S.chidx[q2]) + 1) / 2;
+            L.plansumI = (int)std::max<int64_t>(L.plansumI, rs);
+            L.nchmaxI = std::max<int>(L.nchmaxI, (int)(S.chptr[k + 1] - S.chptr[k]));
+            L.panmaxI = std::max<int>(L.panmaxI, (int)(S.nf(k) * S.nn(k)));
+            L.pkmaxI = std::max<int>(L.pkmaxI, (int)(S.na(k) * (S.na(k) + 1) / 2));
+          } else {
+            L.nII++;
+            L.nnmaxII = std::max<int>(L.nnmaxII, (int)S.nn(k));
+            L.namaxII = std::max<int>(L.namaxII, (int)S.na(k));
+          }
+        }
+      }
+    // the joint maxima may not fit even if every clique does: demote the level's LDS class then
+    if (L.nI && (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double) > LDS_LIMIT) {
+      L.nII += L.nI; L.nI = 0;
+      L.nnmaxII = std::max(L.nnmaxII, L.nnmaxI); L.namaxII = std::max(L.namaxII, L.namaxI);
+      L.nnmaxI = L.namaxI = 0;
+    }
+  }
+  off[S.nlev] = (int64_t)lev2.size();
 }
 
 }  // namespace
@@ -515,42 +562,9 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     c->h_tmpptr.resize(S.nsn + 1);
     for (int64_t k = 0; k <= S.nsn; ++k) c->h_tmpptr[k] = 2 * S.blkptr[k] + 256 * k;
     D.tmplen = 2 * S.blklen() + 256 * S.nsn;
-    // per level: LDS-class cliques first, HBM-class cliques after
-    std::vector<int32_t> lev2(S.nsn);
-    c->lvl.assign(S.nlev, LevelClass());
-    for (int64_t l = 0; l < S.nlev; ++l) {
-      LevelClass& L = c->lvl[l];
-      int64_t b = S.levptr[l], e = S.levptr[l + 1], w = b;
-      for (int pass = 0; pass < 2; ++pass)
-        for (int64_t q = b; q < e; ++q) {
-          int64_t k = S.levidx[q];
-          bool small = (size_t)mfma_lds_doubles((int)S.nn(k), (int)S.na(k)) * sizeof(double) <= LDS_LIMIT;
-          if (small == (pass == 0)) {
-            lev2[w++] = (int32_t)k;
-            if (small) {
-              L.nI++;
-              L.nnmaxI = std::max<int>(L.nnmaxI, (int)S.nn(k));
-              L.namaxI = std::max<int>(L.namaxI, (int)S.na(k));
-              int64_t rs = 0;
-              for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) rs += S.na(S.chidx[q2]) * (S.na(S.chidx[q2]) + 1) / 2;
-              L.plansumI = (int)std::max<int64_t>(L.plansumI, rs);
-              L.nchmaxI = std::max<int>(L.nchmaxI, (int)(S.chptr[k + 1] - S.chptr[k]));
-              L.panmaxI = std::max<int>(L.panmaxI, (int)(S.nf(k) * S.nn(k)));
-              L.pkmaxI = std::max<int>(L.pkmaxI, (int)(S.na(k) * (S.na(k) + 1) / 2));
-            } else {
-              L.nII++;
-              L.nnmaxII = std::max<int>(L.nnmaxII, (int)S.nn(k));
-              L.namaxII = std::max<int>(L.namaxII, (int)S.na(k));
-            }
-          }
-        }
-      // the joint maxima may not fit even if every clique does: demote the level's LDS class then
-      if (L.nI && (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double) > LDS_LIMIT) {
-        L.nII += L.nI; L.nI = 0;
-        L.nnmaxII = std::max(L.nnmaxII, L.nnmaxI); L.namaxII = std::max(L.namaxII, L.namaxI);
-        L.nnmaxI = L.namaxI = 0;
-      }
-    }
+    std::vector<int32_t> lev2;
+    std::vector<int64_t> lev2off;
+    classify_levels(S, [](int64_t) { return true; }, c->lvl, lev2, lev2off);
     int rc = 0;
     {
       // slots of the large fronts (per-front 64 x 64 scratch) and the flat list of LDS-class cliques

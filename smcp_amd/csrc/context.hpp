@@ -108,8 +108,19 @@ struct LevelClass {
 };
 }  // namespace smcp
 
+namespace smcp {
+// A subset of the cliques organised by level (LDS-class cliques first, then large fronts): set 0 = all
+// cliques; sets 1 / 2 = the cliques this rank owns / the replicated top of the tree (multi-GPU sharding)
+struct LevelSet {
+  std::vector<LevelClass> lvl;     // per level
+  std::vector<int64_t> off;        // per level: offset into lev2
+  int32_t* lev2 = nullptr;         // device
+};
+}  // namespace smcp
+
 struct csp_ctx {
   smcp::Symbolic S;
+  smcp::LevelSet sets[3];
   std::vector<smcp::LevelClass> lvl;
   smcp::DeviceCtx D;
   smcp::Profiler prof;

@@ -613,4 +613,20 @@ __global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, 
   tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Kk[m + (int64_t)n * nf] = v; });
 }
 
+
+// ---- multi-GPU boundary exchange: packed update blocks of the listed cliques <-> a contiguous buffer
+// buffer layout: [clique in list][rhs][packed entries];  bptr[c] = start of clique c's slab (in doubles per rhs)
+__global__ void k_exchange_copy(const CliqueDesc* cl, const int64_t* list, const int64_t* bptr, int nrhs,
+                                double* updp, int64_t updplen, double* buf, int unpack) {
+  const int64_t k = list[blockIdx.y];
+  const CliqueDesc d = cl[k];
+  const int np = d.na * (d.na + 1) / 2;
+  const int r = blockIdx.z;
+  double* slab = buf + bptr[blockIdx.y] * nrhs + (int64_t)r * np;
+  double* src = updp + (int64_t)r * updplen + d.updp;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < np; e += gridDim.x * blockDim.x) {
+    if (unpack) src[e] = slab[e]; else slab[e] = src[e];
+  }
+}
+
 }  // namespace smcp

@@ -1059,8 +1059,9 @@ constexpr int GRAM_BLK = 128;   // columns of H per block
 constexpr int GRAM_KS = 64;     // slice of the long dimension staged per step
 constexpr int GRAM_LD = GRAM_BLK + 1;
 
-__global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t ldg, int m, int64_t len,
-                                                      const double* sw, int64_t chunk, double* partial) {
+__global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
+                                                      const double* sw, int64_t chunk, double* partial, int coff,
+                                                      int nchunk_total) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const sA = smem;
   double* const sB = smem + GRAM_KS * GRAM_LD;   // only allocated when the launch has off-diagonal blocks
@@ -1079,7 +1080,7 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
   d4 acc[MAXT];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-  const int64_t e_begin = (int64_t)blockIdx.x * chunk, e_end = min(len, e_begin + chunk);
+  const int64_t e_begin = e_lo + (int64_t)blockIdx.x * chunk, e_end = min(e_hi, e_begin + chunk);
   for (int64_t e0 = e_begin; e0 < e_end; e0 += GRAM_KS) {
     __syncthreads();
     // stage sqrt(w) * G[e0 .. e0+64) for the columns of both blocks: one wave instruction = one column
@@ -1113,7 +1114,7 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
   }
   // write partial tiles: layout [blockIdx.y][blockIdx.x][tile][256], tile elements column-major
   const int ntile = mti * mtj;
-  double* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(64 * 256);
+  double* out = partial + ((int64_t)blockIdx.y * nchunk_total + coff + blockIdx.x) * (int64_t)(64 * 256);
   int slot = 0;
   for (int t = wave; t < ntile; t += 4) {
     const int tm = t % mti, tn = t / mti;

@@ -181,7 +181,8 @@ static bool use_gram() {
 
 // Gram formulation of the whole Schur complement (what kkt_qr implies, solvers.py:414-420):
 // H = G(A)^T G(A) with ONE leaves->root sweep per constraint, then one tall-skinny SYRK.
-static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, hipStream_t st) {
+// ---- Gram formulation, in steps so that the multi-GPU driver can interleave the boundary exchange
+static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_t st) {
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
   prepare_yaa(c, Y, true, st);
@@ -190,14 +191,26 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
   for (int64_t jb = 0; jb < m; jb += 65535)
     launch(c, KID_scatter_constraints, k_scatter_constraints, dim3(8, (unsigned)std::min<int64_t>(65535, m - jb)),
            dim3(256), st, jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
-  for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
-    int nr = (int)std::min(D.max_rhs, m - jb);
-    hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st);     // G(A_j) = (G_NN, R^T G_AN)
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// H = sum over the given blkval ranges of G^T W G (ranges: host array of nranges (begin, end) pairs)
+static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  const int64_t m = D.m, bl = c->S.blklen();
+  int64_t total = 0;
+  for (int64_t q = 0; q < nranges; ++q) total += std::max<int64_t>(0, ranges[2 * q + 1] - ranges[2 * q]);
+  if (total <= 0) {
+    HIPCHK(hipMemset2DAsync(H, ldh * sizeof(double), 0, m * sizeof(double), m, st));
+    return 0;
   }
-  // chunking of the long dimension: ~1.5k workgroups per block column
-  // one resident wave of workgroups (2 per CU) per block column: fewer partial tiles to reduce
-  int64_t chunk = std::max<int64_t>(2048, ((bl / 512 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS);
-  int nchunk = (int)((bl + chunk - 1) / chunk);
+  // ~one resident wave of workgroups (2 per CU) over all ranges
+  int64_t chunk = std::max<int64_t>(2048, ((total / 512 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS);
+  int nchunk = 0;
+  for (int64_t q = 0; q < nranges; ++q) {
+    int64_t len = ranges[2 * q + 1] - ranges[2 * q];
+    if (len > 0) nchunk += (int)((len + chunk - 1) / chunk);
+  }
   int nb = (int)((m + GRAM_BLK - 1) / GRAM_BLK);
   int nblk = nb * (nb + 1) / 2;
   int64_t need = (int64_t)nblk * nchunk * 64 * 256;
@@ -207,11 +220,33 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     if (int rc = dev_alloc(&D.gpart, need, D.bytes)) return rc;
     D.gpart_len = need;
   }
-  launch_lds(c, KID_gram_partial, k_gram_partial, dim3(nchunk, nblk), dim3(256),
-             (size_t)(nblk > 1 ? 2 : 1) * GRAM_KS * GRAM_LD * sizeof(double), st, (const double*)D.ustack, bl, (int)m, bl,
-             (const double*)D.sw, chunk, D.gpart);
+  int coff = 0;
+  for (int64_t q = 0; q < nranges; ++q) {
+    int64_t lo = ranges[2 * q], hi = ranges[2 * q + 1];
+    if (hi <= lo) continue;
+    int nc = (int)((hi - lo + chunk - 1) / chunk);
+    launch_lds(c, KID_gram_partial, k_gram_partial, dim3(nc, nblk), dim3(256),
+               (size_t)(nblk > 1 ? 2 : 1) * GRAM_KS * GRAM_LD * sizeof(double), st, (const double*)D.ustack, bl, (int)m, lo, hi,
+               (const double*)D.sw, chunk, D.gpart, coff, nchunk);
+    coff += nc;
+  }
   launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Gram formulation of the whole Schur complement (what kkt_qr implies, solvers.py:414-420):
+// H = G(A)^T G(A) with ONE leaves->root sweep per constraint, then one tall-skinny SYRK.
+static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  const int64_t m = D.m, bl = c->S.blklen();
+  if (int rc = gram_prepare(c, L, Y, st)) return rc;
+  for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
+    int nr = (int)std::min(D.max_rhs, m - jb);
+    hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st);     // G(A_j) = (G_NN, R^T G_AN)
+  }
+  const int64_t range[2] = {0, bl};
+  if (int rc = gram_accumulate(c, 1, range, H, ldh, st)) return rc;
   if (int f = fetch_info(c, st)) return f;   // chol(Y_AA) failure
   return 0;
 }
@@ -270,6 +305,71 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   hessian_impl(c, L, bx, 1, bl, 2, 0, st);
   launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 0.0, (const double*)nullptr, 1.0 / kk, bx);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+
+// ---- subtree-sharded Gram path (multi-GPU; orchestrated by smcp_amd/kkt.py ShardedSchur) ----------
+int csp_set_partition(csp_ctx* c, const int32_t* owner, int rank) {
+  if (int rc = ready(c)) return rc;
+  const Symbolic& S = c->S;
+  HIPCHK(hipSetDevice(c->D.device));
+  for (int set = 1; set <= 2; ++set) {
+    LevelSet& LS = c->sets[set];
+    if (LS.lev2) { HIPCHK(hipFree(LS.lev2)); LS.lev2 = nullptr; }
+    std::vector<int32_t> lev2;
+    const int want = (set == 1) ? rank : -1;
+    classify_levels(S, [&](int64_t k) { return owner[k] == want; }, LS.lvl, lev2, LS.off);
+    if (int rc = dev_upload(&LS.lev2, lev2, c->D.bytes)) return rc;
+  }
+  return 0;
+}
+int kkt_gram_prepare(csp_ctx* c, const double* L, const double* Y, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (!c->D.m || use_generic()) return SMCP_EINVAL;
+  return gram_prepare(c, L, Y, (hipStream_t)stream);
+}
+int kkt_gram_sweep(csp_ctx* c, int set, int64_t j0, int64_t j1, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  if (set < 0 || set > 2 || j0 < 0 || j1 > D.m || j1 <= j0 || j1 - j0 > D.max_rhs) return SMCP_EINVAL;
+  if (set && !c->sets[set].lev2) return SMCP_EINVAL;
+  const int64_t bl = c->S.blklen();
+  hess_up_fast(c, D.ustack + j0 * bl, (int)(j1 - j0), bl, D.fac, 2, (hipStream_t)stream, set);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int kkt_gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (!c->D.m || ldh < c->D.m || nranges < 0) return SMCP_EINVAL;
+  if (int rc = gram_accumulate(c, nranges, ranges, H, ldh, (hipStream_t)stream)) return rc;
+  return fetch_info(c, (hipStream_t)stream);
+}
+// boundary exchange: copy the packed update blocks of the listed cliques (host list) of nrhs right-hand
+// sides to (unpack = 0) or from (unpack = 1) the contiguous device buffer buf
+int csp_exchange_copy(csp_ctx* c, int64_t nk, const int64_t* cliques, int64_t nrhs, double* buf, int unpack, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (nk <= 0) return 0;
+  if (nrhs < 1 || nrhs > c->D.max_rhs) return SMCP_EINVAL;
+  const Symbolic& S = c->S;
+  std::vector<int64_t> host(2 * nk + 1);
+  int64_t off = 0, npmax = 1;
+  for (int64_t q = 0; q < nk; ++q) {
+    if (cliques[q] < 0 || cliques[q] >= S.nsn) return SMCP_EINVAL;
+    host[q] = cliques[q];
+    host[nk + q] = off;
+    int64_t np = S.na(cliques[q]) * (S.na(cliques[q]) + 1) / 2;
+    off += np;
+    npmax = std::max(npmax, np);
+  }
+  int64_t* dlist = nullptr;
+  HIPCHK(hipMalloc((void**)&dlist, sizeof(int64_t) * 2 * nk));
+  HIPCHK(hipMemcpyAsync(dlist, host.data(), sizeof(int64_t) * 2 * nk, hipMemcpyHostToDevice, (hipStream_t)stream));
+  launch(c, KID_axpby, k_exchange_copy, dim3((unsigned)std::min<int64_t>(32, (npmax + 255) / 256), (unsigned)nk, (unsigned)nrhs),
+         dim3(256), (hipStream_t)stream, (const CliqueDesc*)c->D.cl, (const int64_t*)dlist, (const int64_t*)(dlist + nk), (int)nrhs,
+         c->D.updp, c->S.updplen(), buf, unpack);
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipFree(dlist));
   return 0;
 }
 

@@ -16,12 +16,60 @@ def column_range(m, rank, world):
     return (m * rank) // world, (m * (rank + 1)) // world
 
 
+def _backend_is_gloo(group):
+    import torch.distributed as dist
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, group):
+    """SUM all-reduce; device tensors are staged through the host when the backend is gloo (CPU tests,
+    or two ranks sharing one GPU), RCCL takes them directly."""
+    import torch.distributed as dist
+    if t.is_cuda and _backend_is_gloo(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather(out_list, t, group):
+    import torch.distributed as dist
+    if t.is_cuda and _backend_is_gloo(group):
+        hs = [torch.empty(o.shape, dtype=o.dtype) for o in out_list]
+        dist.all_gather(hs, t.cpu(), group=group)
+        for o, h in zip(out_list, hs):
+            o.copy_(h)
+    else:
+        dist.all_gather(out_list, t, group=group)
+
+
 class ShardedSchur:
-    """Multi-GPU assembly of the Schur complement: the m constraint sweeps are
-    independent, so each rank builds its own column range and ONE all-reduce (RCCL over xGMI on GPUs,
-    gloo in the CPU tests) of the m x m matrix completes H on every rank; potrf(H) and solve_ are
-    replicated.  Subclasses provide _columns(L, Y, j0, j1) (fills self.H[:, j0:j1], column-major) and
-    _potrf() (in-place Cholesky of self.H, raises ArithmeticError)."""
+    """Multi-GPU assembly of the Schur complement.
+
+    Two sharding modes share this host logic (and are exercised on CPU with gloo + the oracle):
+
+    * subtree sharding (default when a partition has been set with ``set_partition``): the clique tree
+      is cut into subtrees owned by single ranks plus a small replicated top.  Gram formulation: every
+      rank sweeps ALL m constraints over its own subtrees, the packed update blocks of the subtree roots
+      are exchanged (one all-gather per chunk of right-hand sides), the top is swept redundantly, each
+      rank forms the partial Gram matrix of its blkval ranges and ONE all-reduce completes H.
+    * column sharding (fallback): each rank builds a column range of H with the reference formulation
+      and one all-reduce of H completes it.
+
+    Subclasses provide the compute: _columns, _potrf, and for the subtree mode _gram_prepare, _gram_sweep,
+    _exchange_pack, _exchange_unpack, _gram_accumulate, _apply_partition."""
+
+    partition = None
+
+    def set_partition(self, group):
+        """Cut the tree for the ranks of `group` (deterministic: every rank computes the same cut)."""
+        import torch.distributed as dist
+        from .shard import subtree_partition
+        world = dist.get_world_size(group)
+        self.partition = subtree_partition(self.symb, world)
+        self._apply_partition(self.partition, dist.get_rank(group))
+        return self.partition
 
     def build_schur(self, L, Y, group=None):
         import torch.distributed as dist
@@ -30,11 +78,38 @@ class ShardedSchur:
             self._columns(L, Y, 0, self.m)
             return
         rank = dist.get_rank(group)
-        j0, j1 = column_range(self.m, rank, world)
-        self.H.zero_()
-        if j1 > j0:
-            self._columns(L, Y, j0, j1)
-        dist.all_reduce(self.H, op=dist.ReduceOp.SUM, group=group)
+        P = self.partition
+        if P is None:
+            j0, j1 = column_range(self.m, rank, world)
+            self.H.zero_()
+            if j1 > j0:
+                self._columns(L, Y, j0, j1)
+            _all_reduce(self.H, group)
+            return
+        # ---- subtree-sharded Gram path
+        self._gram_prepare(L, Y)
+        step = self._gram_chunk()
+        for j0 in range(0, self.m, step):
+            j1 = min(self.m, j0 + step)
+            self._gram_sweep(1, j0, j1)                                  # owned subtrees
+            mine = self._exchange_pack(P.roots_by_rank[rank], j1 - j0)   # 1-D tensor (may be empty)
+            sizes = [self._exchange_size(P.roots_by_rank[r], j1 - j0) for r in range(world)]
+            width = max(max(sizes), 1)
+            send = torch.zeros(width, dtype=torch.float64, device=self.dev)
+            send[:mine.numel()] = mine
+            recv = [torch.empty(width, dtype=torch.float64, device=self.dev) for _ in range(world)]
+            _all_gather(recv, send, group)
+            for r in range(world):
+                if r != rank and sizes[r]:
+                    self._exchange_unpack(P.roots_by_rank[r], j1 - j0, recv[r][:sizes[r]])
+            self._gram_sweep(2, j0, j1)                                  # replicated top
+        ranges = list(P.ranges_by_rank[rank]) + (list(P.top_ranges) if rank == 0 else [])
+        self._gram_accumulate(ranges)
+        _all_reduce(self.H, group)
+
+    def _exchange_size(self, cliques, nrhs):
+        na = np.diff(self.symb.rowptr) - np.diff(self.symb.snptr)
+        return int(sum(int(na[k]) * (int(na[k]) + 1) // 2 for k in cliques) * nrhs)
 
 
 class KKTSystem(ShardedSchur):
@@ -75,6 +150,40 @@ class KKTSystem(ShardedSchur):
 
     def _potrf(self):
         _chk(_lib.lib().dense_potrf(self.symb.handle, self.H.data_ptr(), self.m, self.m, _stream()), "dense_potrf")
+
+    # ---- subtree-sharded Gram path (C-ABI: csp_set_partition, kkt_gram_*, csp_exchange_copy)
+    def _apply_partition(self, P, rank):
+        owner = np.ascontiguousarray(P.owner, dtype=np.int32)
+        _chk(_lib.lib().csp_set_partition(self.symb.handle, owner.ctypes.data, int(rank)), "csp_set_partition")
+
+    def _gram_chunk(self):
+        return int(self.symb._max_rhs)
+
+    def _gram_prepare(self, L, Y):
+        _chk(_lib.lib().kkt_gram_prepare(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), _stream()),
+             "kkt_gram_prepare")
+
+    def _gram_sweep(self, which, j0, j1):
+        _chk(_lib.lib().kkt_gram_sweep(self.symb.handle, int(which), int(j0), int(j1), _stream()), "kkt_gram_sweep")
+
+    def _exchange_pack(self, cliques, nrhs):
+        buf = torch.empty(self._exchange_size(cliques, nrhs), dtype=torch.float64, device=self.dev)
+        if len(cliques):
+            lst = np.ascontiguousarray(cliques, dtype=np.int64)
+            _chk(_lib.lib().csp_exchange_copy(self.symb.handle, len(lst), lst.ctypes.data, int(nrhs), buf.data_ptr(), 0,
+                                              _stream()), "csp_exchange_copy")
+        return buf
+
+    def _exchange_unpack(self, cliques, nrhs, buf):
+        lst = np.ascontiguousarray(cliques, dtype=np.int64)
+        buf = buf.contiguous()
+        _chk(_lib.lib().csp_exchange_copy(self.symb.handle, len(lst), lst.ctypes.data, int(nrhs), buf.data_ptr(), 1,
+                                          _stream()), "csp_exchange_copy")
+
+    def _gram_accumulate(self, ranges):
+        r = np.ascontiguousarray(np.asarray(ranges, dtype=np.int64).reshape(-1))
+        _chk(_lib.lib().kkt_gram_accumulate(self.symb.handle, len(r) // 2, r.ctypes.data if len(r) else None,
+                                            self.H.data_ptr(), self.m, _stream()), "kkt_gram_accumulate")
 
     def factor(self, L, Y, group=None):
         """kkt_chol(L, Y): builds (sharded over `group` if given) and factors the Schur complement;

@@ -42,6 +42,58 @@ class OracleKKT(kkt.ShardedSchur):
             orc.hessian(self.K.S, _np(L), _np(Y), u, adj=None, inv=False)
             self.H[j, :] = torch.from_numpy(self.K.amap(u))
 
+    # ---- subtree-sharded Gram path, emulated with the oracle's masked G sweep
+    def _apply_partition(self, P, rank):
+        self._mask = {1: (P.owner == rank).astype(np.uint8), 2: (P.owner == -1).astype(np.uint8)}
+
+    def _gram_chunk(self):
+        return 3                              # forces several chunks in the tests
+
+    def _gram_prepare(self, L, Y):
+        S = self.K.S
+        self._L = _np(L)
+        self._yaa, self._fac = orc.prepare_fac(S, _np(Y))
+        self._G = [self.K.constraint(j) for j in range(self.m)]
+        self._upd = [np.zeros(max(1, S.updlen)) for _ in range(self.m)]
+
+    def _gram_sweep(self, which, j0, j1):
+        for j in range(j0, j1):
+            orc.hess_g_masked(self.K.S, self._L, self._fac, self._G[j], self._upd[j], self._mask[which])
+        self._chunk = (j0, j1)
+
+    def _exchange_pack(self, cliques, nrhs):
+        S, (j0, j1) = self.K.S, self._chunk
+        parts = [self._upd[j][S.updptr[k]:S.updptr[k + 1]] for k in cliques for j in range(j0, j1)]
+        return torch.from_numpy(np.concatenate(parts)) if parts else torch.empty(0, dtype=torch.float64)
+
+    def _exchange_size(self, cliques, nrhs):        # the oracle exchanges full squares
+        S = self.K.S
+        return int(sum(int(S.updptr[k + 1] - S.updptr[k]) for k in cliques) * nrhs)
+
+    def _exchange_unpack(self, cliques, nrhs, buf):
+        S, (j0, j1) = self.K.S, self._chunk
+        b, o = buf.numpy(), 0
+        for k in cliques:
+            n = int(S.updptr[k + 1] - S.updptr[k])
+            for j in range(j0, j1):
+                self._upd[j][S.updptr[k]:S.updptr[k + 1]] = b[o:o + n]
+                o += n
+
+    def _gram_accumulate(self, ranges):
+        S = self.K.S
+        w = np.zeros(S.blklen)
+        for k in range(S.nsn):
+            nn = int(S.snptr[k + 1] - S.snptr[k])
+            nf = int(S.rowptr[k + 1] - S.rowptr[k])
+            blk = np.full((nf, nn), 2.0)
+            blk[:nn, :nn] = np.tril(np.full((nn, nn), 2.0), -1) + np.eye(nn)
+            w[S.blkptr[k]:S.blkptr[k] + nf * nn] = blk.reshape(-1, order="F")
+        G = np.stack(self._G, axis=1)                       # blklen x m
+        H = np.zeros((self.m, self.m))
+        for a, b in ranges:
+            H += G[a:b].T @ (w[a:b, None] * G[a:b])
+        self.H.copy_(torch.from_numpy(H))
+
     def _potrf(self):
         Hf = np.asfortranarray(self.H.numpy().T)
         orc.dense_potrf(Hf)

@@ -22,7 +22,7 @@ def test_column_ranges_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -44,7 +44,10 @@ def _worker(rank, world, port, out):
         cptr, cidx, cval = problems.random_constraints(symb, m, density=0.1, seed=3)
         L, Y = cspmatrix(symb, torch.from_numpy(Lh)), cspmatrix(symb, torch.from_numpy(Yh))
         sharded = OracleKKT(symb, cptr, cidx, cval)
-        solve = sharded.factor(L, Y, group=dist.group.WORLD)      # each rank builds its columns + all-reduce
+        if mode == "subtree":
+            part = sharded.set_partition(dist.group.WORLD)            # subtree sharding + boundary exchange
+            assert (part.owner >= 0).sum() > 0 and len(part.top) >= 1
+        solve = sharded.factor(L, Y, group=dist.group.WORLD)      # sharded build + all-reduce
         single = OracleKKT(symb, cptr, cidx, cval)
         single.factor(L, Y)                                       # whole matrix on this rank
         err = float((sharded.H - single.H).abs().max() / single.H.abs().max())
@@ -64,18 +67,37 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sharded_schur_two_ranks_gloo():
+def test_partition_covers_tree():
+    from smcp_amd import problems
+    from smcp_amd.shard import subtree_partition
+    from smcp_amd.symbolic import Symbolic
+    symb = Symbolic(problems.nested_block_arrow_pattern(nsub=4, nmid=5, nleaf_per_mid=3, leaf=(2, 4), mid=(3, 5),
+                                                        top=(4, 6), root=8, seed=2))
+    for world in (2, 3, 4):
+        P = subtree_partition(symb, world)
+        par = symb.snpar
+        assert all(P.owner[par[k]] in (P.owner[k], -1) for k in range(symb.Nsn) if par[k] >= 0)   # subtrees are closed
+        assert all(par[k] < 0 or P.owner[par[k]] == -1 for k in P.top)                           # top is upward closed
+        cover = sorted(sum((list(r) for r in P.ranges_by_rank), []) + list(P.top_ranges))
+        assert cover[0][0] == 0 and cover[-1][1] == symb.blklen
+        assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))                # ranges tile blkval
+        for r in range(world):
+            assert all(P.owner[k] == r and P.owner[par[k]] == -1 for k in P.roots_by_rank[r])
+
+
+@pytest.mark.parametrize("mode", ["columns", "subtree"])
+def test_sharded_schur_two_ranks_gloo(mode):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, mode)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
     err, spread = out.get()
-    assert err < 1e-13 and spread == 0.0
+    assert err < 1e-12 and spread == 0.0
