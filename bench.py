@@ -237,8 +237,17 @@ def main():
             per_launch = alg / dom_launches
             avg_s = 1e-3 * dom_ms / dom_launches
             achieved = per_launch / avg_s / 1e9
+            # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled
+            # as the gfx950 guide prescribes), recorded in profiles/ for this kernel and workload -- or null
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+                if tj.get("workload") == label and dom in tj.get("kernels", {}) and world == 1:
+                    traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "bytes_per_launch": per_launch, "avg_launch_us": round(1e6 * avg_s, 2),
                         "launches_per_step": dom_launches}
         if args.verbose and rank == 0:

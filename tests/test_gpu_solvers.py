@@ -142,3 +142,25 @@ def test_sdpa_roundtrip(tmp_path):
     assert abs(sp.csc_matrix(Q.A) - sp.csc_matrix(P.A)).max() < 1e-14
     assert np.allclose(Q.b, P.b)
     assert base.sdpa_readhead(str(fn)) == (12, 4, [12])
+
+
+def test_maxcut_config4_shape():
+    """BASELINE config 4 at test size: max-cut SDP on a random non-chordal graph (n = 300, 900 edges; the
+    full G51-sized instance n = 1000 / 5909 edges runs in scratch/maxcut.py: optimal in 31 iterations).
+    The symbolic layer embeds the pattern with its own minimum-degree ordering; optimality is certified in
+    dense numpy (diag(X) = 1, Diag(y) + S = C, S >= 0, zero gap)."""
+    from smcp_amd import base, solvers
+    solvers.options.update(show_progress=False, maxiters=60)
+    P = base.maxcut_SDP(300, 900, seed=0)
+    assert not P.ischordal
+    C = P.get_A(0)
+    y0 = -np.ones(300) * (abs(C).sum(axis=1).max() + 1.0)
+    sol = P.solve_feas(scaling="dual", dualstart={"y": y0})
+    assert sol["status"] == "optimal"
+    X = np.asarray(sol["x"].todense())
+    S = np.asarray(sol["s"].todense())
+    Cd = np.asarray(C.todense())
+    assert np.allclose(np.diag(X), 1.0, atol=1e-7)
+    assert np.linalg.norm(np.diag(sol["y"]) + S - Cd) < 1e-7 * (1 + np.abs(Cd).max())
+    assert np.linalg.eigvalsh(S).min() > -1e-7
+    assert abs(np.sum(Cd * X) - sol["y"].sum()) < 1e-5 * (1 + abs(sol["y"].sum()))
