@@ -136,6 +136,16 @@ int kkt_gram_accumulate(csp_ctx* ctx, int64_t nranges, const int64_t* ranges, do
 int csp_exchange_copy(csp_ctx* ctx, int64_t nk, const int64_t* cliques, int64_t nrhs, double* buf,
                       int unpack, void* stream);
 
+/* ---- derived-quantity cache ------------------------------------------------------------
+ * csp_hessian, csp_completion and the kkt_* entry points keep quantities derived from their (L, Y)
+ * arguments on the device (the inverse-form factor of L, the separator blocks Y_AA, their Cholesky
+ * factors and the inverses of those), keyed by the DEVICE ADDRESS of L and Y, so that the many
+ * Hessian applications of one interior-point iteration (solvers.py:803-1050: kkt_res, Newton
+ * decrements, step computation) do not redo them.  Every entry point of this library that writes
+ * to a buffer drops the cache entries derived from it.  A caller that changes the contents of L or
+ * Y by any other means (its own kernels, memcpy) must call csp_cache_reset() before the next call. */
+int csp_cache_reset(csp_ctx* ctx);
+
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on its own stream. */
 int csp_profile_enable(csp_ctx* ctx, int on);

@@ -5,7 +5,7 @@ from smcp_amd import base, solvers
 from smcp_amd.symbolic import Symbolic
 n, e = int(sys.argv[1]), int(sys.argv[2])
 P = base.maxcut_SDP(n, e, seed=0)
-solvers.options.update(show_progress=True, maxiters=60)
+solvers.options.update(show_progress=True, maxiters=int(os.environ.get("MAXIT", "60")))
 t0 = time.time()
 # strictly feasible dual start: S = C - Diag(y) > 0 with y = -(max row sum of |C|) - 1
 C = P.get_A(0)

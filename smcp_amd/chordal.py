@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .cspmatrix import cspmatrix, _stream
+from .cspmatrix import cspmatrix, _stream, sync_cache
 
 
 def _chk(rc, what):
@@ -30,21 +30,25 @@ def _ensure(symb, nrhs=1):
 
 def cholesky(X):
     _ensure(X.symb)
+    X.touched()
     _chk(_lib.lib().csp_cholesky(X.symb.handle, X.blkval.data_ptr(), _stream()), "cholesky")
 
 
 def llt(L):
     _ensure(L.symb)
+    L.touched()
     _chk(_lib.lib().csp_llt(L.symb.handle, L.blkval.data_ptr(), _stream()), "llt")
 
 
 def projected_inverse(L):
     _ensure(L.symb)
+    L.touched()
     _chk(_lib.lib().csp_projected_inverse(L.symb.handle, L.blkval.data_ptr(), _stream()), "projected_inverse")
 
 
 def completion(X):
     _ensure(X.symb)
+    X.touched()
     _chk(_lib.lib().csp_completion(X.symb.handle, X.blkval.data_ptr(), _stream()), "completion")
 
 
@@ -57,8 +61,10 @@ def hessian(L, Y, U, adj=False, inv=False):
     symb = L.symb
     _ensure(symb)
     lib = _lib.lib()
+    sync_cache(symb, L, Y)
     a, i = _ADJ[adj], 1 if inv else 0
     if isinstance(U, cspmatrix):
+        U.touched()
         _chk(lib.csp_hessian(symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), U.blkval.data_ptr(), 1,
                              symb.blklen, a, i, _stream()), "hessian")
     elif isinstance(U, torch.Tensor):
@@ -67,6 +73,7 @@ def hessian(L, Y, U, adj=False, inv=False):
                              U.stride(0), a, i, _stream()), "hessian")
     else:
         for Uj in U:
+            Uj.touched()
             _chk(lib.csp_hessian(symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), Uj.blkval.data_ptr(), 1,
                                  symb.blklen, a, i, _stream()), "hessian")
 

@@ -14,13 +14,37 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
 
 
+_uid = [0]
+
+
+def sync_cache(symb, *mats):
+    """Drop the device-side caches derived from (L, Y) unless `mats` are the very matrices, unchanged,
+    that the caches were built from (include/smcp_amd.h, csp_cache_reset).  Contents are tracked by
+    object identity + torch's in-place version counter + the count of in-place library calls."""
+    key = tuple(m.state() for m in mats)
+    if getattr(symb, "_cache_key", None) != key:
+        if symb._device is not None:
+            _lib.lib().csp_cache_reset(symb.handle)
+        symb._cache_key = key
+
+
 class cspmatrix:
     def __init__(self, symb, blkval=None, device=None):
+        _uid[0] += 1
+        self.uid = _uid[0]
+        self._gen = 0
         self.symb = symb
         if blkval is None:
             dev = device if device is not None else ("cuda:%d" % symb._device if symb._device is not None else "cpu")
             blkval = torch.zeros(symb.blklen, dtype=torch.float64, device=dev)
         self.blkval = blkval
+
+    def state(self):
+        return (self.uid, self._gen, self.blkval.data_ptr(), self.blkval._version)
+
+    def touched(self):
+        """Call after the library wrote into blkval through its raw pointer."""
+        self._gen += 1
 
     # ---- construction ------------------------------------------------------------------
     @classmethod
@@ -109,6 +133,7 @@ class cspmatrix:
                                   self.blkval.data_ptr(), _stream())
         if rc:
             raise RuntimeError("csp_axpby failed (%d)" % rc)
+        self.touched()
         return self
 
     def __add__(self, other):

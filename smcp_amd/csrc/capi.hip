@@ -14,6 +14,7 @@
 #include "front_generic.hip"
 #include "front_mfma.hip"
 #include "front_large.hip"
+#include "front_inv.hip"
 
 using namespace smcp;
 
@@ -40,6 +41,9 @@ enum {
   KID_lf_assemble, KID_lf_clear_upd, KID_lf_up1, KID_lf_up2, KID_lf_up3, KID_lf_down1, KID_lf_down2, KID_lf_down3,
   KID_lf_pinv1, KID_lf_pinv2, KID_lf_diag, KID_lf_chol_panel, KID_lf_chol_trail, KID_lf_pack_upd,
   KID_lf_prep_s, KID_lf_prep_row, KID_lf_prep_k, KID_factor_yaa_lds,
+  KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
+  KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
+  KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -52,7 +56,10 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_gram_partial", "k_gram_reduce", "k_hess_up_pad",
   "k_lf_assemble", "k_lf_clear_upd", "k_lf_up1", "k_lf_up2", "k_lf_up3", "k_lf_down1", "k_lf_down2", "k_lf_down3",
   "k_lf_pinv1", "k_lf_pinv2", "k_lf_diag", "k_lf_chol_panel", "k_lf_chol_trail", "k_lf_pack_upd",
-  "k_lf_prep_s", "k_lf_prep_row", "k_lf_prep_k", "k_factor_yaa_lds"};
+  "k_lf_prep_s", "k_lf_prep_row", "k_lf_prep_k", "k_factor_yaa_lds",
+  "k_factor_inverse", "k_hess_down_inv_mfma<true>", "k_hess_down_inv_mfma<false>", "k_hess_up_inv_mfma<true>",
+  "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
+  "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion"};
 
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -152,11 +159,17 @@ void gather_all(csp_ctx* c, const double* x, int64_t ldx, int nrhs, double* updb
   });
 }
 
-int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st);
+int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool need_inv = false);
 
 
 // ---- fast path (front_mfma.hip): per level, LDS-class cliques then HBM-class cliques ----------
 constexpr size_t LDS_LIMIT = 160 * 1024 - 256;
+
+bool cache_off() {
+  static int nocache = -1;
+  if (nocache < 0) { const char* e = getenv("SMCP_NOCACHE"); nocache = (e && e[0] == '1') ? 1 : 0; }
+  return nocache == 1;
+}
 
 bool use_generic() {
   static int g = -1;
@@ -221,7 +234,7 @@ void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t 
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
   launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), blk, st, a);
-  if (a.t.gp_tptr) launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), blk, st, a, U, ldu);
+  if (a.t.gp_tptr) launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), blk, st, a, U, ldu, 0);
   launch(c, KID_lf_up1, k_lf_up1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
   launch(c, KID_lf_up2, k_lf_up2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
   if (a.namax) launch(c, KID_lf_up3, k_lf_up3, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
@@ -251,7 +264,7 @@ void lf_chol(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
   dim3 blk(256);
   const int nfmax = a.nnmax + a.namax;
   launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, 1), blk, st, a);
-  if (a.t.gp_tptr) launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, 1), blk, st, a, x, (int64_t)0);
+  if (a.t.gp_tptr) launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, 1), blk, st, a, x, (int64_t)0, 0);
   const int mtA = tiles64(a.namax);
   for (int jb = 0; jb < a.nnmax; jb += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, x, (double*)nullptr, 0, jb, 1);
@@ -281,8 +294,8 @@ void lf_prep(csp_ctx* c, const MfmaArgs& a, int cnt, const double* L, hipStream_
   dim3 blk(256);
   for (int ib = 0; ib < a.nnmax; ib += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, const_cast<double*>(L), (double*)nullptr, 1, ib, 0);
-    if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, L, c->D.lk, ib);
-    launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, L, c->D.lk, ib);
+    if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, L, c->D.lk, ib, 0);
+    launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, L, c->D.lk, ib, 0);
   }
   if (a.namax) launch(c, KID_lf_prep_k, k_lf_prep_k, dim3(umax1(tiles64(a.namax) * tiles64(a.nnmax)), cnt), blk, st, a, L, c->D.lk);
 }
@@ -306,8 +319,7 @@ void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
 // or Y = projected_inverse(L) was produced by csp_projected_inverse (which prepares LK from L
 // before overwriting it).  In both cases the cached LK is still the inverse form of L.
 void prep_lk_cached(csp_ctx* c, const double* L, const double* Y, hipStream_t st) {
-  static int nocache = -1;
-  if (nocache < 0) { const char* e = getenv("SMCP_NOCACHE"); nocache = (e && e[0] == '1') ? 1 : 0; }
+  const bool nocache = cache_off();
   if (!nocache && ((c->D.lk_tag_L && c->D.lk_tag_L == L) || (c->D.lk_tag_Y && c->D.lk_tag_Y == Y))) return;
   prep_lk(c, L, st);
 }
@@ -315,8 +327,9 @@ void prep_lk_cached(csp_ctx* c, const double* L, const double* Y, hipStream_t st
 void invalidate_tags(csp_ctx* c, const void* p) {
   if (c->D.lk_tag_L == p) c->D.lk_tag_L = nullptr;
   if (c->D.lk_tag_Y == p) c->D.lk_tag_Y = nullptr;
-  if (c->D.yaa_tag == p) c->D.yaa_tag = nullptr;
+  if (c->D.yaa_tag == p) c->D.yaa_tag = c->D.fac_tag = c->D.faci_tag = nullptr;
 }
+
 
 void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0) {
   MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
@@ -346,23 +359,116 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
     });
 }
 
-int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st) {
+// inverse of the triangular factors in fac (large fronts: blocked over the chip; the rest: one workgroup each)
+void lf_factor_inverse(csp_ctx* c, const MfmaArgs& a, int cnt, hipStream_t st) {
+  dim3 blk(256);
+  for (int ib = 0; ib < a.namax; ib += LB) {
+    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, (double*)nullptr, c->D.fac, 4, ib, 0);
+    if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, (const double*)c->D.fac, c->D.faci, ib, 4);
+    launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, (const double*)c->D.fac, c->D.faci, ib, 4);
+  }
+}
+
+// yaa <- separator blocks of Y; fac <- their Cholesky factors (need_fac); faci <- inverses of those (need_inv).
+// Each stage is skipped when the cache already holds it for the matrix at this address (see invalidate_tags).
+int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool need_inv) {
   TreeArgs a = tree_args(c);
-  c->D.yaa_tag = Y;
-  gather_all(c, Y, 0, 1, c->D.yaa, st);
-  if (need_fac && !use_generic() && use_large()) {
-    (void)hipMemcpyAsync(c->D.fac, c->D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st);
-    MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
-    for (int64_t l = 0; l < c->S.nlev; ++l)
-      for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
-        if (!lds) { lf_factor_yaa(c, am, cnt, c->D.fac, st); return; }
-        size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
-        if (am.namax) launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(256), bytes, st, am, (const double*)c->D.yaa, c->D.fac);
-      });
-  } else if (need_fac) {
-    launch(c, KID_factor_yaa, k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), st, a, c->D.yaa, c->D.fac);
+  const bool nocache = cache_off();
+  if (need_inv) need_fac = true;
+  if (nocache || c->D.yaa_tag != Y || !Y) {
+    gather_all(c, Y, 0, 1, c->D.yaa, st);
+    c->D.yaa_tag = Y;
+    c->D.fac_tag = c->D.faci_tag = nullptr;
+  }
+  const bool fast = !use_generic() && use_large();
+  if (need_fac && c->D.fac_tag != Y) {
+    if (fast) {
+      (void)hipMemcpyAsync(c->D.fac, c->D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st);
+      MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+      for (int64_t l = 0; l < c->S.nlev; ++l)
+        for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
+          if (!lds) { lf_factor_yaa(c, am, cnt, c->D.fac, st); return; }
+          size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
+          if (am.namax) launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(256), bytes, st, am, (const double*)c->D.yaa, c->D.fac);
+        });
+    } else {
+      launch(c, KID_factor_yaa, k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), st, a, c->D.yaa, c->D.fac);
+    }
+    c->D.fac_tag = Y;
+    c->D.faci_tag = nullptr;
+  }
+  if (need_inv && c->D.faci_tag != Y) {
+    if (fast) {
+      a.lev = c->D.lev3idx;
+      if (c->D.nI_total) launch(c, KID_factor_inverse, k_factor_inverse, dim3((int)c->D.nI_total), dim3(256), st, a, (const double*)c->D.fac, c->D.faci);
+      MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+      for (int64_t l = 0; l < c->S.nlev; ++l)
+        for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) { if (!lds && am.namax) lf_factor_inverse(c, am, cnt, st); });
+    } else {
+      a.lev = c->D.levidx;
+      launch(c, KID_factor_inverse, k_factor_inverse, dim3((int)c->S.nsn), dim3(256), st, a, (const double*)c->D.fac, c->D.faci);
+    }
+    c->D.faci_tag = Y;
   }
   return 0;
+}
+
+// The inverse-factor kernels keep S (16 KB, completion only) in static LDS next to the dynamic working set
+constexpr size_t INV_STATIC_LDS = 16 * 128 * sizeof(double);
+// fronts with at least this many columns are spread over the chip by the tiled phase kernels; narrower
+// large fronts (long chains of thin cliques with big separators) take one workgroup and one launch each
+constexpr int LF_INV_MIN_NN = 24;
+
+// G^-adj (clique-local once Z_AA of every clique has been gathered from the input), then the scaling `ymode`
+void hess_down_inv_fast(csp_ctx* c, const double* L, double* U, int nrhs, int64_t ldu, int ymode, hipStream_t st) {
+  gather_all(c, U, ldu, nrhs, c->D.upd, st);
+  MfmaArgs a0 = mfma_args(c, c->D.faci, ymode, nrhs);
+  a0.LK = L;
+  dim3 blk(256);
+  for (int64_t l = 0; l < c->S.nlev; ++l)
+    for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
+      if (lds) {
+        int g = rhs_groups(cnt, nrhs, 2048);
+        launch_lds(c, KID_hess_down_inv_mfma, k_hess_down_inv_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+      } else if (use_large() && a.nnmax >= LF_INV_MIN_NN) {
+        const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
+        launch(c, KID_lf_dinv1, k_lf_dinv1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
+        launch(c, KID_lf_dinv2, k_lf_dinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
+        if (ymode == 1 && a.namax) {
+          launch(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu, 1);
+          launch(c, KID_lf_copy_an, k_lf_copy_an, dim3(umax1(std::min(64, (a.namax * a.nnmax + 255) / 256)), cnt, nrhs), blk, st, a, U, ldu, 0);
+        }
+      } else {
+        launch_lds(c, KID_hess_down_inv_mfma_hbm, k_hess_down_inv_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+      }
+    });
+}
+// G^-1, leaves -> root; ymode 3: G_AN = Ri^T Ghat_AN first
+void hess_up_inv_fast(csp_ctx* c, const double* L, double* U, int nrhs, int64_t ldu, int ymode, hipStream_t st) {
+  MfmaArgs a0 = mfma_args(c, c->D.faci, ymode, nrhs);
+  a0.LK = L;
+  dim3 blk(256);
+  for (int64_t l = 0; l < c->S.nlev; ++l)
+    for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
+      if (lds) {
+        int g = rhs_groups(cnt, nrhs, 2048);
+        launch_lds(c, KID_hess_up_inv_mfma, k_hess_up_inv_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+      } else if (use_large() && c->D.gp_tptr && a.nnmax >= LF_INV_MIN_NN) {
+        const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
+        const dim3 gcopy(umax1(std::min(64, (a.namax * a.nnmax + 255) / 256)), cnt, nrhs);
+        if (ymode == 3 && a.namax) {
+          launch(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu, 1);
+          launch(c, KID_lf_copy_an, k_lf_copy_an, gcopy, blk, st, a, U, ldu, 0);
+        }
+        launch(c, KID_lf_uinv1, k_lf_uinv1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
+        launch(c, KID_lf_uinv2, k_lf_uinv2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
+        if (a.namax) launch(c, KID_lf_copy_an, k_lf_copy_an, gcopy, blk, st, a, U, ldu, 0);
+        launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), blk, st, a, U, ldu, 1);
+        if (a.namax) launch(c, KID_lf_pack_upd, k_lf_pack_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 255) / 256)), cnt, nrhs), blk, st, a);
+      } else {
+        launch_lds(c, KID_hess_up_inv_mfma_hbm, k_hess_up_inv_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+      }
+    });
 }
 
 int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t ldu, int adj, int inv,
@@ -403,6 +509,10 @@ int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t l
     if (adj == 0) { up(); scale(0); }
     else if (adj == 1) { scale(1); down(); }
     else { up(); scale(4); down(); }
+  } else if (!use_generic()) {
+    if (adj == 0) hess_up_inv_fast(c, L, U, (int)nrhs, ldu, 3, st);
+    else if (adj == 1) hess_down_inv_fast(c, L, U, (int)nrhs, ldu, 2, st);
+    else { hess_down_inv_fast(c, L, U, (int)nrhs, ldu, 1, st); hess_up_inv_fast(c, L, U, (int)nrhs, ldu, 0, st); }
   } else {
     if (adj == 0) { scale(2); up_inv(); }
     else if (adj == 1) { down_inv(); scale(3); }
@@ -477,7 +587,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
     for (void* p : ptrs) if (p) hipFree(p);
     if (D.info_host) hipHostFree(D.info_host);
@@ -634,10 +744,14 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_chol_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_pinv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_inv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_inv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_completion_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(mx - INV_STATIC_LDS)));
     }
     if ((rc = dev_upload(&D.tmpptr, c->h_tmpptr, D.bytes))) return rc;
     if ((rc = dev_alloc(&D.yaa, S.updlen(), D.bytes))) return rc;
     if ((rc = dev_alloc(&D.fac, S.updlen(), D.bytes))) return rc;
+    if ((rc = dev_alloc(&D.faci, S.updlen(), D.bytes))) return rc;
     if ((rc = dev_alloc(&D.red, 1024, D.bytes))) return rc;
     if ((rc = dev_alloc(&D.info, 4, D.bytes))) return rc;
     HIPCHK(hipMemset(D.info, 0, sizeof(int) * 4));
@@ -726,8 +840,47 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
-  gather_all(c, x, 0, 1, c->D.upd, st);
-  launch(c, KID_completion_all, k_completion_all, dim3((int)c->S.nsn), dim3(NT), st, a, x);
+  if (!use_generic()) {
+    // clique-local given chol(X_AA) and its inverse of every clique (taken from the input before it is overwritten)
+    prepare_yaa(c, x, true, st, true);
+    MfmaArgs a0 = mfma_args(c, c->D.faci, 0, 1);
+    a0.LK = nullptr;
+    dim3 blk(256);
+    for (int64_t l = 0; l < c->S.nlev; ++l)
+      for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
+        if (lds && bytes + INV_STATIC_LDS <= LDS_LIMIT) {
+          launch_lds(c, KID_completion_mfma, k_completion_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
+        } else if (use_large() && am.nnmax >= LF_INV_MIN_NN) {
+          const int mtA = tiles64(am.namax), ntN = tiles64(am.nnmax);
+          if (am.namax) {
+            launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(mtA * ntN), cnt), blk, st, am, x, 0);
+            launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(mtA * ntN), cnt), blk, st, am, x, 1);
+          }
+          launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(ntN * ntN), cnt), blk, st, am, x, 2);
+          for (int jb = 0; jb < am.nnmax; jb += LB) {
+            launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, jb, 1);
+            const int mrem = am.nnmax - jb - 1;
+            if (mrem > 0) {
+              launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(umax1(tiles64(mrem)), cnt), blk, st, am, (double*)nullptr, (double*)nullptr, 3, jb);
+              const int mt = tiles64(mrem);
+              launch(c, KID_lf_chol_trail, k_lf_chol_trail, dim3(umax1(mt * (mt + 1) / 2), cnt), blk, st, am, (double*)nullptr, (double*)nullptr, 3, jb);
+            }
+          }
+          for (int ib = 0; ib < am.nnmax; ib += LB) {
+            launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, ib, 0);
+            if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3);
+            launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3);
+          }
+          launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(ntN * ntN + mtA * ntN), cnt), blk, st, am, x, 3);
+        } else {
+          launch_lds(c, KID_completion_mfma_hbm, k_completion_mfma<false>, dim3(cnt), dim3(lds ? 256 : thr), 0, st, am, x);
+        }
+      });
+    invalidate_tags(c, x);   // x now holds the factor, not the matrix the caches were derived from
+  } else {
+    gather_all(c, x, 0, 1, c->D.upd, st);
+    launch(c, KID_completion_all, k_completion_all, dim3((int)c->S.nsn), dim3(NT), st, a, x);
+  }
   HIPCHK(hipGetLastError());
   return fetch_info(c, st);
 }
@@ -740,14 +893,19 @@ int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t
   bool need_fac = !(adj == 2 && inv == 0);
   invalidate_tags(c, U);
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
-  prepare_yaa(c, Y, need_fac, st);
+  const bool refactor = need_fac && (cache_off() || c->D.fac_tag != Y);
+  prepare_yaa(c, Y, need_fac, st, inv && !use_generic());
   if (!inv && !use_generic()) prep_lk_cached(c, L, Y, st);
   for (int64_t r0 = 0; r0 < nrhs; r0 += c->D.max_rhs) {
     int64_t nr = std::min(c->D.max_rhs, nrhs - r0);
     hessian_impl(c, L, U + r0 * ldu, nr, ldu, adj, inv, st);
   }
   HIPCHK(hipGetLastError());
-  if (need_fac) return fetch_info(c, st);
+  if (refactor) {
+    int rc = fetch_info(c, st);
+    if (rc) c->D.fac_tag = c->D.faci_tag = nullptr;
+    return rc;
+  }
   return 0;
 }
 
@@ -801,6 +959,12 @@ int csp_axpby(int64_t len, double a, const double* x, double b, double* y, void*
   return 0;
 }
 
+
+int csp_cache_reset(csp_ctx* c) {
+  if (!c) return SMCP_EINVAL;
+  c->D.lk_tag_L = c->D.lk_tag_Y = c->D.yaa_tag = c->D.fac_tag = c->D.faci_tag = nullptr;
+  return 0;
+}
 
 int csp_profile_enable(csp_ctx* c, int on) {
   if (!c) return SMCP_EINVAL;

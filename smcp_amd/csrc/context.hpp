@@ -45,6 +45,8 @@ struct DeviceCtx {
   const void* lk_tag_L = nullptr;   // LK was prepared from the factor stored at this address ...
   const void* lk_tag_Y = nullptr;   // ... or from the factor whose projected inverse now lives here
   const void* yaa_tag = nullptr;    // yaa holds the separator blocks of the matrix at this address
+  const void* fac_tag = nullptr;    // fac = chol(yaa) of the matrix at this address
+  const void* faci_tag = nullptr;   // faci = fac^-1 of the matrix at this address
   double* lfd = nullptr;      // 64 x 64 doubles per large front: inverse of the current diagonal block
   int32_t* lev3idx = nullptr; // all LDS-class cliques (any level), then nothing: list for clique-local kernels
   int64_t nI_total = 0;
@@ -54,6 +56,7 @@ struct DeviceCtx {
   double* updp = nullptr;  // max_rhs * updplen : packed lower triangles handed from children to parents (fast up-sweeps, cholesky)
   double* yaa = nullptr;   // updlen : Y[A_k,A_k] cache (Hessian)
   double* fac = nullptr;   // updlen : chol(Y_AA) cache
+  double* faci = nullptr;  // updlen : inverse of fac (lower; positions above the diagonal are scratch)
   double* tmp = nullptr;   // max_rhs * tmplen : per-clique scratch (tmpptr)
   int64_t* tmpptr = nullptr;
   int64_t tmplen = 0;

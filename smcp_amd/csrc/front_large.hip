@@ -107,7 +107,8 @@ __device__ inline LfCtx lf_ctx(const MfmaArgs& a, double* u, int64_t ldu) {
 }
 
 // ---- phase 0: zero the update block and add the children (gather plan: one owner per position)
-__global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu) {
+// sgn 0: U = children, panel += children (U was cleared);  sgn 1: U += children, panel -= children
+__global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
   const int r = blockIdx.z;
@@ -131,8 +132,12 @@ __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu) {
     }
     for (; cc < c1; ++cc) acc += ubase[a.t.gp_src[cc]];
     const int i = code & 0x7fff, j = (code >> 15) & 0x7fff;
-    if (code & (1 << 30)) U[i + (int64_t)j * na] = acc;     // U was cleared: plain store
-    else P[i + (int64_t)j * nf] += acc;
+    if (sgn) {
+      if (code & (1 << 30)) U[i + (int64_t)j * na] += acc; else P[i + (int64_t)j * nf] -= acc;
+    } else {
+      if (code & (1 << 30)) U[i + (int64_t)j * na] = acc;     // U was cleared: plain store
+      else P[i + (int64_t)j * nf] += acc;
+    }
   }
 }
 __global__ void k_lf_clear_upd(MfmaArgs a) {
@@ -425,12 +430,15 @@ struct LfMat {
   double* upd; int na;                     // rows ncol..nrow-1 update this (na = nrow - ncol) or null
   double* dinv;                            // w x w inverse of the current diagonal block (ld = w)
 };
-// mode 0: panel of a front in x (Cholesky), 1: L -> LK preparation (triangular inverse), 2: Y_AA -> its Cholesky factor
+// mode 0: panel of a front in x (Cholesky), 1: L -> LK preparation (triangular inverse), 2: Y_AA -> its Cholesky factor,
+// 3: the nn x nn matrix at the head of the clique's scratch (completion), 4: update-layout matrix in aux, inverse only
 __device__ inline LfMat lf_mat(const MfmaArgs& a, int k, int mode, double* x, double* aux) {
   const CliqueDesc d = a.t.cl[k];
   LfMat m;
   double* scratch = a.lfd + (int64_t)d.pad * (LB * LB);   // d.pad = slot of this clique among the large fronts
-  if (mode == 2) {
+  if (mode == 3) {
+    m.A = a.t.tmp + a.t.tmpptr[k]; m.ld = d.nn; m.nrow = d.nn; m.ncol = d.nn; m.upd = nullptr; m.na = 0;
+  } else if (mode == 2 || mode == 4) {
     m.A = aux + d.upd; m.ld = d.na; m.nrow = d.na; m.ncol = d.na; m.upd = nullptr; m.na = 0;
   } else {
     m.A = x + d.blk; m.ld = d.nn + d.na; m.nrow = d.nn + d.na; m.ncol = d.nn;
@@ -535,8 +543,8 @@ __global__ void k_lf_pack_upd(MfmaArgs a) {
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
   const int na = d.na;
-  const double* U = a.t.upd + d.upd;
-  double* UP = a.t.updp + d.updp;
+  const double* U = a.t.upd + (int64_t)blockIdx.z * a.t.updlen + d.upd;
+  double* UP = a.t.updp + (int64_t)blockIdx.z * a.t.updplen + d.updp;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < na * na; e += gridDim.x * blockDim.x) {
     int i = e % na, j = e / na;
     if (i >= j) UP[pk_idx(i, j, na)] = U[e];
@@ -545,33 +553,54 @@ __global__ void k_lf_pack_upd(MfmaArgs a) {
 
 // ---- inverse-form factor of large fronts: Li = L_NN^-1 by block rows, K = L_AN Li
 // step ib: (after k_lf_diag wrote Dinv of block ib) S = L[ib, 0:ib] Li[0:ib, 0:ib] ; Li[ib, 0:ib] = -Dinv S
-__global__ void __launch_bounds__(256) k_lf_prep_s(MfmaArgs a, const double* L, double* LK, int ib) {
+// view of one triangular inversion: src (lower, ld) -> dst (ld), order n, row-block scratch S
+// mode 0: L_NN -> Li of LK;  3: the scratch-head matrix of the completion, in place;  4: fac -> faci (update layout)
+struct InvView { const double* src; double* dst; int64_t ld; int n; double* S; };
+__device__ inline InvView inv_view(const MfmaArgs& a, int k, const CliqueDesc& d, int mode, const double* L, double* LK) {
+  InvView v;
+  double* tmp = a.t.tmp + a.t.tmpptr[k];
+  if (mode == 3) {
+    v.src = tmp; v.dst = tmp; v.ld = d.nn; v.n = d.nn; v.S = tmp + (int64_t)d.nn * d.nn + 2 * (int64_t)d.na * d.nn;
+  } else if (mode == 4) {
+    // row-block scratch = the (otherwise unused) transposed position above the diagonal of dst
+    v.src = L + d.upd; v.dst = LK + d.upd; v.ld = d.na; v.n = d.na; v.S = LK + d.upd;
+  } else {
+    v.src = L + d.blk; v.dst = LK + d.blk; v.ld = d.nn + d.na; v.n = d.nn; v.S = tmp;
+  }
+  return v;
+}
+__global__ void __launch_bounds__(256) k_lf_prep_s(MfmaArgs a, const double* L, double* LK, int ib, int mode) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
-  const int nn = d.nn, nf = d.nn + d.na;
+  const InvView V = inv_view(a, k, d, mode, L, LK);
+  const int nn = V.n;
+  const int64_t nf = V.ld;
   if (ib >= nn || ib == 0) return;
   const int w = min(LB, nn - ib);
   const int n0 = blockIdx.x * LT;
   if (n0 >= ib) return;
-  const double* Lk = L + d.blk;
-  const double* Li = LK + d.blk;
-  double* S = a.t.tmp + a.t.tmpptr[k];   // w x ib (ld w)
+  const double* Lk = V.src;
+  const double* Li = V.dst;
+  double* S = V.S;   // w x ib (ld w; transposed into dst's upper triangle in mode 4)
+  const int64_t sm = mode == 4 ? nf : 1, sn = mode == 4 ? 1 : w, s0 = mode == 4 ? (int64_t)ib * nf : 0;
   d4 acc[2][2];
   tile64_zero(acc);
   gemm_tile64(acc, w, ib, ib, 0, n0, [=](int m, int kk) { return Lk[(ib + m) + (int64_t)kk * nf]; },
               [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB);
-  tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { S[m + (int64_t)n * w] = v; });
+  tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { S[s0 + m * sm + n * sn] = v; });
 }
-__global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L, double* LK, int ib) {
+__global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L, double* LK, int ib, int mode) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
-  const int nn = d.nn, nf = d.nn + d.na;
+  const InvView V = inv_view(a, k, d, mode, L, LK);
+  const int nn = V.n;
+  const int64_t nf = V.ld;
   if (ib >= nn) return;
   const int w = min(LB, nn - ib);
   const double* Di = a.lfd + (int64_t)d.pad * (LB * LB);       // w x w (ld w)
-  double* Li = LK + d.blk;
+  double* Li = V.dst;
   const int t = blockIdx.x;
   const int ntS = tiles64(ib);
   if (t == ntS) {   // diagonal block of Li (and zeros above it)
@@ -579,19 +608,21 @@ __global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L
       int i = e % w, j = e / w;
       Li[(ib + i) + (int64_t)(ib + j) * nf] = (i >= j) ? Di[i + j * w] : 0.0;
     }
-    for (int e = threadIdx.x; e < ib * w; e += blockDim.x) {   // upper part: rows < ib of these columns
-      int i = e % ib, j = e / ib;
-      Li[i + (int64_t)(ib + j) * nf] = 0.0;
-    }
+    if (mode != 4)
+      for (int e = threadIdx.x; e < ib * w; e += blockDim.x) {   // upper part: rows < ib of these columns
+        int i = e % ib, j = e / ib;
+        Li[i + (int64_t)(ib + j) * nf] = 0.0;
+      }
     return;
   }
   if (t > ntS) return;
   const int n0 = t * LT;
-  const double* S = a.t.tmp + a.t.tmpptr[k];
+  const double* S = V.S;
+  const int64_t sm = mode == 4 ? nf : 1, sn = mode == 4 ? 1 : w, s0 = mode == 4 ? (int64_t)ib * nf : 0;
   d4 acc[2][2];
   tile64_zero(acc);
   gemm_tile64(acc, w, ib, w, 0, n0, [=](int m, int kk) { return Di[m + kk * w]; },
-              [=](int kk, int n) { return S[kk + (int64_t)n * w]; }, sA, sB);
+              [=](int kk, int n) { return S[s0 + kk * sm + n * sn]; }, sA, sB);
   tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { Li[(ib + m) + (int64_t)n * nf] = -v; });
 }
 __global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, double* LK) {
@@ -613,6 +644,243 @@ __global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, 
   tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Kk[m + (int64_t)n * nf] = v; });
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Inverse Hessian factors and completion of large fronts (formulas: front_inv.hip).  a.LK = the factor L
+// itself, a.ysc = faci (R^-1, lower; positions above the diagonal are scratch and must be masked).
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__device__ inline void tile64_foreach2(const d4 (&a1)[2][2], const d4 (&a2)[2][2], int m0, int n0, int M, int N, F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kq = lane >> 4, wm = wave & 1, wn = wave >> 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 32 * wm + 16 * a + l15, n = n0 + 32 * wn + 16 * b + kq + 4 * r;
+        if (m < M && n < N) f(m, n, a1[a][b][r], a2[a][b][r]);
+      }
+}
+// AN rows of the panel <-> G scratch.  dir 0: panel = G, 1: G = panel
+__global__ void k_lf_copy_an(MfmaArgs a, double* u, int64_t ldu, int dir) {
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < na * nn; e += gridDim.x * blockDim.x) {
+    const int i = e % na, j = e / na;
+    if (dir) c.G[e] = c.P[nn + i + (int64_t)j * nf]; else c.P[nn + i + (int64_t)j * nf] = c.G[e];
+  }
+}
+// G = Ri^T (AN rows of the panel)  (tr = 1)   or   G = Ri (AN rows)  (tr = 0)
+__global__ void __launch_bounds__(256) k_lf_ri_an(MfmaArgs a, double* u, int64_t ldu, int tr) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int t = blockIdx.x;
+  if (t >= mtA * ntN) return;
+  const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+  const double* Y = c.Ys; const double* P = c.P;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (tr)
+    gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return kk >= m ? Y[kk + (int64_t)m * na] : 0.0; },
+                [=](int kk, int n) { return P[nn + kk + (int64_t)n * nf]; }, sA, sB);
+  else
+    gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return m >= kk ? Y[m + (int64_t)kk * na] : 0.0; },
+                [=](int kk, int n) { return P[nn + kk + (int64_t)n * nf]; }, sA, sB);
+  double* G = c.G;
+  tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { G[m + (int64_t)n * na] = v; });
+}
+
+// ---- G^-adj phase 1: Q = Z_AN L_NN + Z_AA L_AN (into G) ; Q'' = Z_AN L_NN + Z_AA L_AN / 2 (into E) ; T = Z_NN L_NN
+__global__ void __launch_bounds__(256) k_lf_dinv1(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int nE = mtA * ntN, nT = ntN * ntN;
+  const int t = blockIdx.x;
+  if (t >= nE + nT) return;
+  const double* P = c.P; const double* Lnn = c.Li; const double* Lan = c.K; const double* Z = c.U;
+  auto lnn = [=](int kk, int n) { return Lnn[kk + (int64_t)n * nf]; };
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (t < nE) {
+    const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+    d4 acc2[2][2];
+    tile64_zero(acc2);
+    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, lnn, sA, sB);
+    gemm_tile64(acc2, na, nn, na, m0, n0,
+                [=](int m, int kk) { return m >= kk ? Z[m + (int64_t)kk * na] : Z[kk + (int64_t)m * na]; },
+                [=](int kk, int n) { return Lan[kk + (int64_t)n * nf]; }, sA, sB);
+    double* E = c.E; double* G = c.G;
+    tile64_foreach2(acc, acc2, m0, n0, na, nn, [=](int m, int n, double v1, double v2) {
+      G[m + (int64_t)n * na] = v1 + v2;
+      E[m + (int64_t)n * na] = v1 + 0.5 * v2;
+    });
+  } else {
+    const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
+    gemm_tile64(acc, nn, nn, nn, m0, n0,
+                [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : P[kk + (int64_t)m * nf]; }, lnn, sA, sB);
+    double* T = c.T;
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
+  }
+}
+// ---- G^-adj phase 2: G_NN = L_NN^T T + L_AN^T Q'' + Q''^T L_AN (lower, into the panel) ; AN rows = Q or Ri Q
+__global__ void __launch_bounds__(256) k_lf_dinv2(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int nN = ntN * (ntN + 1) / 2, nA = mtA * ntN;
+  const int t = blockIdx.x;
+  if (t >= nN + nA) return;
+  const double* Lnn = c.Li; const double* Lan = c.K; const double* T = c.T; const double* E = c.E; const double* G = c.G;
+  double* Pw = c.P;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (t < nN) {
+    int tm, tn;
+    lower_pair(t, tm, tn);
+    const int m0 = tm * LT, n0 = tn * LT;
+    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Lnn[kk + (int64_t)m * nf]; },
+                [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB);
+    gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return Lan[kk + (int64_t)m * nf]; },
+                [=](int kk, int n) { return E[kk + (int64_t)n * na]; }, sA, sB);
+    gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return E[kk + (int64_t)m * na]; },
+                [=](int kk, int n) { return Lan[kk + (int64_t)n * nf]; }, sA, sB);
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
+  } else {
+    const int tt = t - nN, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
+    if (a.ymode) {
+      const double* Y = c.Ys;
+      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return m >= kk ? Y[m + (int64_t)kk * na] : 0.0; },
+                  [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB);
+      tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = v; });
+    } else {
+      tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = G[m + (int64_t)n * na]; });
+    }
+  }
+}
+// ---- G^-1 phase 1: V = G_AN + L_AN G_NN / 2 (into E) ; T = G_NN L_NN^T
+__global__ void __launch_bounds__(256) k_lf_uinv1(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int nE = mtA * ntN, nT = ntN * ntN;
+  const int t = blockIdx.x;
+  if (t >= nE + nT) return;
+  const double* P = c.P; const double* Lnn = c.Li; const double* Lan = c.K;
+  auto gsym = [=](int i, int j) { return i >= j ? P[i + (int64_t)j * nf] : P[j + (int64_t)i * nf]; };
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (t < nE) {
+    const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return Lan[m + (int64_t)kk * nf]; }, gsym, sA, sB);
+    double* E = c.E;
+    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = P[nn + m + (int64_t)n * nf] + 0.5 * v; });
+  } else {
+    const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
+    gemm_tile64(acc, nn, nn, nn, m0, n0, gsym, [=](int kk, int n) { return Lnn[n + (int64_t)kk * nf]; }, sA, sB);
+    double* T = c.T;
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
+  }
+}
+// ---- G^-1 phase 2: U = -(V L_AN^T + L_AN V^T) (lower) ; G = (2V - G_AN) L_NN^T ; F_NN = L_NN T (lower, into the panel)
+__global__ void __launch_bounds__(256) k_lf_uinv2(MfmaArgs a, double* u, int64_t ldu) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int nU = mtA * (mtA + 1) / 2, nG = mtA * ntN, nN = ntN * (ntN + 1) / 2;
+  const int t = blockIdx.x;
+  if (t >= nU + nG + nN) return;
+  const double* Lan = c.K; const double* E = c.E; const double* Lnn = c.Li; const double* T = c.T; const double* P = c.P;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (t < nU) {
+    int tm, tn;
+    lower_pair(t, tm, tn);
+    const int m0 = tm * LT, n0 = tn * LT;
+    gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return E[m + (int64_t)kk * na]; },
+                [=](int kk, int n) { return Lan[n + (int64_t)kk * nf]; }, sA, sB);
+    gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return Lan[m + (int64_t)kk * nf]; },
+                [=](int kk, int n) { return E[n + (int64_t)kk * na]; }, sA, sB);
+    double* U = c.U;
+    tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) { if (m >= n) U[m + (int64_t)n * na] = -v; });
+  } else if (t < nU + nG) {
+    const int tt = t - nU, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
+    gemm_tile64(acc, na, nn, nn, m0, n0,
+                [=](int m, int kk) { return 2.0 * E[m + (int64_t)kk * na] - P[nn + m + (int64_t)kk * nf]; },
+                [=](int kk, int n) { return Lnn[n + (int64_t)kk * nf]; }, sA, sB);
+    double* G = c.G;
+    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { G[m + (int64_t)n * na] = v; });
+  } else {
+    int tm, tn;
+    lower_pair(t - nU - nG, tm, tn);
+    const int m0 = tm * LT, n0 = tn * LT;
+    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Lnn[m + (int64_t)kk * nf]; },
+                [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB);
+    __syncthreads();
+    double* Pw = c.P;
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
+  }
+}
+
+// ---- completion, large fronts (scratch: T nn x nn | E na x nn | G na x nn | row-block scratch of the inversion)
+// step 0: E = Ri X_AN ; step 1: G = Ri^T E ; step 2: T = reversed(X_NN - X_AN^T G) ; step 3: L_NN = reversed(T^-1)^T, L_AN = -G L_NN
+__global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, int step) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  if (*a.t.info) return;
+  const LfCtx c = lf_ctx(a, x, 0);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int t = blockIdx.x;
+  const double* Y = c.Ys; const double* P = c.P;
+  double* E = c.E; double* G = c.G; double* T = c.T;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (step <= 1) {
+    if (t >= mtA * ntN) return;
+    const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
+    if (step == 0)
+      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return m >= kk ? Y[m + (int64_t)kk * na] : 0.0; },
+                  [=](int kk, int n) { return P[nn + kk + (int64_t)n * nf]; }, sA, sB);
+    else
+      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return kk >= m ? Y[kk + (int64_t)m * na] : 0.0; },
+                  [=](int kk, int n) { return E[kk + (int64_t)n * na]; }, sA, sB);
+    double* O = step == 0 ? E : G;
+    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { O[m + (int64_t)n * na] = v; });
+  } else if (step == 2) {
+    if (t >= ntN * ntN) return;
+    const int m0 = (t % ntN) * LT, n0 = (t / ntN) * LT;
+    gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return P[nn + kk + (int64_t)m * nf]; },
+                [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB);
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) {
+      const double f = m >= n ? P[m + (int64_t)n * nf] : P[n + (int64_t)m * nf];
+      T[(nn - 1 - m) + (int64_t)(nn - 1 - n) * nn] = f - v;
+    });
+  } else {
+    const int nN = ntN * ntN, nA = mtA * ntN;
+    if (t >= nN + nA) return;
+    double* Pw = c.P;
+    if (t < nN) {
+      const int m0 = (t % ntN) * LT, n0 = (t / ntN) * LT;
+      for (int e = threadIdx.x; e < LT * LT; e += blockDim.x) {
+        const int m = m0 + (e & 63), n = n0 + (e >> 6);
+        if (m < nn && n < nn) Pw[m + (int64_t)n * nf] = m >= n ? T[(nn - 1 - n) + (int64_t)(nn - 1 - m) * nn] : 0.0;
+      }
+    } else {
+      const int tt = t - nN, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
+      gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return G[m + (int64_t)kk * na]; },
+                  [=](int kk, int n) { return kk >= n ? T[(nn - 1 - n) + (int64_t)(nn - 1 - kk) * nn] : 0.0; }, sA, sB);
+      tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = -v; });
+    }
+  }
+}
 
 // ---- multi-GPU boundary exchange: packed update blocks of the listed cliques <-> a contiguous buffer
 // buffer layout: [clique in list][rhs][packed entries];  bptr[c] = start of clique c's slab (in doubles per rhs)

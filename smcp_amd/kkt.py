@@ -8,7 +8,7 @@ import torch
 
 from . import _lib
 from .chordal import _chk, _ensure
-from .cspmatrix import cspmatrix, _stream
+from .cspmatrix import cspmatrix, _stream, sync_cache
 
 
 def column_range(m, rank, world):
@@ -141,10 +141,12 @@ class KKTSystem(ShardedSchur):
 
     def aadj(self, y):
         X = cspmatrix(self.symb, torch.empty(self.symb.blklen, dtype=torch.float64, device=self.dev))
+        X.touched()
         _chk(_lib.lib().kkt_aadj(self.symb.handle, y.data_ptr(), X.blkval.data_ptr(), _stream()), "kkt_aadj")
         return X
 
     def _columns(self, L, Y, j0, j1):
+        sync_cache(self.symb, L, Y)
         _chk(_lib.lib().kkt_schur_columns(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(),
                                           self.H.data_ptr(), self.m, int(j0), int(j1), _stream()), "kkt_schur_columns")
 
@@ -160,6 +162,7 @@ class KKTSystem(ShardedSchur):
         return int(self.symb._max_rhs)
 
     def _gram_prepare(self, L, Y):
+        sync_cache(self.symb, L, Y)
         _chk(_lib.lib().kkt_gram_prepare(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), _stream()),
              "kkt_gram_prepare")
 
@@ -193,6 +196,8 @@ class KKTSystem(ShardedSchur):
 
         def solve_(bx, by, kk):
             """Overwrites bx (cspmatrix) with x and by (device vector) with y."""
+            sync_cache(self.symb, L, Y)
+            bx.touched()
             _chk(_lib.lib().kkt_solve(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(),
                                       self.H.data_ptr(), self.m, float(kk), bx.blkval.data_ptr(),
                                       by.data_ptr(), _stream()), "kkt_solve")

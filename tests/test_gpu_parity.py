@@ -40,6 +40,7 @@ GPU_PATTERNS = dict(PATTERNS)
 GPU_PATTERNS["arrow_big"] = lambda: problems.block_arrow_pattern(12, 64, 128)
 GPU_PATTERNS["nested_mid"] = lambda: problems.nested_block_arrow_pattern(nsub=2, nmid=6, nleaf_per_mid=8, seed=3)
 GPU_PATTERNS["dense200"] = lambda: problems.band_pattern(200, 199)
+GPU_PATTERNS["arrow_thin"] = lambda: problems.block_arrow_pattern(6, 2, 150)   # thin cliques, separators beyond LDS
 GPU_PATTERNS["diag"] = lambda: problems.band_pattern(15, 0)          # LP case: every clique is 1 x 1
 
 
