@@ -150,12 +150,21 @@ void for_levels_down(csp_ctx* c, F f) {
   }
 }
 
+// workgroups per clique of a gather launch whose largest separator is namax
+inline unsigned gather_parts(int namax) { return (unsigned)std::max(1, std::min(64, (namax * namax) / (NT * 32))); }
+inline int namax_of(csp_ctx* c, const int32_t* lev) {   // lev points into D.levidx at the start of a level
+  const int64_t off = lev - c->D.levidx;
+  const auto& lp = c->S.levptr;
+  const int64_t l = std::upper_bound(lp.begin(), lp.end(), off) - lp.begin() - 1;
+  return (l >= 0 && l < (int64_t)c->lev_namax.size()) ? c->lev_namax[l] : 0;
+}
+
 // upd[r][k] <- X_r[A_k, A_k] for all cliques, top-down
 void gather_all(csp_ctx* c, const double* x, int64_t ldx, int nrhs, double* updbase, hipStream_t st) {
   TreeArgs a = tree_args(c);
   for_levels_down(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
-    launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs), dim3(NT), st, a, x, ldx, updbase);
+    launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(namax_of(c, lev))), dim3(NT), st, a, x, ldx, updbase);
   });
 }
 
@@ -190,6 +199,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   { static int sk = -1; if (sk < 0) { const char* e = getenv("SMCP_SKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
   a.dbg = (a.skip & 64) ? (unsigned long long*)(c->D.red + 768) : nullptr;
   a.lfd = c->D.lfd;
+  a.dn = 0; a.dld = 0;
   return a;
 }
 
@@ -223,6 +233,16 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f, int set = 0) {
 }
 
 
+// f(MfmaArgs over ALL large fronts, count): for clique-local operations (no level order needed)
+template <class F>
+void for_all_large(csp_ctx* c, MfmaArgs a, F f) {
+  if (!c->D.nII_total) return;
+  a.t.lev = c->D.lev3idx + c->D.nI_total;
+  a.nnmax = c->D.nnmaxII_all;
+  a.namax = c->D.namaxII_all;
+  f(a, (int)c->D.nII_total);
+}
+
 bool use_large() {
   static int g = -1;
   if (g < 0) { const char* e = getenv("SMCP_LARGE"); g = (e && e[0] == '0') ? 0 : 1; }
@@ -242,7 +262,7 @@ void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t 
 void lf_down(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
-  if (a.namax) launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs), dim3(NT), st, a.t, (const double*)U, ldu, a.t.upd);
+  if (a.namax) launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(a.namax)), dim3(NT), st, a.t, (const double*)U, ldu, a.t.upd);
   launch(c, KID_lf_down1, k_lf_down1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
   if (a.namax) launch(c, KID_lf_down2, k_lf_down2, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
   launch(c, KID_lf_down3, k_lf_down3, dim3(umax1(ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
@@ -251,7 +271,7 @@ void lf_pinv(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
   if (a.namax) {
-    launch(c, KID_gather_level, k_gather_level, dim3(cnt, 1), dim3(NT), st, a.t, (const double*)x, (int64_t)0, a.t.upd);
+    launch(c, KID_gather_level, k_gather_level, dim3(cnt, 1, gather_parts(a.namax)), dim3(NT), st, a.t, (const double*)x, (int64_t)0, a.t.upd);
     launch(c, KID_lf_pinv1, k_lf_pinv1, dim3(umax1(mtA * ntN), cnt, 1), blk, st, a, x);
   }
   launch(c, KID_lf_pinv2, k_lf_pinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, 1), blk, st, a, x);
@@ -306,8 +326,7 @@ void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
     t.lev = c->D.lev3idx;
     if (c->D.nI_total) launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->D.nI_total), dim3(NT), st, t, L, c->D.lk);
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
-    for (int64_t l = 0; l < c->S.nlev; ++l)
-      for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) { if (!lds) lf_prep(c, am, cnt, L, st); });
+    for_all_large(c, a0, [&](MfmaArgs am, int cnt) { lf_prep(c, am, cnt, L, st); });
   } else {
     t.lev = nullptr;
     launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->S.nsn), dim3(NT), st, t, L, c->D.lk);
@@ -387,10 +406,11 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
       MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
       for (int64_t l = 0; l < c->S.nlev; ++l)
         for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
-          if (!lds) { lf_factor_yaa(c, am, cnt, c->D.fac, st); return; }
+          if (!lds) return;
           size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
           if (am.namax) launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(256), bytes, st, am, (const double*)c->D.yaa, c->D.fac);
         });
+      for_all_large(c, a0, [&](MfmaArgs am, int cnt) { if (am.namax) lf_factor_yaa(c, am, cnt, c->D.fac, st); });
     } else {
       launch(c, KID_factor_yaa, k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), st, a, c->D.yaa, c->D.fac);
     }
@@ -402,8 +422,7 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
       a.lev = c->D.lev3idx;
       if (c->D.nI_total) launch(c, KID_factor_inverse, k_factor_inverse, dim3((int)c->D.nI_total), dim3(256), st, a, (const double*)c->D.fac, c->D.faci);
       MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
-      for (int64_t l = 0; l < c->S.nlev; ++l)
-        for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) { if (!lds && am.namax) lf_factor_inverse(c, am, cnt, st); });
+      for_all_large(c, a0, [&](MfmaArgs am, int cnt) { if (am.namax) lf_factor_inverse(c, am, cnt, st); });
     } else {
       a.lev = c->D.levidx;
       launch(c, KID_factor_inverse, k_factor_inverse, dim3((int)c->S.nsn), dim3(256), st, a, (const double*)c->D.fac, c->D.faci);
@@ -430,16 +449,18 @@ void hess_down_inv_fast(csp_ctx* c, const double* L, double* U, int nrhs, int64_
       if (lds) {
         int g = rhs_groups(cnt, nrhs, 2048);
         launch_lds(c, KID_hess_down_inv_mfma, k_hess_down_inv_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
-      } else if (use_large() && a.nnmax >= LF_INV_MIN_NN) {
-        const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
-        launch(c, KID_lf_dinv1, k_lf_dinv1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
-        launch(c, KID_lf_dinv2, k_lf_dinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
-        if (ymode == 1 && a.namax) {
-          launch(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu, 1);
-          launch(c, KID_lf_copy_an, k_lf_copy_an, dim3(umax1(std::min(64, (a.namax * a.nnmax + 255) / 256)), cnt, nrhs), blk, st, a, U, ldu, 0);
-        }
-      } else {
+      } else if (!use_large()) {
         launch_lds(c, KID_hess_down_inv_mfma_hbm, k_hess_down_inv_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+      }
+    });
+  if (use_large())
+    for_all_large(c, a0, [&](MfmaArgs a, int cnt) {   // clique-local: all large fronts of the tree in one set of launches
+      const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
+      launch(c, KID_lf_dinv1, k_lf_dinv1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
+      launch(c, KID_lf_dinv2, k_lf_dinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
+      if (ymode == 1 && a.namax) {
+        launch(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu, 1);
+        launch(c, KID_lf_copy_an, k_lf_copy_an, dim3(umax1(std::min(64, (a.namax * a.nnmax + 255) / 256)), cnt, nrhs), blk, st, a, U, ldu, 0);
       }
     });
 }
@@ -679,16 +700,22 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     {
       // slots of the large fronts (per-front 64 x 64 scratch) and the flat list of LDS-class cliques
       int32_t slot = 0;
-      std::vector<int32_t> lev3;
+      std::vector<int32_t> lev3, large;
+      c->lev_namax.assign(S.nlev, 0);
       for (int64_t l = 0; l < S.nlev; ++l) {
         const LevelClass& L = c->lvl[l];
         int64_t b = S.levptr[l];
         for (int64_t q = 0; q < L.nI; ++q) lev3.push_back(lev2[b + q]);
-        for (int64_t q = L.nI; q < L.nI + L.nII; ++q) cl[lev2[b + q]].pad = slot++;
+        for (int64_t q = L.nI; q < L.nI + L.nII; ++q) { cl[lev2[b + q]].pad = slot++; large.push_back(lev2[b + q]); }
+        c->lev_namax[l] = std::max(L.namaxI, L.namaxII);
+        if (L.nII) { D.nnmaxII_all = std::max(D.nnmaxII_all, L.nnmaxII); D.namaxII_all = std::max(D.namaxII_all, L.namaxII); }
       }
       D.nI_total = (int64_t)lev3.size();
+      D.nII_total = (int64_t)large.size();
+      lev3.insert(lev3.end(), large.begin(), large.end());
       if ((rc = dev_upload(&D.lev3idx, lev3, D.bytes))) return rc;
-      if ((rc = dev_alloc(&D.lfd, (int64_t)std::max(slot, 1) * 64 * 64, D.bytes))) return rc;
+      if ((rc = dev_alloc(&D.lfd, (int64_t)(slot + 1) * 64 * 64, D.bytes))) return rc;
+      D.lfd_dense = D.lfd + (int64_t)slot * 64 * 64;
     }
     if ((rc = dev_upload(&D.cl, cl, D.bytes))) return rc;
     if ((rc = dev_upload(&D.rowidx, S.rowidx, D.bytes))) return rc;
@@ -848,33 +875,34 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
     dim3 blk(256);
     for (int64_t l = 0; l < c->S.nlev; ++l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
-        if (lds && bytes + INV_STATIC_LDS <= LDS_LIMIT) {
+        if (lds && bytes + INV_STATIC_LDS <= LDS_LIMIT)
           launch_lds(c, KID_completion_mfma, k_completion_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
-        } else if (use_large() && am.nnmax >= LF_INV_MIN_NN) {
-          const int mtA = tiles64(am.namax), ntN = tiles64(am.nnmax);
-          if (am.namax) {
-            launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(mtA * ntN), cnt), blk, st, am, x, 0);
-            launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(mtA * ntN), cnt), blk, st, am, x, 1);
-          }
-          launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(ntN * ntN), cnt), blk, st, am, x, 2);
-          for (int jb = 0; jb < am.nnmax; jb += LB) {
-            launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, jb, 1);
-            const int mrem = am.nnmax - jb - 1;
-            if (mrem > 0) {
-              launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(umax1(tiles64(mrem)), cnt), blk, st, am, (double*)nullptr, (double*)nullptr, 3, jb);
-              const int mt = tiles64(mrem);
-              launch(c, KID_lf_chol_trail, k_lf_chol_trail, dim3(umax1(mt * (mt + 1) / 2), cnt), blk, st, am, (double*)nullptr, (double*)nullptr, 3, jb);
-            }
-          }
-          for (int ib = 0; ib < am.nnmax; ib += LB) {
-            launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, ib, 0);
-            if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3);
-            launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3);
-          }
-          launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(ntN * ntN + mtA * ntN), cnt), blk, st, am, x, 3);
-        } else {
+        else if (lds || !use_large())
           launch_lds(c, KID_completion_mfma_hbm, k_completion_mfma<false>, dim3(cnt), dim3(lds ? 256 : thr), 0, st, am, x);
+      });
+    if (use_large())
+      for_all_large(c, a0, [&](MfmaArgs am, int cnt) {
+        const int mtA = tiles64(am.namax), ntN = tiles64(am.nnmax);
+        if (am.namax) {
+          launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(mtA * ntN), cnt), blk, st, am, x, 0);
+          launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(mtA * ntN), cnt), blk, st, am, x, 1);
         }
+        launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(ntN * ntN), cnt), blk, st, am, x, 2);
+        for (int jb = 0; jb < am.nnmax; jb += LB) {
+          launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, jb, 1);
+          const int mrem = am.nnmax - jb - 1;
+          if (mrem > 0) {
+            launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(umax1(tiles64(mrem)), cnt), blk, st, am, (double*)nullptr, (double*)nullptr, 3, jb);
+            const int mt = tiles64(mrem);
+            launch(c, KID_lf_chol_trail, k_lf_chol_trail, dim3(umax1(mt * (mt + 1) / 2), cnt), blk, st, am, (double*)nullptr, (double*)nullptr, 3, jb);
+          }
+        }
+        for (int ib = 0; ib < am.nnmax; ib += LB) {
+          launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, ib, 0);
+          if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3);
+          launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3);
+        }
+        launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(ntN * ntN + mtA * ntN), cnt), blk, st, am, x, 3);
       });
     invalidate_tags(c, x);   // x now holds the factor, not the matrix the caches were derived from
   } else {

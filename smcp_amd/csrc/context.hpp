@@ -48,8 +48,10 @@ struct DeviceCtx {
   const void* fac_tag = nullptr;    // fac = chol(yaa) of the matrix at this address
   const void* faci_tag = nullptr;   // faci = fac^-1 of the matrix at this address
   double* lfd = nullptr;      // 64 x 64 doubles per large front: inverse of the current diagonal block
-  int32_t* lev3idx = nullptr; // all LDS-class cliques (any level), then nothing: list for clique-local kernels
-  int64_t nI_total = 0;
+  int32_t* lev3idx = nullptr; // all LDS-class cliques (any level), then all large fronts: lists for clique-local kernels
+  int64_t nI_total = 0, nII_total = 0;
+  int nnmaxII_all = 0, namaxII_all = 0;   // maxima over the large fronts
+  double* lfd_dense = nullptr;            // the 64 x 64 slot used by the dense (Schur complement) Cholesky
   double* lk = nullptr;       // inverse-form factor [L_NN^-1; L_AN L_NN^-1] of the most recent prep
   // workspaces
   double* upd = nullptr;   // max_rhs * updlen : update matrices
@@ -128,5 +130,6 @@ struct csp_ctx {
   smcp::DeviceCtx D;
   smcp::Profiler prof;
   std::vector<int64_t> h_tmpptr;
+  std::vector<int> lev_namax;   // per level: largest separator (sizes the gather launches)
   std::vector<uint8_t> is_diag_cache;
 };

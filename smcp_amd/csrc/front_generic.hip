@@ -56,14 +56,14 @@ __device__ inline void add_children(const TreeArgs& a, const CliqueDesc& d, cons
 }
 // Uk <- front(parent)[rel, rel]  (lower), parent front = [Pp | Up]
 __device__ inline void gather_sep(const TreeArgs& a, const CliqueDesc& d, const double* xbase,
-                                  const double* updbase, double* Uk) {
+                                  const double* updbase, double* Uk, int part = 0, int nparts = 1) {
   if (d.parent < 0 || d.na == 0) return;
   const CliqueDesc p = a.cl[d.parent];
   const int na = d.na, nnp = p.nn, nfp = p.nn + p.na, nap = p.na;
   const int32_t* rel = a.relidx + d.rel;
   const double* Pp = xbase + p.blk;
   const double* Up = updbase + p.upd;
-  for (int e = SMCP_TID; e < na * na; e += SMCP_NT) {
+  for (int e = part * SMCP_NT + SMCP_TID; e < na * na; e += nparts * SMCP_NT) {
     int i = e % na, j = e / na;
     if (i < j) continue;
     int ri = rel[i], rj = rel[j];
@@ -76,7 +76,7 @@ __global__ void k_gather_level(TreeArgs a, const double* x, int64_t ldx, double*
   const CliqueDesc d = a.cl[a.lev[blockIdx.x]];
   const int r = blockIdx.y;
   double* ub = updbase + (int64_t)r * a.updlen;
-  gather_sep(a, d, x + (int64_t)r * ldx, ub, ub + d.upd);
+  gather_sep(a, d, x + (int64_t)r * ldx, ub, ub + d.upd, blockIdx.z, gridDim.z);
 }
 
 // ---- cholesky ------------------------------------------------------------------------

@@ -431,12 +431,16 @@ struct LfMat {
   double* dinv;                            // w x w inverse of the current diagonal block (ld = w)
 };
 // mode 0: panel of a front in x (Cholesky), 1: L -> LK preparation (triangular inverse), 2: Y_AA -> its Cholesky factor,
-// 3: the nn x nn matrix at the head of the clique's scratch (completion), 4: update-layout matrix in aux, inverse only
+// 3: the nn x nn matrix at the head of the clique's scratch (completion), 4: update-layout matrix in aux, inverse only,
+// 5: one plain dense matrix x (order a.dn, leading dimension a.dld; a.lfd = its 64 x 64 slot; the clique is ignored)
 __device__ inline LfMat lf_mat(const MfmaArgs& a, int k, int mode, double* x, double* aux) {
   const CliqueDesc d = a.t.cl[k];
   LfMat m;
   double* scratch = a.lfd + (int64_t)d.pad * (LB * LB);   // d.pad = slot of this clique among the large fronts
-  if (mode == 3) {
+  if (mode == 5) {
+    m.A = x; m.ld = a.dld; m.nrow = a.dn; m.ncol = a.dn; m.upd = nullptr; m.na = 0;
+    scratch = a.lfd;
+  } else if (mode == 3) {
     m.A = a.t.tmp + a.t.tmpptr[k]; m.ld = d.nn; m.nrow = d.nn; m.ncol = d.nn; m.upd = nullptr; m.na = 0;
   } else if (mode == 2 || mode == 4) {
     m.A = aux + d.upd; m.ld = d.na; m.nrow = d.na; m.ncol = d.na; m.upd = nullptr; m.na = 0;

@@ -88,6 +88,7 @@ struct MfmaArgs {
   int skip;  // debug-only phase mask (SMCP_SKIP env), 0 in production
   unsigned long long* dbg;  // diagnostic builds: cycle-stamp accumulator (null otherwise)
   double* lfd;              // 64 x 64 scratch per large front (inverse of the current diagonal block)
+  int dn; int64_t dld;      // dense-matrix view (blocked Cholesky of the Schur complement): order, leading dimension
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }

@@ -161,7 +161,26 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
   if (int rc = ready(c)) return rc;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
-  launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
+  if (use_generic() || n <= 2 * LB) {
+    launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
+  } else {
+    // blocked right-looking Cholesky, 64-wide block columns: diagonal block by one workgroup, panel and
+    // trailing update as 64 x 64 MFMA tiles over the chip (the kernels of the large fronts, dense view)
+    MfmaArgs a = mfma_args(c, nullptr, 0, 1);
+    a.t.lev = c->D.lev3idx;
+    a.lfd = c->D.lfd_dense;
+    a.dn = (int)n; a.dld = lda;
+    dim3 blk(256);
+    for (int jb = 0; jb < (int)n; jb += LB) {
+      launch_lds(c, KID_lf_diag, k_lf_diag, dim3(1), blk, LF_DIAG_LDS, st, a, A, (double*)nullptr, 5, jb, 1);
+      const int mrem = (int)n - jb - LB;
+      if (mrem > 0) {
+        const int mt = tiles64(mrem);
+        launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(mt, 1), blk, st, a, A, (double*)nullptr, 5, jb);
+        launch(c, KID_lf_chol_trail, k_lf_chol_trail, dim3(mt * (mt + 1) / 2, 1), blk, st, a, A, (double*)nullptr, 5, jb);
+      }
+    }
+  }
   HIPCHK(hipGetLastError());
   return fetch_info(c, st);
 }

@@ -175,3 +175,26 @@ def test_kkt_factor_and_solve(name):
         r, rr = K.residual(L, Yh, host(bxd) * msk, byd.cpu().numpy(), bx, by, kk)
         assert np.sqrt(orc.dot(S, r, r)) / max(1, np.sqrt(orc.dot(S, bx, bx))) < 1e-10
         assert np.linalg.norm(rr) / max(1, np.linalg.norm(by)) < 1e-10
+
+
+@pytest.mark.parametrize("n", [5, 64, 130, 517])
+def test_dense_potrf_potrs(n):
+    """Schur-complement factor/solve (solvers.py:452,499: lapack.potrf / potrs) at sizes on both sides of the
+    switch from the single-workgroup kernel to the blocked MFMA one."""
+    from smcp_amd import _lib
+    symb = Symbolic(GPU_PATTERNS["band"]())
+    chordal._ensure(symb)
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n))
+    Hh = M @ M.T + n * np.eye(n)
+    H = torch.from_numpy(Hh.copy()).cuda()
+    b = rng.standard_normal(n)
+    bd = torch.from_numpy(b.copy()).cuda()
+    lib = _lib.lib()
+    assert lib.dense_potrf(symb.handle, H.data_ptr(), n, n, None) == 0
+    Lref = np.linalg.cholesky(Hh)
+    assert rel(np.tril(H.cpu().numpy().T), Lref) < 1e-12
+    assert lib.dense_potrs(symb.handle, H.data_ptr(), n, n, bd.data_ptr(), 1, n, None) == 0
+    assert rel(bd.cpu().numpy(), np.linalg.solve(Hh, b)) < 1e-10
+    Hbad = torch.from_numpy((Hh - 2 * np.linalg.eigvalsh(Hh)[1] * np.eye(n)).copy()).cuda()
+    assert lib.dense_potrf(symb.handle, Hbad.data_ptr(), n, n, None) > 0
