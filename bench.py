@@ -182,7 +182,7 @@ def main():
     roofline = None
     breakdown = {}
     if prof:
-        nk = 64
+        nk = int(lib.csp_profile_kinds())
         ms = (ctypes.c_double * nk)()
         cnt = (ctypes.c_int64 * nk)()
         nk = int(lib.csp_profile_read(h, ms, cnt))   # events recorded during the timed steps above

@@ -149,8 +149,10 @@ int csp_cache_reset(csp_ctx* ctx);
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on its own stream. */
 int csp_profile_enable(csp_ctx* ctx, int on);
-/* Synchronises, then writes per-kernel accumulated milliseconds and launch counts (arrays of
- * the returned length, host) and clears the record. */
+/* Number of kernel kinds = required length of the arrays passed to csp_profile_read. */
+int64_t csp_profile_kinds(void);
+/* Synchronises, then writes per-kernel accumulated milliseconds and launch counts (host arrays of
+ * csp_profile_kinds() entries; the return value repeats that length) and clears the record. */
 int64_t csp_profile_read(csp_ctx* ctx, double* ms, int64_t* count);
 const char* csp_profile_kernel_name(int kid);
 

@@ -1000,6 +1000,8 @@ int csp_profile_enable(csp_ctx* c, int on) {
   return 0;
 }
 
+int64_t csp_profile_kinds(void) { return KID_COUNT; }
+
 int64_t csp_profile_read(csp_ctx* c, double* ms, int64_t* count) {
   if (int rc = ready(c)) return rc;
   Profiler& P = c->prof;
