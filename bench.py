@@ -230,6 +230,7 @@ def main():
 
         alg = {"k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
                "k_hess_up_pad": up_bytes(lds_ok),
+               "k_hess_up_n16": up_bytes(lds_ok & (nn_ <= 16) & (na_ <= 64)),
                "k_hess_up_mfma<true>": cls_bytes(lds_ok), "k_hess_down_mfma<true>": cls_bytes(lds_ok),
                "k_hess_up_mfma<false>": cls_bytes(~lds_ok), "k_hess_down_mfma<false>": cls_bytes(~lds_ok),
                "k_chol_level": 8.0 * (2 * B + 2 * U), "k_pinv_level": 8.0 * (2 * B + 2 * U)}.get(dom)

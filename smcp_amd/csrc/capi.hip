@@ -15,6 +15,7 @@
 #include "front_mfma.hip"
 #include "front_large.hip"
 #include "front_inv.hip"
+#include "front_n16.hip"
 
 using namespace smcp;
 
@@ -43,7 +44,7 @@ enum {
   KID_lf_prep_s, KID_lf_prep_row, KID_lf_prep_k, KID_factor_yaa_lds,
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
-  KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion,
+  KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -59,7 +60,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_lf_prep_s", "k_lf_prep_row", "k_lf_prep_k", "k_factor_yaa_lds",
   "k_factor_inverse", "k_hess_down_inv_mfma<true>", "k_hess_down_inv_mfma<false>", "k_hess_up_inv_mfma<true>",
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
-  "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion"};
+  "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16"};
 
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -172,7 +173,7 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
 
 
 // ---- fast path (front_mfma.hip): per level, LDS-class cliques then HBM-class cliques ----------
-constexpr size_t LDS_LIMIT = 160 * 1024 - 256;
+constexpr size_t LDS_LIMIT = 160 * 1024 - 2048;   // dynamic working set; the rest is left to small static buffers
 
 bool cache_off() {
   static int nocache = -1;
@@ -350,6 +351,57 @@ void invalidate_tags(csp_ctx* c, const void* p) {
 }
 
 
+// shape-specialised sweep kernel (front_n16.hip) for a class with nn <= 16, na <= 64; false if it does not apply
+template <int NAT, bool CH>
+bool launch_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  const size_t bytes = n16_lds_bytes<NAT, CH>(a.nchmax, a.panmax, a.pkmax, a.plansum);
+  if (bytes > LDS_LIMIT) return false;
+  const int thr = bytes > 48 * 1024 ? 512 : 256;
+  // Split the right-hand sides over g workgroups per clique so that the grid fills a whole number of rounds of
+  // the resident-workgroup slots: cost(g) = rounds x (passes per workgroup + set-up, counted as 4 passes).
+  static size_t nb_bytes = 0;    // occupancy of this instantiation, cached per LDS size
+  static int nb = 1;
+  if (bytes != nb_bytes) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hess_up_n16<NAT, CH>, thr, bytes) != hipSuccess || nb < 1) nb = 1;
+    nb_bytes = bytes;
+  }
+  static int ncu = 0;
+  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, c->D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  const int64_t slots = (int64_t)ncu * nb;
+  const int rb = CH ? 1 : std::max(1, std::min(4, 16 / std::max(a.nnmax, 1)));
+  int g = 1;
+  int64_t best = -1;
+  for (int gc = 1; gc <= std::min(nrhs, 32); ++gc) {
+    const int64_t rounds = ((int64_t)cnt * gc + slots - 1) / slots;
+    const int64_t passes = (nrhs + gc * rb - 1) / (gc * rb);
+    const int64_t cost = rounds * (passes + 4);
+    if (best < 0 || cost < best) { best = cost; g = gc; }
+  }
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("SMCP_OCC"); dbg = (e && e[0] == '1') ? 1 : 0; }
+  if (dbg) fprintf(stderr, "n16<%d,%d>: cnt %d nrhs %d g %d threads %d lds %zu -> %d workgroups/CU\n", NAT, (int)CH, cnt, nrhs, g, thr, bytes, nb);
+  launch_lds(c, KID_hess_up_n16, k_hess_up_n16<NAT, CH>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+  return true;
+}
+bool try_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int g, double* U, int64_t ldu, hipStream_t st) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("SMCP_N16"); off = (e && e[0] == '0') ? 1 : 0; }
+  if (off || a.nnmax > 16 || a.namax > 64) return false;
+  const int nat = std::max(1, (a.namax + 15) / 16);
+  const bool ch = a.nchmax > 0;
+  switch (nat * 2 + (ch ? 1 : 0)) {
+    case 2: return launch_n16<1, false>(c, a, cnt, g, U, ldu, st);
+    case 3: return launch_n16<1, true>(c, a, cnt, g, U, ldu, st);
+    case 4: return launch_n16<2, false>(c, a, cnt, g, U, ldu, st);
+    case 5: return launch_n16<2, true>(c, a, cnt, g, U, ldu, st);
+    case 6: return launch_n16<3, false>(c, a, cnt, g, U, ldu, st);
+    case 7: return launch_n16<3, true>(c, a, cnt, g, U, ldu, st);
+    case 8: return launch_n16<4, false>(c, a, cnt, g, U, ldu, st);
+    case 9: return launch_n16<4, true>(c, a, cnt, g, U, ldu, st);
+  }
+  return false;
+}
+
 void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0) {
   MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
   for (int64_t l = 0; l < c->S.nlev; ++l)
@@ -359,7 +411,8 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         static int oldk = -1;
         if (oldk < 0) { const char* e = getenv("SMCP_OLDLDS"); oldk = (e && e[0] == '1') ? 1 : 0; }
         size_t pbytes = (size_t)pad_layout(a.nnmax, a.namax, a.nchmax, a.panmax, a.pkmax, a.plansum).total * sizeof(double);
-        if (!oldk && pbytes <= LDS_LIMIT)
+        if (!oldk && try_n16(c, a, cnt, nrhs, U, ldu, st)) {
+        } else if (!oldk && pbytes <= LDS_LIMIT)
           launch_lds(c, KID_hess_up_pad, k_hess_up_pad, dim3(cnt, g), dim3(pbytes > 48 * 1024 ? 512 : 256), pbytes, st, a, U, ldu);
         else
           launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
@@ -762,9 +815,17 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     if ((rc = dev_alloc(&D.lk, S.blklen(), D.bytes))) return rc;
     HIPCHK(hipMemset(D.lk, 0, sizeof(double) * std::max<int64_t>(S.blklen(), 1)));
     {
-      const int mx = 160 * 1024;
+      const int mx = 160 * 1024 - 1024;
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_pad, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_gram_partial, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_lf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_factor_yaa_lds, hipFuncAttributeMaxDynamicSharedMemorySize, mx));

@@ -289,54 +289,92 @@ __device__ inline const int32_t* hoist_rel(const TreeArgs& t, const CliqueDesc& 
   return r;
 }
 
+// 16 x 16 diagonal blocks: factorisation and inversion by ONE wavefront, matrix rows in registers (lane i
+// holds row i), pivots and multipliers broadcast with v_readlane -- two workgroup barriers per call
+// instead of three per column.
+__device__ inline double readlane_f64(double v, int srclane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, srclane);
+  hi = __builtin_amdgcn_readlane(hi, srclane);
+  return __hiloint2double(hi, lo);
+}
+// 1/x from the hardware estimate plus two Newton steps (the pivots of a sequential elimination sit on the
+// critical path: a full IEEE division there costs more than the rest of the column)
+__device__ inline double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+// sqrt(x) and 1/sqrt(x) from the hardware rsq estimate plus Newton steps
+__device__ inline void fast_sqrt_rsqrt(double x, double& sq, double& rs) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  double g = x * r;
+  g = fma(0.5 * r, fma(-g, g, x), g);
+  sq = g;
+  rs = fma(r, fma(-g, r, 1.0), r);
+}
+// rows of the inverse of the lower-triangular 16 x 16 matrix held as a[j] = L[lane][j]; lane c gets column c
+__device__ inline void wave_tri_inv16(const double (&a)[16], double (&x)[16], int c) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= readlane_f64(a[k], i) * x[k];
+    x[i] = s * fast_rcp(readlane_f64(a[i], i));
+  }
+}
 // in-place Cholesky of a w x w (w <= 16) block + its inverse (Dinv 16x16, ld 16, zeros elsewhere).
 // Uniform control flow, every thread calls it.  Returns 0 or j+1.
 __device__ inline int potrf_inv16(double* D, int ld, int w, double* Dinv) {
-  const int tid = threadIdx.x;
-  for (int j = 0; j < w; ++j) {
-    __syncthreads();
-    double dd = D[j + j * ld];
-    if (!(dd > 0.0)) return j + 1;
-    double sd = sqrt(dd);
-    __syncthreads();
-    if (tid < w - j) D[(j + tid) + j * ld] = (tid == 0) ? sd : D[(j + tid) + j * ld] / sd;
-    __syncthreads();
-    const int rem = w - j - 1;
-    if (tid < rem * rem) {
-      int i = tid % rem, c = tid / rem;
-      if (i >= c) D[(j + 1 + i) + (j + 1 + c) * ld] -= D[(j + 1 + i) + j * ld] * D[(j + 1 + c) + j * ld];
-    }
-  }
+  __shared__ int fail_flag;
   __syncthreads();
-  if (tid < 16) {
-    const int c = tid;
-    for (int i = 0; i < 16; ++i) {
-      double s = 0.0;
-      if (i >= c && i < w && c < w) {
-        s = (i == c) ? 1.0 : 0.0;
-        for (int k = c; k < i; ++k) s -= D[i + k * ld] * Dinv[k + c * 16];
-        s /= D[i + i * ld];
+  if (threadIdx.x < 64) {
+    const int i = threadIdx.x;
+    double a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = (i < w && j <= i) ? D[i + j * ld] : ((i == j && i < 16) ? 1.0 : 0.0);
+    int fail = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double djj = readlane_f64(a[j], j);
+      if (!(djj > 0.0) && !fail) fail = j + 1;
+      double sd, rsd;
+      fast_sqrt_rsqrt(fail ? 1.0 : djj, sd, rsd);
+      a[j] = (i == j) ? sd : a[j] * rsd;
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) a[c] -= a[j] * readlane_f64(a[j], c);
+    }
+    if (!fail) {
+      double x[16];
+      wave_tri_inv16(a, x, i);
+      if (i < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (i < w && j <= i) D[i + j * ld] = a[j];
+          Dinv[j + i * 16] = (i < w && j < w) ? x[j] : 0.0;   // lane i holds column i of the inverse
+        }
       }
-      Dinv[i + c * 16] = s;
     }
+    if (i == 0) fail_flag = fail;
   }
   __syncthreads();
-  return 0;
+  return fail_flag;
 }
 // inverse only (block already a Cholesky factor / lower triangular)
 __device__ inline void tri_inv16(const double* D, int ld, int w, double* Dinv) {
-  const int tid = threadIdx.x;
   __syncthreads();
-  if (tid < 16) {
-    const int c = tid;
-    for (int i = 0; i < 16; ++i) {
-      double s = 0.0;
-      if (i >= c && i < w && c < w) {
-        s = (i == c) ? 1.0 : 0.0;
-        for (int k = c; k < i; ++k) s -= D[i + k * ld] * Dinv[k + c * 16];
-        s /= D[i + i * ld];
-      }
-      Dinv[i + c * 16] = s;
+  if (threadIdx.x < 64) {
+    const int i = threadIdx.x;
+    double a[16], x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = (i < w && j <= i) ? D[i + j * ld] : ((i == j && i < 16) ? 1.0 : 0.0);
+    wave_tri_inv16(a, x, i);
+    if (i < 16) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) Dinv[j + i * 16] = (i < w && j < w) ? x[j] : 0.0;
     }
   }
   __syncthreads();
@@ -709,7 +747,7 @@ __global__ void __launch_bounds__(256) k_factor_yaa_lds(MfmaArgs a, const double
 // need no bounds checks or branches: each k-step is two ds_read_b64, two pointer bumps, one MFMA.
 struct PadL {
   int NN, NA, ldn, lda;
-  int oK, oLi, oBD, oY, oFnn, oFan, oE, oG, oT, oU, oInt, total;
+  int oK, oBD, oY, oFnn, oFan, oE, oG, oQ, oT, oU, oInt, total;
   int iCh, iPan, iOut, iTgt;   // int-table offsets (in ints, relative to the int region)
 };
 // nchmax: max #children, panmax: max nf*nn, pkmax: max na(na+1)/2, plansum: max sum of the children's packed sizes
@@ -722,15 +760,15 @@ __host__ __device__ inline PadL pad_layout(int nnmax, int namax, int nchmax = 0,
   L.lda = L.NA + 1;
   int o = 0;
   L.oK = o; o += L.lda * L.NN;
-  L.oLi = o; o += L.ldn * L.NN;
   L.oBD = o; o += L.ldn * L.NN;   // kron(I_rb, Li^T): applies Li^T to every stacked right-hand side at once
   L.oY = o; o += L.lda * L.NA;
   L.oFnn = o; o += L.ldn * L.NN;
   L.oFan = o; o += L.lda * L.NN;
   L.oE = o; o += L.lda * L.NN;
-  L.oG = o; o += L.lda * L.NN;
+  // one column tile (NN = 16): G = X BD is computed tile-in-place over X, and Q goes to the (dead) E buffer
+  if (L.NN == 16) { L.oG = L.oFan; L.oQ = L.oE; } else { L.oG = o; o += L.lda * L.NN; L.oQ = L.oFan; }
   L.oT = o; o += L.ldn * L.NN;
-  L.oU = o; o += L.lda * L.NA;
+  L.oU = o; if (nchmax > 0) o += L.lda * L.NA;   // childless classes store their update matrices straight from the accumulators
   L.oInt = o;
   // RHS-invariant index tables, built once per workgroup, so the per-rhs loop has no index arithmetic:
   //   child metadata (4 ints per child), panel position -> LDS offset, packed own-update position ->
@@ -743,6 +781,12 @@ __host__ __device__ inline PadL pad_layout(int nnmax, int namax, int nchmax = 0,
   L.total = o + 2;
   return L;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global
+// load and store (s_waitcnt vmcnt(0)), which would serialise the register prefetch of the next right-hand
+// side and the write-out of the previous one with the compute phases; registers filled by global loads are
+// still guarded by the compiler's own vmcnt bookkeeping at their first use.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // acc += sum over ks k-steps; pa / pb: this lane's operand addresses for k-step 0, sa / sb: bump per k-step
 __device__ inline void mma_run(d4& acc, const double* pa, int sa, const double* pb, int sb, int ks) {
@@ -767,13 +811,13 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
   int* const sOut = sInt + L.iOut;
   int* const sTgt = sInt + L.iTgt;
   double* const sK = smem + L.oK;
-  double* const sLi = smem + L.oLi;
   double* const sBD = smem + L.oBD;
   double* const sY = smem + L.oY;
   double* const sFnn = smem + L.oFnn;
   double* const sFan = smem + L.oFan;
   double* const sE = smem + L.oE;
   double* const sG = smem + L.oG;
+  double* const sQ = smem + L.oQ;
   double* const sT = smem + L.oT;
   double* const sU = smem + L.oU;
   const int ldn = L.ldn, lda = L.lda;
@@ -829,7 +873,6 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
                     [=](int e, double v) {
                       int i = e % nf, j = e / nf;
                       if (i < nn) {
-                        sLi[i + j * ldn] = v;
                         if (i >= j)                               // Li^T on the diagonal blocks of BD
                           for (int q = 0; q < rb; ++q) sBD[(q * nn + j) + (q * nn + i) * ldn] = v;
                       } else sK[(i - nn) + j * lda] = v;
@@ -878,11 +921,23 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
       for (int x = 0; x < PC; ++x) { const int e = lane + 64 * x; pre_c[x] = e < np_ ? Uc[e] : 0.0; }
     }
   };
+  // Childless cliques (stacked right-hand sides): same idea, one panel entry per thread and stacked rhs
+  const bool lpipe = nch == 0 && npan <= nthr;
+  double pre_l[4] = {0.0, 0.0, 0.0, 0.0}, pre_l2[4] = {0.0, 0.0, 0.0, 0.0};   // two passes ahead
+  auto prefetch_leaf = [&](int r0n) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = r0n + q * (int)gridDim.y;
+      pre_l[q] = pre_l2[q];
+      pre_l2[q] = (q < rb && rr < a.nrhs && tid < npan) ? u[(int64_t)rr * ldu + d.blk + tid] : 0.0;
+    }
+  };
   if (pipe_ok && (int)blockIdx.y < a.nrhs) prefetch(blockIdx.y);
+  if (lpipe) { prefetch_leaf(blockIdx.y); prefetch_leaf(blockIdx.y + (int)gridDim.y * rb); }
   for (int r0 = blockIdx.y; r0 < a.nrhs; r0 += gridDim.y * rb) {
     // this pass: right-hand sides r0, r0 + gridDim.y, ... (rbc of them)
     const int rbc = min(rb, (a.nrhs - r0 + (int)gridDim.y - 1) / (int)gridDim.y);
-    __syncthreads();
+    lds_barrier();
     STAMP(0);
     // ---- assemble the front(s): panel + children (lower triangles), then mirror F_NN
     if (pipe_ok) {
@@ -891,6 +946,13 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
         const int e = tid + x * nthr;
         if (e < npan) { const int o = sPan[e]; if (o >= 0) smem[(o & (1 << 30)) ? L.oFnn + (o & 0x3fffffff) : L.oFan + o] = pre_p[x]; }
       }
+    } else if (lpipe) {
+      const int o = tid < npan ? sPan[tid] : -1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < rbc && o >= 0)
+          smem[(o & (1 << 30)) ? L.oFnn + q * nn * ldn + (o & 0x3fffffff) : L.oFan + q * nn * lda + o] = pre_l[q];
+      prefetch_leaf(r0 + 2 * (int)gridDim.y * rb);  // in flight during this pass and the next
     } else
     for (int q = 0; q < rbc; ++q) {
       const double* P = u + (int64_t)(r0 + q * gridDim.y) * ldu + d.blk;
@@ -902,16 +964,16 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
                       });
     }
     if (nch) for (int e = tid; e < npk; e += nthr) smem[sOut[e]] = 0.0;
-    __syncthreads();
+    lds_barrier();
     STAMP(1);
     if (pipe_ok) {
       if (wave < nch) {
         const int nac = sCh[4 * wave + 2], np_ = nac * (nac + 1) / 2;
         const int* tg = sTgt + sCh[4 * wave + 3];
 #pragma unroll
-        for (int x = 0; x < PC; ++x) { const int e = lane + 64 * x; if (e < np_) unsafeAtomicAdd(&smem[tg[e]], pre_c[x]); }
+        for (int x = 0; x < PC; ++x) { const int e = lane + 64 * x; if (e < np_ && !(a.skip & 128)) unsafeAtomicAdd(&smem[tg[e]], pre_c[x]); }
       }
-      __syncthreads();
+      lds_barrier();
       const int rn = r0 + (int)gridDim.y;
       if (rn < a.nrhs) prefetch(rn);          // in flight during the three compute phases below
     } else if (nch) {
@@ -923,14 +985,14 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
         batched_loop<8>(lane, nac * (nac + 1) / 2, 64, [=](int e) { return Uc[e]; },
                         [=](int e, double vv) { unsafeAtomicAdd(&smem[tg[e]], vv); });
       }
-      __syncthreads();
+      lds_barrier();
     }
     for (int q = 0; q < rbc; ++q) {
       double* Fq = sFnn + q * nn * ldn;
       for (int j = wave; j < nn; j += nw)
         for (int i = j + 1 + lane; i < nn; i += 64) Fq[j + i * ldn] = Fq[i + j * ldn];
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(2);
     // ---- phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place of F_AN) ; T = Li F_NN   (all stacked columns)
     {
@@ -950,14 +1012,15 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
           }
         } else {
           const int tt = t - nE, tm = tt % NNt, tn = tt / NNt;
-          mma_run(acc, sLi + tm * 16 + l15 + kq * ldn, 4 * ldn, sFnn + kq + (tn * 16 + l15) * ldn, 4, ksn);
+          // Li[m][k] = BD[k][m] (first diagonal block of BD)
+          mma_run(acc, sBD + kq + (tm * 16 + l15) * ldn, 4, sFnn + kq + (tn * 16 + l15) * ldn, 4, ksn);
           const int m = tm * 16 + l15;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) sT[m + (tn * 16 + kq + 4 * rr) * ldn] = acc[rr];
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(3);
     // ---- phase 2: U_q -= K E_q^T + E_q K^T (lower tiles, per stacked rhs) ; G = X BD ; G_NN = T BD (into sFnn)
     {
@@ -1002,7 +1065,7 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(4);
     // ---- phase 3: Q = Ysc G into the F_AN buffer (X is dead), or plain G
     {
@@ -1014,22 +1077,22 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
           d4 acc = {0.0, 0.0, 0.0, 0.0};
           mma_run(acc, sY + m + kq * lda, 4 * lda, sG + kq + (tn * 16 + l15) * lda, 4, ksa);
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) sFan[m + (tn * 16 + kq + 4 * rr) * lda] = acc[rr];
+          for (int rr = 0; rr < 4; ++rr) sQ[m + (tn * 16 + kq + 4 * rr) * lda] = acc[rr];
         } else {
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int n = tn * 16 + kq + 4 * rr;
-            sFan[m + n * lda] = sG[m + n * lda];
+            sQ[m + n * lda] = sG[m + n * lda];
           }
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(5);
     // ---- write out: panel(s) (lower of NN + AN) and, with children, the update matrix (lower, packed)
     for (int q = 0; q < rbc; ++q) {
       double* P = u + (int64_t)(r0 + q * gridDim.y) * ldu + d.blk;
-      const int oan = L.oFan + q * nn * lda, onn = L.oFnn + q * nn * ldn;
+      const int oan = L.oQ + q * nn * lda, onn = L.oFnn + q * nn * ldn;
       for (int e = tid; e < npan; e += nthr) {
         const int o = sPan[e];
         if (o >= 0) P[e] = smem[(o & (1 << 30)) ? onn + (o & 0x3fffffff) : oan + o];
