@@ -1189,6 +1189,77 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
   }
 }
 
+// Single-block variant (m <= 128: the whole lower triangle of H is one 128 x 128 block).  The accumulators of
+// the (at most 9) lower tiles a wave owns stay in registers under compile-time indices, the slice of the next
+// step is fetched into registers while the MFMAs of the current one run (barriers order LDS traffic only), and
+// the k-steps of a tile use immediate LDS offsets.  Same partial-tile output layout as k_gram_partial.
+__global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
+                                                      const double* sw, int64_t chunk, double* partial, int coff,
+                                                      int nchunk_total) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const sA = smem;                         // [k = 64][column], ld GRAM_LD
+  const int ni = m;
+  const int mti = (ni + 15) >> 4;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int MAXT = 9, NC = GRAM_BLK / 4;
+  // this wave's lower tiles p = wave, wave + 4, ... of the (tm >= tn) enumeration
+  int tms[MAXT], tns[MAXT];
+  const int ntl = mti * (mti + 1) / 2;
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    int p = wave + 4 * i, tm = 0;
+    if (p < ntl) { while (p > tm) { p -= tm + 1; ++tm; } tms[i] = tm; tns[i] = p; } else { tms[i] = -1; tns[i] = 0; }
+  }
+  d4 acc[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int e = threadIdx.x; e < GRAM_KS * GRAM_LD; e += 256) sA[e] = 0.0;   // columns >= m stay zero
+  const int64_t e_begin = e_lo + (int64_t)blockIdx.x * chunk, e_end = min(e_hi, e_begin + chunk);
+  double pre[NC], pre_sw = 0.0;
+  auto fetch = [&](int64_t e0) {
+    const int64_t e = e0 + lane;
+    const bool ein = e < e_end;
+    pre_sw = ein ? sw[e] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int cc = wave + 4 * j;
+      pre[j] = (ein && cc < ni) ? G[(int64_t)cc * ldg + e] : 0.0;
+    }
+  };
+  if (e_begin < e_end) fetch(e_begin);
+  const double* const lbase = sA + kq * GRAM_LD + l15;
+  for (int64_t e0 = e_begin; e0 < e_end; e0 += GRAM_KS) {
+    lds_barrier();                                 // the tiles of the previous slice have been consumed
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int cc = wave + 4 * j;
+      if (cc < ni) sA[lane * GRAM_LD + cc] = pre[j] * pre_sw;
+    }
+    lds_barrier();
+    if (e0 + GRAM_KS < e_end) fetch(e0 + GRAM_KS); // in flight while the MFMAs below run
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      if (tms[i] < 0) continue;
+      const double* const pa = lbase + 16 * tms[i];
+      const double* const pb = lbase + 16 * tns[i];
+      d4 a = acc[i];
+#pragma unroll
+      for (int s2 = 0; s2 < GRAM_KS / 4; ++s2)
+        a = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[s2 * 4 * GRAM_LD], pa[s2 * 4 * GRAM_LD], a, 0, 0, 0);
+      acc[i] = a;
+    }
+  }
+  double* out = partial + ((int64_t)coff + blockIdx.x) * (int64_t)(64 * 256);
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    if (tms[i] < 0) continue;
+    const int t = tms[i] + tns[i] * mti;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(int64_t)t * 256 + (kq + 4 * r) * 16 + l15] = acc[i][r];
+  }
+}
+
 // H (m x m, ld ldh, both triangles) <- sum over chunks of the partial tiles
 __global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* H, int64_t ldh) {
   int bi = 0, rem = blockIdx.y;
