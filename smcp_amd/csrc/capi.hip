@@ -251,11 +251,26 @@ bool use_large() {
 }
 inline unsigned umax1(int x) { return (unsigned)std::max(1, x); }
 
+// children -> front extend-add of the large fronts of one level: gather plan (one owner thread per front position;
+// measured 1.27 ms on the synth50k top level) or, without a plan / with SMCP_ASM=tiled, the child-major tiled kernel
+// (coalesced reads but a latency-bound scan of every child by every tile: 2.40 ms on the same level)
+void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, int sgn, hipStream_t st) {
+  static int plan = -1;
+  if (plan < 0) { const char* e = getenv("SMCP_ASM"); plan = (e && e[0] == 't') ? 0 : 1; }
+  if (plan && a.t.gp_tptr) {
+    launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
+    return;
+  }
+  const int nfmax = a.nnmax + a.namax;
+  const int ncb = (nfmax + LF_TW - 1) / LF_TW, nrb = (nfmax + LF_TR - 1) / LF_TR;
+  launch(c, KID_lf_assemble, k_lf_assemble_tiled, dim3(ncb * nrb, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
+}
+
 void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
   launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), blk, st, a);
-  if (a.t.gp_tptr) launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), blk, st, a, U, ldu, 0);
+  lf_assemble(c, a, cnt, nrhs, U, ldu, 0, st);
   launch(c, KID_lf_up1, k_lf_up1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
   launch(c, KID_lf_up2, k_lf_up2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
   if (a.namax) launch(c, KID_lf_up3, k_lf_up3, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
@@ -285,7 +300,7 @@ void lf_chol(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
   dim3 blk(256);
   const int nfmax = a.nnmax + a.namax;
   launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, 1), blk, st, a);
-  if (a.t.gp_tptr) launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, 1), blk, st, a, x, (int64_t)0, 0);
+  lf_assemble(c, a, cnt, 1, x, 0, 0, st);
   const int mtA = tiles64(a.namax);
   for (int jb = 0; jb < a.nnmax; jb += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, x, (double*)nullptr, 0, jb, 1);
@@ -537,7 +552,7 @@ void hess_up_inv_fast(csp_ctx* c, const double* L, double* U, int nrhs, int64_t 
         launch(c, KID_lf_uinv1, k_lf_uinv1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
         launch(c, KID_lf_uinv2, k_lf_uinv2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
         if (a.namax) launch(c, KID_lf_copy_an, k_lf_copy_an, gcopy, blk, st, a, U, ldu, 0);
-        launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), blk, st, a, U, ldu, 1);
+        lf_assemble(c, a, cnt, nrhs, U, ldu, 1, st);
         if (a.namax) launch(c, KID_lf_pack_upd, k_lf_pack_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 255) / 256)), cnt, nrhs), blk, st, a);
       } else {
         launch_lds(c, KID_hess_up_inv_mfma_hbm, k_hess_up_inv_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);

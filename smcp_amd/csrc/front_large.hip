@@ -140,6 +140,66 @@ __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
     }
   }
 }
+// Tiled extend-add: one workgroup owns an LF_TR x LF_TW tile of the front of (clique, rhs) in LDS and streams the
+// children's packed update matrices through it CHILD-MAJOR -- every child column is a contiguous segment, so the
+// reads are coalesced and each fetched line is used entirely (the gather plan above reads one 8-byte word per
+// line).  The relative indices of a child are ascending, hence the part of the child that lands in the tile is a
+// contiguous range of its rows and of its columns, found with two ballots per 64 indices.  Waves take children
+// round-robin; collisions between children inside the tile are LDS atomic adds.  Same sgn convention as above.
+constexpr int LF_TR = 256, LF_TW = 16;
+__global__ void __launch_bounds__(256) k_lf_assemble_tiled(MfmaArgs a, double* u, int64_t ldu, int sgn) {
+  __shared__ double T[LF_TR * LF_TW];
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  if (d.chend == d.chbeg) return;
+  const int r = blockIdx.z;
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  const int ncb = (a.nnmax + a.namax + LF_TW - 1) / LF_TW;
+  const int cb = blockIdx.x % ncb, rbk = blockIdx.x / ncb;
+  const int c0 = cb * LF_TW, r0 = rbk * LF_TR;
+  if (c0 >= nf || r0 >= nf || r0 + LF_TR <= c0) return;           // outside the front or strictly above the diagonal
+  const int c1 = min(c0 + LF_TW, nf), r1 = min(r0 + LF_TR, nf);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int e = threadIdx.x; e < LF_TR * LF_TW; e += blockDim.x) T[e] = 0.0;
+  __syncthreads();
+  const double* ubase = a.t.updp + (int64_t)r * a.t.updplen;
+  for (int q = d.chbeg + wave; q < d.chend; q += nw) {
+    const CliqueDesc c = a.t.cl[a.t.chidx[q]];
+    const int nac = c.na;
+    const int32_t* rel = a.t.relidx + c.rel;
+    const double* Uc = ubase + c.updp;
+    // [j0, j1): child columns landing in [c0, c1);  [i0, i1): child rows landing in [r0, r1)
+    int j0 = 0, j1 = 0, i0 = 0, i1 = 0;
+    for (int b = 0; b < nac; b += 64) {
+      const int v = (b + lane < nac) ? rel[b + lane] : 0x7fffffff;
+      j0 += __popcll(__ballot(v < c0));
+      j1 += __popcll(__ballot(v < c1));
+      i0 += __popcll(__ballot(v < r0));
+      i1 += __popcll(__ballot(v < r1));
+    }
+    for (int j = j0; j < j1; ++j) {
+      const int cj = rel[j] - c0;
+      const double* col = Uc + pk_col(j, nac) - j;               // col[i] = U_c(i, j), i >= j
+      for (int i = max(i0, j) + lane; i < i1; i += 64) unsafeAtomicAdd(&T[(rel[i] - r0) + cj * LF_TR], col[i]);
+    }
+  }
+  __syncthreads();
+  double* P = u + (int64_t)r * ldu + d.blk;
+  double* U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+  const int nr = r1 - r0;
+  for (int e = threadIdx.x; e < nr * (c1 - c0); e += blockDim.x) {
+    const int i = r0 + e % nr, j = c0 + e / nr;
+    if (i < j) continue;
+    const double v = T[(i - r0) + (j - c0) * LF_TR];
+    if (j < nn) {
+      if (v != 0.0) P[i + (int64_t)j * nf] += sgn ? -v : v;
+    } else if (sgn) {
+      if (v != 0.0) U[(i - nn) + (int64_t)(j - nn) * na] += v;
+    } else {
+      U[(i - nn) + (int64_t)(j - nn) * na] = v;                    // full assignment: no prior clear needed
+    }
+  }
+}
 __global__ void k_lf_clear_upd(MfmaArgs a) {
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
