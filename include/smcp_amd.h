@@ -149,6 +149,9 @@ int csp_cache_reset(csp_ctx* ctx);
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on its own stream. */
 int csp_profile_enable(csp_ctx* ctx, int on);
+/* Restrict the timing to launches of one kernel id (so that a throughput measurement can carry the HIP events of
+ * its dominant kernel without paying for events around every launch); kid < 0 times all kernels again. */
+int csp_profile_filter(csp_ctx* ctx, int kid);
 /* Number of kernel kinds = required length of the arrays passed to csp_profile_read. */
 int64_t csp_profile_kinds(void);
 /* Synchronises, then writes per-kernel accumulated milliseconds and launch counts (host arrays of

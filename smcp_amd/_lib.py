@@ -41,6 +41,7 @@ SIGNATURES = {
     "csp_cache_reset": (ctypes.c_int, [c_vp]),
     "csp_profile_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "csp_profile_kinds": (c_i64, []),
+    "csp_profile_filter": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "csp_profile_read": (c_i64, [c_vp, c_vp, c_vp]),
     "csp_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
     "csp_set_partition": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int]),

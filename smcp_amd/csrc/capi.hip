@@ -65,9 +65,10 @@ const char* const KID_NAMES[KID_COUNT] = {
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
   Profiler& P = c->prof;
-  if (P.on) (void)hipEventRecord(P.next(), st);
+  const bool timed = P.want(kid);
+  if (timed) (void)hipEventRecord(P.next(), st);
   hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
-  if (P.on) {
+  if (timed) {
     (void)hipEventRecord(P.next(), st);
     P.kids.push_back(kid);
   }
@@ -75,9 +76,10 @@ inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_
 template <class K, class... A>
 inline void launch(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, hipStream_t st, A... args) {
   Profiler& P = c->prof;
-  if (P.on) (void)hipEventRecord(P.next(), st);
+  const bool timed = P.want(kid);
+  if (timed) (void)hipEventRecord(P.next(), st);
   hipLaunchKernelGGL(kern, grid, block, 0, st, args...);
-  if (P.on) {
+  if (timed) {
     (void)hipEventRecord(P.next(), st);
     P.kids.push_back(kid);
   }
@@ -1074,6 +1076,12 @@ int csp_cache_reset(csp_ctx* c) {
 int csp_profile_enable(csp_ctx* c, int on) {
   if (!c) return SMCP_EINVAL;
   c->prof.on = on != 0;
+  return 0;
+}
+
+int csp_profile_filter(csp_ctx* c, int kid) {
+  if (!c || kid >= KID_COUNT) return SMCP_EINVAL;
+  c->prof.filter = kid < 0 ? -1 : kid;
   return 0;
 }
 

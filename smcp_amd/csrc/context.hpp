@@ -90,6 +90,8 @@ namespace smcp {
 // optional per-kernel timing with HIP events on the launch stream
 struct Profiler {
   bool on = false;
+  int filter = -1;   // time only launches of this kernel id (-1: all)
+  bool want(int kid) const { return on && (filter < 0 || filter == kid); }
   std::vector<hipEvent_t> ev;
   std::vector<int> kids;
   size_t used = 0;
