@@ -100,6 +100,11 @@ int csp_axpby(int64_t len, double a, const double* x, double b, double* y, void*
  * values cval (lower-triangle values, diagonal positions flagged by the context itself). */
 int kkt_set_constraints(csp_ctx* ctx, int64_t m, const int64_t* cptr, const int64_t* cidx,
                         const double* cval);
+/* options['tnzcols'] (solvers.py:31,210-216; default 0.1): a constraint whose entries touch at most
+ * int(n * tnzcols) distinct rows/columns is handled as misc.SCMcolumn2 does (misc.c:620-663, solvers.py:489-497:
+ * S^-1[:, K] by two chompack.trsm calls, then pairwise contractions) instead of a Hessian sweep; misc.nzcolumns /
+ * misc.matperm (misc.c:682-773) are folded into kkt_set_constraints.  Call before kkt_set_constraints. */
+int kkt_set_tnzcols(csp_ctx* ctx, double tnzcols);
 /* Amap (solvers.py:369-380): y[i] = <A_i, X>, i < m;  y device, length m. */
 int kkt_amap(csp_ctx* ctx, const double* X, double* y, void* stream);
 /* Aadj (solvers.py:382-386): X <- sum_i y[i] A_i (overwrites X). */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "kkt_gram_sweep": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_i64, c_vp]),
     "kkt_gram_accumulate": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "csp_exchange_copy": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, ctypes.c_int, c_vp]),
+    "kkt_set_tnzcols": (ctypes.c_int, [c_vp, ctypes.c_double]),
     "dense_potrf": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "dense_potrs": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "kkt_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, c_vp, c_vp, c_vp]),

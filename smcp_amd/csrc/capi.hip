@@ -1025,12 +1025,12 @@ int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, 
   if (!trans) {
     for_levels_up(c, [&](const int32_t* lev, int cnt) {
       a.lev = lev;
-      launch(c, KID_trsm_fwd_level, k_trsm_fwd_level, dim3(cnt), dim3(NT), st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
+      launch(c, KID_trsm_fwd_level, k_trsm_fwd_level, dim3(cnt, (unsigned)((nrhs + TRSM_CB - 1) / TRSM_CB)), dim3(NT), st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
     });
   } else {
     for_levels_down(c, [&](const int32_t* lev, int cnt) {
       a.lev = lev;
-      launch(c, KID_trsm_bwd_level, k_trsm_bwd_level, dim3(cnt), dim3(NT), st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
+      launch(c, KID_trsm_bwd_level, k_trsm_bwd_level, dim3(cnt, (unsigned)((nrhs + TRSM_CB - 1) / TRSM_CB)), dim3(NT), st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
     });
   }
   HIPCHK(hipGetLastError());

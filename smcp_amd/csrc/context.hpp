@@ -78,6 +78,19 @@ struct DeviceCtx {
   double* rval = nullptr;
   double* ustack = nullptr;  // max(m, max_rhs) * blklen : constraint matrices swept by the Hessian
   int64_t ustack_cols = 0;
+  // column-sparse constraints (misc.SCMcolumn2 path, solvers.py:489-497): constraint entries in matrix
+  // coordinates, the dense / sparse split, and per sparse constraint its nonzero-column set K_s
+  int32_t* a_r = nullptr;    // cnnz : row of each constraint entry (permuted matrix coordinates)
+  int32_t* a_c = nullptr;    // cnnz : column
+  int32_t* s_rloc = nullptr; // cnnz : position of a_r within K_s (sparse constraints only)
+  int32_t* s_cloc = nullptr; // cnnz : position of a_c within K_s
+  int32_t* dlist = nullptr;  // md : constraints swept through the Hessian (Gram) path
+  int32_t* slist = nullptr;  // ns : column-sparse constraints
+  int32_t* kidx = nullptr;   // sum |K_s| : the column sets, concatenated in slist order
+  int64_t md = 0, ns = 0;
+  double* vbuf = nullptr;    // n x vcols : S^-1[:, K_s] of the chunk in flight
+  int64_t vcols = 0;
+  double* hd = nullptr;      // md x md Gram block of the dense constraints (when ns > 0)
   double* sw = nullptr;      // blklen : sqrt of the inner-product weights (Gram path)
   double* gpart = nullptr;   // partial Gram tiles
   int64_t gpart_len = 0;
@@ -134,4 +147,7 @@ struct csp_ctx {
   std::vector<int64_t> h_tmpptr;
   std::vector<int> lev_namax;   // per level: largest separator (sizes the gather launches)
   std::vector<uint8_t> is_diag_cache;
+  double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)
+  std::vector<int64_t> h_kptr;          // ns + 1 : offsets into kidx, host copy for chunk planning
+  std::vector<int32_t> h_slist;
 };

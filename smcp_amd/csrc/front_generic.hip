@@ -422,21 +422,25 @@ __global__ void k_factor_yaa(TreeArgs a, const double* yaa, double* fac) {
 
 // ---- supernodal triangular solves with a dense right-hand side ------------------------
 // Update vectors travel through the (na x nrhs) blocks of the update workspace (ld na).
+// Right-hand-side columns are independent: blockIdx.y takes a block of TRSM_CB columns of B.
+constexpr int TRSM_CB = 16;
 __global__ void k_trsm_fwd_level(TreeArgs a, const double* L, double* B, int nrhs, int64_t ldb,
                                  const int32_t* rowidx) {
   const int k = a.lev[blockIdx.x];
   const CliqueDesc d = a.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
+  const int c0 = blockIdx.y * TRSM_CB, nc = min(TRSM_CB, nrhs - c0);
+  if (nc <= 0) return;
   const double* Lk = L + d.blk;
-  double* Bn = B + d.first;
-  double* Uk = a.tmp + d.rel * nrhs;  // na x nrhs (ld na); d.rel == sepptr[k]
+  double* Bn = B + d.first + (int64_t)c0 * ldb;
+  double* Uk = a.tmp + d.rel * nrhs + (int64_t)c0 * na;  // na x nrhs (ld na); d.rel == sepptr[k]
   // gather children's update vectors: rows of the child separator map into this clique's rows
-  zero((int64_t)na * nrhs, Uk);
+  zero((int64_t)na * nc, Uk);
   for (int q = d.chbeg; q < d.chend; ++q) {
     const CliqueDesc c = a.cl[a.chidx[q]];
     const int32_t* rel = a.relidx + c.rel;
-    const double* Uc = a.tmp + c.rel * nrhs;
-    for (int e = SMCP_TID; e < c.na * nrhs; e += SMCP_NT) {
+    const double* Uc = a.tmp + c.rel * nrhs + (int64_t)c0 * c.na;
+    for (int e = SMCP_TID; e < c.na * nc; e += SMCP_NT) {
       int i = e % c.na, col = e / c.na;
       int ri = rel[i];
       double v = Uc[i + (int64_t)col * c.na];
@@ -445,26 +449,29 @@ __global__ void k_trsm_fwd_level(TreeArgs a, const double* L, double* B, int nrh
     }
     __syncthreads();
   }
-  trsm_llN(nn, nrhs, Lk, nf, Bn, ldb);
-  if (na) gemm(na, nrhs, nn, -1.0, Mat{Lk + nn, nf}, Mat{Bn, ldb}, 1.0, Uk, na);
+  trsm_llN(nn, nc, Lk, nf, Bn, ldb);
+  if (na) gemm(na, nc, nn, -1.0, Mat{Lk + nn, nf}, Mat{Bn, ldb}, 1.0, Uk, na);
 }
 __global__ void k_trsm_bwd_level(TreeArgs a, const double* L, double* B, int nrhs, int64_t ldb,
                                  const int32_t* rowidx) {
   const int k = a.lev[blockIdx.x];
   const CliqueDesc d = a.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
+  const int c0 = blockIdx.y * TRSM_CB, nc = min(TRSM_CB, nrhs - c0);
+  if (nc <= 0) return;
   const double* Lk = L + d.blk;
-  double* Bn = B + d.first;
+  double* Bc = B + (int64_t)c0 * ldb;
+  double* Bn = Bc + d.first;
   const int32_t* rows = rowidx + d.rows;
   // B_N <- L_NN^-T (B_N - L_AN^T B_A); B_A rows are final (ancestors processed earlier)
-  for (int e = SMCP_TID; e < nn * nrhs; e += SMCP_NT) {
+  for (int e = SMCP_TID; e < nn * nc; e += SMCP_NT) {
     int j = e % nn, col = e / nn;
     double acc = 0.0;
-    for (int i = 0; i < na; ++i) acc += Lk[nn + i + (int64_t)j * nf] * B[rows[nn + i] + (int64_t)col * ldb];
+    for (int i = 0; i < na; ++i) acc += Lk[nn + i + (int64_t)j * nf] * Bc[rows[nn + i] + (int64_t)col * ldb];
     Bn[j + (int64_t)col * ldb] -= acc;
   }
   __syncthreads();
-  trsm_llT(nn, nrhs, Lk, nf, Bn, ldb);
+  trsm_llT(nn, nc, Lk, nf, Bn, ldb);
 }
 
 // ---- flat reductions -------------------------------------------------------------------

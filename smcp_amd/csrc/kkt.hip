@@ -40,6 +40,56 @@ __global__ void k_scatter_constraints(int64_t j0, const int64_t* cptr, const int
     u[cidx[e]] = cval[e];
 }
 
+// U_q (pre-zeroed) <- A_{ids[q]} scattered into blkval coordinates
+__global__ void k_scatter_constraints_ids(const int32_t* ids, const int64_t* cptr, const int64_t* cidx,
+                                          const double* cval, double* U, int64_t ldu) {
+  const int64_t j = ids[blockIdx.y];
+  double* u = U + (int64_t)blockIdx.y * ldu;
+  for (int64_t e = cptr[j] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cptr[j + 1];
+       e += (int64_t)gridDim.x * blockDim.x)
+    u[cidx[e]] = cval[e];
+}
+// H[ids[i], ids[j]] <- Hd[i, j]  (md x md, both triangles)
+__global__ void k_scatter_hd(const int32_t* ids, int md, const double* Hd, double* H, int64_t ldh) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)md * md; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e % md), j = (int)(e / md);
+    H[ids[i] + (int64_t)ids[j] * ldh] = Hd[e];
+  }
+}
+// V (n x ncols, zeroed) <- unit vectors: column q has a one in row kidx[q]
+__global__ void k_unit_columns(const int32_t* kidx, int64_t ncols, double* V, int64_t n) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < ncols) V[kidx[q] + q * n] = 1.0;
+}
+// misc.SCMcolumn2 (misc.c:620-663): H[i, s] = tr(A_i S^-1 A_s S^-1) from V_s = S^-1[:, K_s], for every
+// constraint i and the column-sparse constraints s of this chunk (one wave per pair; H is symmetric, both
+// triangles are written).  voff[q]: first column of V_s inside V for the q-th sparse constraint of the chunk.
+__global__ void k_scm_columns(int64_t m, const int64_t* cptr, const int32_t* a_r, const int32_t* a_c, const double* cval,
+                              const int32_t* slist, const int64_t* voff, const int32_t* rloc, const int32_t* cloc,
+                              const double* V, int64_t n, double* H, int64_t ldh) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = blockIdx.x;
+  const int64_t s = slist[blockIdx.y];
+  const double* Vs = V + voff[blockIdx.y] * n;
+  double acc = 0.0;
+  for (int64_t q = cptr[i] + lane; q < cptr[i + 1]; q += 64) {
+    const int r1 = a_r[q], c1 = a_c[q];
+    const double beta = cval[q];
+    double t = 0.0;
+    for (int64_t p = cptr[s]; p < cptr[s + 1]; ++p) {
+      const double alpha = (a_r[p] != a_c[p]) ? 2.0 * cval[p] : cval[p];
+      const double* Vr = Vs + (int64_t)rloc[p] * n;
+      const double* Vc = Vs + (int64_t)cloc[p] * n;
+      double w = Vr[r1] * Vc[c1];
+      if (r1 != c1) w += Vr[c1] * Vc[r1];
+      t += alpha * w;
+    }
+    acc += beta * t;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) { H[i + s * ldh] = acc; H[s + i * ldh] = acc; }
+}
+
 // single-workgroup dense Cholesky / triangular solves (generic path)
 __global__ void k_dense_potrf(double* A, int n, int64_t lda, int* info) {
   int f = wg::potrf(n, A, lda);
@@ -81,13 +131,18 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   DeviceCtx& D = c->D;
   const Symbolic& S = c->S;
   HIPCHK(hipSetDevice(D.device));
-  void* old[] = {D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
+  void* old[] = {D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack,
+                 D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd};
   for (void* p : old) if (p) hipFree(p);
   D.cptr = nullptr; D.cidx = nullptr; D.cval = nullptr; D.cwval = nullptr; D.rpos = nullptr;
   D.rptr = nullptr; D.rcon = nullptr; D.rval = nullptr; D.ustack = nullptr;
+  D.a_r = D.a_c = D.s_rloc = D.s_cloc = D.dlist = D.slist = D.kidx = nullptr;
+  D.vbuf = D.hd = nullptr;
+  D.md = D.ns = D.vcols = 0;
   const int64_t nnz = cptr[m];
   // diagonal flags: position -> is it a diagonal entry of its NN block?
   std::vector<double> w(nnz);
+  std::vector<int32_t> ar(nnz), ac(nnz);   // entries in (permuted) matrix coordinates
   {
     // locate clique by binary search on blkptr
     for (int64_t e = 0; e < nnz; ++e) {
@@ -98,8 +153,42 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
       int64_t col = off / nf, row = off % nf;
       if (row < col) return SMCP_EINVAL;  // upper triangle of the NN block is not part of V
       w[e] = (row == col) ? cval[e] : 2.0 * cval[e];
+      ar[e] = (int32_t)S.rowidx[S.rowptr[k] + row];
+      ac[e] = (int32_t)(S.snptr[k] + col);
     }
   }
+  // Column-sparse constraints (misc.nzcolumns / misc.matperm, misc.c:682-773, solvers.py:246-268): a constraint
+  // whose entries touch at most int(n * tnzcols) distinct rows/columns takes the SCMcolumn2 path (two sparse
+  // triangular solves for S^-1[:, K_s], then pairwise contractions) instead of a Hessian sweep.
+  std::vector<int32_t> dl, sl, kidx, rloc(nnz, 0), cloc(nnz, 0);
+  c->h_kptr.assign(1, 0);
+  {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("SMCP_SCM"); off = (e && e[0] == '0') ? 1 : 0; }
+    const int64_t tnz = (int64_t)((double)S.n * c->tnzcols);
+    // at most this many columns of S^-1 are formed per constraint (n x |K| doubles of workspace)
+    const int64_t kcap = std::min<int64_t>(tnz, std::max<int64_t>(1, ((int64_t)256 << 20) / std::max<int64_t>(1, S.n * 8)));
+    const int64_t sepsum = std::max<int64_t>(1, S.sepptr[S.nsn]);
+    const int64_t trsm_cap = std::max<int64_t>(1, (D.max_rhs * D.tmplen) / sepsum);
+    std::vector<int32_t> ks;
+    for (int64_t j = 0; j < m; ++j) {
+      ks.clear();
+      for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) { ks.push_back(ar[e]); ks.push_back(ac[e]); }
+      std::sort(ks.begin(), ks.end());
+      ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+      const int64_t nz = (int64_t)ks.size();
+      const bool sparse = !off && !use_generic() && nz > 0 && nz <= std::min(kcap, trsm_cap);
+      if (!sparse) { dl.push_back((int32_t)j); continue; }
+      sl.push_back((int32_t)j);
+      for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+        rloc[e] = (int32_t)(std::lower_bound(ks.begin(), ks.end(), ar[e]) - ks.begin());
+        cloc[e] = (int32_t)(std::lower_bound(ks.begin(), ks.end(), ac[e]) - ks.begin());
+      }
+      kidx.insert(kidx.end(), ks.begin(), ks.end());
+      c->h_kptr.push_back((int64_t)kidx.size());
+    }
+  }
+  c->h_slist = sl;
   // CSR by position
   std::vector<int64_t> order(nnz);
   for (int64_t e = 0; e < nnz; ++e) order[e] = e;
@@ -128,6 +217,25 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   if ((rc = dev_upload(&D.rptr, rptr, D.bytes))) return rc;
   if ((rc = dev_upload(&D.rcon, rcon, D.bytes))) return rc;
   if ((rc = dev_upload(&D.rval, rval, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.a_r, ar, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.a_c, ac, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.s_rloc, rloc, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.s_cloc, cloc, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.dlist, dl, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.slist, sl, D.bytes))) return rc;
+  if ((rc = dev_upload(&D.kidx, kidx, D.bytes))) return rc;
+  D.md = (int64_t)dl.size();
+  D.ns = (int64_t)sl.size();
+  if (D.ns) {
+    int64_t kmax = 1;
+    for (int64_t q = 0; q < D.ns; ++q) kmax = std::max(kmax, c->h_kptr[q + 1] - c->h_kptr[q]);
+    const int64_t sepsum = std::max<int64_t>(1, S.sepptr[S.nsn]);
+    const int64_t trsm_cap = std::max<int64_t>(1, (D.max_rhs * D.tmplen) / sepsum);
+    const int64_t want = std::min<int64_t>((int64_t)kidx.size(), ((int64_t)256 << 20) / std::max<int64_t>(1, S.n * 8));
+    D.vcols = std::min(trsm_cap, std::max(kmax, want));
+    if ((rc = dev_alloc(&D.vbuf, D.vcols * S.n, D.bytes))) return rc;
+    if (D.md && (rc = dev_alloc(&D.hd, D.md * D.md, D.bytes))) return rc;
+  }
   D.ustack_cols = std::max(D.max_rhs, m);
   if ((rc = dev_alloc(&D.ustack, D.ustack_cols * S.blklen(), D.bytes))) return rc;
   if (!D.sw) {
@@ -138,6 +246,12 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   D.m = m;
   D.cnnz = nnz;
   D.rnnz = (int64_t)rpos.size();
+  return 0;
+}
+
+int kkt_set_tnzcols(csp_ctx* c, double tnzcols) {
+  if (!c || !(tnzcols >= 0.0 && tnzcols <= 1.0)) return SMCP_EINVAL;
+  c->tnzcols = tnzcols;
   return 0;
 }
 
@@ -214,9 +328,10 @@ static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_
   return 0;
 }
 // H = sum over the given blkval ranges of G^T W G (ranges: host array of nranges (begin, end) pairs)
-static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, hipStream_t st) {
+static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, hipStream_t st,
+                           int64_t mcols = -1) {
   DeviceCtx& D = c->D;
-  const int64_t m = D.m, bl = c->S.blklen();
+  const int64_t m = mcols < 0 ? D.m : mcols, bl = c->S.blklen();
   int64_t total = 0;
   for (int64_t q = 0; q < nranges; ++q) total += std::max<int64_t>(0, ranges[2 * q + 1] - ranges[2 * q]);
   if (total <= 0) {
@@ -263,14 +378,62 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
 static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, hipStream_t st) {
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
-  if (int rc = gram_prepare(c, L, Y, st)) return rc;
-  for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
-    int nr = (int)std::min(D.max_rhs, m - jb);
-    hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st);     // G(A_j) = (G_NN, R^T G_AN)
+  if (!D.ns) {
+    if (int rc = gram_prepare(c, L, Y, st)) return rc;
+    for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
+      int nr = (int)std::min(D.max_rhs, m - jb);
+      hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st);     // G(A_j) = (G_NN, R^T G_AN)
+    }
+    const int64_t range[2] = {0, bl};
+    if (int rc = gram_accumulate(c, 1, range, H, ldh, st)) return rc;
+    if (int f = fetch_info(c, st)) return f;   // chol(Y_AA) failure
+    return 0;
   }
-  const int64_t range[2] = {0, bl};
-  if (int rc = gram_accumulate(c, 1, range, H, ldh, st)) return rc;
-  if (int f = fetch_info(c, st)) return f;   // chol(Y_AA) failure
+  // ---- hybrid (solvers.py:479-497): Gram block of the swept constraints + SCMcolumn2 columns of the sparse ones
+  const int64_t md = D.md, n = c->S.n;
+  if (md) {
+    prepare_yaa(c, Y, true, st);
+    prep_lk_cached(c, L, Y, st);
+    HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * md * bl, st));
+    for (int64_t jb = 0; jb < md; jb += 65535)
+      launch(c, KID_scatter_constraints, k_scatter_constraints_ids, dim3(8, (unsigned)std::min<int64_t>(65535, md - jb)),
+             dim3(256), st, (const int32_t*)D.dlist + jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
+    for (int64_t jb = 0; jb < md; jb += D.max_rhs) {
+      int nr = (int)std::min(D.max_rhs, md - jb);
+      hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st);
+    }
+    const int64_t range[2] = {0, bl};
+    if (int rc = gram_accumulate(c, 1, range, D.hd, md, st, md)) return rc;
+    launch(c, KID_scatter_constraints, k_scatter_hd, dim3((unsigned)std::min<int64_t>(1024, (md * md + 255) / 256)), dim3(256), st,
+           (const int32_t*)D.dlist, (int)md, (const double*)D.hd, H, ldh);
+  }
+  // sparse constraints in chunks of at most vcols columns of S^-1
+  std::vector<int64_t> voff;
+  for (int64_t q0 = 0; q0 < D.ns;) {
+    int64_t q1 = q0, cols = 0;
+    voff.clear();
+    while (q1 < D.ns && cols + (c->h_kptr[q1 + 1] - c->h_kptr[q1]) <= D.vcols && q1 - q0 < 65535) {
+      voff.push_back(cols);
+      cols += c->h_kptr[q1 + 1] - c->h_kptr[q1];
+      ++q1;
+    }
+    if (q1 == q0) return SMCP_ENOMEM;   // cannot happen: vcols >= max |K_s|
+    HIPCHK(hipMemsetAsync(D.vbuf, 0, sizeof(double) * cols * n, st));
+    launch(c, KID_scatter_constraints, k_unit_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), st,
+           (const int32_t*)D.kidx + c->h_kptr[q0], cols, D.vbuf, n);
+    if (int rc = csp_trsm(c, L, D.vbuf, cols, n, 0, st)) return rc;      // V = L^-T L^-1 E_K  (solvers.py:491-492)
+    if (int rc = csp_trsm(c, L, D.vbuf, cols, n, 1, st)) return rc;
+    // chunk offsets: a small device array behind the reduction scratch would not fit 65535 entries; use tmp's head
+    int64_t* dvoff = reinterpret_cast<int64_t*>(D.tmp);
+    HIPCHK(hipMemcpyAsync(dvoff, voff.data(), sizeof(int64_t) * voff.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));    // voff is reused by the next chunk
+    launch(c, KID_scatter_constraints, k_scm_columns, dim3((unsigned)m, (unsigned)(q1 - q0)), dim3(64), st, m, D.cptr,
+           (const int32_t*)D.a_r, (const int32_t*)D.a_c, (const double*)D.cval, (const int32_t*)D.slist + q0,
+           (const int64_t*)dvoff, (const int32_t*)D.s_rloc, (const int32_t*)D.s_cloc, (const double*)D.vbuf, n, H, ldh);
+    q0 = q1;
+  }
+  HIPCHK(hipGetLastError());
+  if (md) { if (int f = fetch_info(c, st)) return f; }
   return 0;
 }
 

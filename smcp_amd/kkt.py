@@ -115,7 +115,7 @@ class ShardedSchur:
 class KKTSystem(ShardedSchur):
     """Holds the constraint matrices A_1..A_m (blkval coordinates) on the device."""
 
-    def __init__(self, symb, cptr, cidx, cval, max_rhs=None):
+    def __init__(self, symb, cptr, cidx, cval, max_rhs=None, tnzcols=None):
         self.symb = symb
         self.m = len(cptr) - 1
         if max_rhs is None:
@@ -129,6 +129,8 @@ class KKTSystem(ShardedSchur):
         cptr = np.ascontiguousarray(cptr, dtype=np.int64)
         cidx = np.ascontiguousarray(cidx, dtype=np.int64)
         cval = np.ascontiguousarray(cval, dtype=np.float64)
+        if tnzcols is not None:
+            _chk(_lib.lib().kkt_set_tnzcols(symb.handle, float(tnzcols)), "kkt_set_tnzcols")
         _chk(_lib.lib().kkt_set_constraints(symb.handle, self.m, cptr.ctypes.data, cidx.ctypes.data,
                                             cval.ctypes.data), "kkt_set_constraints")
         self.dev = torch.device("cuda", symb._device)

@@ -101,7 +101,12 @@ class _Problem:
         sl = slice(colptr[0], colptr[1])
         np.add.at(h, pos[sl], vals[sl])
         cptr = colptr[1:] - colptr[1]
-        self.kkt = KKTSystem(symb, cptr, pos[colptr[1]:], vals[colptr[1]:])
+        tnz = options.get("tnzcols", 0.1)
+        if type(tnz) is not float:
+            raise TypeError("tnzcols must be a float between 0.0 and 1.0")
+        if tnz > 1 or tnz < 0:
+            raise ValueError("tnzcols must be between 0.0 and 1.0")
+        self.kkt = KKTSystem(symb, cptr, pos[colptr[1]:], vals[colptr[1]:], tnzcols=tnz)
         self.C = cspmatrix(symb, torch.from_numpy(h).to(self.dev))
         self.b = torch.from_numpy(b.copy()).to(self.dev)
         self.bh = b

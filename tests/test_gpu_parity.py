@@ -198,3 +198,46 @@ def test_dense_potrf_potrs(n):
     assert rel(bd.cpu().numpy(), np.linalg.solve(Hh, b)) < 1e-10
     Hbad = torch.from_numpy((Hh - 2 * np.linalg.eigvalsh(Hh)[1] * np.eye(n)).copy()).cuda()
     assert lib.dense_potrf(symb.handle, Hbad.data_ptr(), n, n, None) > 0
+
+
+@pytest.mark.parametrize("name,tnz", [("rand2", 0.3), ("arrow", 0.5), ("nested_mid", 0.2), ("diag", 0.5), ("arrow", 0.0)])
+def test_kkt_column_sparse_constraints(name, tnz):
+    """Row a9: constraints touching few columns go through the SCMcolumn2 path (solvers.py:489-497,
+    misc.c:620-663); the Schur complement and the solve must not depend on which path a constraint took."""
+    symb, S, A, msk = setup(name, 11)
+    rng = np.random.default_rng(12)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    valid = problems.lower_positions(symb)
+    cidx, cval, cptr = [], [], [0]
+    ndiag = problems.lower_positions(symb)
+    for j in range(9):
+        if j % 3 == 0:      # dense on V
+            idx = valid
+        elif j % 3 == 1:    # a handful of entries
+            idx = np.sort(rng.choice(valid, size=min(3, len(valid)), replace=False))
+        else:               # a single entry
+            idx = np.sort(rng.choice(valid, size=1))
+        cidx.append(idx)
+        cval.append(rng.standard_normal(len(idx)))
+        cptr.append(cptr[-1] + len(idx))
+    cptr = np.asarray(cptr, dtype=np.int64)
+    cidx = np.concatenate(cidx).astype(np.int64)
+    cval = np.concatenate(cval)
+    m = len(cptr) - 1
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=4, tnzcols=tnz)
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    solve = sys.factor(Ld, Yd)
+    Hg = np.tril(sys.H.cpu().numpy().T)
+    assert rel(Hg, np.tril(Href)) < 1e-9
+    bx = rng.standard_normal(symb.blklen) * msk
+    by = rng.standard_normal(m)
+    xr, yr = K.solve(L, Yh, Href, bx, by, 1.0)
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    solve(bxd, byd, 1.0)
+    assert rel(host(bxd)[msk], xr[msk]) < 1e-8
+    assert rel(byd.cpu().numpy(), yr) < 1e-8
