@@ -91,6 +91,10 @@ struct DeviceCtx {
   double* vbuf = nullptr;    // n x vcols : S^-1[:, K_s] of the chunk in flight
   int64_t vcols = 0;
   double* hd = nullptr;      // md x md Gram block of the dense constraints (when ns > 0)
+  // blocked dense Cholesky of the Schur complement: inverses of its 64 x 64 diagonal blocks (for the blocked potrs)
+  double* hinv = nullptr;    // nblocks * 4096 + 2 n doubles (the tail holds the two work vectors of the solve)
+  int64_t hinv_cap = 0, hinv_n = 0;
+  const void* hinv_tag = nullptr;   // the factor these inverses belong to
   double* sw = nullptr;      // blklen : sqrt of the inner-product weights (Gram path)
   double* gpart = nullptr;   // partial Gram tiles
   int64_t gpart_len = 0;

@@ -99,6 +99,43 @@ __global__ void k_dense_potrs(const double* A, int n, int64_t lda, double* B, in
   wg::trsm_llN(n, nrhs, A, lda, B, ldb);
   wg::trsm_llT(n, nrhs, A, lda, B, ldb);
 }
+// One block step of the blocked triangular solves with the Cholesky factor A (lower, n x n) whose 64 x 64 diagonal
+// blocks have explicit inverses dinv (w x w, ld w).  Every workgroup recomputes x_blk = Dinv b_blk (or Dinv^T b_blk)
+// in LDS; workgroup 0 publishes it to xout; then the workgroups update their slice of the remaining rows:
+//   trans 0 (L y = b):    b[i] -= sum_j A[i, jb + j] x[j],  i >= jb + w   (one thread per row, coalesced)
+//   trans 1 (L^T x = y):  b[i] -= sum_j A[jb + j, i] x[j],  i <  jb       (one wave per row, lanes over j)
+__global__ void __launch_bounds__(256) k_dense_trsv_step(const double* A, int n, int64_t lda, const double* dinv, int jb, int w,
+                                                         double* b, double* xout, int trans) {
+  __shared__ double t[64], x[64];
+  const int tid = threadIdx.x;
+  if (tid < w) t[tid] = b[jb + tid];
+  __syncthreads();
+  if (tid < w) {
+    double acc = 0.0;
+    if (!trans) { for (int j = 0; j <= tid; ++j) acc += dinv[tid + j * w] * t[j]; }
+    else { for (int j = tid; j < w; ++j) acc += dinv[j + tid * w] * t[j]; }
+    x[tid] = acc;
+    if (blockIdx.x == 0) xout[jb + tid] = acc;
+  }
+  __syncthreads();
+  if (!trans) {
+    const int i = jb + w + blockIdx.x * 256 + tid;
+    if (i < n) {
+      double acc = 0.0;
+      const double* Ai = A + i + (int64_t)jb * lda;
+      for (int j = 0; j < w; ++j) acc += Ai[(int64_t)j * lda] * x[j];
+      b[i] -= acc;
+    }
+  } else {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = blockIdx.x * 4 + wave; i < jb; i += gridDim.x * 4) {
+      double acc = (lane < w) ? A[(jb + lane) + (int64_t)i * lda] * x[lane] : 0.0;
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+      if (lane == 0) b[i] -= acc;
+    }
+  }
+}
+
 // y = a*y + x (length m), small
 __global__ void k_vec_axpby(int64_t m, double a, const double* x, double b, double* y) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,8 +322,17 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
     a.lfd = c->D.lfd_dense;
     a.dn = (int)n; a.dld = lda;
     dim3 blk(256);
+    const int64_t nblocks = (n + LB - 1) / LB, need = nblocks * LB * LB + 2 * n;
+    if (c->D.hinv_cap < need) {
+      if (c->D.hinv) { HIPCHK(hipFree(c->D.hinv)); c->D.bytes -= c->D.hinv_cap * 8; }
+      c->D.hinv = nullptr; c->D.hinv_cap = 0;
+      if (int rc = dev_alloc(&c->D.hinv, need, c->D.bytes)) return rc;
+      c->D.hinv_cap = need;
+    }
+    c->D.hinv_tag = nullptr;
     for (int jb = 0; jb < (int)n; jb += LB) {
       launch_lds(c, KID_lf_diag, k_lf_diag, dim3(1), blk, LF_DIAG_LDS, st, a, A, (double*)nullptr, 5, jb, 1);
+      HIPCHK(hipMemcpyAsync(c->D.hinv + (int64_t)(jb / LB) * LB * LB, c->D.lfd_dense, sizeof(double) * LB * LB, hipMemcpyDeviceToDevice, st));
       const int mrem = (int)n - jb - LB;
       if (mrem > 0) {
         const int mt = tiles64(mrem);
@@ -296,12 +342,39 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
     }
   }
   HIPCHK(hipGetLastError());
-  return fetch_info(c, st);
+  int rc = fetch_info(c, st);
+  if (!rc && !(use_generic() || n <= 2 * LB)) { c->D.hinv_tag = A; c->D.hinv_n = n; }
+  return rc;
+}
+// potrs with the factor of dense_potrf.  A single right-hand side of a factor produced by the blocked dense_potrf
+// (its diagonal-block inverses are still cached) runs as 2 * ceil(n / 64) block steps over the chip.
+static int potrs_impl(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs, int64_t ldb, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  if (nrhs == 1 && D.hinv_tag == A && D.hinv_n == n && n > 2 * LB) {
+    const int64_t nblocks = (n + LB - 1) / LB;
+    double* y = D.hinv + nblocks * LB * LB;      // forward solution
+    double* z = y + n;                            // backward solution
+    for (int jb = 0; jb < (int)n; jb += LB) {
+      const int w = (int)std::min<int64_t>(LB, n - jb);
+      const int rest = (int)n - jb - w;
+      launch(c, KID_dense_potrs, k_dense_trsv_step, dim3((unsigned)std::max(1, (rest + 255) / 256)), dim3(256), st, A, (int)n, lda,
+             (const double*)(D.hinv + (int64_t)(jb / LB) * LB * LB), jb, w, B, y, 0);
+    }
+    for (int jb = (int)((nblocks - 1) * LB); jb >= 0; jb -= LB) {
+      const int w = (int)std::min<int64_t>(LB, n - jb);
+      launch(c, KID_dense_potrs, k_dense_trsv_step, dim3((unsigned)std::max(1, std::min(256, (jb + 3) / 4))), dim3(256), st, A, (int)n, lda,
+             (const double*)(D.hinv + (int64_t)(jb / LB) * LB * LB), jb, w, y, z, 1);
+    }
+    HIPCHK(hipMemcpyAsync(B, z, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  launch(c, KID_dense_potrs, k_dense_potrs, dim3(1), dim3(1024), st, A, (int)n, lda, B, (int)nrhs, ldb);
+  return 0;
 }
 int dense_potrs(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs, int64_t ldb,
                 void* stream) {
   if (int rc = ready(c)) return rc;
-  launch(c, KID_dense_potrs, k_dense_potrs, dim3(1), dim3(1024), (hipStream_t)stream, A, (int)n, lda, B, (int)nrhs, ldb);
+  if (int rc = potrs_impl(c, A, n, lda, B, nrhs, ldb, (hipStream_t)stream)) return rc;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -485,7 +558,7 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   hessian_impl(c, L, r1, 1, bl, 2, 0, st);                      // r1 = W(bx)
   amap_impl(c, r1, 0, 1, ytmp, 0, st);                          // Amap(r1)
   launch(c, KID_vec_axpby, k_vec_axpby, dim3((unsigned)((m + 255) / 256)), dim3(256), st, m, 1.0, ytmp, kk, by);  // y = kk*by + Amap(r1)
-  launch(c, KID_dense_potrs, k_dense_potrs, dim3(1), dim3(1024), st, H, (int)m, ldh, by, 1, m);
+  if (int rc = potrs_impl(c, H, m, ldh, by, 1, m, st)) return rc;
   if (int rc = aadj_impl(c, by, r1, st)) return rc;             // r1 = Aadj(y)
   launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 1.0, (const double*)r1, -1.0, bx);  // bx = Aadj(y) - bx
   hessian_impl(c, L, bx, 1, bl, 2, 0, st);
