@@ -99,23 +99,134 @@ __global__ void k_dense_potrs(const double* A, int n, int64_t lda, double* B, in
   wg::trsm_llN(n, nrhs, A, lda, B, ldb);
   wg::trsm_llT(n, nrhs, A, lda, B, ldb);
 }
-// One block step of the blocked triangular solves with the Cholesky factor A (lower, n x n) whose 64 x 64 diagonal
-// blocks have explicit inverses dinv (w x w, ld w).  Every workgroup recomputes x_blk = Dinv b_blk (or Dinv^T b_blk)
-// in LDS; workgroup 0 publishes it to xout; then the workgroups update their slice of the remaining rows:
+// m <= 128: the whole factorisation in the LDS of one workgroup -- 16-wide block columns, diagonal blocks factored
+// and inverted by one wavefront (potrf_inv16), panel and trailing updates on MFMA (the scheme of k_factor_yaa_lds).
+// The inverses of the diagonal blocks are kept (dinv: 256 doubles per block) for k_dense_potrs_small.
+__global__ void __launch_bounds__(256) k_dense_potrf_small(double* A, int n, int64_t lda, int* info, double* dinv) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int ld = n | 1;
+  double* const M = smem;
+  double* const D16 = smem + (int64_t)ld * n;
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    const int i = e % n, j = e / n;
+    M[i + j * ld] = (i >= j) ? A[i + (int64_t)j * lda] : 0.0;
+  }
+  for (int jb = 0; jb < n; jb += 16) {
+    const int bw = min(16, n - jb);
+    const int f = potrf_inv16(M + jb + jb * ld, ld, bw, D16);
+    if (f) { if (threadIdx.x == 0) *info = jb + f; return; }
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) dinv[(jb >> 4) * 256 + e] = D16[e];
+    const int mrem = n - jb - bw;
+    if (mrem > 0) {
+      double* Pj = M + (jb + bw) + jb * ld;
+      wg_mma(mrem, bw, bw, [=](int m, int kk) { return Pj[m + kk * ld]; },
+             [=](int kk, int nn_) { return D16[nn_ + kk * 16]; },
+             [=](int m, int nn_, double acc) { Pj[m + nn_ * ld] = acc; });
+      __syncthreads();
+      double* Tr = M + (jb + bw) + (jb + bw) * ld;
+      wg_mma(mrem, mrem, bw, [=](int m, int kk) { return Pj[m + kk * ld]; },
+             [=](int kk, int nn_) { return Pj[nn_ + kk * ld]; },
+             [=](int m, int nn_, double acc) { if (m >= nn_) Tr[m + nn_ * ld] -= acc; }, true);
+      __syncthreads();
+    }
+  }
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    const int i = e % n, j = e / n;
+    if (i >= j) A[i + (int64_t)j * lda] = M[i + j * ld];
+  }
+}
+// Triangular solve with one 16 x 16 (bw x bw) diagonal block of the factor by ONE wavefront, by substitution
+// (backward stable; multiplying by the explicit block inverse costs the interior-point endgame several digits):
+// lane i holds entry i of the right-hand side and row i (trans 0: L y = t) or column i (trans 1: L^T x = t) of
+// the block in registers; the solved entries are broadcast with shuffles.  Returns entry `lane` of the solution.
+__device__ inline double wave_trsv16(const double* A, int64_t lda, int jb, int bw, double ti, int trans) {
+  const int i = threadIdx.x & 63;
+  double Lr[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const bool in = i < bw && j < bw && (trans ? j >= i : j <= i);
+    Lr[j] = in ? (trans ? A[(jb + j) + (int64_t)(jb + i) * lda] : A[(jb + i) + (int64_t)(jb + j) * lda]) : (i == j ? 1.0 : 0.0);
+  }
+  double dii = 1.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) if (j == i) dii = Lr[j];
+  double xi = 0.0;
+  if (!trans) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double xj = __shfl(ti / dii, j, 64);
+      if (i == j) xi = xj;
+      if (i > j) ti -= Lr[j] * xj;
+    }
+  } else {
+#pragma unroll
+    for (int j = 15; j >= 0; --j) {
+      const double xj = __shfl(ti / dii, j, 64);
+      if (i == j) xi = xj;
+      if (i < j) ti -= Lr[j] * xj;
+    }
+  }
+  return xi;
+}
+// A x = b with the factor of k_dense_potrf_small (one right-hand side, one workgroup, n <= 128)
+__global__ void __launch_bounds__(256) k_dense_potrs_small(const double* A, int n, int64_t lda, const double* dinv, double* b) {
+  __shared__ double x[128], t[16];
+  const int tid = threadIdx.x;
+  if (tid < n) x[tid] = b[tid];
+  __syncthreads();
+  for (int jb = 0; jb < n; jb += 16) {            // L y = b
+    const int bw = min(16, n - jb);
+    if (tid < 64) {
+      const double v = wave_trsv16(A, lda, jb, bw, tid < bw ? x[jb + tid] : 0.0, 0);
+      if (tid < bw) t[tid] = v;
+    }
+    __syncthreads();
+    if (tid < bw) x[jb + tid] = t[tid];
+    const int i = jb + bw + tid;
+    if (i < n) { double acc = 0.0; for (int j = 0; j < bw; ++j) acc += A[i + (int64_t)(jb + j) * lda] * t[j]; x[i] -= acc; }
+    __syncthreads();
+  }
+  for (int jb = ((n - 1) >> 4) << 4; jb >= 0; jb -= 16) {   // L^T x = y
+    const int bw = min(16, n - jb);
+    if (tid < 64) {
+      const double v = wave_trsv16(A, lda, jb, bw, tid < bw ? x[jb + tid] : 0.0, 1);
+      if (tid < bw) t[tid] = v;
+    }
+    __syncthreads();
+    if (tid < bw) x[jb + tid] = t[tid];
+    if (tid < jb) { double acc = 0.0; for (int j = 0; j < bw; ++j) acc += A[(jb + j) + (int64_t)tid * lda] * t[j]; x[tid] -= acc; }
+    __syncthreads();
+  }
+  if (tid < n) b[tid] = x[tid];
+}
+
+// One block step of the blocked triangular solves with the Cholesky factor A (lower, n x n).  Every workgroup
+// solves the 64-wide diagonal block redundantly (four 16-wide substitutions by wavefront 0, see wave_trsv16);
+// workgroup 0 publishes x_blk to xout; then the workgroups update their slice of the remaining rows:
 //   trans 0 (L y = b):    b[i] -= sum_j A[i, jb + j] x[j],  i >= jb + w   (one thread per row, coalesced)
 //   trans 1 (L^T x = y):  b[i] -= sum_j A[jb + j, i] x[j],  i <  jb       (one wave per row, lanes over j)
 __global__ void __launch_bounds__(256) k_dense_trsv_step(const double* A, int n, int64_t lda, const double* dinv, int jb, int w,
                                                          double* b, double* xout, int trans) {
   __shared__ double t[64], x[64];
   const int tid = threadIdx.x;
-  if (tid < w) t[tid] = b[jb + tid];
+  if (tid < 64) t[tid] = tid < w ? b[jb + tid] : 0.0;
   __syncthreads();
-  if (tid < w) {
-    double acc = 0.0;
-    if (!trans) { for (int j = 0; j <= tid; ++j) acc += dinv[tid + j * w] * t[j]; }
-    else { for (int j = tid; j < w; ++j) acc += dinv[j + tid * w] * t[j]; }
-    x[tid] = acc;
-    if (blockIdx.x == 0) xout[jb + tid] = acc;
+  if (tid < 64) {
+    const int nsb = (w + 15) >> 4;
+    for (int q = 0; q < nsb; ++q) {
+      const int sb = trans ? nsb - 1 - q : q;          // forward: top sub-block first; transposed: bottom first
+      const int s0 = 16 * sb, bw = min(16, w - s0);
+      const double v = wave_trsv16(A, lda, jb + s0, bw, tid < bw ? t[s0 + tid] : 0.0, trans);
+      if (tid < bw) x[s0 + tid] = v;
+      // remaining sub-blocks of this diagonal block (same wavefront: LDS traffic is program-ordered)
+      if (!trans) {
+        const int i = s0 + bw + tid;
+        if (i < w) { double acc = 0.0; for (int j = 0; j < bw; ++j) acc += A[(jb + i) + (int64_t)(jb + s0 + j) * lda] * x[s0 + j]; t[i] -= acc; }
+      } else {
+        if (tid < s0) { double acc = 0.0; for (int j = 0; j < bw; ++j) acc += A[(jb + s0 + j) + (int64_t)(jb + tid) * lda] * x[s0 + j]; t[tid] -= acc; }
+      }
+    }
+    if (blockIdx.x == 0 && tid < w) xout[jb + tid] = x[tid];
   }
   __syncthreads();
   if (!trans) {
@@ -312,7 +423,30 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
   if (int rc = ready(c)) return rc;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
-  if (use_generic() || n <= 2 * LB) {
+  c->D.hinv_tag = nullptr;
+  static int oldp = -1;
+  if (oldp < 0) { const char* e = getenv("SMCP_POTRF_OLD"); oldp = (e && e[0] == '1') ? 1 : 0; }
+  if (oldp) {
+    launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
+    HIPCHK(hipGetLastError());
+    return fetch_info(c, st);
+  }
+  if (!use_generic() && n <= 2 * LB) {
+    const int64_t need = 8 * 256 + 2 * n;
+    if (c->D.hinv_cap < need) {
+      if (c->D.hinv) { HIPCHK(hipFree(c->D.hinv)); c->D.bytes -= c->D.hinv_cap * 8; }
+      c->D.hinv = nullptr; c->D.hinv_cap = 0;
+      if (int rc = dev_alloc(&c->D.hinv, need, c->D.bytes)) return rc;
+      c->D.hinv_cap = need;
+    }
+    const size_t lds = ((size_t)((n | 1) * n) + 256 + 8) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_dense_potrf_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+      attr_set = true;
+    }
+    launch_lds(c, KID_dense_potrf, k_dense_potrf_small, dim3(1), dim3(256), lds, st, A, (int)n, lda, c->D.info, c->D.hinv);
+  } else if (use_generic()) {
     launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
   } else {
     // blocked right-looking Cholesky, 64-wide block columns: diagonal block by one workgroup, panel and
@@ -329,7 +463,6 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
       if (int rc = dev_alloc(&c->D.hinv, need, c->D.bytes)) return rc;
       c->D.hinv_cap = need;
     }
-    c->D.hinv_tag = nullptr;
     for (int jb = 0; jb < (int)n; jb += LB) {
       launch_lds(c, KID_lf_diag, k_lf_diag, dim3(1), blk, LF_DIAG_LDS, st, a, A, (double*)nullptr, 5, jb, 1);
       HIPCHK(hipMemcpyAsync(c->D.hinv + (int64_t)(jb / LB) * LB * LB, c->D.lfd_dense, sizeof(double) * LB * LB, hipMemcpyDeviceToDevice, st));
@@ -343,13 +476,23 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
   }
   HIPCHK(hipGetLastError());
   int rc = fetch_info(c, st);
-  if (!rc && !(use_generic() || n <= 2 * LB)) { c->D.hinv_tag = A; c->D.hinv_n = n; }
+  if (!rc && !use_generic()) { c->D.hinv_tag = A; c->D.hinv_n = n; }
   return rc;
 }
 // potrs with the factor of dense_potrf.  A single right-hand side of a factor produced by the blocked dense_potrf
 // (its diagonal-block inverses are still cached) runs as 2 * ceil(n / 64) block steps over the chip.
 static int potrs_impl(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs, int64_t ldb, hipStream_t st) {
   DeviceCtx& D = c->D;
+  static int olds = -1;
+  if (olds < 0) { const char* e = getenv("SMCP_POTRS_OLD"); olds = (e && e[0] == '1') ? 1 : 0; }
+  if (olds) {
+    launch(c, KID_dense_potrs, k_dense_potrs, dim3(1), dim3(1024), st, A, (int)n, lda, B, (int)nrhs, ldb);
+    return 0;
+  }
+  if (nrhs == 1 && D.hinv_tag == A && D.hinv_n == n && n <= 2 * LB) {
+    launch(c, KID_dense_potrs, k_dense_potrs_small, dim3(1), dim3(256), st, A, (int)n, lda, (const double*)D.hinv, B);
+    return 0;
+  }
   if (nrhs == 1 && D.hinv_tag == A && D.hinv_n == n && n > 2 * LB) {
     const int64_t nblocks = (n + LB - 1) / LB;
     double* y = D.hinv + nblocks * LB * LB;      // forward solution
