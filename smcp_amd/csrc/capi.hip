@@ -44,7 +44,7 @@ enum {
   KID_lf_prep_s, KID_lf_prep_row, KID_lf_prep_k, KID_factor_yaa_lds,
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
-  KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16,
+  KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -60,7 +60,8 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_lf_prep_s", "k_lf_prep_row", "k_lf_prep_k", "k_factor_yaa_lds",
   "k_factor_inverse", "k_hess_down_inv_mfma<true>", "k_hess_down_inv_mfma<false>", "k_hess_up_inv_mfma<true>",
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
-  "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16"};
+  "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
+  "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt"};
 
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -443,7 +444,16 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
       if (lds) launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
-      else if (use_large() && ymode == 0) lf_down(c, a, cnt, nrhs, U, ldu, st);
+      else if (use_large() && (ymode == 0 || ymode == 3 || ymode == 2)) {
+        if (ymode && a.namax) {   // Q = R Ghat_AN (ymode 3) / R^T Ghat_AN (ymode 2) first, then the unscaled sweep
+          const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
+          launch(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), dim3(256), st, a, U, ldu, ymode == 2 ? 1 : 0);
+          launch(c, KID_lf_copy_an, k_lf_copy_an, dim3(umax1(std::min(64, (a.namax * a.nnmax + 255) / 256)), cnt, nrhs), dim3(256), st, a, U, ldu, 0);
+        }
+        MfmaArgs a2 = a;
+        a2.ymode = 0; a2.ysc = nullptr;
+        lf_down(c, a2, cnt, nrhs, U, ldu, st);
+      }
       else launch_lds(c, KID_hess_down_mfma_hbm, k_hess_down_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
     });
 }
@@ -852,6 +862,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       HIPCHK(hipFuncSetAttribute((const void*)k_pinv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_inv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_inv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_llt_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_completion_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(mx - INV_STATIC_LDS)));
     }
     if ((rc = dev_upload(&D.tmpptr, c->h_tmpptr, D.bytes))) return rc;
@@ -907,6 +918,23 @@ int csp_llt(csp_ctx* c, double* x, void* stream) {
   invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
+  if (!use_generic()) {
+    MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+    a0.LK = nullptr;
+    dim3 blk(256);
+    for (int64_t l = 0; l < c->S.nlev; ++l)
+      for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
+        if (lds) launch_lds(c, KID_llt_mfma, k_llt_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
+        else if (use_large()) {
+          const int mtA = tiles64(am.namax), ntN = tiles64(am.nnmax);
+          const int ntile = ntN * (ntN + 1) / 2 + mtA * ntN + mtA * (mtA + 1) / 2;
+          launch(c, KID_lf_llt, k_lf_llt, dim3(umax1(ntile), cnt), blk, st, am, x, 0);
+          launch(c, KID_lf_llt, k_lf_llt, dim3(umax1(ntile), cnt), blk, st, am, x, 1);
+          lf_assemble(c, am, cnt, 1, x, 0, 2, st);
+          if (am.namax) launch(c, KID_lf_pack_upd, k_lf_pack_upd, dim3(umax1(std::min(64, (am.namax * am.namax + 255) / 256)), cnt), blk, st, am);
+        } else launch_lds(c, KID_llt_mfma_hbm, k_llt_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
+      });
+  } else
   for_levels_up(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
     launch(c, KID_llt_level, k_llt_level, dim3(cnt), dim3(NT), st, a, x);

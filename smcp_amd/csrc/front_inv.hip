@@ -282,4 +282,54 @@ __global__ void k_completion_mfma(MfmaArgs a, double* x) {
   }
 }
 
+// ---------------------------------------------------------------- llt: X = L L^T on V (leaves -> root)
+// X_NN = L_NN L_NN^T + children ; X_AN = L_AN L_NN^T + children ; update = L_AN L_AN^T + children
+template <bool LDS>
+__global__ void k_llt_mfma(MfmaArgs a, double* x) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  Work w = make_work<LDS>(a, d, smem, k, 0);
+  double* P = x + d.blk;
+  double* UkG = a.t.upd + d.upd;
+  double* UkP = a.t.updp + d.updp;
+  if (LDS) {
+    double* Fl = w.F; const int ldfl = w.ldf;
+    batched_loop<8>(threadIdx.x, nf * nn, blockDim.x, [=](int e) { return P[e]; },
+                    [=](int e, double v) { Fl[(e % nf) + (e / nf) * ldfl] = v; });
+  } else {
+    w.F = P;
+    w.U = UkG;
+  }
+  __syncthreads();
+  const Work v = w;
+  auto lnnT = [=](int kk, int n) { return n >= kk ? v.F[n + kk * v.ldf] : 0.0; };     // (L_NN^T)[kk][n]
+  wg_mma(nn, nn, nn, [=](int m, int kk) { return m >= kk ? v.F[m + kk * v.ldf] : 0.0; }, lnnT,
+         [=](int m, int n, double acc) { if (m >= n) v.T[m + n * v.ldt] = acc; }, true);
+  wg_mma(na, nn, nn, [=](int m, int kk) { return v.F[nn + m + kk * v.ldf]; }, lnnT,
+         [=](int m, int n, double acc) { v.E[m + n * v.lde] = acc; }, false, 2);
+  wg_mma(na, na, nn, [=](int m, int kk) { return v.F[nn + m + kk * v.ldf]; },
+         [=](int kk, int n) { return v.F[nn + n + kk * v.ldf]; },
+         [=](int m, int n, double acc) { if (m >= n) v.U[m + n * v.ldu] = acc; }, true, 5);
+  __syncthreads();
+  for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
+    const int i = e % nf, j = e / nf;
+    if (i >= nn) v.F[i + j * v.ldf] = v.E[(i - nn) + j * v.lde];
+    else if (i >= j) v.F[i + j * v.ldf] = v.T[i + j * v.ldt];
+  }
+  __syncthreads();
+  add_children_front(a.t, d, a.t.updp, v.F, v.ldf, v.U, v.ldu, 1.0, 1.0);
+  if (LDS) {
+    for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
+      const int i = e % nf, j = e / nf;
+      if (i >= j) P[e] = v.F[i + j * v.ldf];
+    }
+  }
+  for (int e = threadIdx.x; e < na * na; e += blockDim.x) {
+    const int i = e % na, j = e / na;
+    if (i >= j) UkP[pk_idx(i, j, na)] = v.U[i + j * v.ldu];
+  }
+}
+
 }  // namespace smcp

@@ -107,7 +107,8 @@ __device__ inline LfCtx lf_ctx(const MfmaArgs& a, double* u, int64_t ldu) {
 }
 
 // ---- phase 0: zero the update block and add the children (gather plan: one owner per position)
-// sgn 0: U = children, panel += children (U was cleared);  sgn 1: U += children, panel -= children
+// sgn 0: U = children, panel += children (U was cleared);  sgn 1: U += children, panel -= children;
+// sgn 2: U += children, panel += children
 __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
@@ -133,7 +134,7 @@ __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
     for (; cc < c1; ++cc) acc += ubase[a.t.gp_src[cc]];
     const int i = code & 0x7fff, j = (code >> 15) & 0x7fff;
     if (sgn) {
-      if (code & (1 << 30)) U[i + (int64_t)j * na] += acc; else P[i + (int64_t)j * nf] -= acc;
+      if (code & (1 << 30)) U[i + (int64_t)j * na] += acc; else P[i + (int64_t)j * nf] += (sgn == 2 ? acc : -acc);
     } else {
       if (code & (1 << 30)) U[i + (int64_t)j * na] = acc;     // U was cleared: plain store
       else P[i + (int64_t)j * nf] += acc;
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(256) k_lf_assemble_tiled(MfmaArgs a, double* u
     if (i < j) continue;
     const double v = T[(i - r0) + (j - c0) * LF_TR];
     if (j < nn) {
-      if (v != 0.0) P[i + (int64_t)j * nf] += sgn ? -v : v;
+      if (v != 0.0) P[i + (int64_t)j * nf] += (sgn == 1) ? -v : v;
     } else if (sgn) {
       if (v != 0.0) U[(i - nn) + (int64_t)(j - nn) * na] += v;
     } else {
@@ -943,6 +944,56 @@ __global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, in
                   [=](int kk, int n) { return kk >= n ? T[(nn - 1 - n) + (int64_t)(nn - 1 - kk) * nn] : 0.0; }, sA, sB);
       tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = -v; });
     }
+  }
+}
+
+// ---- llt, large fronts.  step 0: T = L_NN L_NN^T (lower), G = L_AN L_NN^T, U = L_AN L_AN^T (lower, assigned);
+// step 1: panel <- (T lower, G).  The children are added afterwards by the assemble kernel (sgn 2) and the update
+// block is published packed by k_lf_pack_upd.
+__global__ void __launch_bounds__(256) k_lf_llt(MfmaArgs a, double* x, int step) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, x, 0);
+  const int nn = c.nn, na = c.na, nf = c.nf;
+  const int mtA = tiles64(na), ntN = tiles64(nn);
+  const int nT = ntN * (ntN + 1) / 2, nG = mtA * ntN, nU = mtA * (mtA + 1) / 2;
+  const int t = blockIdx.x;
+  if (t >= nT + nG + nU) return;
+  double* Pw = c.P;
+  if (step == 1) {
+    if (t >= nT + nG) return;
+    int tm, tn;
+    if (t < nT) lower_pair(t, tm, tn); else { tm = (t - nT) % mtA; tn = (t - nT) / mtA; }
+    for (int e = threadIdx.x; e < LT * LT; e += blockDim.x) {
+      const int m = tm * LT + (e & 63), n = tn * LT + (e >> 6);
+      if (t < nT) { if (m < nn && n < nn && m >= n) Pw[m + (int64_t)n * nf] = c.T[m + (int64_t)n * nn]; }
+      else if (m < na && n < nn) Pw[nn + m + (int64_t)n * nf] = c.G[m + (int64_t)n * na];
+    }
+    return;
+  }
+  const double* P = c.P;
+  auto lnnT = [=](int kk, int n) { return n >= kk ? P[n + (int64_t)kk * nf] : 0.0; };
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (t < nT) {
+    int tm, tn;
+    lower_pair(t, tm, tn);
+    const int m0 = tm * LT, n0 = tn * LT;
+    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : 0.0; }, lnnT, sA, sB);
+    double* T = c.T;
+    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) T[m + (int64_t)n * nn] = v; });
+  } else if (t < nT + nG) {
+    const int tt = t - nT, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
+    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, lnnT, sA, sB);
+    double* G = c.G;
+    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { G[m + (int64_t)n * na] = v; });
+  } else {
+    int tm, tn;
+    lower_pair(t - nT - nG, tm, tn);
+    const int m0 = tm * LT, n0 = tn * LT;
+    gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; },
+                [=](int kk, int n) { return P[nn + n + (int64_t)kk * nf]; }, sA, sB);
+    double* U = c.U;
+    tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) { if (m >= n) U[m + (int64_t)n * na] = v; });
   }
 }
 
