@@ -868,6 +868,10 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     if ((rc = dev_upload(&D.tmpptr, c->h_tmpptr, D.bytes))) return rc;
     if ((rc = dev_alloc(&D.yaa, S.updlen(), D.bytes))) return rc;
     if ((rc = dev_alloc(&D.fac, S.updlen(), D.bytes))) return rc;
+    if (!D.sw) {
+      if ((rc = dev_alloc(&D.sw, S.blklen(), D.bytes))) return rc;
+      hipLaunchKernelGGL(k_fill_sqrt_weights, dim3((unsigned)std::min<int64_t>(S.nsn, 4096)), dim3(256), 0, 0, D.cl, (int)S.nsn, D.sw);
+    }
     if ((rc = dev_alloc(&D.faci, S.updlen(), D.bytes))) return rc;
     if ((rc = dev_alloc(&D.red, 1024, D.bytes))) return rc;
     if ((rc = dev_alloc(&D.info, 4, D.bytes))) return rc;
@@ -1066,8 +1070,13 @@ int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, 
 }
 
 static int reduce_impl(csp_ctx* c, const double* X, const double* Y, int mode, double* out, hipStream_t st) {
-  int nb = (int)std::min<int64_t>(c->S.nsn, 512);
-  launch(c, KID_reduce_cliques, k_reduce_cliques, dim3(nb), dim3(NT), st, c->D.cl, (int)c->S.nsn, X, Y, mode, c->D.red);
+  int nb = 512;
+  if (c->D.sw && !use_generic()) {
+    launch(c, KID_reduce_cliques, k_reduce_flat, dim3(nb), dim3(NT), st, c->S.blklen(), (const double*)c->D.sw, X, Y, mode, c->D.red);
+  } else {
+    nb = (int)std::min<int64_t>(c->S.nsn, 512);
+    launch(c, KID_reduce_cliques, k_reduce_cliques, dim3(nb), dim3(NT), st, c->D.cl, (int)c->S.nsn, X, Y, mode, c->D.red);
+  }
   launch(c, KID_reduce_final, k_reduce_final, dim3(1), dim3(NT), st, c->D.red, nb, c->D.red + 512);
   HIPCHK(hipGetLastError());
   double* h = (double*)(c->D.info_host + 2);

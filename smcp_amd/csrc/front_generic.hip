@@ -504,6 +504,24 @@ __global__ void k_reduce_cliques(const CliqueDesc* cl, int nsn, const double* x,
   }
   if (SMCP_TID == 0) partial[blockIdx.x] = sh[0];
 }
+// the same reductions over the flat blkval with the inner-product weights read from sw (1 diagonal, sqrt 2
+// strictly lower, 0 unused upper): every workgroup takes a slice, so one huge front does not serialise
+__global__ void k_reduce_flat(int64_t len, const double* sw, const double* x, const double* y, int mode, double* partial) {
+  double acc = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * SMCP_NT + SMCP_TID; e < len; e += (int64_t)gridDim.x * SMCP_NT) {
+    const double s = sw[e];
+    if (mode == 0) { if (s != 0.0) { const double v = x[e] * y[e]; acc += (s == 1.0) ? v : 2.0 * v; } }
+    else if (s == 1.0) acc += log(x[e]);
+  }
+  __shared__ double sh[256];
+  sh[SMCP_TID] = acc;
+  __syncthreads();
+  for (int s2 = SMCP_NT / 2; s2 > 0; s2 >>= 1) {
+    if (SMCP_TID < s2) sh[SMCP_TID] += sh[SMCP_TID + s2];
+    __syncthreads();
+  }
+  if (SMCP_TID == 0) partial[blockIdx.x] = sh[0];
+}
 __global__ void k_reduce_final(const double* partial, int n, double* out) {
   __shared__ double sh[256];
   double acc = 0.0;

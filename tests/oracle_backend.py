@@ -23,7 +23,7 @@ def _np(X):
 class OracleKKT(kkt.ShardedSchur):
     """Same host-side sharding logic as the product's KKTSystem, compute by the CPU oracle."""
 
-    def __init__(self, symb, cptr, cidx, cval, max_rhs=None):
+    def __init__(self, symb, cptr, cidx, cval, max_rhs=None, tnzcols=None):
         self.symb = symb
         self.m = len(cptr) - 1
         self.K = orc.KKT(_S(symb), np.asarray(cptr), np.asarray(cidx), np.asarray(cval))
