@@ -1123,28 +1123,39 @@ constexpr int GRAM_BLK = 128;   // columns of H per block
 constexpr int GRAM_KS = 64;     // slice of the long dimension staged per step
 constexpr int GRAM_LD = GRAM_BLK + 1;
 
+template <bool DIAG>
 __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
                                                       const double* sw, int64_t chunk, double* partial, int coff,
-                                                      int nchunk_total) {
+                                                      int nchunk_total, int bi, int bj) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const sA = smem;
-  double* const sB = smem + GRAM_KS * GRAM_LD;   // only allocated when the launch has off-diagonal blocks
-  // block (bi, bj), bi >= bj, from the linear index blockIdx.y
-  int bi = 0, rem = blockIdx.y;
-  while (rem > bi) { rem -= bi + 1; ++bi; }
-  const int bj = rem;
-  const bool diag = bi == bj;
+  double* const sB = DIAG ? smem : smem + GRAM_KS * GRAM_LD;
+  // block (bi, bj), bi >= bj (DIAG: bi == bj), one launch per block; its index in the partial buffer is that of the
+  // lower-triangular enumeration
+  const int blk = bi * (bi + 1) / 2 + bj;
   const int ci0 = bi * GRAM_BLK, cj0 = bj * GRAM_BLK;
   const int ni = min(GRAM_BLK, m - ci0), nj = min(GRAM_BLK, m - cj0);
   const int mti = (ni + 15) >> 4, mtj = (nj + 15) >> 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l15 = lane & 15, kq = lane >> 4;
-  // tiles of this block owned by this wave (lower tiles only on diagonal blocks): up to 16 per wave
-  constexpr int MAXT = 16;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // tiles of this block owned by this wave, decoded once (compile-time accumulator indices keep them in registers)
+  constexpr int MAXT = DIAG ? 9 : 16;
+  int tms[MAXT], tns[MAXT];
+  const int ntile = DIAG ? mti * (mti + 1) / 2 : mti * mtj;
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    int p = wave + 4 * i;
+    if (p >= ntile) { tms[i] = -1; tns[i] = 0; continue; }
+    if (DIAG) { int tm = 0; while (p > tm) { p -= tm + 1; ++tm; } tms[i] = tm; tns[i] = p; }
+    else { tms[i] = p % mti; tns[i] = p / mti; }
+  }
   d4 acc[MAXT];
 #pragma unroll
-  for (int t = 0; t < MAXT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < MAXT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int e = threadIdx.x; e < (DIAG ? 1 : 2) * GRAM_KS * GRAM_LD; e += 256) smem[e] = 0.0;   // columns beyond the block stay zero
   const int64_t e_begin = e_lo + (int64_t)blockIdx.x * chunk, e_end = min(e_hi, e_begin + chunk);
+  const double* const la = sA + kq * GRAM_LD + l15;
+  const double* const lb = sB + kq * GRAM_LD + l15;
   for (int64_t e0 = e_begin; e0 < e_end; e0 += GRAM_KS) {
     __syncthreads();
     // stage sqrt(w) * G[e0 .. e0+64) for the columns of both blocks: one wave instruction = one column
@@ -1154,38 +1165,31 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
       const double swe = ein ? sw[e] : 0.0;
       batched_loop<16>(wave, ni, 4, [=](int c) { return ein ? G[(int64_t)(ci0 + c) * ldg + e] : 0.0; },
                        [=](int c, double v) { sA[lane * GRAM_LD + c] = v * swe; });
-      if (!diag)
+      if (!DIAG)
         batched_loop<16>(wave, nj, 4, [=](int c) { return ein ? G[(int64_t)(cj0 + c) * ldg + e] : 0.0; },
                          [=](int c, double v) { sB[lane * GRAM_LD + c] = v * swe; });
     }
     __syncthreads();
-    const double* pB = diag ? sA : sB;
-    int slot = 0;
-    for (int t = wave; t < mti * mtj; t += 4) {
-      const int tm = t % mti, tn = t / mti;
-      if (diag && tm < tn) continue;
-      const int ia = tm * 16 + l15, jb = tn * 16 + l15;
-      d4 a = acc[slot];
 #pragma unroll
-      for (int k0 = 0; k0 < GRAM_KS; k0 += 4) {
-        double av = (ia < ni) ? sA[(k0 + kq) * GRAM_LD + ia] : 0.0;
-        double bv = (jb < nj) ? pB[(k0 + kq) * GRAM_LD + jb] : 0.0;
-        a = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, a, 0, 0, 0);
-      }
-      acc[slot] = a;
-      ++slot;
+    for (int i = 0; i < MAXT; ++i) {
+      if (tms[i] < 0) continue;
+      const double* const pa = la + 16 * tms[i];
+      const double* const pb = lb + 16 * tns[i];
+      d4 a = acc[i];
+#pragma unroll
+      for (int s2 = 0; s2 < GRAM_KS / 4; ++s2)
+        a = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[s2 * 4 * GRAM_LD], pa[s2 * 4 * GRAM_LD], a, 0, 0, 0);
+      acc[i] = a;
     }
   }
-  // write partial tiles: layout [blockIdx.y][blockIdx.x][tile][256], tile elements column-major
-  const int ntile = mti * mtj;
-  double* out = partial + ((int64_t)blockIdx.y * nchunk_total + coff + blockIdx.x) * (int64_t)(64 * 256);
-  int slot = 0;
-  for (int t = wave; t < ntile; t += 4) {
-    const int tm = t % mti, tn = t / mti;
-    if (diag && tm < tn) continue;
+  // write partial tiles: layout [block][chunk][tile][256], tile elements column-major
+  double* out = partial + ((int64_t)blk * nchunk_total + coff + blockIdx.x) * (int64_t)(64 * 256);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[(int64_t)t * 256 + (kq + 4 * r) * 16 + l15] = acc[slot][r];
-    ++slot;
+  for (int i = 0; i < MAXT; ++i) {
+    if (tms[i] < 0) continue;
+    const int t = tms[i] + tns[i] * mti;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(int64_t)t * 256 + (kq + 4 * r) * 16 + l15] = acc[i][r];
   }
 }
 

@@ -579,9 +579,15 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
       launch_lds(c, KID_gram_partial, k_gram_diag128, dim3(nc, 1), dim3(256), (size_t)GRAM_KS * GRAM_LD * sizeof(double), st,
                  (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk);
     else
-    launch_lds(c, KID_gram_partial, k_gram_partial, dim3(nc, nblk), dim3(256),
-               (size_t)(nblk > 1 ? 2 : 1) * GRAM_KS * GRAM_LD * sizeof(double), st, (const double*)D.ustack, bl, (int)m, lo, hi,
-               (const double*)D.sw, chunk, D.gpart, coff, nchunk);
+      for (int bi = 0; bi < nb; ++bi)
+        for (int bj = 0; bj <= bi; ++bj) {
+          if (bi == bj)
+            launch_lds(c, KID_gram_partial, k_gram_partial<true>, dim3(nc), dim3(256), (size_t)GRAM_KS * GRAM_LD * sizeof(double), st,
+                       (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, bi, bj);
+          else
+            launch_lds(c, KID_gram_partial, k_gram_partial<false>, dim3(nc), dim3(256), (size_t)2 * GRAM_KS * GRAM_LD * sizeof(double), st,
+                       (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, bi, bj);
+        }
     coff += nc;
   }
   launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);

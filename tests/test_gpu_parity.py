@@ -241,3 +241,30 @@ def test_kkt_column_sparse_constraints(name, tnz):
     solve(bxd, byd, 1.0)
     assert rel(host(bxd)[msk], xr[msk]) < 1e-8
     assert rel(byd.cpu().numpy(), yr) < 1e-8
+
+
+def test_kkt_many_constraints():
+    """m > 128: the Gram matrix spans several 128-column blocks (diagonal and off-diagonal block kernels) and
+    H takes the blocked dense Cholesky / blocked triangular solves."""
+    symb, S, A, msk = setup("nested_mid", 21)
+    rng = np.random.default_rng(22)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    m = 150
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.02, seed=23)
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=64, tnzcols=0.0)
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    solve = sys.factor(Ld, Yd)
+    Hg = np.tril(sys.H.cpu().numpy().T)
+    assert rel(Hg, np.tril(Href)) < 1e-9
+    bx = rng.standard_normal(symb.blklen) * msk
+    by = rng.standard_normal(m)
+    xr, yr = K.solve(L, Yh, Href, bx, by, 0.5)
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    solve(bxd, byd, 0.5)
+    assert rel(host(bxd)[msk], xr[msk]) < 1e-8
+    assert rel(byd.cpu().numpy(), yr) < 1e-8
