@@ -59,7 +59,7 @@ def lds_fits(nn, na):
     pad = lambda x: x | 1
     lk, ll, lf = pad(na), pad(nn), pad(nn + na)
     d = lk * nn + ll * nn + lk * na + lf * nn + ll * nn + lk * nn + lk * nn + ll * nn + lk * na + 256 + 8
-    return d * 8 <= 160 * 1024 - 256
+    return d * 8 <= 160 * 1024 - 2048
 
 
 def main():
