@@ -86,6 +86,80 @@ class SDP:
         return solvers.chordalsolver_feas(self._A, self._b, primalstart, dualstart, scaling=scaling,
                                           kktsolver=kktsolver)
 
+    def solve_phase1(self, kktsolver="chol", MM=1e5):
+        """Primal Phase I with the feasible-start solver (reference: base.py:370-470, misc.phase1_sdp
+        misc.c:1004-1054).  Returns (X0, sol): a primal strictly feasible X0 (symmetric scipy matrix) and the
+        Phase-I solution dict (None when the least-norm solution of <A_i, X> = b_i is already feasible), or
+        (None, P1) with the Phase-I SDP object when no strictly feasible point was found."""
+        import scipy.sparse.linalg as spla
+
+        from . import chordal, solvers
+        n, m = self.n, self.m
+        k = 1e-3
+        A = sp.csc_matrix(self._A)
+        Id = np.arange(n) * (n + 1)
+        b = np.asarray(self._b, dtype=np.float64).reshape(-1)
+        # least-norm solution X = 1/2 sum_i u_i A_i with (As^T As) u = b, As = A scaled by 1/sqrt 2 on the diagonal rows
+        scale = np.ones(n * n)
+        scale[Id] = 1.0 / math.sqrt(2.0)
+        As = sp.diags(scale) @ A[:, 1:]
+        Mm = (As.T @ As).tocsc()
+        u = spla.spsolve(Mm, b) if m > 1 else b / Mm[0, 0]
+        x = 0.5 * (A[:, 1:] @ u)
+        V = self.V.tocoo()
+        X0 = sp.csc_matrix((x[V.row + V.col * n], (V.row, V.col)), shape=(n, n))     # lower triangle on the pattern
+        P = solvers._Problem(A, b)
+
+        def feasible(Xlow):
+            Xc = P.from_sym(Xlow)
+            try:
+                chordal.completion(Xc)
+                return True
+            except ArithmeticError:
+                return False
+
+        sym = lambda L_: L_ + sp.tril(L_, -1).T
+        if feasible(X0):
+            return sym(X0), None
+        # Phase-I SDP:  minimize  X'[n,n]  s.t.  <A_i, X> - tr(A_i) X'[n,n] = b_i - k tr(A_i),
+        #                                       tr(X) + X'[n+1,n+1] = MM,   X' = blkdiag(X, x_n, x_{n+1}) psd
+        trA = np.asarray(A[Id, 1:].sum(axis=0)).reshape(-1)
+        n2 = n + 2
+        rows, cols, vals = [n * n2 + n], [0], [1.0]
+        Ac = A[:, 1:].tocoo()
+        rows += list(Ac.row + 2 * (Ac.row // n)); cols += list(Ac.col + 1); vals += list(Ac.data)
+        rows += [n * n2 + n] * m; cols += list(range(1, m + 1)); vals += list(-trA)
+        rows += list(np.arange(n) * n2 + np.arange(n)) + [n2 * n2 - 1]; cols += [m + 1] * (n + 1); vals += [1.0] * (n + 1)
+        P1 = SDP()
+        P1._A = sp.csc_matrix((vals, (rows, cols)), shape=(n2 * n2, m + 2))
+        P1._b = np.concatenate([b - k * trA, [MM]])
+        P1._blockstruct = [n, -2]
+        # strictly feasible start of the Phase-I problem: X0 + t I completable (bisection on t), then lift
+        tmin, tmax = 0.0, 1.0
+        eye = sp.identity(n, format="csc")
+        while True:
+            t = 0.5 * (tmin + tmax)
+            if feasible(X0 + t * eye):
+                tmax = t
+                if tmax - tmin < 1e-1:
+                    break
+            else:
+                tmax *= 2.0
+                tmin = t
+        tt = t + 1.0
+        U = sym(X0) + tt * eye
+        trU = U.diagonal().sum()
+        Z0 = sp.block_diag([U, sp.diags([tt + k, MM - trU])], format="csc")
+        sol = P1.solve_feas(primalstart={"x": Z0}, kktsolver=kktsolver)
+        Xs = sp.csc_matrix(sol["x"])
+        s_ = Xs[n, n] - k
+        if s_ > 0:
+            return None, P1
+        sol.pop("y", None)
+        sol.pop("s", None)
+        X = sp.csc_matrix(sol.pop("x"))[:n, :n] - s_ * eye
+        return sp.csc_matrix(X), sol
+
     def write_sdpa(self, filename):
         sdpa_write(filename, self._A, self._b, self._blockstruct or [self.n])
 

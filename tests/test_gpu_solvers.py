@@ -170,3 +170,27 @@ def test_maxcut_config4_shape():
     assert np.linalg.norm(np.diag(sol["y"]) + S - Cd) < 1e-7 * (1 + np.abs(Cd).max())
     assert np.linalg.eigvalsh(S).min() > -1e-7
     assert abs(np.sum(Cd * X) - sol["y"].sum()) < 1e-5 * (1 + abs(sol["y"].sum()))
+
+
+def test_phase1_finds_strictly_feasible_point():
+    """Row N3: SDP.solve_phase1 (base.py:370-470, misc.phase1_sdp): when the least-norm solution of the
+    equality constraints is not positive definite, the Phase-I SDP solved by the feasible-start driver must
+    return a strictly feasible primal point, which then starts the main problem."""
+    from smcp_amd import base, chordal, solvers
+    solvers.options.update(show_progress=False, maxiters=100)
+    P = base.band_SDP(60, 20, 2, seed=4)
+    X0, sol1 = P.solve_phase1()
+    assert X0 is not None
+    assert sol1 is not None and sol1["status"] == "optimal"     # the least-norm point was infeasible: Phase-I SDP solved
+    n = P.n
+    Xd = np.asarray(X0.todense())
+    for i in range(P.m):                                    # <A_i, X0> = b_i
+        Ai = np.asarray(P.get_A(i + 1).todense())
+        assert abs(np.sum(Ai * Xd) - P.b[i]) < 1e-6 * (1 + abs(P.b[i]))
+    Pr = solvers._Problem(P.A, P.b)
+    Xc = Pr.from_sym(X0)
+    chordal.completion(Xc)                                  # strictly inside the cone of PSD-completable matrices
+    sol = P.solve_feas(primalstart={"x": X0}, scaling="primal")
+    assert sol["status"] == "optimal"
+    ref = P.solve_feas(scaling="dual", primalstart=_starts(P)[0], dualstart=_starts(P)[1])
+    assert abs(sol["primal objective"] - ref["primal objective"]) < 1e-4 * (1 + abs(ref["primal objective"]))
