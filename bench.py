@@ -244,8 +244,13 @@ def main():
         up_chunks = chunks if world == 1 else chunks
 
         def up_bytes(mask):
-            return sum(8.0 * (r * (2 * Bk[mask].sum() + Upk[mask].sum() + Upch[mask].sum()) + Bk[mask].sum())
-                       for r in up_chunks)
+            # the sweeps of the Schur complement (all chunks but the two single right-hand sides of solve_) build
+            # their input panels from the constraints' own entries: panels are written once, not read
+            tot = 0.0
+            for i, r in enumerate(up_chunks):
+                panel = (1 if i < len(up_chunks) - 2 else 2) * Bk[mask].sum()
+                tot += 8.0 * (r * (panel + Upk[mask].sum() + Upch[mask].sum()) + Bk[mask].sum())
+            return tot
 
         alg = {"k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
                "k_hess_up_pad": up_bytes(lds_ok),

@@ -204,6 +204,8 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.dbg = (a.skip & 64) ? (unsigned long long*)(c->D.red + 768) : nullptr;
   a.lfd = c->D.lfd;
   a.dn = 0; a.dld = 0;
+  a.kc_ptr = nullptr; a.kc_off = nullptr; a.kc_val = nullptr; a.kc_ids = nullptr;
+  a.kc_stride = 0; a.kc_j0 = 0;
   return a;
 }
 
@@ -420,8 +422,26 @@ bool try_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int g, double* U, int64_t l
   return false;
 }
 
-void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0) {
+// sparse_j0 >= 0: the right-hand sides are the constraints sparse_j0 .. (through `ids` if given) and are taken from
+// their per-clique entry lists (MfmaArgs::kc_*) -- U is output only and need not be cleared or scattered into
+void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0,
+                  int64_t sparse_j0 = -1, const int32_t* ids = nullptr) {
   MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
+  const bool sparse = sparse_j0 >= 0 && c->D.kc_ptr;
+  if (sparse) {
+    a0.kc_ptr = c->D.kc_ptr; a0.kc_off = c->D.kc_off; a0.kc_val = c->D.kc_val; a0.kc_ids = ids;
+    a0.kc_stride = (int)(c->D.m + 1); a0.kc_j0 = (int)sparse_j0;
+  }
+  // kernels that read their input from U get dense panels built first (zeros + the constraint's entries)
+  auto dense_input = [&](MfmaArgs& a, int cnt) {
+    if (!sparse) return;
+    for (int r0 = 0; r0 < nrhs; r0 += 65535) {
+      MfmaArgs af = a;
+      af.kc_j0 = a.kc_j0 + r0;
+      launch(c, KID_scatter_constraints, k_panel_fill, dim3(cnt, std::min(65535, nrhs - r0)), dim3(256), st, af, U + (int64_t)r0 * ldu, ldu);
+    }
+    a.kc_ptr = nullptr;
+  };
   for (int64_t l = 0; l < c->S.nlev; ++l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
@@ -430,12 +450,15 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         if (oldk < 0) { const char* e = getenv("SMCP_OLDLDS"); oldk = (e && e[0] == '1') ? 1 : 0; }
         size_t pbytes = (size_t)pad_layout(a.nnmax, a.namax, a.nchmax, a.panmax, a.pkmax, a.plansum).total * sizeof(double);
         if (!oldk && try_n16(c, a, cnt, nrhs, U, ldu, st)) {
-        } else if (!oldk && pbytes <= LDS_LIMIT)
+        } else if (!oldk && pbytes <= LDS_LIMIT) {
+          dense_input(a, cnt);
           launch_lds(c, KID_hess_up_pad, k_hess_up_pad, dim3(cnt, g), dim3(pbytes > 48 * 1024 ? 512 : 256), pbytes, st, a, U, ldu);
-        else
+        } else {
+          dense_input(a, cnt);
           launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
-      } else if (use_large() && c->D.gp_tptr) lf_up(c, a, cnt, nrhs, U, ldu, st);
-      else launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
+        }
+      } else if (use_large() && c->D.gp_tptr) { dense_input(a, cnt); lf_up(c, a, cnt, nrhs, U, ldu, st); }
+      else { dense_input(a, cnt); launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu); }
     }, set);
 }
 void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {

@@ -88,6 +88,10 @@ struct DeviceCtx {
   int32_t* slist = nullptr;  // ns : column-sparse constraints
   int32_t* kidx = nullptr;   // sum |K_s| : the column sets, concatenated in slist order
   int64_t md = 0, ns = 0;
+  // constraint entries grouped by clique (sparse input of the Schur-complement sweeps, MfmaArgs::kc_*)
+  int32_t* kc_ptr = nullptr; // nsn * (m + 1) : clique k, constraint j -> first entry
+  int32_t* kc_off = nullptr; // cnnz : position inside the clique's panel
+  double* kc_val = nullptr;  // cnnz
   double* vbuf = nullptr;    // n x vcols : S^-1[:, K_s] of the chunk in flight
   int64_t vcols = 0;
   double* hd = nullptr;      // md x md Gram block of the dense constraints (when ns > 0)

@@ -89,6 +89,12 @@ struct MfmaArgs {
   unsigned long long* dbg;  // diagnostic builds: cycle-stamp accumulator (null otherwise)
   double* lfd;              // 64 x 64 scratch per large front (inverse of the current diagonal block)
   int dn; int64_t dld;      // dense-matrix view (blocked Cholesky of the Schur complement): order, leading dimension
+  // Sparse input of the Schur-complement sweeps: right-hand side r is the constraint matrix A_j, j = kc_ids ?
+  // kc_ids[kc_j0 + r] : kc_j0 + r, given per clique k as the entries kc_ptr[k * kc_stride + j] .. [+1) of
+  // (kc_off: position inside the clique's panel, kc_val).  The sweep then never reads its input from u (u is output
+  // only), so the m x blklen stack needs neither clearing nor scattering.  null = dense input in u.
+  const int32_t* kc_ptr; const int32_t* kc_off; const double* kc_val; const int32_t* kc_ids;
+  int kc_stride, kc_j0;
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }
@@ -1164,10 +1170,10 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
       const bool ein = e < e_end;
       const double swe = ein ? sw[e] : 0.0;
       batched_loop<16>(wave, ni, 4, [=](int c) { return ein ? G[(int64_t)(ci0 + c) * ldg + e] : 0.0; },
-                       [=](int c, double v) { sA[lane * GRAM_LD + c] = v * swe; });
+                       [=](int c, double v) { sA[lane * GRAM_LD + c] = swe != 0.0 ? v * swe : 0.0; });
       if (!DIAG)
         batched_loop<16>(wave, nj, 4, [=](int c) { return ein ? G[(int64_t)(cj0 + c) * ldg + e] : 0.0; },
-                         [=](int c, double v) { sB[lane * GRAM_LD + c] = v * swe; });
+                         [=](int c, double v) { sB[lane * GRAM_LD + c] = swe != 0.0 ? v * swe : 0.0; });
     }
     __syncthreads();
 #pragma unroll
@@ -1238,7 +1244,7 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int cc = wave + 4 * j;
-      if (cc < ni) sA[lane * GRAM_LD + cc] = pre[j] * pre_sw;
+      if (cc < ni) sA[lane * GRAM_LD + cc] = pre_sw != 0.0 ? pre[j] * pre_sw : 0.0;   // weight 0: never-written entries
     }
     lds_barrier();
     if (e0 + GRAM_KS < e_end) fetch(e0 + GRAM_KS); // in flight while the MFMAs below run

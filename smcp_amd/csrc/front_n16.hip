@@ -152,11 +152,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
   bool pipe_ok = CH && nch > 0 && nch <= nw && npan <= PP * nthr && a.plansum > 0;
   if (pipe_ok)
     for (int q = 0; q < nch; ++q) pipe_ok = pipe_ok && (sCh[4 * q + 2] * (sCh[4 * q + 2] + 1) / 2 <= PC * 64);
+  const bool sp = a.kc_ptr != nullptr;         // sparse input: the panels are built from the constraint entries
   double pre_p[PP], pre_c[PC];
   auto prefetch = [&](int rr) {
     const double* P = u + (int64_t)rr * ldu + d.blk;
 #pragma unroll
-    for (int x = 0; x < PP; ++x) { const int e = tid + x * nthr; pre_p[x] = e < npan ? P[e] : 0.0; }
+    for (int x = 0; x < PP; ++x) { const int e = tid + x * nthr; pre_p[x] = (!sp && e < npan) ? P[e] : 0.0; }
     if (wave < nch) {
       const int nac = sCh[4 * wave + 2], np_ = nac * (nac + 1) / 2;
       const double* Uc = a.t.updp + (int64_t)rr * a.t.updplen + (((int64_t)sCh[4 * wave + 1] << 32) | (uint32_t)sCh[4 * wave]);
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
     for (int q = 0; q < 4; ++q) {
       const int rr = r0n + q * gy;
       pre_l[q] = pre_l2[q];
-      pre_l2[q] = (q < rb && rr < a.nrhs && tid < npan) ? u[(int64_t)rr * ldu + d.blk + tid] : 0.0;
+      pre_l2[q] = (!sp && q < rb && rr < a.nrhs && tid < npan) ? u[(int64_t)rr * ldu + d.blk + tid] : 0.0;
     }
   };
   if (pipe_ok && (int)blockIdx.y < a.nrhs) prefetch(blockIdx.y);
@@ -183,7 +184,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
     const int rbc = min(rb, (a.nrhs - r0 + gy - 1) / gy);   // right-hand sides r0, r0 + gy, ... of this pass
     lds_barrier();
     // ---- assemble the front(s): panel + children (lower triangles), then mirror F_NN
-    if (pipe_ok) {
+    if (sp) {
+      for (int e = tid; e < (LDN + LDA) * 16; e += nthr) smem[L.oFnn + e] = 0.0;     // F_NN and F_AN are adjacent
+    } else if (pipe_ok) {
 #pragma unroll
       for (int x = 0; x < PP; ++x) {
         const int e = tid + x * nthr;
@@ -210,6 +213,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
     }
     if (CH) for (int e = tid; e < npk; e += nthr) smem[sOut[e]] = 0.0;
     lds_barrier();
+    if (sp) {
+      // the constraint's entries of this clique (a handful): with children they are added concurrently with the
+      // children's atomics; without, both triangles of F_NN are written here and the mirror pass is skipped
+      const int32_t* kp = a.kc_ptr + (int64_t)k * a.kc_stride;
+      for (int q = 0; q < rbc; ++q) {
+        const int r = r0 + q * gy;
+        const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
+        const int qan = q * nn * LDA, qnn = q * nn * LDN;
+        for (int p = kp[j] + tid; p < kp[j + 1]; p += nthr) {
+          const int o = sPan[a.kc_off[p]];
+          if (o == NONE) continue;
+          const double v = a.kc_val[p];
+          if (CH) unsafeAtomicAdd(&smem[o], v);
+          else if (o >= L.oFan) smem[o + qan] = v;
+          else {
+            const int rel = o - L.oFnn, i = rel % LDN, jj = rel / LDN;
+            smem[o + qnn] = v;
+            smem[L.oFnn + jj + i * LDN + qnn] = v;
+          }
+        }
+      }
+    }
     if (CH) {
       if (pipe_ok) {
         if (wave < nch) {
@@ -231,8 +256,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
                           [=](int e, double vv) { unsafeAtomicAdd(&smem[tg[e]], vv); });
         }
         lds_barrier();
-      }
+      } else if (sp) lds_barrier();
     }
+    if (CH || !sp)
     for (int q = 0; q < rbc; ++q) {              // mirror the strict lower triangle of each F_NN
       double* Fq = smem + L.oFnn + q * nn * LDN;
       for (int e = tid; e < nn * nn; e += nthr) {
@@ -348,6 +374,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
       for (int e = tid; e < npk; e += nthr) UkP[e] = smem[sOut[e]];
     }
   }
+}
+
+// Dense input panels for the cliques of one launch whose sweep kernel reads its input from u: panel of (clique,
+// rhs r) <- A_j restricted to the clique (zeros + the constraint's entries), j as in MfmaArgs::kc_*.
+__global__ void k_panel_fill(MfmaArgs a, double* u, int64_t ldu) {
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int r = blockIdx.y;
+  double* P = u + (int64_t)r * ldu + d.blk;
+  const int npan = (d.nn + d.na) * d.nn;
+  for (int e = threadIdx.x; e < npan; e += blockDim.x) P[e] = 0.0;
+  __syncthreads();
+  const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
+  const int32_t* kp = a.kc_ptr + (int64_t)k * a.kc_stride;
+  for (int p = kp[j] + threadIdx.x; p < kp[j + 1]; p += blockDim.x) P[a.kc_off[p]] = a.kc_val[p];
 }
 
 }  // namespace smcp

@@ -280,17 +280,19 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   const Symbolic& S = c->S;
   HIPCHK(hipSetDevice(D.device));
   void* old[] = {D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack,
-                 D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd};
+                 D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val};
   for (void* p : old) if (p) hipFree(p);
   D.cptr = nullptr; D.cidx = nullptr; D.cval = nullptr; D.cwval = nullptr; D.rpos = nullptr;
   D.rptr = nullptr; D.rcon = nullptr; D.rval = nullptr; D.ustack = nullptr;
   D.a_r = D.a_c = D.s_rloc = D.s_cloc = D.dlist = D.slist = D.kidx = nullptr;
   D.vbuf = D.hd = nullptr;
+  D.kc_ptr = D.kc_off = nullptr; D.kc_val = nullptr;
   D.md = D.ns = D.vcols = 0;
   const int64_t nnz = cptr[m];
   // diagonal flags: position -> is it a diagonal entry of its NN block?
   std::vector<double> w(nnz);
   std::vector<int32_t> ar(nnz), ac(nnz);   // entries in (permuted) matrix coordinates
+  std::vector<int32_t> ek(nnz), eoff(nnz); // clique of each entry, position inside that clique's panel
   {
     // locate clique by binary search on blkptr
     for (int64_t e = 0; e < nnz; ++e) {
@@ -303,6 +305,8 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
       w[e] = (row == col) ? cval[e] : 2.0 * cval[e];
       ar[e] = (int32_t)S.rowidx[S.rowptr[k] + row];
       ac[e] = (int32_t)(S.snptr[k] + col);
+      ek[e] = (int32_t)k;
+      eoff[e] = (int32_t)off;
     }
   }
   // Column-sparse constraints (misc.nzcolumns / misc.matperm, misc.c:682-773, solvers.py:246-268): a constraint
@@ -384,8 +388,40 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
     if ((rc = dev_alloc(&D.vbuf, D.vcols * S.n, D.bytes))) return rc;
     if (D.md && (rc = dev_alloc(&D.hd, D.md * D.md, D.bytes))) return rc;
   }
+  // entries grouped by (clique, constraint): the sweeps of the Schur complement build their input panels from these
+  if (nnz < ((int64_t)1 << 31) && S.nsn * (m + 1) <= ((int64_t)1 << 28)) {
+    std::vector<int32_t> kptr((size_t)(S.nsn * (m + 1)) + 1, 0), koff(nnz);
+    std::vector<double> kval(nnz);
+    for (int64_t j = 0; j < m; ++j)
+      for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) kptr[(size_t)ek[e] * (m + 1) + j + 1]++;
+    // exclusive scan over (clique, constraint); slot (k, m) of a clique doubles as the start of clique k + 1
+    {
+      int64_t run = 0;
+      for (int64_t k = 0; k < S.nsn; ++k) {
+        for (int64_t j = 0; j <= m; ++j) {
+          const size_t idx = (size_t)k * (m + 1) + j;
+          const int32_t cnt = (j < m) ? kptr[idx + 1] : 0;
+          kptr[idx] = (int32_t)run;
+          if (j < m) run += cnt;
+        }
+      }
+    }
+    std::vector<int32_t> fill(kptr.begin(), kptr.end() - 1);
+    for (int64_t j = 0; j < m; ++j)
+      for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+        const int32_t q = fill[(size_t)ek[e] * (m + 1) + j]++;
+        koff[q] = eoff[e];
+        kval[q] = cval[e];
+      }
+    kptr.pop_back();
+    if ((rc = dev_upload(&D.kc_ptr, kptr, D.bytes))) return rc;
+    if ((rc = dev_upload(&D.kc_off, koff, D.bytes))) return rc;
+    if ((rc = dev_upload(&D.kc_val, kval, D.bytes))) return rc;
+  }
   D.ustack_cols = std::max(D.max_rhs, m);
   if ((rc = dev_alloc(&D.ustack, D.ustack_cols * S.blklen(), D.bytes))) return rc;
+  // entries the sweeps never write (strict upper triangles of the NN blocks) must stay finite
+  HIPCHK(hipMemset(D.ustack, 0, sizeof(double) * D.ustack_cols * S.blklen()));
   if (!D.sw) {
     if ((rc = dev_alloc(&D.sw, S.blklen(), D.bytes))) return rc;
     hipLaunchKernelGGL(k_fill_sqrt_weights, dim3((unsigned)std::min<int64_t>(S.nsn, 4096)), dim3(256), 0, 0, D.cl, (int)S.nsn, D.sw);
@@ -536,10 +572,12 @@ static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_
   const int64_t m = D.m, bl = c->S.blklen();
   prepare_yaa(c, Y, true, st);
   prep_lk_cached(c, L, Y, st);
-  HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * m * bl, st));
-  for (int64_t jb = 0; jb < m; jb += 65535)
-    launch(c, KID_scatter_constraints, k_scatter_constraints, dim3(8, (unsigned)std::min<int64_t>(65535, m - jb)),
-           dim3(256), st, jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
+  if (!D.kc_ptr) {   // the sweeps read their input from the stack: clear it and scatter the constraints into it
+    HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * m * bl, st));
+    for (int64_t jb = 0; jb < m; jb += 65535)
+      launch(c, KID_scatter_constraints, k_scatter_constraints, dim3(8, (unsigned)std::min<int64_t>(65535, m - jb)),
+             dim3(256), st, jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -604,7 +642,7 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     if (int rc = gram_prepare(c, L, Y, st)) return rc;
     for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
       int nr = (int)std::min(D.max_rhs, m - jb);
-      hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st);     // G(A_j) = (G_NN, R^T G_AN)
+      hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st, 0, D.kc_ptr ? jb : -1);     // G(A_j) = (G_NN, R^T G_AN)
     }
     const int64_t range[2] = {0, bl};
     if (int rc = gram_accumulate(c, 1, range, H, ldh, st)) return rc;
@@ -616,13 +654,15 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
   if (md) {
     prepare_yaa(c, Y, true, st);
     prep_lk_cached(c, L, Y, st);
-    HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * md * bl, st));
-    for (int64_t jb = 0; jb < md; jb += 65535)
-      launch(c, KID_scatter_constraints, k_scatter_constraints_ids, dim3(8, (unsigned)std::min<int64_t>(65535, md - jb)),
-             dim3(256), st, (const int32_t*)D.dlist + jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
+    if (!D.kc_ptr) {
+      HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * md * bl, st));
+      for (int64_t jb = 0; jb < md; jb += 65535)
+        launch(c, KID_scatter_constraints, k_scatter_constraints_ids, dim3(8, (unsigned)std::min<int64_t>(65535, md - jb)),
+               dim3(256), st, (const int32_t*)D.dlist + jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
+    }
     for (int64_t jb = 0; jb < md; jb += D.max_rhs) {
       int nr = (int)std::min(D.max_rhs, md - jb);
-      hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st);
+      hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st, 0, D.kc_ptr ? jb : -1, D.kc_ptr ? D.dlist : nullptr);
     }
     const int64_t range[2] = {0, bl};
     if (int rc = gram_accumulate(c, 1, range, D.hd, md, st, md)) return rc;
@@ -743,7 +783,7 @@ int kkt_gram_sweep(csp_ctx* c, int set, int64_t j0, int64_t j1, void* stream) {
   if (set < 0 || set > 2 || j0 < 0 || j1 > D.m || j1 <= j0 || j1 - j0 > D.max_rhs) return SMCP_EINVAL;
   if (set && !c->sets[set].lev2) return SMCP_EINVAL;
   const int64_t bl = c->S.blklen();
-  hess_up_fast(c, D.ustack + j0 * bl, (int)(j1 - j0), bl, D.fac, 2, (hipStream_t)stream, set);
+  hess_up_fast(c, D.ustack + j0 * bl, (int)(j1 - j0), bl, D.fac, 2, (hipStream_t)stream, set, D.kc_ptr ? j0 : -1);
   HIPCHK(hipGetLastError());
   return 0;
 }
