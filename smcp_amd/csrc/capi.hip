@@ -1168,8 +1168,8 @@ int64_t csp_profile_read(csp_ctx* c, double* ms, int64_t* count) {
 int csp_debug_stamps(csp_ctx* c, unsigned long long* out, int reset) {
   if (int rc = ready(c)) return rc;
   HIPCHK(hipDeviceSynchronize());
-  if (out) HIPCHK(hipMemcpy(out, c->D.red + 768, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  if (reset) HIPCHK(hipMemset(c->D.red + 768, 0, 16 * sizeof(unsigned long long)));
+  if (out) HIPCHK(hipMemcpy(out, c->D.red + 768, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(c->D.red + 768, 0, 32 * sizeof(unsigned long long)));
   return 0;
 }
 

@@ -180,9 +180,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
   if (pipe_ok && (int)blockIdx.y < a.nrhs) prefetch(blockIdx.y);
   if (lpipe) { prefetch_leaf(blockIdx.y); prefetch_leaf(blockIdx.y + gy * rb); }
 
+#ifdef SMCP_STAMPS   // diagnostic build only (SMCP_STAMPS=1 python -m smcp_amd.build --force; scratch/stamps2.py): cycle stamps of thread 0
+  const bool stamp = tid == 0 && a.dbg;
+  unsigned long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamp ? clock64() : 0;
+#define STAMP(i) do { if (stamp) { unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
   for (int r0 = blockIdx.y; r0 < a.nrhs; r0 += gy * rb) {
     const int rbc = min(rb, (a.nrhs - r0 + gy - 1) / gy);   // right-hand sides r0, r0 + gy, ... of this pass
     lds_barrier();
+    STAMP(0);
     // ---- assemble the front(s): panel + children (lower triangles), then mirror F_NN
     if (sp) {
       for (int e = tid; e < (LDN + LDA) * 16; e += nthr) smem[L.oFnn + e] = 0.0;     // F_NN and F_AN are adjacent
@@ -213,6 +221,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
     }
     if (CH) for (int e = tid; e < npk; e += nthr) smem[sOut[e]] = 0.0;
     lds_barrier();
+    STAMP(1);
     if (sp) {
       // the constraint's entries of this clique (a handful): with children they are added concurrently with the
       // children's atomics; without, both triangles of F_NN are written here and the mirror pass is skipped
@@ -258,6 +267,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
         lds_barrier();
       } else if (sp) lds_barrier();
     }
+    STAMP(2);
     if (CH || !sp)
     for (int q = 0; q < rbc; ++q) {              // mirror the strict lower triangle of each F_NN
       double* Fq = smem + L.oFnn + q * nn * LDN;
@@ -267,6 +277,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
       }
     }
     lds_barrier();
+    STAMP(3);
     // ---- phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place of F_AN) ; T = Li F_NN   (all stacked columns)
     for (int t = wave; t < NAT + 1; t += nw) {
       d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -287,6 +298,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
       }
     }
     lds_barrier();
+    STAMP(4);
     // ---- phase 2: U_q -= K E_q^T + E_q K^T (lower tiles, per stacked rhs) ; G = X BD (tile in place) ; G_NN = T BD (into F_NN)
     {
       const int nU = NU * rbc;
@@ -331,6 +343,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
       }
     }
     lds_barrier();
+    STAMP(5);
     // ---- phase 3: Q = Ysc G into the (dead) E buffer, or plain G
     for (int t = wave; t < NAT; t += nw) {
       double* const qo = cA + L.oE + 16 * t;
@@ -349,6 +362,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
       }
     }
     lds_barrier();
+    STAMP(6);
     // ---- write out: panel(s) (lower of NN + AN) and, with children, the update matrix (lower, packed)
     if (lpipe) {
       if (myPan >= 0) {
@@ -369,11 +383,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
         }
       }
     }
+    STAMP(7);
     if (CH) {
       double* UkP = a.t.updp + (int64_t)r0 * a.t.updplen + d.updp;
       for (int e = tid; e < npk; e += nthr) UkP[e] = smem[sOut[e]];
     }
+    STAMP(8);
   }
+#ifdef SMCP_STAMPS
+  if (stamp) for (int i = 0; i < 9; ++i) atomicAdd(a.dbg + i + 16 * (CH ? 1 : 0), tph[i]);
+#endif
+#undef STAMP
 }
 
 // Dense input panels for the cliques of one launch whose sweep kernel reads its input from u: panel of (clique,
