@@ -30,6 +30,14 @@ options = {
     "cholmod": False, "order": "AMD", "tnzcols": 0.1, "show_progress": True, "dimacs": True, "eta": None,
     "delta": 0.9, "alpha": 1e-1, "beta": 0.7, "minstep": 1e-8, "lifting": True, "t0": 1e-1,
     "equalsteps": True, "prediction": True, "step": 0.98,
+    # Two additions for chordalsolver_esd (not in the reference).  The reference refines only the outer
+    # 5-block Newton system and forms dS through the inverse Hessian (solvers.py:2017-2022, 2082-2086); with
+    # exactly that scheme the normal-equations solve loses A*x = by to cancellation once t ~ 1/mu is large
+    # (x = t*H(A'y - bx)) and the iterates stall at feasibility residuals of 1e-6..1e-7 on the band problems
+    # (same behaviour with the CPU oracle as backend).  One refinement step on the 2x2 KKT solve and dS from
+    # the dual-feasibility row (the variant the reference keeps commented out at solvers.py:2014-2016)
+    # restore convergence to the default tolerances in ~20 iterations.  Set (0, True) for the reference's scheme.
+    "esd_kkt_refinement": 1, "esd_ds_from_hessian": False,
 }
 _defaults = _copy.deepcopy(options)
 
@@ -168,6 +176,8 @@ def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", 
     REFINEMENT = _opt("refinement", int, 0)
     show_progress = _opt("show_progress", bool)
     DIMACS = _opt("dimacs", bool)
+    KKTREF = _opt("esd_kkt_refinement", int, 0)
+    DS_HESS = _opt("esd_ds_from_hessian", bool)
     if scaling not in ("primal", "dual"):
         raise ValueError("scaling must be 'primal' or 'dual'")
     if kktsolver != "chol":
@@ -252,6 +262,24 @@ def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", 
     def solve(bx, by):
         x, yy = bx.copy(), by.clone()
         st["f"](x, yy, st["kk"])
+        for _ in range(KKTREF):
+            r = x.copy()
+            hess(r, True)
+            r *= -st["kk"]
+            r += Aadj(yy)
+            r -= bx
+            rr = Amap(x) - by
+            st["f"](r, rr, st["kk"])
+            x -= r
+            yy = yy - rr
+        if DEBUG:   # the reference's KKT residual check (solvers.py:1801-1811, 1962-1966)
+            r = x.copy()
+            hess(r, True)
+            r *= -st["kk"]
+            r += Aadj(yy)
+            r -= bx
+            print("   KKTsolver: %.2e %.2e" % (math.sqrt(max(dot(r, r), 0.0)) / max(math.sqrt(dot(bx, bx)), 1e-300),
+                                              _nrm2(Amap(x) - by) / max(_nrm2(by), 1e-300)))
         return x, yy
 
     def newton_once(sigma, dz):
@@ -270,7 +298,7 @@ def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", 
             dtau = (rbz[4] - dkappa) * t * tau ** 2
         else:
             dtau = rbz[4] - dkappa / (t * kappa ** 2)
-        if options.get("esd_ds_from_hessian", True):
+        if DS_HESS:
             # the reference's choice (solvers.py:2017-2022, 2082-2086): dS through the inverse Hessian
             if scaling == "primal":
                 dS = dX * (-1.0 / t)

@@ -56,29 +56,25 @@ def test_band_sdp_config1_feas_primal_and_dual_scaling():
 
 
 def test_band_sdp_config1_via_conelp():
-    """Config 1 "via smcp.solvers.conelp": the same band SDP in CVXOPT cone-LP form (dims s=[n]),
-    which runs the self-dual-embedding driver.  The embedding has to drive infeasibility to zero
-    together with the gap; on these band problems this restatement of the driver plateaus between 1e-6
-    and 1e-7 (with the generic triangular-solve kernels and with the CPU oracle as backend alike), and
-    whether the relaxed tolerances below are crossed before the plateau (iteration ~20) or the run
-    wanders until maxiters depends on rounding-level differences in the dense Cholesky of H.  What this
-    test pins is the plumbing of the path (cone-LP form -> embedding -> chordal kernels): the iterate
-    it stops at must agree with the feasible-start solver's optimum and be nearly feasible."""
+    """Config 1 "via smcp.solvers.conelp": the same band SDP in CVXOPT cone-LP form (dims s=[n]), which runs
+    the self-dual-embedding driver, at the DEFAULT tolerances (feastol 1e-8, abstol/reltol 1e-6), both scalings
+    through the embedding driver; the optimum must agree with the feasible-start solver's."""
     from smcp_amd import base, solvers
-    solvers.options.update(show_progress=False, maxiters=60, feastol=1e-6, abstol=1e-5, reltol=1e-5)
-    try:
-        P = base.band_SDP(200, 100, 3, seed=0)
-        n, m = P.n, P.m
-        G = sp.hstack([sp.csc_matrix(P.get_A(i + 1).reshape((n * n, 1), order="F")) for i in range(m)]).tocsc()
-        h = np.asarray(P.get_A(0).todense()).reshape(-1, order="F")
-        sol = solvers.conelp(-P.b, G, h, {"l": 0, "q": [], "s": [n]})
-        assert sol["status"] in ("optimal", "unknown")
-        assert sol["primal infeasibility"] < 1e-3 and sol["dual infeasibility"] < 1e-3
-        ref = P.solve_feas(scaling="dual", primalstart=_starts(P)[0], dualstart=_starts(P)[1])
-        assert abs(sol["dual objective"] - ref["dual objective"]) < 1e-3 * (1 + abs(ref["dual objective"]))
-        assert abs(sol["primal objective"] - ref["dual objective"]) < 1e-3 * (1 + abs(ref["dual objective"]))
-    finally:
-        solvers.options.update(feastol=1e-8, abstol=1e-6, reltol=1e-6, maxiters=100)
+    solvers.options.update(show_progress=False, maxiters=100, feastol=1e-8, abstol=1e-6, reltol=1e-6)
+    P = base.band_SDP(200, 100, 3, seed=0)
+    n, m = P.n, P.m
+    G = sp.hstack([sp.csc_matrix(P.get_A(i + 1).reshape((n * n, 1), order="F")) for i in range(m)]).tocsc()
+    h = np.asarray(P.get_A(0).todense()).reshape(-1, order="F")
+    sol = solvers.conelp(-P.b, G, h, {"l": 0, "q": [], "s": [n]})
+    assert sol["status"] == "optimal" and sol["iterations"] <= 40
+    assert sol["primal infeasibility"] <= 1e-8 and sol["dual infeasibility"] <= 1e-8
+    ref = P.solve_feas(scaling="dual", primalstart=_starts(P)[0], dualstart=_starts(P)[1])
+    assert abs(sol["dual objective"] - ref["dual objective"]) < 1e-5 * (1 + abs(ref["dual objective"]))
+    assert abs(sol["primal objective"] - ref["dual objective"]) < 1e-5 * (1 + abs(ref["dual objective"]))
+    for sc in ("primal", "dual"):
+        se = P.solve_esd(scaling=sc)
+        assert se["status"] == "optimal" and se["iterations"] <= 40
+        _certify(P, se)
 
 
 def test_reference_conelp_example():
@@ -92,13 +88,8 @@ def test_reference_conelp_example():
                   [5., 0., -15., 12., -6., 17., 0., 0., 0., -1., 9., 6., -6., 6., -7., -7., -6., -7., -11.]]).T
     h = np.array([-3., 5., 12., -2., -14., -13., 10., 0., 0., 0., 68., -30., -19., -30., 99., 23., -19., 23., 10.])
     dims = {"l": 2, "q": [4, 4], "s": [3]}
-    # feastol one decade above the default: the embedding's last iterations hover around 1e-8 and
-    # whether 1e-8 is crossed depends on rounding (same behaviour with the CPU oracle backend)
-    solvers.options["feastol"] = 1e-7
-    try:
-        sol = solvers.conelp(c, G, h, dims)
-    finally:
-        solvers.options["feastol"] = 1e-8
+    solvers.options.update(feastol=1e-8, abstol=1e-6, reltol=1e-6)      # the defaults
+    sol = solvers.conelp(c, G, h, dims)
     assert sol["status"] == "optimal"
     x, s, z = sol["x"], sol["s"], sol["z"]
     assert np.linalg.norm(G @ x + s - h) < 1e-6 * (1 + np.linalg.norm(h))      # primal feasibility

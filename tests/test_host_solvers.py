@@ -67,6 +67,23 @@ def test_conelp_reference_example_and_lp():
     assert sol["status"] == "optimal" and abs(cl @ sol["x"] - ref.fun) < 1e-5 * (1 + abs(ref.fun))
 
 
+def test_esd_band_default_tolerances_both_scalings():
+    """The embedding driver reaches the reference's default tolerances (feastol 1e-8, abstol/reltol 1e-6,
+    solvers.py:22-44) on band problems with either scaling; with the reference's exact refinement scheme
+    (options esd_kkt_refinement=0, esd_ds_from_hessian=True) the same runs stall near 1e-6 feasibility."""
+    with oracle_backend():
+        for (n, m, bw) in ((60, 20, 3), (100, 50, 5)):
+            P = base.band_SDP(n, m, bw, seed=0)
+            ref = P.solve_feas(scaling="primal", primalstart={"x": sp.csc_matrix(np.tril(P._X0))},
+                               dualstart={"y": P._y0, "s": sp.csc_matrix(np.tril(P._S0))})
+            for sc in ("primal", "dual"):
+                sol = P.solve_esd(scaling=sc)
+                assert sol["status"] == "optimal" and sol["iterations"] <= 35
+                assert sol["primal infeasibility"] <= 1e-8 and sol["dual infeasibility"] <= 1e-8
+                assert abs(sol["primal objective"] - ref["primal objective"]) < 1e-5 * (1 + abs(ref["primal objective"]))
+                assert max(abs(v) for v in sol["dimacs"]) < 1e-6
+
+
 def test_infeasibility_certificates():
     """esd returns certificates (solvers.py:2299-2327).  As in the reference, conelp maps the cone LP
     onto the DUAL of the SDP pair and does not rename the status (solvers.py:2535-2597), so an
