@@ -16,6 +16,7 @@
 #include "front_large.hip"
 #include "front_inv.hip"
 #include "front_n16.hip"
+#include "front_fam.hip"
 
 using namespace smcp;
 
@@ -45,6 +46,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
+  KID_hess_up_fam,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -61,7 +63,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_factor_inverse", "k_hess_down_inv_mfma<true>", "k_hess_down_inv_mfma<false>", "k_hess_up_inv_mfma<true>",
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
-  "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt"};
+  "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam"};
 
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -206,6 +208,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.dn = 0; a.dld = 0;
   a.kc_ptr = nullptr; a.kc_off = nullptr; a.kc_val = nullptr; a.kc_ids = nullptr;
   a.kc_stride = 0; a.kc_j0 = 0;
+  a.level = 0; a.nS = 0; a.famna = a.fampan = a.fampk = a.famcna = 0;
   return a;
 }
 
@@ -227,6 +230,7 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f, int set = 0) {
     a.panmax = L.panmaxI;
     a.pkmax = L.pkmaxI;
     a.plansum = L.plansumI;
+    a.level = (int)l; a.nS = (int)L.nS; a.famna = L.famna; a.fampan = L.fampan; a.fampk = L.fampk; a.famcna = L.famcna;
     size_t lds = (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double);
     f(true, a, (int)L.nI, lds, lds > 48 * 1024 ? 512 : 256);
   }
@@ -422,6 +426,47 @@ bool try_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int g, double* U, int64_t l
   return false;
 }
 
+// family kernel (front_fam.hip) for the nS family parents at the tail of a level's LDS class
+template <int NAT, int NATC>
+bool launch_fam(csp_ctx* c, MfmaArgs a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  a.panmax = a.fampan;
+  a.pkmax = a.fampk;
+  const size_t bytes = fam_lds_bytes<NAT, NATC>(a.fampan, a.fampk);
+  if (bytes > LDS_LIMIT) return false;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k_hess_up_fam<NAT, NATC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    attr = true;
+  }
+  static int ncu = 0;
+  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, c->D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  // one workgroup per CU (LDS): split the right-hand sides so that the grid fills whole rounds; set-up ~ 3 passes
+  int g = 1;
+  int64_t best = -1;
+  for (int gc = 1; gc <= std::min(nrhs, 32); ++gc) {
+    const int64_t rounds = ((int64_t)cnt * gc + ncu - 1) / ncu;
+    const int64_t passes = (nrhs + gc - 1) / gc;
+    const int64_t cost = rounds * (passes + 3);
+    if (best < 0 || cost < best) { best = cost; g = gc; }
+  }
+  launch_lds(c, KID_hess_up_fam, k_hess_up_fam<NAT, NATC>, dim3(cnt, g), dim3(512), bytes, st, a, U, ldu);
+  return true;
+}
+bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  const int nat = std::max(1, (a.famna + 15) / 16), natc = std::max(1, (a.famcna + 15) / 16);
+  switch (nat * 2 + natc - 1) {
+    case 2: return launch_fam<1, 1>(c, a, cnt, nrhs, U, ldu, st);
+    case 3: return launch_fam<1, 2>(c, a, cnt, nrhs, U, ldu, st);
+    case 4: return launch_fam<2, 1>(c, a, cnt, nrhs, U, ldu, st);
+    case 5: return launch_fam<2, 2>(c, a, cnt, nrhs, U, ldu, st);
+    case 6: return launch_fam<3, 1>(c, a, cnt, nrhs, U, ldu, st);
+    case 7: return launch_fam<3, 2>(c, a, cnt, nrhs, U, ldu, st);
+    case 8: return launch_fam<4, 1>(c, a, cnt, nrhs, U, ldu, st);
+    case 9: return launch_fam<4, 2>(c, a, cnt, nrhs, U, ldu, st);
+  }
+  return false;
+}
+
 // sparse_j0 >= 0: the right-hand sides are the constraints sparse_j0 .. (through `ids` if given) and are taken from
 // their per-clique entry lists (MfmaArgs::kc_*) -- U is output only and need not be cleared or scattered into
 void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0,
@@ -444,6 +489,18 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
   };
   for (int64_t l = 0; l < c->S.nlev; ++l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
+      if (lds && sparse && a.nS > 0) {
+        // families: the childless members (level 0) are swept inside their parents' workgroups (k_hess_up_fam)
+        const int nS = a.nS;
+        a.nS = 0;
+        if (a.level > 0) {
+          MfmaArgs af = a;
+          af.t.lev = a.t.lev + (cnt - nS);
+          if (!try_fam(c, af, nS, nrhs, U, ldu, st)) fprintf(stderr, "smcp_amd: family kernel launch failed\n");
+        }
+        cnt -= nS;
+        if (cnt == 0) return;
+      }
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
       if (lds) {
         static int oldk = -1;
@@ -646,48 +703,116 @@ int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t l
 }
 
 
-// Splits the cliques selected by `keep` into per-level lists (LDS-class first, large fronts after) and
-// records the sizing maxima of each class.  lev2 is the concatenation of the lists, off[l] its start.
+bool fam_off() {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("SMCP_FAM"); off = (e && e[0] == '0') ? 1 : 0; }
+  return off == 1;
+}
+// dynamic LDS of the family kernel instantiation that serves (parent separator famna, child separator famcna)
+size_t fam_bytes_for(int famna, int famcna, int fampan, int fampk) {
+  const int nat = std::max(1, (famna + 15) / 16), natc = std::max(1, (famcna + 15) / 16);
+  switch (nat * 2 + natc - 1) {
+    case 2: return fam_lds_bytes<1, 1>(fampan, fampk);
+    case 3: return fam_lds_bytes<1, 2>(fampan, fampk);
+    case 4: return fam_lds_bytes<2, 1>(fampan, fampk);
+    case 5: return fam_lds_bytes<2, 2>(fampan, fampk);
+    case 6: return fam_lds_bytes<3, 1>(fampan, fampk);
+    case 7: return fam_lds_bytes<3, 2>(fampan, fampk);
+    case 8: return fam_lds_bytes<4, 1>(fampan, fampk);
+    case 9: return fam_lds_bytes<4, 2>(fampan, fampk);
+  }
+  return (size_t)1 << 30;
+}
+
+// Splits the cliques selected by `keep` into per-level lists (LDS-class first -- its family tail last --, large
+// fronts after) and records the sizing maxima of each class.  lev2 is the concatenation of the lists, off[l] its start.
 template <class Keep>
 void classify_levels(const Symbolic& S, Keep keep, std::vector<LevelClass>& lvl, std::vector<int32_t>& lev2,
                      std::vector<int64_t>& off) {
   lvl.assign(S.nlev, LevelClass());
   lev2.clear();
   off.assign(S.nlev + 1, 0);
+  auto fits = [&](int64_t k) { return (size_t)mfma_lds_doubles((int)S.nn(k), (int)S.na(k)) * sizeof(double) <= LDS_LIMIT; };
+  // pass 1: sizing of the LDS class of every level; the joint maxima may not fit even if every clique does: the
+  // level's LDS class is demoted to the large-front class then
+  std::vector<uint8_t> demoted(S.nlev, 0);
+  for (int64_t l = 0; l < S.nlev; ++l) {
+    int nnm = 0, nam = 0;
+    bool any = false;
+    for (int64_t q = S.levptr[l]; q < S.levptr[l + 1]; ++q) {
+      const int64_t k = S.levidx[q];
+      if (!keep(k) || !fits(k)) continue;
+      any = true;
+      nnm = std::max<int>(nnm, (int)S.nn(k));
+      nam = std::max<int>(nam, (int)S.na(k));
+    }
+    if (any && (size_t)mfma_lds_doubles(nnm, nam) * sizeof(double) > LDS_LIMIT) demoted[l] = 1;
+  }
+  auto small = [&](int64_t k) { return fits(k) && !demoted[S.level[k]]; };
+  // pass 2: families.  Parent: small front, nn <= 16, na <= 64, 1..8 children, every child kept, childless, small,
+  // nn <= 16, na <= 32; all candidates of a level or none (one launch geometry per level).
+  std::vector<uint8_t> special(S.nsn, 0);
+  if (!fam_off())
+    for (int64_t l = 1; l < S.nlev; ++l) {
+      std::vector<int64_t> cand;
+      int famna = 0, fampan = 0, fampk = 0, famcna = 0;
+      for (int64_t q = S.levptr[l]; q < S.levptr[l + 1]; ++q) {
+        const int64_t k = S.levidx[q];
+        if (!keep(k) || !small(k) || S.nn(k) > 16 || S.na(k) > 64) continue;
+        const int64_t nch = S.chptr[k + 1] - S.chptr[k];
+        if (nch < 1 || nch > 8) continue;
+        bool ok = true;
+        int cna = 0;
+        for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1] && ok; ++q2) {
+          const int64_t ch = S.chidx[q2];
+          ok = keep(ch) && S.chptr[ch + 1] == S.chptr[ch] && small(ch) && S.nn(ch) <= 16 && S.na(ch) <= 32 && S.na(ch) >= 1;
+          cna = std::max<int>(cna, (int)S.na(ch));
+        }
+        if (!ok) continue;
+        cand.push_back(k);
+        famna = std::max<int>(famna, (int)S.na(k));
+        fampan = std::max<int>(fampan, (int)(S.nf(k) * S.nn(k)));
+        fampk = std::max<int>(fampk, (int)(S.na(k) * (S.na(k) + 1) / 2));
+        famcna = std::max(famcna, cna);
+      }
+      if (cand.empty() || fam_bytes_for(famna, famcna, fampan, fampk) > LDS_LIMIT) continue;
+      LevelClass& L = lvl[l];
+      L.famna = famna; L.fampan = fampan; L.fampk = fampk; L.famcna = famcna;
+      for (int64_t k : cand) {
+        special[k] = 1;
+        for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) special[S.chidx[q2]] = 1;
+      }
+    }
+  // pass 3: the lists
   for (int64_t l = 0; l < S.nlev; ++l) {
     LevelClass& L = lvl[l];
     off[l] = (int64_t)lev2.size();
     int64_t b = S.levptr[l], e = S.levptr[l + 1];
-    for (int pass = 0; pass < 2; ++pass)
+    for (int pass = 0; pass < 3; ++pass)
       for (int64_t q = b; q < e; ++q) {
         int64_t k = S.levidx[q];
         if (!keep(k)) continue;
-        bool small = (size_t)mfma_lds_doubles((int)S.nn(k), (int)S.na(k)) * sizeof(double) <= LDS_LIMIT;
-        if (small == (pass == 0)) {
-          lev2.push_back((int32_t)k);
-          if (small) {
-            L.nI++;
-            L.nnmaxI = std::max<int>(L.nnmaxI, (int)S.nn(k));
-            L.namaxI = std::max<int>(L.namaxI, (int)S.na(k));
-            int64_t rs = 0;
-            for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) rs += S.na(S.chidx[q2]) * (S.na(S.chidx[q2]) + 1) / 2;
-            L.plansumI = (int)std::max<int64_t>(L.plansumI, rs);
-            L.nchmaxI = std::max<int>(L.nchmaxI, (int)(S.chptr[k + 1] - S.chptr[k]));
-            L.panmaxI = std::max<int>(L.panmaxI, (int)(S.nf(k) * S.nn(k)));
-            L.pkmaxI = std::max<int>(L.pkmaxI, (int)(S.na(k) * (S.na(k) + 1) / 2));
-          } else {
-            L.nII++;
-            L.nnmaxII = std::max<int>(L.nnmaxII, (int)S.nn(k));
-            L.namaxII = std::max<int>(L.namaxII, (int)S.na(k));
-          }
+        const bool sm = small(k);
+        const int cls = sm ? (special[k] ? 1 : 0) : 2;
+        if (cls != pass) continue;
+        lev2.push_back((int32_t)k);
+        if (sm) {
+          L.nI++;
+          if (special[k]) L.nS++;
+          L.nnmaxI = std::max<int>(L.nnmaxI, (int)S.nn(k));
+          L.namaxI = std::max<int>(L.namaxI, (int)S.na(k));
+          int64_t rs = 0;
+          for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) rs += S.na(S.chidx[q2]) * (S.na(S.chidx[q2]) + 1) / 2;
+          L.plansumI = (int)std::max<int64_t>(L.plansumI, rs);
+          L.nchmaxI = std::max<int>(L.nchmaxI, (int)(S.chptr[k + 1] - S.chptr[k]));
+          L.panmaxI = std::max<int>(L.panmaxI, (int)(S.nf(k) * S.nn(k)));
+          L.pkmaxI = std::max<int>(L.pkmaxI, (int)(S.na(k) * (S.na(k) + 1) / 2));
+        } else {
+          L.nII++;
+          L.nnmaxII = std::max<int>(L.nnmaxII, (int)S.nn(k));
+          L.namaxII = std::max<int>(L.namaxII, (int)S.na(k));
         }
       }
-    // the joint maxima may not fit even if every clique does: demote the level's LDS class then
-    if (L.nI && (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double) > LDS_LIMIT) {
-      L.nII += L.nI; L.nI = 0;
-      L.nnmaxII = std::max(L.nnmaxII, L.nnmaxI); L.namaxII = std::max(L.namaxII, L.namaxI);
-      L.nnmaxI = L.namaxI = 0;
-    }
   }
   off[S.nlev] = (int64_t)lev2.size();
 }

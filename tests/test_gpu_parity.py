@@ -42,6 +42,14 @@ GPU_PATTERNS["nested_mid"] = lambda: problems.nested_block_arrow_pattern(nsub=2,
 GPU_PATTERNS["dense200"] = lambda: problems.band_pattern(200, 199)
 GPU_PATTERNS["arrow_thin"] = lambda: problems.block_arrow_pattern(6, 2, 150)   # thin cliques, separators beyond LDS
 GPU_PATTERNS["diag"] = lambda: problems.band_pattern(15, 0)          # LP case: every clique is 1 x 1
+# families (front_fam.hip: small parents swept together with their childless children): largest member sizes,
+# odd sizes with few children, and nine children per parent (one more than the waves of a workgroup: no family)
+GPU_PATTERNS["fam_max"] = lambda: problems.nested_block_arrow_pattern(nsub=1, nmid=3, nleaf_per_mid=8, leaf=(16, 32),
+                                                                      mid=(16, 64), top=(40, 50), root=60, seed=5)
+GPU_PATTERNS["fam_odd"] = lambda: problems.nested_block_arrow_pattern(nsub=2, nmid=4, nleaf_per_mid=5, leaf=(3, 17),
+                                                                      mid=(7, 33), top=(20, 30), root=40, seed=6)
+GPU_PATTERNS["fam_nine"] = lambda: problems.nested_block_arrow_pattern(nsub=1, nmid=2, nleaf_per_mid=9, leaf=(2, 9),
+                                                                       mid=(6, 20), top=(20, 20), root=30, seed=7)
 
 
 def setup(name, seed):
@@ -141,7 +149,7 @@ def test_trsm(name):
         assert rel(Bd.cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("name", ["arrow", "rand2", "nested_mid", "diag"])
+@pytest.mark.parametrize("name", ["arrow", "rand2", "nested_mid", "diag", "fam_max", "fam_odd", "fam_nine", "nested", "rand1"])
 def test_kkt_factor_and_solve(name):
     symb, S, A, msk = setup(name, 7)
     rng = np.random.default_rng(8)
