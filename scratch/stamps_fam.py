@@ -19,7 +19,8 @@ L_.csp_debug_stamps(symb.handle, None, 1)
 kkt.build_schur(L, Y, None)
 out = (ctypes.c_ulonglong * 32)()
 L_.csp_debug_stamps(symb.handle, out, 1)
-names = ['top-barrier', 'zero', 'parent-entries', 'child zero+scatter', 'child p1', 'child p2', 'child p3', 'child tail', 'wait children', 'mirror', 'p1', 'p2', 'p3', 'writeout']
-names = ['top-barrier', 'zero', 'parent-entries', 'child zero+scatter', 'child p1', 'child p2', 'child p3+prefetch', 'barrier(children)', 'mirror', 'p1', 'p2', 'p3', 'writeout']
-tot = sum(out[i] for i in range(13))
-print({names[i]: round(100.0 * out[i] / max(tot, 1), 1) for i in range(13)}, 'total cycles', tot)
+pn = ['stage barrier', 'mirror', 'p1', 'p2', 'p3', 'writeout', 'clear']
+cn = ['stage barrier', 'refresh+parent entries', 'children 0-3', 'children 4-7']
+tp = sum(out[i] for i in range(7)); tc = sum(out[16 + i] for i in range(4))
+print('parent group', {pn[i]: round(100.0 * out[i] / max(tp, 1), 1) for i in range(7)}, 'cycles', tp)
+print('child group ', {cn[i]: round(100.0 * out[16 + i] / max(tc, 1), 1) for i in range(4)}, 'cycles', tc)
