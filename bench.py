@@ -252,7 +252,19 @@ def main():
                 tot += 8.0 * (r * (panel + Upk[mask].sum() + Upch[mask].sum()) + Bk[mask].sum())
             return tot
 
-        alg = {"k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
+        # family kernel: one launch sweeps the family parents AND their childless children for all the right-hand
+        # sides of the Schur complement.  Its algorithmic bytes are those of the per-level formulation (SURVEY 8d:
+        # every update matrix written once and read once) although the children's updates never reach HBM here.
+        fam = symb.family_roles()
+        fam_mask = lds_ok & (fam > 0)
+
+        def fam_bytes():
+            tot = 0.0
+            for r in up_chunks[:-2]:
+                tot += 8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask].sum() + Upch[fam_mask].sum()) + Bk[fam_mask].sum())
+            return tot
+
+        alg = {"k_hess_up_fam": fam_bytes(), "k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
                "k_hess_up_pad": up_bytes(lds_ok),
                "k_hess_up_n16": up_bytes(lds_ok & (nn_ <= 16) & (na_ <= 64)),
                "k_hess_up_mfma<true>": cls_bytes(lds_ok), "k_hess_down_mfma<true>": cls_bytes(lds_ok),
@@ -275,6 +287,13 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "bytes_per_launch": per_launch, "avg_launch_us": round(1e6 * avg_s, 2),
                         "launches_per_step": dom_launches}
+            if dom == "k_hess_up_fam":
+                # bytes this kernel really has to move: output panels + the parents' packed updates + constants
+                moved = sum(8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask & (fam == 2)].sum()) + Bk[fam_mask].sum())
+                            for r in up_chunks[:-2]) / dom_launches
+                roofline["fused_min_bytes_per_launch"] = moved
+                roofline["note"] = ("algorithmic bytes are SURVEY 8d's per-level figure; the fused kernel keeps the "
+                                    "children's update matrices in LDS, so it moves fewer (fused_min_bytes_per_launch)")
         if args.verbose and rank == 0:
             for k, (t, c) in sorted(breakdown.items(), key=lambda kv: -kv[1][0]):
                 print("  %-26s %9.3f ms/step  %5d launches" % (k, t, c), file=sys.stderr)

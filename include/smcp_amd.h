@@ -46,7 +46,9 @@ enum {
   CSP_Q_PERM = 1, CSP_Q_IPERM = 2, CSP_Q_SNPTR = 3, CSP_Q_SNPAR = 4, CSP_Q_ROWPTR = 5,
   CSP_Q_ROWIDX = 6, CSP_Q_SEPPTR = 7, CSP_Q_RELIDX = 8, CSP_Q_BLKPTR = 9, CSP_Q_UPDPTR = 10,
   CSP_Q_CHPTR = 11, CSP_Q_CHIDX = 12, CSP_Q_LEVPTR = 13, CSP_Q_LEVIDX = 14, CSP_Q_CCSPTR = 15,
-  CSP_Q_SNODE = 16
+  CSP_Q_SNODE = 16,
+  CSP_Q_FAMILY = 17  /* nsn, after csp_device_init: 2 = small front swept together with its childless children in one
+                        workgroup (family kernel of the sparse-input Schur sweeps), 1 = such a child, 0 = neither */
 };
 int64_t csp_symbolic_query(const csp_ctx* ctx, int what, int64_t* out);
 

@@ -871,6 +871,11 @@ int64_t csp_symbolic_query(const csp_ctx* c, int what, int64_t* out) {
     case CSP_Q_LEVIDX: return put64(S.levidx);
     case CSP_Q_CCSPTR: return put64(S.ccsptr);
     case CSP_Q_SNODE: return put64(S.snode);
+    case CSP_Q_FAMILY: {
+      std::vector<int64_t> f = c->fam;
+      f.resize(S.nsn, 0);
+      return put64(f);
+    }
   }
   return SMCP_EINVAL;
 }
@@ -930,9 +935,11 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       int32_t slot = 0;
       std::vector<int32_t> lev3, large;
       c->lev_namax.assign(S.nlev, 0);
+      c->fam.assign(S.nsn, 0);
       for (int64_t l = 0; l < S.nlev; ++l) {
         const LevelClass& L = c->lvl[l];
         int64_t b = S.levptr[l];
+        for (int64_t q = L.nI - L.nS; q < L.nI; ++q) c->fam[lev2[b + q]] = l ? 2 : 1;
         for (int64_t q = 0; q < L.nI; ++q) lev3.push_back(lev2[b + q]);
         for (int64_t q = L.nI; q < L.nI + L.nII; ++q) { cl[lev2[b + q]].pad = slot++; large.push_back(lev2[b + q]); }
         c->lev_namax[l] = std::max(L.namaxI, L.namaxII);

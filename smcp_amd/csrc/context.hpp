@@ -160,6 +160,7 @@ struct csp_ctx {
   smcp::Profiler prof;
   std::vector<int64_t> h_tmpptr;
   std::vector<int> lev_namax;   // per level: largest separator (sizes the gather launches)
+  std::vector<int64_t> fam;     // per clique: family role (CSP_Q_FAMILY)
   std::vector<uint8_t> is_diag_cache;
   double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)
   std::vector<int64_t> h_kptr;          // ns + 1 : offsets into kidx, host copy for chunk planning

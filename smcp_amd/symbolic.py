@@ -185,6 +185,14 @@ class Symbolic:
         self._max_rhs = max(self._max_rhs, int(max_rhs))
         return self
 
+    def family_roles(self):
+        """Per clique, after device_init: 2 = small front swept in one workgroup together with its childless
+        children by the family kernel of the sparse-input Schur sweeps (csrc/front_fam.hip), 1 = such a child."""
+        L = _lib.lib()
+        out = np.zeros(self.Nsn, dtype=np.int64)
+        L.csp_symbolic_query(self._h, 17, _ptr(out))
+        return out
+
     def device_bytes(self):
         return int(_lib.lib().csp_device_bytes(self._h))
 
