@@ -19,7 +19,7 @@ L_.csp_debug_stamps(symb.handle, None, 1)
 kkt.build_schur(L, Y, None)
 out = (ctypes.c_ulonglong * 32)()
 L_.csp_debug_stamps(symb.handle, out, 1)
-pn = ['stage barrier', 'mirror', 'p1', 'p2', 'p3', 'writeout', 'clear']
+pn = ['stage barrier', 'operands + E/X/T', 'U/G/G_NN tiles + stores', 'group barrier', 'Q', 'clear', '-']
 cn = ['stage barrier', 'refresh+parent entries', 'children 0-3', 'children 4-7']
 tp = sum(out[i] for i in range(7)); tc = sum(out[16 + i] for i in range(4))
 print('parent group', {pn[i]: round(100.0 * out[i] / max(tp, 1), 1) for i in range(7)}, 'cycles', tp)

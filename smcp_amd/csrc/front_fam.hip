@@ -16,30 +16,27 @@
 namespace smcp {
 
 struct FamL {   // LDS layout (doubles)
-  int oK, oBD, oE, oT, oB0, bw, oC, cw, oInt;
+  int oG, oB0, bw, oC, cw, oInt;
 };
-// one front buffer: F_NN | F_AN (adjacent, as in k_hess_up_n16) | U
+// one front buffer: F_NN | F_AN (adjacent) | U
 template <int NAT, int NATC>
 __host__ __device__ constexpr FamL fam_layout() {
   constexpr int NA = 16 * NAT, LDA = NA + 1, LDN = 17, LDC = 16 * NATC + 1;
   FamL L{};
   int o = 0;
-  L.oK = o; o += LDA * 16;
-  L.oBD = o; o += LDN * 16;
-  L.oE = o; o += LDA * 16;
-  L.oT = o; o += LDN * 16;
+  L.oG = o; o += LDA * 16;                    // G of the parent, transposed through LDS for the scaling product
   L.oB0 = o;
   L.bw = LDN * 16 + LDA * 16 + LDA * NA;
   o += 2 * L.bw;
-  L.oC = o;                                   // per child wave: F_NN (later T) | F_AN (later X, G) | E
-  L.cw = LDN * 16 + 2 * LDC * 16;
+  L.oC = o;                                   // per child wave: F_NN | F_AN (later G)
+  L.cw = LDN * 16 + LDC * 16;
   o += 4 * L.cw;
   L.oInt = o;
   return L;
 }
 template <int NAT, int NATC>
-__host__ inline size_t fam_lds_bytes(int panmax, int pkmax) {
-  return (size_t)(fam_layout<NAT, NATC>().oInt + 2 + (panmax + pkmax + 3) / 4 + 2) * sizeof(double);
+__host__ inline size_t fam_lds_bytes(int panmax, int /*pkmax*/) {
+  return (size_t)(fam_layout<NAT, NATC>().oInt + 2 + (panmax + 3) / 4 + 2) * sizeof(double);
 }
 
 // acc += Left * Right for one k-step: left = Left[row l15][k = kq + 4 s], right = Right[k = kq + 4 s][col l15];
@@ -94,7 +91,6 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
   const int nn = d.nn, na = d.na, nf = nn + na;
   int* const gcnt = reinterpret_cast<int*>(smem + L.oInt);          // parent-group barrier counter
   u16* const sPan = reinterpret_cast<u16*>(smem + L.oInt + 2);      // panel entry -> offset inside a front buffer
-  u16* const sOut = sPan + a.panmax;                                 // packed own update entry -> offset inside a buffer
   const int tid = threadIdx.x;
   const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,23 +108,6 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
     const int i = e % nf, j = e / nf;
     sPan[e] = (u16)((i >= nn) ? bFan + (i - nn) + j * LDA : (i >= j ? bFnn + i + j * LDN : NONE));
   }
-  for (int e = tid; e < npk; e += 512) {
-    int i, j;
-    pk_unpack(e, na, i, j);
-    sOut[e] = (u16)(bU + i + j * LDA);
-  }
-  __syncthreads();
-  {
-    const double* src = a.LK + d.blk;
-    double* const sK = smem + L.oK;
-    double* const sBD = smem + L.oBD;
-    batched_loop<8>(tid, npan, 512, [=](int e) { return src[e]; },
-                    [=](int e, double v) {
-                      const int i = e % nf, j = e / nf;
-                      if (i < nn) { if (i >= j) sBD[j + i * LDN] = v; }      // BD = Li^T
-                      else sK[(i - nn) + j * LDA] = v;
-                    });
-  }
   __syncthreads();
 
 #ifdef SMCP_STAMPS   // diagnostic build only (SMCP_STAMPS=1 python -m smcp_amd.build --force; scratch/stamps_fam.py)
@@ -142,7 +121,29 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
     // =====================================================================================================
     // parent group
     // =====================================================================================================
-    double yreg[4 * NAT];       // this wave's 16-row slice of the scaling operand (as k_hess_up_n16)
+    // Constants as MFMA operands in registers: K (all row tiles), Li, and this wave's 16-row slice of the scaling
+    // operand.  Every wave forms ALL tiles of E / X / T itself (20 MFMAs instead of 5): the result register rr of
+    // a tile is the operand of k-step rr of the next product, so phases 1 and 2 need no LDS exchange and no barrier.
+    double yreg[4 * NAT], kP[NAT][4], bdP[4];
+    {
+      const double* lk = a.LK + d.blk;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = kq + 4 * s;
+        bdP[s] = (l15 < nn && kk <= l15) ? lk[l15 + (int64_t)kk * nf] : 0.0;              // Li[l15][kk]
+#pragma unroll
+        for (int t = 0; t < NAT; ++t) {
+          const int m = 16 * t + l15;
+          kP[t][s] = (m < na && kk < nn) ? lk[(nn + m) + (int64_t)kk * nf] : 0.0;          // K[m][kk]
+        }
+      }
+    }
+    double kPm[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kk = kq + 4 * s, m = 16 * gw + l15;
+      kPm[s] = (m < na && kk < nn) ? a.LK[d.blk + (nn + m) + (int64_t)kk * nf] : 0.0;
+    }
 #pragma unroll
     for (int s2 = 0; s2 < 4 * NAT; ++s2) yreg[s2] = 0.0;
     if (ymode && gw < NAT) {
@@ -160,124 +161,133 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
         yreg[s2] = v;
       }
     }
-    const double* const aRowA = smem + l15 + kq * LDA;
-    const double* const bColA = smem + kq + l15 * LDA;
-    const double* const bColN = smem + kq + l15 * LDN;
-    double* const cA = smem + l15 + kq * LDA;
-    double* const cN = smem + l15 + kq * LDN;
-    // this thread's panel / packed-update entries e = gtid + 256 i: buffer offsets kept in registers, so the
-    // write-out and the clearing pass read no index table
-    constexpr int NPO = (NA + 16) * 16 / 256, NUO = (NA * (NA + 1) / 2 + 255) / 256;
-    u16 po[NPO], uo[NUO];
-#pragma unroll
-    for (int i = 0; i < NPO; ++i) { const int e = gtid + 256 * i; po[i] = e < npan ? sPan[e] : NONE; }
-#pragma unroll
-    for (int i = 0; i < NUO; ++i) { const int e = gtid + 256 * i; uo[i] = e < npk ? sOut[e] : NONE; }
     int gtarget = 0;
     for (int st = 0; st <= npass; ++st) {
       if (st > 0) {
         const int r = (int)blockIdx.y + (st - 1) * gy;
         const int oB = L.oB0 + ((st - 1) & 1) * L.bw;        // the front of this right-hand side
         const int oFnn = oB + bFnn, oFan = oB + bFan, oU = oB + bU;
-        for (int e = gtid; e < nn * nn; e += 256) {          // mirror the strict lower triangle of F_NN
-          const int i = e % nn, j = e / nn;
-          if (i > j) smem[oFnn + j + i * LDN] = smem[oFnn + i + j * LDN];
+        double* const P = u + (int64_t)r * ldu + d.blk;
+        double* const UkP = a.t.updp + (int64_t)r * a.t.updplen + d.updp;
+        // Wave gw owns row tile gw of the update matrix, of G and of Q.  It forms the E tiles 0..gw itself (the
+        // result register rr of a tile is the operand of k-step rr of the next product: no LDS exchange, no barrier
+        // before the update products); wave 0 also forms T and G_NN.
+        double ev[NAT][4], evm[4] = {0.0, 0.0, 0.0, 0.0}, xvm[4] = {0.0, 0.0, 0.0, 0.0};
+        d4 accT = {0.0, 0.0, 0.0, 0.0};
+        {
+          double fnn[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int kr = kq + 4 * s;                       // F_NN[kr][l15] from the lower triangle (symmetric)
+            fnn[s] = smem[oFnn + (kr >= l15 ? kr + l15 * LDN : l15 + kr * LDN)];
+          }
+#pragma unroll
+          for (int t = 0; t < NAT; ++t) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) ev[t][rr] = 0.0;
+            if (t <= gw && 16 * t < na) {
+              double fan[4];
+#pragma unroll
+              for (int s = 0; s < 4; ++s) fan[s] = smem[oFan + (16 * t + l15) + (kq + 4 * s) * LDA];
+              d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                if (s < ksn) fmma(acc, kP[t][s], fnn[s]);
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) ev[t][rr] = fan[rr] - 0.5 * acc[rr];       // E = F_AN - K F_NN / 2
+              if (t == gw) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { evm[rr] = ev[t][rr]; xvm[rr] = fan[rr] - acc[rr]; }   // X = F_AN - K F_NN
+              }
+            }
+          }
+          if (gw == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              if (s < ksn) fmma(accT, bdP[s], fnn[s]);
+          }
         }
-        group_barrier(gcnt, gtarget, lane, a.t.info);
         STAMP(1);
-        // phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place of F_AN) ; T = Li F_NN
-        for (int t = gw; t < NAT + 1; t += 4) {
-          d4 acc = {0.0, 0.0, 0.0, 0.0};
-          if (t < NAT) {
-            mma_pre(acc, aRowA + L.oK + 16 * t, 4 * LDA, bColN + oFnn, 4, ksn);
-            double* const f = cA + oFan + 16 * t;
-            double* const e = cA + L.oE + 16 * t;
+        // update tiles (gw, tn), tn <= gw: U_out = U_assembled - K E^T - E K^T, packed, straight to HBM; the LDS
+        // entries are cleared on the way for the right-hand side after next
+        if (gw < NAT && 16 * gw < na) {
+          const int m = 16 * gw + l15;
+#pragma unroll
+          for (int tn = 0; tn < NAT; ++tn) {
+            if (tn > gw) continue;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              if (s < ksn) {
+                fmma(acc, kPm[s], ev[tn][s]);
+                fmma(acc, evm[s], kP[tn][s]);
+              }
+            double* const up = smem + oU + m + (16 * tn + kq) * LDA;
+            double uv[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) uv[rr] = up[rr * 4 * LDA];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-              const double fv = f[rr * 4 * LDA];
-              e[rr * 4 * LDA] = fv - 0.5 * acc[rr];
-              f[rr * 4 * LDA] = fv - acc[rr];
+              const int n = 16 * tn + kq + 4 * rr;
+              if (m >= n) {
+                up[rr * 4 * LDA] = 0.0;
+                if (m < na) UkP[n * na - ((n * (n - 1)) >> 1) + (m - n)] = uv[rr] - acc[rr];
+              }
             }
-          } else {
-            mma_pre(acc, bColN + L.oBD, 4, bColN + oFnn, 4, ksn);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) (cN + L.oT)[rr * 4 * LDN] = acc[rr];
           }
-        }
-        group_barrier(gcnt, gtarget, lane, a.t.info);
-        STAMP(2);
-        // phase 2: U -= K E^T + E K^T (lower tiles) ; G = X BD (in place) ; G_NN = T BD (into F_NN)
-        for (int t = gw; t < NU + NAT + 1; t += 4) {
-          d4 acc = {0.0, 0.0, 0.0, 0.0};
-          if (t < NU) {
-            int tm = 0, rem = t;
-            while (rem > tm) { rem -= tm + 1; ++tm; }
-            const int tn = rem;
-            mma_pre(acc, aRowA + L.oK + 16 * tm, 4 * LDA, aRowA + L.oE + 16 * tn, 4 * LDA, ksn);
-            mma_pre(acc, aRowA + L.oE + 16 * tm, 4 * LDA, aRowA + L.oK + 16 * tn, 4 * LDA, ksn);
-            const int m = 16 * tm + l15;
-            double* const up = cA + oU + 16 * tm + 16 * tn * LDA;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-              if (m >= 16 * tn + kq + 4 * rr) up[rr * 4 * LDA] -= acc[rr];
-          } else if (t < NU + NAT) {
-            const int tm = t - NU;
-            mma_pre(acc, aRowA + oFan + 16 * tm, 4 * LDA, bColN + L.oBD, 4, ksn);
-            double* const g = cA + oFan + 16 * tm;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) g[rr * 4 * LDA] = acc[rr];
-          } else {
-            mma_pre(acc, smem + L.oT + l15 + kq * LDN, 4 * LDN, bColN + L.oBD, 4, ksn);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) (cN + oFnn)[rr * 4 * LDN] = acc[rr];
-          }
-        }
-        group_barrier(gcnt, gtarget, lane, a.t.info);
-        STAMP(3);
-        // phase 3: Q = Ysc G into the (dead) E buffer, or plain G
-        for (int t = gw; t < NAT; t += 4) {
-          double* const qo = cA + L.oE + 16 * t;
-          if (ymode) {
+          // G = X Li^T: row tile gw
+          {
             d4 acc = {0.0, 0.0, 0.0, 0.0};
-            const double* const pg = bColA + oFan;
-            double gv[4 * NAT];
 #pragma unroll
-            for (int s2 = 0; s2 < 4 * NAT; ++s2) gv[s2] = pg[4 * s2];
+            for (int s = 0; s < 4; ++s)
+              if (s < ksn) fmma(acc, xvm[s], bdP[s]);
+            if (ymode) {
 #pragma unroll
-            for (int s2 = 0; s2 < 4 * NAT; ++s2)      // R^T (ymode 2) is zero left of the diagonal block, R (3) right of it
-              if (s2 < ksa && !(ymode == 2 && s2 < 4 * t) && !(ymode == 3 && s2 >= 4 * (t + 1)))
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[s2], yreg[s2], acc, 0, 0, 0);
+              for (int rr = 0; rr < 4; ++rr) smem[L.oG + m + (kq + 4 * rr) * LDA] = acc[rr];
+            } else {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) qo[rr * 4 * LDA] = acc[rr];
-          } else {
-            const double* const g = cA + oFan + 16 * t;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) qo[rr * 4 * LDA] = g[rr * 4 * LDA];
+              for (int rr = 0; rr < 4; ++rr) {
+                const int n = kq + 4 * rr;
+                if (m < na && n < nn) P[(nn + m) + (int64_t)n * nf] = acc[rr];
+              }
+            }
           }
         }
-        group_barrier(gcnt, gtarget, lane, a.t.info);
-        STAMP(4);
-        // write out: the panel (lower of NN from F_NN, AN rows from the E buffer) and the packed update
-        {
-          double* P = u + (int64_t)r * ldu + d.blk;
-          double pv[NPO], uv[NUO];
+        // G_NN = T Li^T (lower), straight to HBM
+        if (gw == 0) {
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int i = 0; i < NPO; ++i) pv[i] = po[i] != NONE ? (po[i] < bFan ? smem[oB + po[i]] : smem[L.oE + (po[i] - bFan)]) : 0.0;
+          for (int s = 0; s < 4; ++s)
+            if (s < ksn) fmma(acc, accT[s], bdP[s]);
 #pragma unroll
-          for (int i = 0; i < NUO; ++i) uv[i] = uo[i] != NONE ? smem[oB + uo[i]] : 0.0;
-#pragma unroll
-          for (int i = 0; i < NPO; ++i) if (po[i] != NONE) P[gtid + 256 * i] = pv[i];
-          double* UkP = a.t.updp + (int64_t)r * a.t.updplen + d.updp;
-#pragma unroll
-          for (int i = 0; i < NUO; ++i) if (uo[i] != NONE) UkP[gtid + 256 * i] = uv[i];
+          for (int rr = 0; rr < 4; ++rr) {
+            const int jn = kq + 4 * rr;
+            if (l15 < nn && jn <= l15) P[l15 + (int64_t)jn * nf] = acc[rr];
+          }
         }
-        group_barrier(gcnt, gtarget, lane, a.t.info);
-        STAMP(5);
-        // clear the buffer for the right-hand side after next
-        for (int e = gtid; e < (LDN + LDA) * 16; e += 256) smem[oFnn + e] = 0.0;
+        STAMP(2);
+        group_barrier(gcnt, gtarget, lane, a.t.info);      // G complete; every wave is done with F_NN / F_AN
+        STAMP(3);
+        // Q = Ysc G (row tile gw), straight to HBM
+        if (ymode && gw < NAT && 16 * gw < na) {
+          double gv[4 * NAT];
 #pragma unroll
-        for (int i = 0; i < NUO; ++i) if (uo[i] != NONE) smem[oB + uo[i]] = 0.0;
-        STAMP(6);
+          for (int s2 = 0; s2 < 4 * NAT; ++s2) gv[s2] = smem[L.oG + (kq + 4 * s2) + l15 * LDA];
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s2 = 0; s2 < 4 * NAT; ++s2)      // R^T (ymode 2) is zero left of the diagonal block, R (3) right of it
+            if (s2 < ksa && !(ymode == 2 && s2 < 4 * gw) && !(ymode == 3 && s2 >= 4 * (gw + 1)))
+              fmma(acc, yreg[s2], gv[s2]);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int m = 16 * gw + l15, n = kq + 4 * rr;
+            if (m < na && n < nn) P[(nn + m) + (int64_t)n * nf] = acc[rr];
+          }
+        }
+        STAMP(4);
+        // clear F_NN / F_AN of this buffer for the right-hand side after next (U was cleared tile by tile above)
+        for (int e = gtid; e < (LDN + LDA) * 16; e += 256) smem[oFnn + e] = 0.0;
+        STAMP(5);
       }
       lds_barrier();        // stage boundary (whole workgroup)
       STAMP(0);
@@ -355,9 +365,8 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
         }
       }
     }
-    double* const cFnn = smem + L.oC + gw * L.cw;       // F_NN (full symmetric), then T
-    double* const cFan = cFnn + LDN * 16;               // F_AN, then X, then G
-    double* const cE = cFan + LDC * 16;
+    double* const cFnn = smem + L.oC + gw * L.cw;       // F_NN (full symmetric)
+    double* const cFan = cFnn + LDN * 16;               // F_AN, later G (transposed for the scaling product)
     // Entry lists of the sparse input.  Their two dependent global loads (range, then entries) would cost two
     // memory latencies per right-hand side, so: lane l of a wave keeps the entry ranges of pass 64 b + l (refreshed
     // every 64 passes) and the entries of the NEXT pass are fetched into registers (one per lane per child, one per
@@ -435,12 +444,21 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
               for (int p = p0[c] + 64 + lane; p < p1[c]; p += 64) put(a.kc_off[p], a.kc_val[p]);
             }
             wave_sync();
-            // phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place), T = Li F_NN (over F_NN)
+            // phases 1 and 2 in registers: the result register rr of a 16 x 16 tile (row l15, column kq + 4 rr) is
+            // exactly what the next product needs as its operand of k-step rr (row l15, k = kq + 4 rr), so E, X and T
+            // go from accumulator to operand without passing through LDS.
+            //   E = F_AN - K F_NN / 2, X = F_AN - K F_NN, T = Li F_NN;
+            //   update -(K E^T + E K^T) -> parent front (LDS atomics); G = X Li^T; G_NN = T Li^T
+            d4 accG[NATC], accN = {0.0, 0.0, 0.0, 0.0};
             {
               d4 accE[NATC], accT = {0.0, 0.0, 0.0, 0.0};
-              double fnn[4];
+              double fnn[4], fan[NATC][4];
 #pragma unroll
-              for (int s = 0; s < 4; ++s) fnn[s] = cFnn[(kq + 4 * s) + l15 * LDN];
+              for (int s = 0; s < 4; ++s) {
+                fnn[s] = cFnn[(kq + 4 * s) + l15 * LDN];
+#pragma unroll
+                for (int t = 0; t < NATC; ++t) fan[t][s] = cFan[(16 * t + l15) + (kq + 4 * s) * LDC];
+              }
 #pragma unroll
               for (int t = 0; t < NATC; ++t) {
                 accE[t] = d4{0.0, 0.0, 0.0, 0.0};
@@ -451,36 +469,25 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
 #pragma unroll
               for (int s = 0; s < 4; ++s)
                 if (s < ksnc) fmma(accT, bdreg[c][s], fnn[s]);
-              wave_sync();                               // every lane has its F_NN operands before T overwrites them
+              double ev[NATC][4], xv[NATC][4];
 #pragma unroll
               for (int t = 0; t < NATC; ++t)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                  const int idx = (16 * t + l15) + (kq + 4 * rr) * LDC;
-                  const double fv = cFan[idx];
-                  cE[idx] = fv - 0.5 * accE[t][rr];
-                  cFan[idx] = fv - accE[t][rr];
+                  ev[t][rr] = fan[t][rr] - 0.5 * accE[t][rr];
+                  xv[t][rr] = fan[t][rr] - accE[t][rr];
                 }
-#pragma unroll
-              for (int rr = 0; rr < 4; ++rr) cFnn[l15 + (kq + 4 * rr) * LDN] = accT[rr];
-            }
-            wave_sync();
-            // phase 2: update -(K E^T + E K^T) -> parent front (LDS atomics); G = X Li^T; G_NN = T Li^T
-            {
 #pragma unroll
               for (int tm = 0; tm < NATC; ++tm)
 #pragma unroll
                 for (int tn = 0; tn <= tm; ++tn) {
                   if (16 * tm >= nac_) continue;
                   d4 acc = {0.0, 0.0, 0.0, 0.0};
-                  double en[4], em[4];
-#pragma unroll
-                  for (int s = 0; s < 4; ++s) { en[s] = cE[(16 * tn + l15) + (kq + 4 * s) * LDC]; em[s] = cE[(16 * tm + l15) + (kq + 4 * s) * LDC]; }
 #pragma unroll
                   for (int s = 0; s < 4; ++s)
                     if (s < ksnc) {
-                      fmma(acc, kreg[c][tm][s], en[s]);
-                      fmma(acc, em[s], kreg[c][tn][s]);
+                      fmma(acc, kreg[c][tm][s], ev[tn][s]);
+                      fmma(acc, ev[tm][s], kreg[c][tn][s]);
                     }
                   const int ri = rm[c][tm];
 #pragma unroll
@@ -489,14 +496,6 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
                     if (ri >= 0 && rj >= 0 && 16 * tm + l15 >= 16 * tn + kq + 4 * rr) unsafeAtomicAdd(&smem[ptgt(ri, rj)], -acc[rr]);
                   }
                 }
-              d4 accG[NATC], accN = {0.0, 0.0, 0.0, 0.0};
-              double xv[NATC][4], tv[4];
-#pragma unroll
-              for (int s = 0; s < 4; ++s) {
-                tv[s] = cFnn[l15 + (kq + 4 * s) * LDN];
-#pragma unroll
-                for (int t = 0; t < NATC; ++t) xv[t][s] = cFan[(16 * t + l15) + (kq + 4 * s) * LDC];
-              }
 #pragma unroll
               for (int t = 0; t < NATC; ++t) {
                 accG[t] = d4{0.0, 0.0, 0.0, 0.0};
@@ -506,8 +505,8 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
               }
 #pragma unroll
               for (int s = 0; s < 4; ++s)
-                if (s < ksnc) fmma(accN, tv[s], bdreg[c][s]);
-              wave_sync();                               // all X operands read before G overwrites them
+                if (s < ksnc) fmma(accN, accT[s], bdreg[c][s]);
+              wave_sync();                               // every lane has read its F_AN values before G overwrites them
 #pragma unroll
               for (int rr = 0; rr < 4; ++rr) {
                 const int jn = kq + 4 * rr;
