@@ -449,7 +449,7 @@ bool launch_fam(csp_ctx* c, MfmaArgs a, int cnt, int nrhs, double* U, int64_t ld
     const int64_t cost = rounds * (passes + 3);
     if (best < 0 || cost < best) { best = cost; g = gc; }
   }
-  launch_lds(c, KID_hess_up_fam, k_hess_up_fam<NAT, NATC>, dim3(cnt, g), dim3(512), bytes, st, a, U, ldu);
+  launch_lds(c, KID_hess_up_fam, k_hess_up_fam<NAT, NATC>, dim3(cnt, g), dim3(768), bytes, st, a, U, ldu);
   return true;
 }
 bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {

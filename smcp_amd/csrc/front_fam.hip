@@ -3,7 +3,7 @@
 // of the Schur complement.  The per-level kernels (front_n16.hip) hand every child's update matrix to the parent
 // through HBM: na(na+1)/2 doubles written by the child and read back by the parent per right-hand side -- on
 // synth50k that is 5.7 of the 9 GB a Gram sweep moves.  Here the update matrices never exist in HBM:
-//   * waves 4..7 (the child group) each own up to two children.  A child's constants K, Li, R^T never change and
+//   * waves 4..11 (the child group) each own one child.  A child's constants K, Li, R^T never change and
 //     live in VGPRs as MFMA operands; its sweep runs out of a wave-private LDS scratch, the output panel is written
 //     straight from the accumulators and the update -K E^T - E K^T is added to the parent's front in LDS (ds_add_f64);
 //   * waves 0..3 (the parent group) run the phases of k_hess_up_n16<NAT, true> on the assembled front;
@@ -16,7 +16,7 @@
 namespace smcp {
 
 struct FamL {   // LDS layout (doubles)
-  int oG, oB0, bw, oC, cw, oInt;
+  int oK, oG, oB0, bw, oC, cw, oInt;
 };
 // one front buffer: F_NN | F_AN (adjacent) | U
 template <int NAT, int NATC>
@@ -24,13 +24,14 @@ __host__ __device__ constexpr FamL fam_layout() {
   constexpr int NA = 16 * NAT, LDA = NA + 1, LDN = 17, LDC = 16 * NATC + 1;
   FamL L{};
   int o = 0;
+  L.oK = o; o += LDA * 16;                    // K of the parent (operand of the E and update products)
   L.oG = o; o += LDA * 16;                    // G of the parent, transposed through LDS for the scaling product
   L.oB0 = o;
   L.bw = LDN * 16 + LDA * 16 + LDA * NA;
   o += 2 * L.bw;
   L.oC = o;                                   // per child wave: F_NN | F_AN (later G)
   L.cw = LDN * 16 + LDC * 16;
-  o += 4 * L.cw;
+  o += 8 * L.cw;
   L.oInt = o;
   return L;
 }
@@ -78,7 +79,7 @@ __device__ inline void mma_pre(d4& acc, const double* pa, int sa, const double* 
 }
 
 template <int NAT, int NATC>
-__global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int64_t ldu) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NA = 16 * NAT, LDA = NA + 1, LDN = 17, LDC = 16 * NATC + 1;
   constexpr FamL L = fam_layout<NAT, NATC>();
@@ -94,8 +95,9 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
   const int tid = threadIdx.x;
   const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool isP = wave < 4;                    // parent group: waves 0..3, child group: waves 4..7
-  const int gw = wave & 3, gtid = tid & 255;    // wave / thread index inside the group
+  const bool isP = wave < 4;                    // parent group: waves 0..3, child group: waves 4..11
+  const int gw = isP ? wave : wave - 4;         // wave index inside the group
+  const int gtid = isP ? tid : tid - 256;       // thread index inside the group
   const int ymode = a.ymode;
   const int npan = nf * nn, npk = na * (na + 1) / 2;
   const int nch = d.chend - d.chbeg;            // <= 8 (host guarantee)
@@ -103,10 +105,14 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
   const int ksn = (nn + 3) >> 2, ksa = (na + 3) >> 2;
   const int npass = ((int)a.nrhs - (int)blockIdx.y + gy - 1) / gy;
 
-  for (int e = tid; e < L.oInt + 2; e += 512) smem[e] = 0.0;    // pads must be (and stay) zero; counter = 0
-  for (int e = tid; e < npan; e += 512) {
+  for (int e = tid; e < L.oInt + 2; e += 768) smem[e] = 0.0;    // pads must be (and stay) zero; counter = 0
+  for (int e = tid; e < npan; e += 768) {
     const int i = e % nf, j = e / nf;
     sPan[e] = (u16)((i >= nn) ? bFan + (i - nn) + j * LDA : (i >= j ? bFnn + i + j * LDN : NONE));
+  }
+  for (int e = tid; e < npan; e += 768) {
+    const int i = e % nf, j = e / nf;
+    if (i >= nn) smem[L.oK + (i - nn) + j * LDA] = a.LK[d.blk + e];
   }
   __syncthreads();
 
@@ -124,18 +130,13 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
     // Constants as MFMA operands in registers: K (all row tiles), Li, and this wave's 16-row slice of the scaling
     // operand.  Every wave forms ALL tiles of E / X / T itself (20 MFMAs instead of 5): the result register rr of
     // a tile is the operand of k-step rr of the next product, so phases 1 and 2 need no LDS exchange and no barrier.
-    double yreg[4 * NAT], kP[NAT][4], bdP[4];
+    double yreg[4 * NAT], bdP[4];
     {
       const double* lk = a.LK + d.blk;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int kk = kq + 4 * s;
         bdP[s] = (l15 < nn && kk <= l15) ? lk[l15 + (int64_t)kk * nf] : 0.0;              // Li[l15][kk]
-#pragma unroll
-        for (int t = 0; t < NAT; ++t) {
-          const int m = 16 * t + l15;
-          kP[t][s] = (m < na && kk < nn) ? lk[(nn + m) + (int64_t)kk * nf] : 0.0;          // K[m][kk]
-        }
       }
     }
     double kPm[4];
@@ -161,8 +162,46 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
         yreg[s2] = v;
       }
     }
+    // The front's own constraint entries of right-hand side st go into the buffer the child group is assembling
+    // (atomics, concurrent with the children's).  Their two dependent global loads (range, then entries) would cost
+    // two memory latencies per right-hand side, so: lane l keeps the entry range of pass 64 b + l (refreshed every
+    // 64 passes) and the entries of the NEXT pass are fetched into registers (one per thread; longer lists finish
+    // with direct loads) once those of the current pass are consumed.
+    const int32_t* const kpp = a.kc_ptr + (int64_t)k * a.kc_stride;
+    int pp0 = 0, pp1 = 0, q_off = 0;
+    double q_val = 0.0;
+    bool pre_ok = false;
     int gtarget = 0;
     for (int st = 0; st <= npass; ++st) {
+      if (st < npass) {
+        const int sl = st & 63;
+        if (sl == 0) {
+          const int rl = (int)blockIdx.y + (st + lane) * gy;
+          pp0 = pp1 = 0;
+          if (rl < a.nrhs) {
+            const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + rl] : a.kc_j0 + rl;
+            pp0 = kpp[j]; pp1 = kpp[j + 1];
+          }
+          pre_ok = false;
+        }
+        const int q0 = __builtin_amdgcn_readlane(pp0, sl), q1 = __builtin_amdgcn_readlane(pp1, sl);
+        if (!pre_ok && gtid < q1 - q0) { q_off = a.kc_off[q0 + gtid]; q_val = a.kc_val[q0 + gtid]; }
+        const int oBn = L.oB0 + (st & 1) * L.bw;
+        if (gtid < q1 - q0) {
+          const int o = sPan[q_off];
+          if (o != NONE) unsafeAtomicAdd(&smem[oBn + o], q_val);
+        }
+        for (int p = q0 + 256 + gtid; p < q1; p += 256) {
+          const int o = sPan[a.kc_off[p]];
+          if (o != NONE) unsafeAtomicAdd(&smem[oBn + o], a.kc_val[p]);
+        }
+        pre_ok = sl != 63 && st + 1 < npass;
+        if (pre_ok) {
+          const int sn = (sl + 1) & 63;
+          const int q0n = __builtin_amdgcn_readlane(pp0, sn), q1n = __builtin_amdgcn_readlane(pp1, sn);
+          if (gtid < q1n - q0n) { q_off = a.kc_off[q0n + gtid]; q_val = a.kc_val[q0n + gtid]; }
+        }
+      }
       if (st > 0) {
         const int r = (int)blockIdx.y + (st - 1) * gy;
         const int oB = L.oB0 + ((st - 1) & 1) * L.bw;        // the front of this right-hand side
@@ -190,9 +229,12 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
 #pragma unroll
               for (int s = 0; s < 4; ++s) fan[s] = smem[oFan + (16 * t + l15) + (kq + 4 * s) * LDA];
               d4 acc = {0.0, 0.0, 0.0, 0.0};
+              double kt[4];
+#pragma unroll
+              for (int s = 0; s < 4; ++s) kt[s] = smem[L.oK + (16 * t + l15) + (kq + 4 * s) * LDA];
 #pragma unroll
               for (int s = 0; s < 4; ++s)
-                if (s < ksn) fmma(acc, kP[t][s], fnn[s]);
+                if (s < ksn) fmma(acc, kt[s], fnn[s]);
 #pragma unroll
               for (int rr = 0; rr < 4; ++rr) ev[t][rr] = fan[rr] - 0.5 * acc[rr];       // E = F_AN - K F_NN / 2
               if (t == gw) {
@@ -216,11 +258,14 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
           for (int tn = 0; tn < NAT; ++tn) {
             if (tn > gw) continue;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
+            double kt[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kt[s] = smem[L.oK + (16 * tn + l15) + (kq + 4 * s) * LDA];
 #pragma unroll
             for (int s = 0; s < 4; ++s)
               if (s < ksn) {
                 fmma(acc, kPm[s], ev[tn][s]);
-                fmma(acc, evm[s], kP[tn][s]);
+                fmma(acc, evm[s], kt[s]);
               }
             double* const up = smem + oU + m + (16 * tn + kq) * LDA;
             double uv[4];
@@ -297,9 +342,8 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
 #endif
   } else {
     // =====================================================================================================
-    // child group: wave gw owns children gw and gw + 4
+    // child group: wave gw owns child gw
     // =====================================================================================================
-    const int32_t* const kpp = a.kc_ptr + (int64_t)k * a.kc_stride;
     const int32_t* kpc[2];
     CliqueDesc cd[2];
     bool hasc[2];
@@ -307,9 +351,9 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
     double kreg[2][NATC][4], bdreg[2][4], ycreg[2][NATC][4 * NATC];
     int rm[2][NATC], rn[2][NATC][4];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      hasc[c] = gw + 4 * c < nch;
-      const int ck = hasc[c] ? a.t.chidx[d.chbeg + gw + 4 * c] : 0;
+    for (int c = 0; c < 1; ++c) {
+      hasc[c] = gw + 8 * c < nch;
+      const int ck = hasc[c] ? a.t.chidx[d.chbeg + gw + 8 * c] : 0;
       cd[c] = a.t.cl[ck];
       kpc[c] = a.kc_ptr + (int64_t)ck * a.kc_stride;
       nnc[c] = hasc[c] ? cd[c].nn : 0;
@@ -367,13 +411,10 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
     }
     double* const cFnn = smem + L.oC + gw * L.cw;       // F_NN (full symmetric)
     double* const cFan = cFnn + LDN * 16;               // F_AN, later G (transposed for the scaling product)
-    // Entry lists of the sparse input.  Their two dependent global loads (range, then entries) would cost two
-    // memory latencies per right-hand side, so: lane l of a wave keeps the entry ranges of pass 64 b + l (refreshed
-    // every 64 passes) and the entries of the NEXT pass are fetched into registers (one per lane per child, one per
-    // thread for the parent; longer lists finish with direct loads) once those of the current pass are consumed.
-    int cp0[2] = {0, 0}, cp1[2] = {0, 0}, pp0 = 0, pp1 = 0;
-    int e_off[2] = {0, 0}, q_off = 0;
-    double e_val[2] = {0.0, 0.0}, q_val = 0.0;
+    // entry lists of the child: ranges in the lanes, entries of the next pass prefetched (as in the parent group)
+    int cp0[2] = {0, 0}, cp1[2] = {0, 0};
+    int e_off[2] = {0, 0};
+    double e_val[2] = {0.0, 0.0};
     bool pre_ok = false;
     for (int st = 0; st <= npass; ++st) {
       if (st < npass) {
@@ -382,48 +423,32 @@ __global__ void __launch_bounds__(512) k_hess_up_fam(MfmaArgs a, double* u, int6
         const int sl = st & 63;
         if (sl == 0) {
           const int rl = r + lane * gy;
-          cp0[0] = cp1[0] = cp0[1] = cp1[1] = pp0 = pp1 = 0;
+          cp0[0] = cp1[0] = cp0[1] = cp1[1] = 0;
           if (rl < a.nrhs) {
             const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + rl] : a.kc_j0 + rl;
-            pp0 = kpp[j]; pp1 = kpp[j + 1];
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 1; ++c)
               if (hasc[c]) { cp0[c] = kpc[c][j]; cp1[c] = kpc[c][j + 1]; }
           }
           pre_ok = false;
         }
-        const int q0 = __builtin_amdgcn_readlane(pp0, sl), q1 = __builtin_amdgcn_readlane(pp1, sl);
         int p0[2], p1[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) { p0[c] = __builtin_amdgcn_readlane(cp0[c], sl); p1[c] = __builtin_amdgcn_readlane(cp1[c], sl); }
+        for (int c = 0; c < 1; ++c) { p0[c] = __builtin_amdgcn_readlane(cp0[c], sl); p1[c] = __builtin_amdgcn_readlane(cp1[c], sl); }
         if (!pre_ok) {
-          if (gtid < q1 - q0) { q_off = a.kc_off[q0 + gtid]; q_val = a.kc_val[q0 + gtid]; }
 #pragma unroll
-          for (int c = 0; c < 2; ++c)
+          for (int c = 0; c < 1; ++c)
             if (lane < p1[c] - p0[c]) { e_off[c] = a.kc_off[p0[c] + lane]; e_val[c] = a.kc_val[p0[c] + lane]; }
         }
         const bool more = sl != 63 && st + 1 < npass;      // the next pass exists and its ranges are in the lanes
         const int sn = (sl + 1) & 63;
-        // the parent's own constraint entries (the buffer was cleared by the parent group two stages ago)
-        if (gtid < q1 - q0) {
-          const int o = sPan[q_off];
-          if (o != NONE) unsafeAtomicAdd(&smem[oB + o], q_val);
-        }
-        for (int p = q0 + 256 + gtid; p < q1; p += 256) {
-          const int o = sPan[a.kc_off[p]];
-          if (o != NONE) unsafeAtomicAdd(&smem[oB + o], a.kc_val[p]);
-        }
-        if (more) {
-          const int q0n = __builtin_amdgcn_readlane(pp0, sn), q1n = __builtin_amdgcn_readlane(pp1, sn);
-          if (gtid < q1n - q0n) { q_off = a.kc_off[q0n + gtid]; q_val = a.kc_val[q0n + gtid]; }
-        }
         STAMP(1);
         // LDS offset of the parent-front position (ri, rj), ri >= rj
         auto ptgt = [&](int ri, int rj) -> int {
           return oB + (rj >= nn ? bU + (ri - nn) + (rj - nn) * LDA : (ri >= nn ? bFan + (ri - nn) + rj * LDA : bFnn + ri + rj * LDN));
         };
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < 1; ++c) {
           if (!hasc[c]) continue;
           double* const Pc = u + (int64_t)r * ldu + cd[c].blk;
           const int nnc_ = nnc[c], nac_ = nac[c], nfc_ = nfc[c];
