@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int6
   __syncthreads();
 
 #ifdef SMCP_STAMPS   // diagnostic build only (SMCP_STAMPS=1 python -m smcp_amd.build --force; scratch/stamps_fam.py)
-  const bool stamp = gtid == 0 && a.dbg;
+  const bool stamp = (isP ? gtid == 192 : gtid == 0) && a.dbg;   // parent wave 3 (the heaviest row), child wave 0
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamp ? clock64() : 0;
 #define STAMP(i) do { if (stamp) { unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; } } while (0)
 #else
