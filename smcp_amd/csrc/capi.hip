@@ -238,6 +238,7 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f, int set = 0) {
     a.t.lev = base + L.nI;
     a.nnmax = L.nnmaxII;
     a.namax = L.namaxII;
+    a.nchmax = L.nchmaxII;
     f(false, a, (int)L.nII, (size_t)0, 1024);
   }
 }
@@ -266,6 +267,21 @@ inline unsigned umax1(int x) { return (unsigned)std::max(1, x); }
 void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, int sgn, hipStream_t st) {
   static int plan = -1;
   if (plan < 0) { const char* e = getenv("SMCP_ASM"); plan = (e && e[0] == 't') ? 0 : 1; }
+  {
+    // fronts whose packed lower triangle fits LDS: stream the children through it (k_lf_assemble_lds)
+    static int alds = -1;
+    if (alds < 0) { const char* e = getenv("SMCP_ALDS"); alds = (e && e[0] == '0') ? 0 : 1; }
+    const int nfmax = a.nnmax + a.namax;
+    const size_t bytes = (size_t)(lf_alds_doubles(nfmax) + 3 * a.nchmax + 2) * sizeof(double);   // front + child table
+    if (alds && a.nchmax > 0 && (int64_t)cnt * nrhs >= 32 && nfmax <= LF_ALDS_MAXNF && bytes <= LDS_LIMIT) {   // enough workgroups to fill the chip
+      static bool attr = false;
+      if (!attr) { attr = hipFuncSetAttribute((const void*)k_lf_assemble_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess; }
+      if (attr) {
+        launch_lds(c, KID_lf_assemble, k_lf_assemble_lds, dim3(cnt, nrhs), dim3(1024), bytes, st, a, U, ldu, sgn);
+        return;
+      }
+    }
+  }
   if (plan && a.t.gp_tptr) {
     launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
     return;
@@ -811,6 +827,7 @@ void classify_levels(const Symbolic& S, Keep keep, std::vector<LevelClass>& lvl,
           L.nII++;
           L.nnmaxII = std::max<int>(L.nnmaxII, (int)S.nn(k));
           L.namaxII = std::max<int>(L.namaxII, (int)S.na(k));
+          L.nchmaxII = std::max<int>(L.nchmaxII, (int)(S.chptr[k + 1] - S.chptr[k]));
         }
       }
   }

@@ -133,6 +133,7 @@ struct LevelClass {
   int nnmaxI = 0, namaxI = 0;  // LDS layout sizing for the LDS class
   int nchmaxI = 0, panmaxI = 0, pkmaxI = 0, plansumI = 0;  // index tables of the padded kernels (see pad_layout)
   int nnmaxII = 0, namaxII = 0;  // tile-grid sizing for the large-front (HBM) class
+  int nchmaxII = 0;              // most children of a large front (child table of k_lf_assemble_lds)
   // Families (front_fam.hip): the LAST nS cliques of the LDS class of this level are either childless cliques whose
   // parent is a family parent (level 0) or family parents (levels >= 1: small fronts all of whose children are such
   // childless cliques, at most one per wave).  A family-enabled sweep skips the former and hands the latter to

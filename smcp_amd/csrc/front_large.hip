@@ -141,6 +141,106 @@ __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
     }
   }
 }
+// Extend-add with the whole front in LDS: one workgroup owns the packed lower triangle of the front of (clique,
+// rhs) -- nf (nf + 1) / 2 doubles, i.e. fronts of up to 198 rows -- and STREAMS the children's packed update matrices
+// through it child-major: every child column is one contiguous, fully used segment (the gather plan above reads
+// 8-byte words scattered over the children, ~1.2 TB/s), the scatter into the front is an LDS atomic add
+// (ds_add_f64) at (rel[i], rel[j]).  Waves take children round-robin and keep four columns in flight.
+// Same sgn convention as k_lf_assemble.
+__device__ inline double col_at(const double* Uc, int nac, int i, int j) { return Uc[pk_col(j, nac) - j + i]; }
+constexpr int LF_ALDS_MAXNF = 198;
+__host__ __device__ inline int lf_alds_doubles(int nf) { return nf * (nf + 1) / 2; }
+__global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u, int64_t ldu, int sgn) {
+  extern __shared__ __attribute__((aligned(16))) double T[];
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  if (d.chend == d.chbeg) return;
+  const int r = blockIdx.y;
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+  const int ntot = lf_alds_doubles(nf);
+  // child table in LDS (packed-update offset, separator size, relative-index offset): a wave starting on a child
+  // then pays one memory latency (its relative indices and first columns together), not a chain of four
+  const int nch = d.chend - d.chbeg;
+  int64_t* const sCu = reinterpret_cast<int64_t*>(T + lf_alds_doubles(a.nnmax + a.namax));
+  int64_t* const sCr = sCu + a.nchmax;
+  int* const sCn = reinterpret_cast<int*>(sCr + a.nchmax);
+  for (int q = tid; q < nch; q += nthr) {
+    const CliqueDesc c = a.t.cl[a.t.chidx[d.chbeg + q]];
+    sCu[q] = c.updp; sCr[q] = c.rel; sCn[q] = c.na;
+  }
+  for (int e = tid; e < ntot; e += nthr) T[e] = 0.0;
+  __syncthreads();
+  const double* ubase = a.t.updp + (int64_t)r * a.t.updplen;
+  // packed column start minus the column index: T[cb(j) + i] = front(i, j), i >= j
+  auto cb = [nf](int j) { return j * nf - ((j * (j - 1)) >> 1) - j; };
+  for (int q = wave; q < nch; q += nw) {
+    const int nac = sCn[q];
+    const int32_t* rel = a.t.relidx + sCr[q];
+    const double* Uc = ubase + sCu[q];
+    // lane l owns rows l and l + 64 of the child (separators of up to 128 rows; longer ones finish with a plain
+    // loop): each wave load is one contiguous run of a packed column.  Eight columns are fetched per batch and the
+    // next batch is in flight while the current one is added into the front.
+    const int iA = lane, iB = lane + 64;
+    const int rA = iA < nac ? rel[iA] : 0, rB = iB < nac ? rel[iB] : 0;
+    constexpr int CB = 8;
+    double cur[CB][2], nxt[CB][2];
+    auto fetch = [&](int j0, double (&v)[CB][2]) {
+#pragma unroll
+      for (int x = 0; x < CB; ++x) {
+        const int j = j0 + x;
+        v[x][0] = v[x][1] = 0.0;
+        if (j < nac) {
+          const double* col = Uc + pk_col(j, nac) - j;               // col[i] = U_c(i, j), i >= j
+          if (iA >= j && iA < nac) v[x][0] = col[iA];
+          if (iB >= j && iB < nac) v[x][1] = col[iB];
+        }
+      }
+    };
+    fetch(0, cur);
+    for (int j0 = 0; j0 < nac; j0 += CB) {
+      if (j0 + CB < nac) fetch(j0 + CB, nxt);
+#pragma unroll
+      for (int x = 0; x < CB; ++x) {
+        const int j = j0 + x;
+        if (j < nac) {
+          const int cj = j < 64 ? __builtin_amdgcn_readlane(rA, j & 63) : (j < 128 ? __builtin_amdgcn_readlane(rB, j & 63) : rel[j]);
+          const int cbj = cb(cj);
+          if (iA >= j && iA < nac) unsafeAtomicAdd(&T[cbj + rA], cur[x][0]);
+          if (iB >= j && iB < nac) unsafeAtomicAdd(&T[cbj + rB], cur[x][1]);
+          for (int i = lane + 128; i < nac; i += 64)                 // separators beyond 128 rows (rare)
+            if (i >= j) unsafeAtomicAdd(&T[cbj + rel[i]], col_at(Uc, nac, i, j));
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < CB; ++x) { cur[x][0] = nxt[x][0]; cur[x][1] = nxt[x][1]; }
+    }
+  }
+  __syncthreads();
+  double* P = u + (int64_t)r * ldu + d.blk;
+  double* U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+  // write-out: flat loops over the rectangular panel / the square update block with eight read-modify-writes in
+  // flight per thread (a column-by-column loop would pay one memory latency per column)
+  const double sp = (sgn == 1) ? -1.0 : 1.0;
+  batched_loop<8>(tid, nf * nn, nthr, [=](int e) { return P[e]; },
+                  [=](int e, double pv) {
+                    const int i = e % nf, j = e / nf;
+                    if (i >= j) { const double v = T[cb(j) + i]; if (v != 0.0) P[e] = pv + sp * v; }
+                  });
+  if (sgn) {
+    batched_loop<8>(tid, na * na, nthr, [=](int e) { return U[e]; },
+                    [=](int e, double uv) {
+                      const int i = e % na, j = e / na;
+                      if (i >= j) { const double v = T[cb(nn + j) + nn + i]; if (v != 0.0) U[e] = uv + v; }
+                    });
+  } else {
+    for (int e = tid; e < na * na; e += nthr) {
+      const int i = e % na, j = e / na;
+      if (i >= j) U[e] = T[cb(nn + j) + nn + i];                       // full assignment of the lower triangle
+    }
+  }
+}
 // Tiled extend-add: one workgroup owns an LF_TR x LF_TW tile of the front of (clique, rhs) in LDS and streams the
 // children's packed update matrices through it CHILD-MAJOR -- every child column is a contiguous segment, so the
 // reads are coalesced and each fetched line is used entirely (the gather plan above reads one 8-byte word per
