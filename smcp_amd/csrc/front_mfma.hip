@@ -1130,6 +1130,7 @@ __global__ void __launch_bounds__(512) k_hess_up_pad(MfmaArgs a, double* u, int6
 constexpr int GRAM_BLK = 128;   // columns of H per block
 constexpr int GRAM_KS = 64;     // slice of the long dimension staged per step
 constexpr int GRAM_LD = GRAM_BLK + 1;
+constexpr int GRAM_LDK = GRAM_KS + 2;   // k_gram_diag128: [column][k] image
 
 template <bool DIAG>
 __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
@@ -1209,7 +1210,10 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
                                                       const double* sw, int64_t chunk, double* partial, int coff,
                                                       int nchunk_total) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* const sA = smem;                         // [k = 64][column], ld GRAM_LD
+  // LDS image [column][k = 64], ld GRAM_LDK = 66 doubles: the staging store is contiguous along k (no transpose)
+  // and the operand reads (row = column l15, k = kq + 4 s) hit 32 distinct 8-byte bank pairs per half wave
+  // (bank = 4 l15 + 2 kq): conflict-free, where the [k][column] image with ld 129 had two-way conflicts on every read
+  double* const sA = smem;
   const int ni = m;
   const int mti = (ni + 15) >> 4;
   const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
@@ -1226,7 +1230,7 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
   d4 acc[MAXT];
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
-  for (int e = threadIdx.x; e < GRAM_KS * GRAM_LD; e += 256) sA[e] = 0.0;   // columns >= m stay zero
+  for (int e = threadIdx.x; e < GRAM_BLK * GRAM_LDK; e += 256) sA[e] = 0.0;   // columns >= m stay zero
   const int64_t e_begin = e_lo + (int64_t)blockIdx.x * chunk, e_end = min(e_hi, e_begin + chunk);
   double pre[NC], pre_sw = 0.0;
   auto fetch = [&](int64_t e0) {
@@ -1240,25 +1244,25 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
     }
   };
   if (e_begin < e_end) fetch(e_begin);
-  const double* const lbase = sA + kq * GRAM_LD + l15;
+  const double* const lbase = sA + l15 * GRAM_LDK + kq;
   for (int64_t e0 = e_begin; e0 < e_end; e0 += GRAM_KS) {
     lds_barrier();                                 // the tiles of the previous slice have been consumed
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int cc = wave + 4 * j;
-      if (cc < ni) sA[lane * GRAM_LD + cc] = pre_sw != 0.0 ? pre[j] * pre_sw : 0.0;   // weight 0: never-written entries
+      if (cc < ni) sA[cc * GRAM_LDK + lane] = pre_sw != 0.0 ? pre[j] * pre_sw : 0.0;   // weight 0: never-written entries
     }
     lds_barrier();
     if (e0 + GRAM_KS < e_end) fetch(e0 + GRAM_KS); // in flight while the MFMAs below run
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
       if (tms[i] < 0) continue;
-      const double* const pa = lbase + 16 * tms[i];
-      const double* const pb = lbase + 16 * tns[i];
+      const double* const pa = lbase + 16 * GRAM_LDK * tms[i];
+      const double* const pb = lbase + 16 * GRAM_LDK * tns[i];
       d4 a = acc[i];
 #pragma unroll
       for (int s2 = 0; s2 < GRAM_KS / 4; ++s2)
-        a = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[s2 * 4 * GRAM_LD], pa[s2 * 4 * GRAM_LD], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[s2 * 4], pa[s2 * 4], a, 0, 0, 0);
       acc[i] = a;
     }
   }

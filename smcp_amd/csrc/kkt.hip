@@ -614,7 +614,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     if (hi <= lo) continue;
     int nc = (int)((hi - lo + chunk - 1) / chunk);
     if (nblk == 1)
-      launch_lds(c, KID_gram_partial, k_gram_diag128, dim3(nc, 1), dim3(256), (size_t)GRAM_KS * GRAM_LD * sizeof(double), st,
+      launch_lds(c, KID_gram_partial, k_gram_diag128, dim3(nc, 1), dim3(256), (size_t)GRAM_BLK * GRAM_LDK * sizeof(double), st,
                  (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk);
     else
       for (int bi = 0; bi < nb; ++bi)
