@@ -22,7 +22,7 @@ import torch
 from . import chordal
 from .cspmatrix import cspmatrix
 from .kkt import KKTSystem
-from .symbolic import Symbolic, maxcardsearch, mindegree
+from .symbolic import Symbolic, amalgamate, maxcardsearch, mindegree
 
 # same keys / defaults as the reference (solvers.py:22-44)
 options = {
@@ -38,6 +38,8 @@ options = {
     # the dual-feasibility row (the variant the reference keeps commented out at solvers.py:2014-2016)
     # restore convergence to the default tolerances in ~20 iterations.  Set (0, True) for the reference's scheme.
     "esd_kkt_refinement": 1, "esd_ds_from_hessian": False,
+    # relaxed supernode amalgamation of deep, thin clique trees (smcp_amd.symbolic.amalgamate; not in the reference)
+    "amalgamate": True,
 }
 _defaults = _copy.deepcopy(options)
 
@@ -95,8 +97,16 @@ class _Problem:
                 symb = Symbolic(pat, p)
         else:
             symb = Symbolic(pat, np.asarray(p, dtype=np.int64))
-        self.symb = symb
         self.ischordal = symb.fill == 0
+        # deep, thin clique trees are launch-bound: merge runs of small cliques (relaxed supernodes, a chordal
+        # embedding with a few explicit zeros; off with options['amalgamate'] = False)
+        self.amalgamated = False
+        if options.get("amalgamate", True):
+            emb = amalgamate(symb)
+            if emb is not None:
+                symb = Symbolic(emb[0], emb[1])
+                self.amalgamated = True
+        self.symb = symb
         if torch.cuda.is_available():
             self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         else:

@@ -197,5 +197,66 @@ class Symbolic:
         return int(_lib.lib().csp_device_bytes(self._h))
 
 
+def amalgamate(symb, nn_max=16, growth=1.3, nf_small=40):
+    """Relaxed supernode amalgamation for deep, thin clique trees (chains of tiny cliques: band patterns, the tail
+    of a minimum-degree embedding).  Every tree operation costs one kernel launch per level, so a chain of 197
+    one-column cliques (config 1: band n = 200) is launch-bound; merging runs of small cliques into supernodes of
+    up to `nn_max` columns cuts the depth by the same factor at the price of a few explicit zeros -- the same
+    kind of chordal embedding the reference applies to non-chordal patterns (solvers.py:278-319).
+
+    A clique k is merged into its parent p when it is p's LAST child in the postorder (its columns are adjacent to
+    p's: no reordering), the merged supernode has at most nn_max columns and the dense block grows by at most
+    `growth` (or the merged front has at most nf_small rows).  Returns (pattern, perm) of the embedded pattern --
+    pattern as (n, colptr, rowind) in ORIGINAL coordinates, perm[new] = orig -- or None when nothing was merged."""
+    nsn = symb.Nsn
+    snptr, rowptr, rowidx, par = symb.snptr, symb.rowptr, symb.rowidx, symb.snpar
+    nn = np.diff(snptr).astype(np.int64)
+    first = snptr[:-1].astype(np.int64).copy()          # first permuted column of the (merged) supernode
+    rows = [rowidx[rowptr[k]:rowptr[k + 1]].astype(np.int64) for k in range(nsn)]   # front rows, permuted indices
+    alive = np.ones(nsn, dtype=bool)
+    merged_any = False
+    for k in range(nsn - 1):
+        p_ = int(par[k])
+        if p_ != k + 1:                                  # only the last child: columns adjacent
+            continue
+        nn_new = int(nn[k] + nn[p_])
+        if nn_new > nn_max:
+            continue
+        nf_k, nf_p = len(rows[k]), len(rows[p_])
+        nf_new = int(nn[k]) + nf_p
+        if not (nf_new * nn_new <= growth * (nf_k * nn[k] + nf_p * nn[p_]) or nf_new <= nf_small):
+            continue
+        # merged front: columns of k followed by the whole front of p (A_k is contained in it)
+        rows[p_] = np.concatenate([np.arange(first[k], first[k] + nn[k], dtype=np.int64), rows[p_]])
+        first[p_] = first[k]
+        nn[p_] = nn_new
+        alive[k] = False
+        merged_any = True
+    if not merged_any:
+        return None
+    perm = np.asarray(symb.p, dtype=np.int64)
+    n = symb.n
+    ii, jj = [], []
+    for k in range(nsn):
+        if not alive[k]:
+            continue
+        r = rows[k]
+        c = int(nn[k])                                   # the first c rows of the front are its own columns
+        # lower-triangular entries of the dense block [rows x own columns] (permuted indices)
+        I = np.repeat(r[:, None], c, axis=1)
+        J = np.repeat(r[None, :c], len(r), axis=0)
+        m = I >= J
+        ii.append(I[m])
+        jj.append(J[m])
+    I = perm[np.concatenate(ii)]
+    J = perm[np.concatenate(jj)]
+    lo, hi = np.minimum(I, J), np.maximum(I, J)
+    key = np.unique(lo * n + hi)
+    cj, ci = key // n, key % n
+    cp = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(cp, cj + 1, 1)
+    return (n, np.cumsum(cp), np.ascontiguousarray(ci)), perm
+
+
 def symbolic(A, p=None):
     return Symbolic(A, p)

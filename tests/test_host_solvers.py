@@ -84,6 +84,41 @@ def test_esd_band_default_tolerances_both_scalings():
                 assert max(abs(v) for v in sol["dimacs"]) < 1e-6
 
 
+def test_amalgamation_of_deep_thin_trees():
+    """Relaxed supernode amalgamation (smcp_amd.symbolic.amalgamate, on by default in the drivers): a band pattern's
+    chain of one-column cliques becomes supernodes of up to 16 columns; the embedded pattern contains the original
+    one, is chordal in the returned order (no fill) and the optimum does not change."""
+    from smcp_amd import problems
+    from smcp_amd.symbolic import Symbolic, amalgamate
+    pat = problems.band_pattern(200, 3)
+    s0 = Symbolic(pat)
+    emb = amalgamate(s0)
+    assert emb is not None
+    s1 = Symbolic(emb[0], emb[1])
+    assert s1.fill == 0 and s1.Nsn <= 14 and s1.nlev <= 14 and s0.Nsn == 197
+    nn, na = s1.clique_sizes()
+    assert nn.max() <= 16
+    n, cp, ri = pat
+    cols = np.repeat(np.arange(n), np.diff(cp))
+    assert (s1.index_map(ri, cols) >= 0).all()            # every original entry has a position
+    assert amalgamate(Symbolic(problems.nested_block_arrow_pattern(nsub=2, nmid=6))) is None   # families are left alone
+    P = base.band_SDP(60, 20, 3, seed=1)
+    ps = {"x": sp.csc_matrix(np.tril(P._X0))}
+    ds = {"y": P._y0, "s": sp.csc_matrix(np.tril(P._S0))}
+    objs = []
+    for am in (True, False):
+        solvers.options["amalgamate"] = am
+        with oracle_backend():
+            sol = P.solve_feas(scaling="dual", primalstart=ps, dualstart=ds)
+        assert sol["status"] == "optimal"
+        objs.append(sol["primal objective"])
+        # the returned X restricted to the original band is feasible
+        X = np.asarray(sol["x"].todense())
+        for i in range(P.m):
+            assert abs(np.sum(np.asarray(P.get_A(i + 1).todense()) * X) - P.b[i]) < 1e-7 * (1 + abs(P.b[i]))
+    assert abs(objs[0] - objs[1]) < 1e-5 * (1 + abs(objs[1]))
+
+
 def test_infeasibility_certificates():
     """esd returns certificates (solvers.py:2299-2327).  As in the reference, conelp maps the cone LP
     onto the DUAL of the SDP pair and does not rename the status (solvers.py:2535-2597), so an
