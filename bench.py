@@ -270,6 +270,21 @@ def main():
                "k_hess_up_mfma<true>": cls_bytes(lds_ok), "k_hess_down_mfma<true>": cls_bytes(lds_ok),
                "k_hess_up_mfma<false>": cls_bytes(~lds_ok), "k_hess_down_mfma<false>": cls_bytes(~lds_ok),
                "k_chol_level": 8.0 * (2 * B + 2 * U), "k_pinv_level": 8.0 * (2 * B + 2 * U)}.get(dom)
+        # large-front phase kernels (configs 2 and 3): MFMA-bound, canonical BLAS-3 flop counts per (front, rhs)
+        # (SURVEY 8d): up1 = E, T (2 na nn^2 + nn^3); up2 = update, G, G_NN (2 na^2 nn + na nn^2 + nn^3 / 3);
+        # up3 = scaling product (na^2 nn, triangular operand)
+        big = ~lds_ok
+        nnf, naf = nn_[big].astype(np.float64), na_[big].astype(np.float64)
+        lf_flops = {"k_lf_up1": (2 * naf * nnf ** 2 + nnf ** 3).sum(),
+                    "k_lf_up2": (2 * naf ** 2 * nnf + naf * nnf ** 2 + nnf ** 3 / 3).sum(),
+                    "k_lf_up3": (naf ** 2 * nnf).sum()}
+        if dom in lf_flops and alg is None:
+            nr = sum(chunks)
+            tfl = lf_flops[dom] * nr / (1e-3 * dom_ms) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tfl, 2), "peak": FP64_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tfl / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                        "flops_per_step": lf_flops[dom] * nr, "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2),
+                        "launches_per_step": dom_launches}
         if alg is not None:
             per_launch = alg / dom_launches
             avg_s = 1e-3 * dom_ms / dom_launches

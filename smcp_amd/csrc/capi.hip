@@ -443,7 +443,7 @@ bool try_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int g, double* U, int64_t l
 }
 
 // family kernel (front_fam.hip) for the nS family parents at the tail of a level's LDS class
-template <int NAT, int NATC>
+template <int NAT, int NATC, bool SP>
 bool launch_fam(csp_ctx* c, MfmaArgs a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   a.panmax = a.fampan;
   a.pkmax = a.fampk;
@@ -451,7 +451,7 @@ bool launch_fam(csp_ctx* c, MfmaArgs a, int cnt, int nrhs, double* U, int64_t ld
   if (bytes > LDS_LIMIT) return false;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)k_hess_up_fam<NAT, NATC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)k_hess_up_fam<NAT, NATC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
     attr = true;
   }
   static int ncu = 0;
@@ -465,22 +465,26 @@ bool launch_fam(csp_ctx* c, MfmaArgs a, int cnt, int nrhs, double* U, int64_t ld
     const int64_t cost = rounds * (passes + 3);
     if (best < 0 || cost < best) { best = cost; g = gc; }
   }
-  launch_lds(c, KID_hess_up_fam, k_hess_up_fam<NAT, NATC>, dim3(cnt, g), dim3(768), bytes, st, a, U, ldu);
+  launch_lds(c, KID_hess_up_fam, k_hess_up_fam<NAT, NATC, SP>, dim3(cnt, g), dim3(768), bytes, st, a, U, ldu);
   return true;
 }
-bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+template <bool SP>
+bool try_fam_sp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   const int nat = std::max(1, (a.famna + 15) / 16), natc = std::max(1, (a.famcna + 15) / 16);
   switch (nat * 2 + natc - 1) {
-    case 2: return launch_fam<1, 1>(c, a, cnt, nrhs, U, ldu, st);
-    case 3: return launch_fam<1, 2>(c, a, cnt, nrhs, U, ldu, st);
-    case 4: return launch_fam<2, 1>(c, a, cnt, nrhs, U, ldu, st);
-    case 5: return launch_fam<2, 2>(c, a, cnt, nrhs, U, ldu, st);
-    case 6: return launch_fam<3, 1>(c, a, cnt, nrhs, U, ldu, st);
-    case 7: return launch_fam<3, 2>(c, a, cnt, nrhs, U, ldu, st);
-    case 8: return launch_fam<4, 1>(c, a, cnt, nrhs, U, ldu, st);
-    case 9: return launch_fam<4, 2>(c, a, cnt, nrhs, U, ldu, st);
+    case 2: return launch_fam<1, 1, SP>(c, a, cnt, nrhs, U, ldu, st);
+    case 3: return launch_fam<1, 2, SP>(c, a, cnt, nrhs, U, ldu, st);
+    case 4: return launch_fam<2, 1, SP>(c, a, cnt, nrhs, U, ldu, st);
+    case 5: return launch_fam<2, 2, SP>(c, a, cnt, nrhs, U, ldu, st);
+    case 6: return launch_fam<3, 1, SP>(c, a, cnt, nrhs, U, ldu, st);
+    case 7: return launch_fam<3, 2, SP>(c, a, cnt, nrhs, U, ldu, st);
+    case 8: return launch_fam<4, 1, SP>(c, a, cnt, nrhs, U, ldu, st);
+    case 9: return launch_fam<4, 2, SP>(c, a, cnt, nrhs, U, ldu, st);
   }
   return false;
+}
+bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  return a.kc_ptr ? try_fam_sp<true>(c, a, cnt, nrhs, U, ldu, st) : try_fam_sp<false>(c, a, cnt, nrhs, U, ldu, st);
 }
 
 // sparse_j0 >= 0: the right-hand sides are the constraints sparse_j0 .. (through `ids` if given) and are taken from
@@ -505,8 +509,9 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
   };
   for (int64_t l = 0; l < c->S.nlev; ++l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
-      if (lds && sparse && a.nS > 0) {
-        // families: the childless members (level 0) are swept inside their parents' workgroups (k_hess_up_fam)
+      if (lds && a.nS > 0 && (sparse || nrhs >= 4)) {
+        // families: the childless members (level 0) are swept inside their parents' workgroups (k_hess_up_fam);
+        // for one or two dense right-hand sides the per-workgroup set-up outweighs the saved exchange (measured)
         const int nS = a.nS;
         a.nS = 0;
         if (a.level > 0) {

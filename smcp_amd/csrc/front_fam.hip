@@ -78,7 +78,10 @@ __device__ inline void mma_pre(d4& acc, const double* pa, int sa, const double* 
     if (s < ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[s], av[s], acc, 0, 0, 0);
 }
 
-template <int NAT, int NATC>
+// SP: sparse input (the right-hand sides are constraints given by their per-clique entry lists, MfmaArgs::kc_*) or
+// dense input panels read from u (a template parameter: the sparse instantiation carries none of the dense path's
+// registers)
+template <int NAT, int NATC, bool SP>
 __global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int64_t ldu) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NA = 16 * NAT, LDA = NA + 1, LDN = 17, LDC = 16 * NATC + 1;
@@ -104,6 +107,7 @@ __global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int6
   const int gy = (int)gridDim.y;
   const int ksn = (nn + 3) >> 2, ksa = (na + 3) >> 2;
   const int npass = ((int)a.nrhs - (int)blockIdx.y + gy - 1) / gy;
+  constexpr bool sp = SP;
 
   for (int e = tid; e < L.oInt + 2; e += 768) smem[e] = 0.0;    // pads must be (and stay) zero; counter = 0
   for (int e = tid; e < npan; e += 768) {
@@ -167,13 +171,23 @@ __global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int6
     // two memory latencies per right-hand side, so: lane l keeps the entry range of pass 64 b + l (refreshed every
     // 64 passes) and the entries of the NEXT pass are fetched into registers (one per thread; longer lists finish
     // with direct loads) once those of the current pass are consumed.
-    const int32_t* const kpp = a.kc_ptr + (int64_t)k * a.kc_stride;
+    const int32_t* const kpp = sp ? a.kc_ptr + (int64_t)k * a.kc_stride : nullptr;
     int pp0 = 0, pp1 = 0, q_off = 0;
     double q_val = 0.0;
     bool pre_ok = false;
     int gtarget = 0;
     for (int st = 0; st <= npass; ++st) {
-      if (st < npass) {
+      if (st < npass && !sp) {
+        // dense input: the front's own panel (lower of NN + AN rows) is added to the buffer being assembled
+        const double* Pin = u + (int64_t)((int)blockIdx.y + st * gy) * ldu + d.blk;
+        const int oBn = L.oB0 + (st & 1) * L.bw;
+        batched_loop<8>(gtid, npan, 256, [=](int e) { return Pin[e]; },
+                        [=](int e, double v) {
+                          const int o = sPan[e];
+                          if (o != NONE) unsafeAtomicAdd(&smem[oBn + o], v);
+                        });
+      }
+      if (st < npass && sp) {
         const int sl = st & 63;
         if (sl == 0) {
           const int rl = (int)blockIdx.y + (st + lane) * gy;
@@ -355,7 +369,7 @@ __global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int6
       hasc[c] = gw + 8 * c < nch;
       const int ck = hasc[c] ? a.t.chidx[d.chbeg + gw + 8 * c] : 0;
       cd[c] = a.t.cl[ck];
-      kpc[c] = a.kc_ptr + (int64_t)ck * a.kc_stride;
+      kpc[c] = sp ? a.kc_ptr + (int64_t)ck * a.kc_stride : nullptr;
       nnc[c] = hasc[c] ? cd[c].nn : 0;
       nac[c] = hasc[c] ? cd[c].na : 0;
       nfc[c] = nnc[c] + nac[c];
@@ -424,7 +438,7 @@ __global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int6
         if (sl == 0) {
           const int rl = r + lane * gy;
           cp0[0] = cp1[0] = cp0[1] = cp1[1] = 0;
-          if (rl < a.nrhs) {
+          if (sp && rl < a.nrhs) {
             const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + rl] : a.kc_j0 + rl;
 #pragma unroll
             for (int c = 0; c < 1; ++c)
@@ -435,12 +449,12 @@ __global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int6
         int p0[2], p1[2];
 #pragma unroll
         for (int c = 0; c < 1; ++c) { p0[c] = __builtin_amdgcn_readlane(cp0[c], sl); p1[c] = __builtin_amdgcn_readlane(cp1[c], sl); }
-        if (!pre_ok) {
+        if (!pre_ok && sp) {
 #pragma unroll
           for (int c = 0; c < 1; ++c)
             if (lane < p1[c] - p0[c]) { e_off[c] = a.kc_off[p0[c] + lane]; e_val[c] = a.kc_val[p0[c] + lane]; }
         }
-        const bool more = sl != 63 && st + 1 < npass;      // the next pass exists and its ranges are in the lanes
+        const bool more = sp && sl != 63 && st + 1 < npass;      // the next pass exists and its ranges are in the lanes
         const int sn = (sl + 1) & 63;
         STAMP(1);
         // LDS offset of the parent-front position (ri, rj), ri >= rj
@@ -453,10 +467,19 @@ __global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int6
           double* const Pc = u + (int64_t)r * ldu + cd[c].blk;
           const int nnc_ = nnc[c], nac_ = nac[c], nfc_ = nfc[c];
           const int ksnc = (nnc_ + 3) >> 2, ksac = (nac_ + 3) >> 2;
-          if (p0[c] == p1[c]) {
+          if (sp && p0[c] == p1[c]) {
             // the constraint does not touch this child: zero panel, zero update
             for (int e = lane; e < nfc_ * nnc_; e += 64) Pc[e] = 0.0;
           } else {
+            if (!sp) {
+              // dense input: the child's panel overwrites every valid entry of the scratch (the pads stay zero)
+              auto putd = [&](int e, double v) {
+                const int i = e % nfc_, j = e / nfc_;
+                if (i >= nnc_) cFan[(i - nnc_) + j * LDC] = v;
+                else if (i >= j) { cFnn[i + j * LDN] = v; cFnn[j + i * LDN] = v; }
+              };
+              batched_loop<8>(lane, nfc_ * nnc_, 64, [=](int e) { return Pc[e]; }, putd);
+            } else {
             for (int e = lane; e < LDN * 16 + LDC * 16; e += 64) cFnn[e] = 0.0;        // F_NN and F_AN (adjacent)
             wave_sync();
             {
@@ -467,6 +490,7 @@ __global__ void __launch_bounds__(768) k_hess_up_fam(MfmaArgs a, double* u, int6
               };
               if (lane < p1[c] - p0[c]) put(e_off[c], e_val[c]);
               for (int p = p0[c] + 64 + lane; p < p1[c]; p += 64) put(a.kc_off[p], a.kc_val[p]);
+            }
             }
             wave_sync();
             // phases 1 and 2 in registers: the result register rr of a 16 x 16 tile (row l15, column kq + 4 rr) is
