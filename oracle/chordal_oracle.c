@@ -26,11 +26,14 @@
  * meaningful.  Update matrices (na x na, lower triangle meaningful) live at upd + updptr[k].
  * Cliques are numbered in postorder (children before parents).
  *
- * Plain C, single thread, straightforward loops: clique-by-clique in postorder, dense
- * BLAS-3-shaped operations per clique, exactly the structure CHOMPACK's Python/C routines
- * have ([EXT]).
+ * Plain C, straightforward loops: clique-by-clique in postorder, dense BLAS-3-shaped
+ * operations per clique, exactly the structure CHOMPACK's Python/C routines have ([EXT],
+ * SURVEY.md App. A).  Every routine is single threaded; orc_schur_columns (bottom of the file)
+ * spreads the INDEPENDENT columns of the Schur complement over OpenMP threads so that bench.py's
+ * cpu_baseline can use the host's cores.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -682,4 +685,53 @@ void orc_scmcolumn2(int64_t m, int64_t n, double *H, const int64_t *ptr, const i
         if (r1 != c1) H[j * m + i] += alpha * beta * V[n * r + c1] * V[n * c + r1];
       }
   }
+}
+
+/* ------------------------------------------------------------------ CPU baseline helper
+ * Columns j0..j1-1 of the (unfactored) Schur complement H_ij = <A_i, hessian(L, Y)(A_j)>: one Hessian
+ * application per column exactly as the reference's loop does (solvers.py:479-487), the independent columns
+ * spread over `nthreads` OpenMP threads, each with its own right-hand side and workspace.  Constraints: CSC over
+ * blkval positions (cptr, cidx, cval); w = cval with off-diagonal entries doubled (Amap weights,
+ * solvers.py:369-375).  H: m x (j1 - j0), column-major.  Returns 0 or the first nonzero orc_hessian code. */
+int orc_schur_columns(const orc_sym *s, const double *L, const double *Y, int64_t m, const int64_t *cptr,
+                      const int64_t *cidx, const double *cval, const double *w, int64_t j0, int64_t j1, double *H,
+                      int nthreads, double *seconds) {
+  const int64_t bl = s->blkptr[s->nsn], ul = s->updptr[s->nsn];
+  int rc = 0;
+  double t_begin = 0.0, t_end = 0.0;
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+    /* per-thread right-hand side and workspace, touched before the clock starts (a long-running solver pays the
+     * page faults of its workspaces once, not per column) */
+    const size_t nu = (size_t)(bl > 0 ? bl : 1), nw = (size_t)(3 * ul > 0 ? 3 * ul : 1);
+    double *u = (double *)malloc(sizeof(double) * nu);
+    double *work = (double *)malloc(sizeof(double) * nw);
+    memset(u, 0, sizeof(double) * nu);
+    memset(work, 0, sizeof(double) * nw);
+#pragma omp barrier
+#pragma omp master
+    t_begin = omp_get_wtime();
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t j = j0; j < j1; ++j) {
+      memset(u, 0, sizeof(double) * (size_t)bl);
+      for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) u[cidx[e]] = cval[e];
+      int r = orc_hessian(s, L, Y, u, 2, 0, work);
+      if (r) {
+#pragma omp critical
+        if (!rc) rc = r;
+      }
+      double *h = H + (j - j0) * m;
+      for (int64_t i = 0; i < m; ++i) {
+        double acc = 0.0;
+        for (int64_t e = cptr[i]; e < cptr[i + 1]; ++e) acc += w[e] * u[cidx[e]];
+        h[i] = acc;
+      }
+    }
+#pragma omp master
+    t_end = omp_get_wtime();
+    free(u);
+    free(work);
+  }
+  if (seconds) *seconds = t_end - t_begin;
+  return rc;
 }

@@ -58,6 +58,8 @@ def lib():
         L.orc_prepare_fac.argtypes = [S, P, P, P]
         L.orc_hess_g_masked.restype = None
         L.orc_hess_g_masked.argtypes = [S, P, P, P, P, P]
+        L.orc_schur_columns.restype = ctypes.c_int
+        L.orc_schur_columns.argtypes = [S, P, P, ctypes.c_int64, P, P, P, P, ctypes.c_int64, ctypes.c_int64, P, ctypes.c_int, P]
         L.orc_scmcolumn2.restype = None
         L.orc_scmcolumn2.argtypes = [ctypes.c_int64, ctypes.c_int64, P, P, P, P, P, P, P, ctypes.c_int64]
         _lib = L
@@ -249,6 +251,21 @@ class KKT:
             H[:, j] = self.amap(u)
         if ncols is None:
             dense_potrf(H)
+        return H
+
+    def schur_columns_threaded(self, L, Y, j0, j1, nthreads):
+        """Columns j0..j1-1 of the (unfactored) Schur complement on `nthreads` OpenMP threads, one Hessian application
+        per column as in schur_factor (orc_schur_columns).  Used by bench.py's cpu_baseline to time the oracle on the
+        host's cores."""
+        H = np.zeros((self.m, j1 - j0), order="F")
+        cptr = np.ascontiguousarray(self.cptr, dtype=np.int64)
+        cidx = np.ascontiguousarray(self.cidx, dtype=np.int64)
+        cval = np.ascontiguousarray(self.cval, dtype=np.float64)
+        w = np.ascontiguousarray(self.w, dtype=np.float64)
+        sec = ctypes.c_double(0.0)
+        _chk(lib().orc_schur_columns(self.S.ref(), _p(L), _p(Y), self.m, _p(cptr), _p(cidx), _p(cval), _p(w),
+                                     int(j0), int(j1), _p(H), int(nthreads), ctypes.byref(sec)), "schur_columns")
+        self.last_seconds = sec.value          # compute time without the per-thread workspace allocation
         return H
 
     def solve(self, L, Y, H, bx, by, kk):
