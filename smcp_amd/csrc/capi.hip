@@ -294,8 +294,10 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
 void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
-  launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), blk, st, a);
-  lf_assemble(c, a, cnt, nrhs, U, ldu, 0, st);
+  if (a.nchmax > 0) {     // a level of childless large fronts has nothing to assemble (k_lf_up2 does not read their update blocks)
+    launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), blk, st, a);
+    lf_assemble(c, a, cnt, nrhs, U, ldu, 0, st);
+  }
   launch(c, KID_lf_up1, k_lf_up1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
   launch(c, KID_lf_up2, k_lf_up2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
   if (a.namax) launch(c, KID_lf_up3, k_lf_up3, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);

@@ -80,6 +80,7 @@ __device__ inline void lower_pair(int t, int& tm, int& tn) {
 
 struct LfCtx {   // per-workgroup view of one (clique, rhs) pair
   int k, nn, na, nf;
+  bool hasch;                          // the front has children (its assembled update block is not identically zero)
   const double* Li; const double* K;   // ld nf
   const double* Ys;                    // ld na (lower stored) or null
   double* P;                           // panel of this rhs (ld nf)
@@ -93,6 +94,7 @@ __device__ inline LfCtx lf_ctx(const MfmaArgs& a, double* u, int64_t ldu) {
   const CliqueDesc d = a.t.cl[c.k];
   const int r = blockIdx.z;
   c.nn = d.nn; c.na = d.na; c.nf = d.nn + d.na;
+  c.hasch = d.chend > d.chbeg;
   c.Li = a.LK ? a.LK + d.blk : nullptr;
   c.K = a.LK ? a.LK + d.blk + d.nn : nullptr;
   c.Ys = a.ysc ? a.ysc + d.upd : nullptr;
@@ -360,10 +362,19 @@ __global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t l
                 [=](int kk, int n) { return E[n + (int64_t)kk * na]; }, sA, sB);
     gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return E[m + (int64_t)kk * na]; },
                 [=](int kk, int n) { return K[n + (int64_t)kk * nf]; }, sA, sB);
-    double* U = c.U; double* UP = c.UP;
-    tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) {
-      if (m >= n) { const double w = U[m + (int64_t)n * na] - v; U[m + (int64_t)n * na] = w; UP[pk_idx(m, n, na)] = w; }
-    });
+    // The parent takes the update from the packed exchange buffer only; the square block is read (what the extend-add
+    // assembled) but never written back, and a childless front does not even read it: its assembled block is zero
+    // and the host skips clearing / assembling it (lf_up).  For config 3 (1999 childless (64,128) fronts x 100
+    // right-hand sides) that is 26 GB of reads + 26 GB of writes + 26 GB of clears per sweep less.
+    const double* U = c.U; double* UP = c.UP;
+    if (c.hasch)
+      tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) {
+        if (m >= n) UP[pk_idx(m, n, na)] = U[m + (int64_t)n * na] - v;
+      });
+    else
+      tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) {
+        if (m >= n) UP[pk_idx(m, n, na)] = -v;
+      });
   } else if (t < nU + nG) {
     const int tt = t - nU, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
     gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; },
