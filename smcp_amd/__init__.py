@@ -7,8 +7,8 @@ the KKT/Schur-complement layer around them.  The interior-point drivers stay in 
 from .symbolic import Symbolic, symbolic, maxcardsearch, mindegree  # noqa: F401
 from .cspmatrix import cspmatrix  # noqa: F401
 from . import base, solvers  # noqa: F401
-from .base import SDP, band_SDP  # noqa: F401
-from .chordal import (cholesky, completion, projected_inverse, hessian, llt, trsm, dot,  # noqa: F401
-                      logdiagsum)
+from .base import SDP, band_SDP, mtxnorm_SDP, completion  # noqa: F401  (smcp.__init__: same four names)
+from .chordal import cholesky, projected_inverse, hessian, llt, trsm, dot, logdiagsum  # noqa: F401
+# the CHOMPACK-level in-place completion (factor of the inverse) is smcp_amd.chordal.completion
 
 __version__ = "0.1.0"

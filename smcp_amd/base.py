@@ -215,6 +215,86 @@ class band_SDP(SDP):
         return self._bw
 
 
+class mtxnorm_SDP(SDP):
+    """Matrix norm minimization  minimize || A_1 y_1 + ... + A_r y_r + B ||_2  (p x q matrices) as the SDP
+
+        minimize t   subject to   [ t I  (A(y)+B)' ; A(y)+B  t I ] >= 0      (order n = p + q)
+
+    P = mtxnorm_SDP(p, q, r, density=1.0, seed=0).  Same construction as the reference (base.py:639-773): column 0
+    of A holds B in the (2,1) block (rows q..n-1, columns 0..q-1), columns 1..r the data matrices with
+    nz = min(max(1, round(density p q)), p q) random entries of that block each, column r+1 is -I, b = (0,...,0,-1);
+    values are standard normal (seeded numpy generator -- the reference's cvxopt generator is not reproducible here).
+    Structural known answer of the reference's documentation (docs.rst:596,608): mtxnorm_SDP(200, 10, 200) has
+    n = 210, m = 201, nnz = 2210."""
+
+    def __init__(self, p, q, r, density=1.0, seed=0):
+        super().__init__()
+        if isinstance(density, float):
+            if density > 1 or density <= 0:
+                raise ValueError("density must be between 0 and 1")
+            dens = [density] * r
+            self._pname = ("mtxnorm_p%i_q%i_r%i" % (p, q, r) if density == 1.0
+                           else "mtxnorm_p%i_q%i_r%i_d%i" % (p, q, r, int(density * 1000)))
+        elif isinstance(density, list):
+            if len(density) != r:
+                raise TypeError("density must be a float between 0 and 1 or a list of r floats")
+            dens = density
+            self._pname = "mtxnorm_p%i_q%i_r%i_vd" % (p, q, r)
+        else:
+            raise TypeError("density must be a float between 0 and 1 or a list of r floats")
+        if not isinstance(seed, int):
+            raise ValueError("seed must be an integer")
+        rng = np.random.default_rng(seed)
+        n = p + q
+        I1 = np.tile(np.arange(q, n), q)                 # (2,1) block, column-major: rows q..n-1 of columns 0..q-1
+        J1 = np.repeat(np.arange(q), p)
+        lin = I1 + n * J1
+        rows, cols, vals = [lin], [np.zeros(p * q, dtype=np.int64)], [rng.standard_normal(p * q)]
+        for j in range(r):
+            nz = min(max(1, int(round(dens[j] * p * q))), p * q)
+            rows.append(rng.choice(lin, size=nz, replace=False))
+            cols.append(np.full(nz, j + 1, dtype=np.int64))
+            vals.append(rng.standard_normal(nz))
+        rows.append(np.arange(0, n * n, n + 1))
+        cols.append(np.full(n, r + 1, dtype=np.int64))
+        vals.append(-np.ones(n))
+        self._A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n * n, r + 2))
+        b = np.zeros(r + 1)
+        b[-1] = -1.0
+        self._b = b
+        self._p, self._q, self._density = p, q, density
+        self._blockstruct = [n]
+
+
+def completion(X):
+    """Maximum-determinant positive definite completion of the sparse symmetric matrix X (scipy sparse, either
+    triangle or both), returned as a dense numpy array; ArithmeticError if X has no positive definite completion.
+    Counterpart of smcp.completion (base.py:952-973): embed the pattern (perfect elimination order if it is chordal,
+    minimum degree otherwise), chompack-level completion -> factor L of the inverse, then Z = (L L^T)^-1 by two
+    supernodal triangular solves with the identity."""
+    import torch
+    from . import chordal
+    from .cspmatrix import cspmatrix
+    from .symbolic import Symbolic, maxcardsearch, mindegree
+    X = sp.csc_matrix(X)
+    n = X.shape[0]
+    Xl = sp.tril(X + sp.triu(X, 1).T if (sp.triu(X, 1).nnz and not sp.tril(X, -1).nnz) else X).tocoo()
+    pat = sp.csc_matrix((np.ones(Xl.nnz), (Xl.row, Xl.col)), shape=(n, n)) + sp.identity(n, format="csc")
+    symb = Symbolic(pat, maxcardsearch(pat))
+    if symb.fill > 0:
+        symb = Symbolic(pat, mindegree(pat))
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    L = cspmatrix.from_entries(symb, Xl.row, Xl.col, Xl.data, device=dev)
+    chordal.completion(L)
+    B = torch.eye(n, dtype=torch.float64, device=dev)          # rows = right-hand sides, PERMUTED coordinates
+    chordal.trsm(L, B)
+    chordal.trsm(L, B, trans="T")
+    Z = B.cpu().numpy()
+    ip = np.asarray(symb.ip)
+    Z = Z[np.ix_(ip, ip)]
+    return 0.5 * (Z + Z.T)
+
+
 def maxcut_SDP(n=1000, nedges=5909, seed=0):
     """Max-cut relaxation on a random graph with the size of SDPLIB maxG51 (config 4):
     minimize <C,X>, diag(X) = 1, C = -(Diag(W1) - W)/4."""

@@ -129,6 +129,7 @@ def oracle_backend():
             orc.hessian(_S(L.symb), _np(L), _np(Y), _np(u), adj=adj, inv=inv)
 
     chordal.hessian = hessian
+    chordal.trsm = lambda L, B, trans="N": orc.trsm(_S(L.symb), _np(L), B.numpy(), trans)
     chordal.dot = lambda X, Y: orc.dot(_S(X.symb), _np(X), _np(Y))
     chordal.logdiagsum = lambda X: orc.logdiagsum(_S(X.symb), _np(X))
     kkt.KKTSystem = OracleKKT

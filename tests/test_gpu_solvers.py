@@ -185,3 +185,28 @@ def test_phase1_finds_strictly_feasible_point():
     assert sol["status"] == "optimal"
     ref = P.solve_feas(scaling="dual", primalstart=_starts(P)[0], dualstart=_starts(P)[1])
     assert abs(sol["primal objective"] - ref["primal objective"]) < 1e-4 * (1 + abs(ref["primal objective"]))
+
+
+def test_dense_completion_and_mtxnorm_on_device():
+    """smcp.completion (dense maximum-determinant completion, base.py:952-973) and a matrix-norm SDP
+    (base.py:639-773) through the HIP path."""
+    import smcp_amd
+    from smcp_amd import base, solvers
+    rng = np.random.default_rng(0)
+    n = 40
+    mask = np.abs(np.subtract.outer(np.arange(n), np.arange(n))) <= 3
+    Lb = np.where(np.tril(mask), rng.standard_normal((n, n)) * 0.4, 0.0)
+    Lb[np.diag_indices(n)] = 1.0 + rng.random(n)
+    Si = np.linalg.inv(Lb @ Lb.T)
+    Z = smcp_amd.completion(sp.csc_matrix(np.where(np.tril(mask), Si, 0.0)))
+    assert np.linalg.norm(Z - Si) < 1e-9 * np.linalg.norm(Si)
+    solvers.options.update(show_progress=False, maxiters=100, feastol=1e-8, abstol=1e-6, reltol=1e-6)
+    p, q, r = 12, 4, 6
+    P = base.mtxnorm_SDP(p, q, r, seed=1)
+    sol = P.solve_esd()
+    assert sol["status"] == "optimal"
+    y = sol["y"]
+    nn = p + q
+    blk = lambda col: np.asarray(P.A[:, col].todense()).reshape((nn, nn), order="F")[q:, :q]
+    M = blk(0) - sum(y[i] * blk(i + 1) for i in range(r))
+    assert abs(np.linalg.norm(M, 2) - y[r]) < 1e-5 * (1 + y[r])

@@ -119,6 +119,58 @@ def test_amalgamation_of_deep_thin_trees():
     assert abs(objs[0] - objs[1]) < 1e-5 * (1 + abs(objs[1]))
 
 
+def test_mtxnorm_sdp_structure_and_solution():
+    """mtxnorm_SDP (base.py:639-773): structural known answer of the reference's documentation, and on a small
+    instance the optimum returned through the embedding driver equals the minimised spectral norm."""
+    P = base.mtxnorm_SDP(200, 10, 200)
+    assert (P.n, P.m, P.nnz) == (210, 201, 2210)                      # docs.rst:596,608
+    p, q, r = 6, 3, 4
+    P = base.mtxnorm_SDP(p, q, r, seed=3)
+    with oracle_backend():
+        sol = P.solve_esd()
+    assert sol["status"] == "optimal"
+    y = sol["y"]
+    n = p + q
+    blk = lambda col: np.asarray(P.A[:, col].todense()).reshape((n, n), order="F")[q:, :q]
+    M = blk(0) - sum(y[i] * blk(i + 1) for i in range(r))            # S = C - sum y_i A_i: (2,1) block = B - A(y)
+    t = y[r]
+    assert abs(np.linalg.norm(M, 2) - t) < 1e-5 * (1 + t)              # the bound t is tight at the optimum
+    assert abs(sol["dual objective"] + t) < 1e-6 * (1 + t)
+    # t is the MINIMAL norm: compare with a direct minimisation over y (scipy, derivative-free on 4 variables)
+    from scipy.optimize import minimize
+    f = lambda v: np.linalg.norm(blk(0) - sum(v[i] * blk(i + 1) for i in range(r)), 2)
+    best = minimize(f, y[:r], method="Nelder-Mead", options={"xatol": 1e-9, "fatol": 1e-12, "maxiter": 4000}).fun
+    assert t <= best + 1e-5 * (1 + best)
+
+
+def test_completion_dense_return():
+    """smcp.completion (base.py:952-973): dense maximum-determinant completion.  For X = P_V(S^-1) with S positive
+    definite on a chordal pattern V the completion is S^-1 itself; a non-chordal pattern goes through the embedding;
+    a matrix without positive definite completion raises ArithmeticError."""
+    import smcp_amd
+    rng = np.random.default_rng(0)
+    n = 14
+    mask = np.abs(np.subtract.outer(np.arange(n), np.arange(n))) <= 2            # band: chordal
+    Lb = np.where(np.tril(mask), rng.standard_normal((n, n)) * 0.4, 0.0)
+    Lb[np.diag_indices(n)] = 1.0 + rng.random(n)
+    S = Lb @ Lb.T
+    Si = np.linalg.inv(S)
+    X = sp.csc_matrix(np.where(np.tril(mask), Si, 0.0))
+    with oracle_backend():
+        Z = smcp_amd.completion(X)
+        assert np.linalg.norm(Z - Si) < 1e-9 * np.linalg.norm(Si)
+        # non-chordal pattern (a 5-cycle plus diagonal): entries on the pattern are kept, the result is positive definite
+        C = np.eye(5) * 2.0
+        for i in range(5):
+            C[i, (i + 1) % 5] = C[(i + 1) % 5, i] = 0.5
+        Zc = smcp_amd.completion(sp.csc_matrix(np.tril(C)))
+        assert np.linalg.eigvalsh(Zc).min() > 0 and np.abs((Zc - C)[C != 0]).max() < 1e-10
+        Xbad = X.tolil()
+        Xbad[0, 0] = -1.0
+        with pytest.raises(ArithmeticError):
+            smcp_amd.completion(sp.csc_matrix(Xbad))
+
+
 def test_infeasibility_certificates():
     """esd returns certificates (solvers.py:2299-2327).  As in the reference, conelp maps the cone LP
     onto the DUAL of the SDP pair and does not rename the status (solvers.py:2535-2597), so an
