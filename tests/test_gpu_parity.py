@@ -276,3 +276,37 @@ def test_kkt_many_constraints():
     solve(bxd, byd, 0.5)
     assert rel(host(bxd)[msk], xr[msk]) < 1e-8
     assert rel(byd.cpu().numpy(), yr) < 1e-8
+
+
+def test_kkt_wide_separators_stream_through_lds_front():
+    """Extend-add of a large front whose packed lower triangle fits LDS (k_lf_assemble_lds) with child separators
+    beyond 128 rows (the per-lane row registers cover 128; the rest goes through the plain loop): thin cliques (2, 150)
+    under a (150, 0) root, 40 constraints in one chunk so that the streaming kernel is selected."""
+    symb = Symbolic(problems.block_arrow_pattern(6, 2, 150))
+    symb.device_init(0, 40)
+    S = orc.Sym(symb)
+    A = problems.random_factor_blkval(symb, 31)
+    orc.llt(S, A)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    m = 40
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.03, seed=32)
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=40, tnzcols=0.0)
+    sys_.factor(dev(symb, L), dev(symb, Yh))
+    assert rel(np.tril(sys_.H.cpu().numpy().T), np.tril(Href)) < 1e-9
+    # dense multi-RHS Hessian through the same level (40 right-hand sides)
+    rng = np.random.default_rng(33)
+    msk = lowmask(symb)
+    U = rng.standard_normal((40, symb.blklen)) * msk
+    ref = U.copy()
+    for r in range(0, 40, 13):
+        orc.hessian(S, L, Yh, ref[r], adj=None, inv=False)
+    Ud = torch.from_numpy(U).cuda()
+    chordal.hessian(dev(symb, L), dev(symb, Yh), Ud, adj=None, inv=False)
+    got = Ud.cpu().numpy()
+    for r in range(0, 40, 13):
+        assert rel(got[r][msk], ref[r][msk]) < 1e-9
