@@ -1206,6 +1206,11 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
 // the (at most 9) lower tiles a wave owns stay in registers under compile-time indices, the slice of the next
 // step is fetched into registers while the MFMAs of the current one run (barriers order LDS traffic only), and
 // the k-steps of a tile use immediate LDS offsets.  Same partial-tile output layout as k_gram_partial.
+// NT = lower tiles per wave (ceil(ntl / 4), a template parameter: the tile loop is straight-line code, tiles are
+// processed in PAIRS with independent accumulator chains so that an MFMA never waits for the operands or the result
+// of the one before it -- with one dependent chain per tile the MFMA pipe was busy 45 % of the time, PMC
+// SQ_VALU_MFMA_BUSY_CYCLES).  Slots past the last tile of a wave recompute tile 0 and are not stored.
+template <int NT>
 __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
                                                       const double* sw, int64_t chunk, double* partial, int coff,
                                                       int nchunk_total) {
@@ -1218,18 +1223,22 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
   const int mti = (ni + 15) >> 4;
   const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int MAXT = 9, NC = GRAM_BLK / 4;
+  constexpr int NC = GRAM_BLK / 4;
   // this wave's lower tiles p = wave, wave + 4, ... of the (tm >= tn) enumeration
-  int tms[MAXT], tns[MAXT];
+  int tms[NT], tns[NT];
+  bool tv[NT];
   const int ntl = mti * (mti + 1) / 2;
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
+  for (int i = 0; i < NT; ++i) {
     int p = wave + 4 * i, tm = 0;
-    if (p < ntl) { while (p > tm) { p -= tm + 1; ++tm; } tms[i] = tm; tns[i] = p; } else { tms[i] = -1; tns[i] = 0; }
+    tv[i] = p < ntl;
+    if (!tv[i]) p = 0;
+    while (p > tm) { p -= tm + 1; ++tm; }
+    tms[i] = tm; tns[i] = p;
   }
-  d4 acc[MAXT];
+  d4 acc[NT];
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < NT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
   for (int e = threadIdx.x; e < GRAM_BLK * GRAM_LDK; e += 256) sA[e] = 0.0;   // columns >= m stay zero
   const int64_t e_begin = e_lo + (int64_t)blockIdx.x * chunk, e_end = min(e_hi, e_begin + chunk);
   double pre[NC], pre_sw = 0.0;
@@ -1245,6 +1254,10 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
   };
   if (e_begin < e_end) fetch(e_begin);
   const double* const lbase = sA + l15 * GRAM_LDK + kq;
+  const double* pa[NT];
+  const double* pb[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) { pa[i] = lbase + 16 * GRAM_LDK * tms[i]; pb[i] = lbase + 16 * GRAM_LDK * tns[i]; }
   for (int64_t e0 = e_begin; e0 < e_end; e0 += GRAM_KS) {
     lds_barrier();                                 // the tiles of the previous slice have been consumed
 #pragma unroll
@@ -1255,21 +1268,21 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
     lds_barrier();
     if (e0 + GRAM_KS < e_end) fetch(e0 + GRAM_KS); // in flight while the MFMAs below run
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      if (tms[i] < 0) continue;
-      const double* const pa = lbase + 16 * GRAM_LDK * tms[i];
-      const double* const pb = lbase + 16 * GRAM_LDK * tns[i];
-      d4 a = acc[i];
+    for (int i = 0; i < NT; i += 2) {
+      d4 a0 = acc[i], a1 = acc[(i + 1 < NT) ? i + 1 : i];
 #pragma unroll
-      for (int s2 = 0; s2 < GRAM_KS / 4; ++s2)
-        a = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[s2 * 4], pa[s2 * 4], a, 0, 0, 0);
-      acc[i] = a;
+      for (int s2 = 0; s2 < GRAM_KS / 4; ++s2) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i][s2 * 4], pa[i][s2 * 4], a0, 0, 0, 0);
+        if (i + 1 < NT) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i + 1][s2 * 4], pa[i + 1][s2 * 4], a1, 0, 0, 0);
+      }
+      acc[i] = a0;
+      if (i + 1 < NT) acc[i + 1] = a1;
     }
   }
   double* out = partial + ((int64_t)coff + blockIdx.x) * (int64_t)(64 * 256);
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    if (tms[i] < 0) continue;
+  for (int i = 0; i < NT; ++i) {
+    if (!tv[i]) continue;
     const int t = tms[i] + tns[i] * mti;
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(int64_t)t * 256 + (kq + 4 * r) * 16 + l15] = acc[i][r];

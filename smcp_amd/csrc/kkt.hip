@@ -635,8 +635,17 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     if (hi <= lo) continue;
     int nc = (int)((hi - lo + chunk - 1) / chunk);
     if (nblk == 1)
-      launch_lds(c, KID_gram_partial, k_gram_diag128, dim3(nc, 1), dim3(256), (size_t)GRAM_BLK * GRAM_LDK * sizeof(double), st,
-                 (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk);
+    {
+      const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + 3) / 4;   // lower tiles per wave
+      const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
+#define SMCP_GRAM_CASE(N) case N: launch_lds(c, KID_gram_partial, k_gram_diag128<N>, dim3(nc, 1), dim3(256), lds, st, \
+                 (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk); break;
+      switch (npw) {
+        SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)
+        SMCP_GRAM_CASE(6) SMCP_GRAM_CASE(7) SMCP_GRAM_CASE(8) SMCP_GRAM_CASE(9)
+      }
+#undef SMCP_GRAM_CASE
+    }
     else
       for (int bi = 0; bi < nb; ++bi)
         for (int bj = 0; bj <= bi; ++bj) {
