@@ -1,0 +1,66 @@
+// Microbenchmark: read bandwidth of the Gram kernel's access pattern.  G is (m columns) x (B entries), column-major
+// (column stride ldg = B).  512 workgroups of 256 threads; workgroup b owns entries [b*chunk, (b+1)*chunk) and walks
+// them in slices of KS entries; per slice wave w loads columns w, w+4, ... (one KS*8-byte segment per column).
+// Variants: KS = 64 (one double per lane per column, as k_gram_diag128), KS = 128 (two), prefetch depth 1 or 2.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+template <int VEC, int DEPTH>
+__global__ void __launch_bounds__(256) k(const double* __restrict__ G, long ldg, int m, long chunk, double* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long e_begin = (long)blockIdx.x * chunk, e_end = e_begin + chunk;
+  constexpr int KS = 64 * VEC, NC = 32;
+  double acc = 0.0;
+  double pre[DEPTH][NC][VEC];
+  auto fetch = [&](int d, long e0) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int cc = wave + 4 * j;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) pre[d][j][v] = (cc < m && e0 < e_end) ? G[(long)cc * ldg + e0 + lane * VEC + v] : 0.0;
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) fetch(d, e_begin + (long)d * KS);
+  for (long e0 = e_begin; e0 < e_end; e0 += (long)KS * DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc += pre[d][j][v];
+      // stand-in for the MFMA phase: ~7000 cycles of dependent math per 64-entry slice
+      double t = acc;
+      for (int q = 0; q < 110 * VEC; ++q) t = fma(t, 1.0000001, 1e-9);
+      acc = t;
+      fetch(d, e0 + (long)(DEPTH + d) * KS);
+    }
+  }
+  if (acc == 1.2345) out[0] = acc;
+}
+int main() {
+  setvbuf(stdout, nullptr, _IOLBF, 0);
+  const long B = 2493568; const int m = 100;
+  const long chunk = 4864;                     // 512 workgroups
+  const int nb = 512;
+  double* G; double* out;
+  CK(hipMalloc(&G, sizeof(double) * (size_t)B * m + (1 << 20))); CK(hipMalloc(&out, 64));
+  CK(hipMemset(G, 0, sizeof(double) * (size_t)B * m));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto run = [&](const char* name, auto kern) {
+    float best = 1e9;
+    for (int it = 0; it < 3; ++it) {
+      hipEventRecord(e0);
+      kern<<<nb, 256>>>(G, B, m, chunk, out);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best) best = ms;
+    }
+    printf("%-28s %.3f ms  %.2f TB/s\n", name, best, (double)nb * chunk * m * 8 / best / 1e9);
+    return 0;
+  };
+  run("KS=64  depth 1", k<1, 1>);
+  run("KS=64  depth 2", k<1, 2>);
+  run("KS=128 depth 1", k<2, 1>);
+  return 0;
+}
