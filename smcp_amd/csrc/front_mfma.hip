@@ -1213,7 +1213,7 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
 template <int NT>
 __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
                                                       const double* sw, int64_t chunk, double* partial, int coff,
-                                                      int nchunk_total) {
+                                                      int nchunk_total, int skip) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // LDS image [column][k = 64], ld GRAM_LDK = 66 doubles: the staging store is contiguous along k (no transpose)
   // and the operand reads (row = column l15, k = kq + 4 s) hit 32 distinct 8-byte bank pairs per half wave
@@ -1249,7 +1249,7 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int cc = wave + 4 * j;
-      pre[j] = (ein && cc < ni) ? G[(int64_t)cc * ldg + e] : 0.0;
+      pre[j] = (ein && cc < ni) ? ((skip & 2) ? 1.0 : G[(int64_t)cc * ldg + e]) : 0.0;
     }
   };
   if (e_begin < e_end) fetch(e_begin);
@@ -1267,6 +1267,7 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
     }
     lds_barrier();
     if (e0 + GRAM_KS < e_end) fetch(e0 + GRAM_KS); // in flight while the MFMAs below run
+    if (!(skip & 1))
 #pragma unroll
     for (int i = 0; i < NT; i += 2) {
       d4 a0 = acc[i], a1 = acc[(i + 1 < NT) ? i + 1 : i];

@@ -637,9 +637,11 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     if (nblk == 1)
     {
       const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + 3) / 4;   // lower tiles per wave
+      static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
+      if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
       const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
 #define SMCP_GRAM_CASE(N) case N: launch_lds(c, KID_gram_partial, k_gram_diag128<N>, dim3(nc, 1), dim3(256), lds, st, \
-                 (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk); break;
+                 (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); break;
       switch (npw) {
         SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)
         SMCP_GRAM_CASE(6) SMCP_GRAM_CASE(7) SMCP_GRAM_CASE(8) SMCP_GRAM_CASE(9)
