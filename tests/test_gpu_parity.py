@@ -310,3 +310,22 @@ def test_kkt_wide_separators_stream_through_lds_front():
     got = Ud.cpu().numpy()
     for r in range(0, 40, 13):
         assert rel(got[r][msk], ref[r][msk]) < 1e-9
+
+
+def test_kkt_family_kernel_dense_constraints():
+    """Family kernel with long entry lists: constraints dense on V give a (5,31) child 180 entries (more than the 64
+    prefetched per wave) and a (15,64) parent 1185 (more than the 256 prefetched per group): the direct-load tails
+    of the entry loops."""
+    symb, S, A, msk = setup("nested_mid", 41)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    m = 4
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=1.0, seed=42)
+    assert (np.diff(cptr) > 0.9 * msk.sum()).all()
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=4, tnzcols=0.0)
+    sys_.factor(dev(symb, L), dev(symb, Yh))
+    assert rel(np.tril(sys_.H.cpu().numpy().T), np.tril(Href)) < 1e-9
