@@ -210,3 +210,34 @@ def test_dense_completion_and_mtxnorm_on_device():
     blk = lambda col: np.asarray(P.A[:, col].todense()).reshape((nn, nn), order="F")[q:, :q]
     M = blk(0) - sum(y[i] * blk(i + 1) for i in range(r))
     assert abs(np.linalg.norm(M, 2) - y[r]) < 1e-5 * (1 + y[r])
+
+
+@pytest.mark.parametrize("n,m,bw", [(10, 1, 2), (3, 1, 1), (2, 1, 0), (6, 3, 5), (40, 5, 0)])
+def test_edge_sizes_through_all_drivers(n, m, bw):
+    """Smallest and degenerate shapes: one constraint, diagonal (LP) patterns, a single dense clique; every driver
+    reaches the default tolerances and primal and dual objectives agree."""
+    from smcp_amd import base, solvers
+    solvers.options.update(show_progress=False, maxiters=100, feastol=1e-8, abstol=1e-6, reltol=1e-6)
+    P = base.band_SDP(n, m, bw, seed=1)
+    st = dict(primalstart={"x": P._X0}, dualstart={"y": P._y0, "s": P._S0})
+    sols = [P.solve_feas(scaling="primal", **st), P.solve_feas(scaling="dual", **st), P.solve_esd()]
+    for sol in sols:
+        assert sol["status"] == "optimal"
+        assert abs(sol["primal objective"] - sol["dual objective"]) < 1e-4 * (1 + abs(sol["dual objective"]))
+    assert abs(sols[0]["primal objective"] - sols[2]["primal objective"]) < 1e-4 * (1 + abs(sols[2]["primal objective"]))
+
+
+def test_one_by_one_sdp():
+    """n = 1: minimize 2 x subject to x = 3, x >= 0."""
+    from smcp_amd import base, solvers
+    solvers.options.update(show_progress=False, maxiters=100)
+
+    class One(base.SDP):
+        def __init__(self):
+            super().__init__()
+            self._A = sp.csc_matrix(np.array([[2.0, 1.0]]))
+            self._b = np.array([3.0])
+            self._blockstruct = [1]
+
+    sol = One().solve_esd()
+    assert sol["status"] == "optimal" and abs(sol["primal objective"] - 6.0) < 1e-5 and abs(sol["dual objective"] - 6.0) < 1e-5
