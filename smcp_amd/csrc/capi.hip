@@ -1034,15 +1034,20 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_gram_partial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_gram_partial<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<5>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<6>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<7>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<9>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<5, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<5, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<7, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<9, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_lf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_factor_yaa_lds, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));

@@ -1210,8 +1210,8 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
 // processed in PAIRS with independent accumulator chains so that an MFMA never waits for the operands or the result
 // of the one before it -- with one dependent chain per tile the MFMA pipe was busy 45 % of the time, PMC
 // SQ_VALU_MFMA_BUSY_CYCLES).  Slots past the last tile of a wave recompute tile 0 and are not stored.
-template <int NT>
-__global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
+template <int NT, int NW>
+__global__ void __launch_bounds__(64 * NW) k_gram_diag128(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
                                                       const double* sw, int64_t chunk, double* partial, int coff,
                                                       int nchunk_total, int skip) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1223,14 +1223,14 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
   const int mti = (ni + 15) >> 4;
   const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int NC = GRAM_BLK / 4;
+  constexpr int NC = GRAM_BLK / NW;
   // this wave's lower tiles p = wave, wave + 4, ... of the (tm >= tn) enumeration
   int tms[NT], tns[NT];
   bool tv[NT];
   const int ntl = mti * (mti + 1) / 2;
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
-    int p = wave + 4 * i, tm = 0;
+    int p = wave + NW * i, tm = 0;
     tv[i] = p < ntl;
     if (!tv[i]) p = 0;
     while (p > tm) { p -= tm + 1; ++tm; }
@@ -1239,7 +1239,7 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
   d4 acc[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
-  for (int e = threadIdx.x; e < GRAM_BLK * GRAM_LDK; e += 256) sA[e] = 0.0;   // columns >= m stay zero
+  for (int e = threadIdx.x; e < GRAM_BLK * GRAM_LDK; e += 64 * NW) sA[e] = 0.0;   // columns >= m stay zero
   const int64_t e_begin = e_lo + (int64_t)blockIdx.x * chunk, e_end = min(e_hi, e_begin + chunk);
   double pre[NC], pre_sw = 0.0;
   auto fetch = [&](int64_t e0) {
@@ -1248,7 +1248,7 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
     pre_sw = ein ? sw[e] : 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      const int cc = wave + 4 * j;
+      const int cc = wave + NW * j;
       pre[j] = (ein && cc < ni) ? ((skip & 2) ? 1.0 : G[(int64_t)cc * ldg + e]) : 0.0;
     }
   };
@@ -1262,7 +1262,7 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
     lds_barrier();                                 // the tiles of the previous slice have been consumed
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      const int cc = wave + 4 * j;
+      const int cc = wave + NW * j;
       if (cc < ni) sA[cc * GRAM_LDK + lane] = pre_sw != 0.0 ? pre[j] * pre_sw : 0.0;   // weight 0: never-written entries
     }
     lds_barrier();
@@ -1270,14 +1270,22 @@ __global__ void __launch_bounds__(256) k_gram_diag128(const double* G, int64_t l
     if (!(skip & 1))
 #pragma unroll
     for (int i = 0; i < NT; i += 2) {
+      if (!tv[i]) continue;                              // slots are filled in order: nothing beyond an empty one
+      const bool two = (i + 1 < NT) && tv[(i + 1 < NT) ? i + 1 : i];
       d4 a0 = acc[i], a1 = acc[(i + 1 < NT) ? i + 1 : i];
+      if (two) {
 #pragma unroll
-      for (int s2 = 0; s2 < GRAM_KS / 4; ++s2) {
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i][s2 * 4], pa[i][s2 * 4], a0, 0, 0, 0);
-        if (i + 1 < NT) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i + 1][s2 * 4], pa[i + 1][s2 * 4], a1, 0, 0, 0);
+        for (int s2 = 0; s2 < GRAM_KS / 4; ++s2) {
+          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i][s2 * 4], pa[i][s2 * 4], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[(i + 1 < NT) ? i + 1 : i][s2 * 4], pa[(i + 1 < NT) ? i + 1 : i][s2 * 4], a1, 0, 0, 0);
+        }
+        acc[(i + 1 < NT) ? i + 1 : i] = a1;
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < GRAM_KS / 4; ++s2)
+          a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[i][s2 * 4], pa[i][s2 * 4], a0, 0, 0, 0);
       }
       acc[i] = a0;
-      if (i + 1 < NT) acc[i + 1] = a1;
     }
   }
   double* out = partial + ((int64_t)coff + blockIdx.x) * (int64_t)(64 * 256);
