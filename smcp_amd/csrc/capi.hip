@@ -1034,6 +1034,9 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_n16<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_gram_partial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_gram_partial<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<3, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_gram_diag128<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));

@@ -1211,7 +1211,7 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
 // of the one before it -- with one dependent chain per tile the MFMA pipe was busy 45 % of the time, PMC
 // SQ_VALU_MFMA_BUSY_CYCLES).  Slots past the last tile of a wave recompute tile 0 and are not stored.
 template <int NT, int NW>
-__global__ void __launch_bounds__(64 * NW) k_gram_diag128(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
+__global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
                                                       const double* sw, int64_t chunk, double* partial, int coff,
                                                       int nchunk_total, int skip) {
   extern __shared__ __attribute__((aligned(16))) double smem[];

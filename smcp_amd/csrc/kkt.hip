@@ -636,15 +636,17 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     int nc = (int)((hi - lo + chunk - 1) / chunk);
     if (nblk == 1)
     {
-      // eight waves per workgroup (two workgroups per CU: four waves per SIMD hide the staging and operand latency
-      // better than two; SMCP_GRAM_NW=4 selects the four-wave variant)
+      // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
+      // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
       static int nw = -1;
-      if (nw < 0) { const char* e = getenv("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : 8; }
+      if (nw < 0) { const char* e = getenv("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
       const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + nw - 1) / nw;   // lower tiles per wave
       static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
       if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
       const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
-#define SMCP_GRAM_CASE(N) case N: if (nw == 8) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nc, 1), dim3(512), lds, st, \
+#define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nc, 1), dim3(1024), lds, st, \
+                 (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
+               else if (nw == 8) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nc, 1), dim3(512), lds, st, \
                  (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
                else launch_lds(c, KID_gram_partial, k_gram_diag128<N, 4>, dim3(nc, 1), dim3(256), lds, st, \
                  (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); break;
