@@ -329,3 +329,53 @@ def test_kkt_family_kernel_dense_constraints():
     sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=4, tnzcols=0.0)
     sys_.factor(dev(symb, L), dev(symb, Yh))
     assert rel(np.tril(sys_.H.cpu().numpy().T), np.tril(Href)) < 1e-9
+
+
+@pytest.mark.parametrize("spread,tol", [(0, 1e-12), (3, 1e-9), (5, 1e-5)])
+def test_kkt_solve_at_ill_conditioned_scaling_points(spread, tol):
+    """Late interior-point iterations scale by matrices whose pivots spread over many decades.  The HIP path (explicit
+    inverses of the diagonal blocks, GEMM-only sweeps) must degrade no faster than the oracle (triangular solves): the
+    search directions agree to rounding x condition, and the residuals of the defining equations (solvers.py:401-411),
+    evaluated by the oracle for both, are of the same size."""
+    symb = Symbolic(problems.nested_block_arrow_pattern(nsub=2, nmid=6, nleaf_per_mid=8, seed=3))
+    symb.device_init(0, 8)
+    S = orc.Sym(symb)
+    msk = lowmask(symb)
+    rng = np.random.default_rng(10 + spread)
+    Lh = problems.random_factor_blkval(symb, 5)
+    nn, na = symb.clique_sizes()
+    for k in range(symb.Nsn):
+        nf = nn[k] + na[k]
+        blk = Lh[symb.blkptr[k]:symb.blkptr[k] + nf * nn[k]].reshape((nf, nn[k]), order="F")
+        blk *= (10.0 ** (-spread * rng.random(nn[k])))[None, :]
+    A = Lh.copy()
+    orc.llt(S, A)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    m = 8
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.05, seed=9)
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=8)
+    Ld = dev(symb, A)
+    chordal.cholesky(Ld)
+    Yd = Ld.copy()
+    chordal.projected_inverse(Yd)
+    solve = sys_.factor(Ld, Yd)
+    bx = rng.standard_normal(symb.blklen) * msk
+    by = rng.standard_normal(m)
+    xr, yr = K.solve(L, Yh, Href, bx, by, 1.0)
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    solve(bxd, byd, 1.0)
+    xg, yg = host(bxd), byd.cpu().numpy()
+    assert np.linalg.norm((xg - xr)[msk]) / np.linalg.norm(xr[msk]) < tol
+    assert np.linalg.norm(yg - yr) / np.linalg.norm(yr) < tol
+
+    def res(x, y):
+        r, rr = K.residual(L, Yh, x * msk, y, bx, by, 1.0)
+        return np.sqrt(orc.dot(S, r, r)), np.linalg.norm(rr)
+
+    (g1, g2), (o1, o2) = res(xg, yg), res(xr, yr)
+    assert g1 <= 10 * o1 + 1e-12 and g2 <= 10 * o2 + 1e-10
