@@ -295,6 +295,59 @@ def completion(X):
     return 0.5 * (Z + Z.T)
 
 
+class pattern_SDP(SDP):
+    """Random strictly feasible SDP on a given chordal sparsity pattern: P = pattern_SDP(pat, m, density, seed) with
+    pat = (n, colptr, rowind) (lower triangle).  The band_SDP recipe (base.py:600-636) on any pattern: X0 and S0 are
+    positive definite with pattern V (L L^T of a random factor on V, formed on the device), the A_i have
+    max(1, round(density |V|)) random entries of V each (the reference's UFSMC recipe, doc benchmarks index.rst:479),
+    b = A(X0), C = S0 + sum_i y0_i A_i.  Used for whole interior-point runs on the benchmark patterns (synth50k)."""
+
+    def __init__(self, pat, m, density=0.005, seed=0):
+        super().__init__()
+        import torch
+        from . import chordal, problems
+        from .cspmatrix import cspmatrix
+        from .symbolic import Symbolic
+        n, cp, ri = pat
+        rng = np.random.default_rng(seed)
+        J = np.repeat(np.arange(n, dtype=np.int64), np.diff(cp))
+        I = np.asarray(ri, dtype=np.int64)
+        nv = len(I)
+        symb = Symbolic(pat)
+        if symb.fill:
+            raise ValueError("pattern_SDP needs a chordal pattern in a perfect elimination order")
+
+        def posdef(sd):
+            X = cspmatrix(symb, torch.from_numpy(problems.random_factor_blkval(symb, sd)).cuda())
+            chordal.llt(X)
+            return sp.csc_matrix(X.spmatrix(reordered=False, symmetric=False))
+
+        X0, S0 = posdef(seed + 1), posdef(seed + 2)
+        per = max(1, int(round(density * nv)))
+        y0 = rng.standard_normal(m)
+        y0 /= np.linalg.norm(y0)
+        x0v = np.asarray(X0[I, J]).ravel()
+        rows, cols, vals = [], [], []
+        b = np.zeros(m)
+        csum = np.zeros(nv)
+        for i in range(m):
+            sel = np.sort(rng.choice(nv, size=per, replace=False))
+            v = rng.standard_normal(per) / np.sqrt(per)
+            rows.append(I[sel] + n * J[sel])
+            cols.append(np.full(per, i + 1, dtype=np.int64))
+            vals.append(v)
+            b[i] = np.sum(np.where(I[sel] == J[sel], 1.0, 2.0) * v * x0v[sel])
+            csum[sel] += y0[i] * v
+        rows.insert(0, I + n * J)
+        cols.insert(0, np.zeros(nv, dtype=np.int64))
+        vals.insert(0, np.asarray(S0[I, J]).ravel() + csum)
+        self._A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n * n, m + 1))
+        self._b = b
+        self._blockstruct = [n]
+        self._pname = "pattern_n%i_m%i" % (n, m)
+        self._X0, self._y0, self._S0 = X0, y0, S0
+
+
 def maxcut_SDP(n=1000, nedges=5909, seed=0):
     """Max-cut relaxation on a random graph with the size of SDPLIB maxG51 (config 4):
     minimize <C,X>, diag(X) = 1, C = -(Diag(W1) - W)/4."""
