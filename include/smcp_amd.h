@@ -153,6 +153,16 @@ int csp_exchange_copy(csp_ctx* ctx, int64_t nk, const int64_t* cliques, int64_t 
  * Y by any other means (its own kernels, memcpy) must call csp_cache_reset() before the next call. */
 int csp_cache_reset(csp_ctx* ctx);
 
+/* Device-resident line search: the reference's line searches factor X + alpha*dX for a ladder of alpha one
+ * after the other, each behind a read-back of the failure flag (src/python/solvers.py:615-689 bisection / backtracking of
+ * the feasible-start solver, 928-939, 2172-2209 embedding solver).  Here K trial matrices are factored CONCURRENTLY:
+ * reserve K private workspace slots (K <= max_rhs of csp_device_init), launch probe `slot` on its own stream (kind 0:
+ * cholesky, 1: completion; in place on x; returns without waiting), synchronise the streams, then read the K failure
+ * flags (0 = inside the cone, k+1 = failed at clique k) with one copy. */
+int csp_probe_reserve(csp_ctx* ctx, int64_t K);
+int csp_probe_launch(csp_ctx* ctx, int kind, double* x, int64_t slot, void* stream);
+int csp_probe_results(csp_ctx* ctx, int64_t K, int* out);
+
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on its own stream. */
 int csp_profile_enable(csp_ctx* ctx, int on);

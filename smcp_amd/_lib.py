@@ -39,6 +39,9 @@ SIGNATURES = {
     "kkt_schur_factor": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kkt_schur_columns": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "csp_cache_reset": (ctypes.c_int, [c_vp]),
+    "csp_probe_reserve": (ctypes.c_int, [c_vp, c_i64]),
+    "csp_probe_launch": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp]),
+    "csp_probe_results": (ctypes.c_int, [c_vp, c_i64, c_vp]),
     "csp_profile_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "csp_profile_kinds": (c_i64, []),
     "csp_profile_filter": (ctypes.c_int, [c_vp, ctypes.c_int]),

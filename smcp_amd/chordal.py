@@ -103,3 +103,39 @@ def logdiagsum(X):
     out = ctypes.c_double(0.0)
     _chk(_lib.lib().csp_logdiagsum(X.symb.handle, X.blkval.data_ptr(), ctypes.byref(out), _stream()), "logdiagsum")
     return out.value
+
+
+_probe_streams = []
+
+
+def probe_cone(base, d, alphas, kind):
+    """Concurrent trial factorisations (device-resident line search, include/smcp_amd.h csp_probe_*): for every
+    alpha in `alphas`, is base + alpha * d inside the cone?  kind 'd': positive definite on V (cholesky, the dual cone
+    K_V); kind 'p': positive definite completable (completion, the primal cone C_V).  The K trial matrices are formed
+    with one broadcast, each is factored on its own stream with its own workspace slot, and the K failure flags come
+    back with one copy -- the reference probes them one after the other (solvers.py:615-689)."""
+    import torch
+    symb = base.symb
+    K = len(alphas)
+    _ensure(symb, K)
+    if symb._max_rhs < K:                       # slot s uses right-hand-side copy s of the update workspaces
+        symb.device_init(symb._device, K)
+    L = _lib.lib()
+    _chk(L.csp_probe_reserve(symb.handle, K), "csp_probe_reserve")
+    main = torch.cuda.current_stream()
+    al = torch.as_tensor(list(alphas), dtype=torch.float64, device=base.blkval.device)
+    T = base.blkval.unsqueeze(0) + al.unsqueeze(1) * d.blkval.unsqueeze(0)        # (K, blklen), one launch
+    while len(_probe_streams) < K:
+        _probe_streams.append(torch.cuda.Stream())
+    k_id = 1 if kind == "p" else 0
+    for k in range(K):
+        s = _probe_streams[k]
+        s.wait_stream(main)
+        rc = L.csp_probe_launch(symb.handle, k_id, T[k].data_ptr(), k, s.cuda_stream)
+        if rc < 0:
+            raise RuntimeError("csp_probe_launch failed (%d)" % rc)
+    for k in range(K):
+        _probe_streams[k].synchronize()
+    out = (ctypes.c_int * K)()
+    _chk(L.csp_probe_results(symb.handle, K, out), "csp_probe_results")
+    return [out[k] == 0 for k in range(K)]

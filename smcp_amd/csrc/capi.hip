@@ -134,6 +134,7 @@ int ready(csp_ctx* c) {
 
 // read back the device failure flag (synchronises the stream)
 int fetch_info(csp_ctx* c, hipStream_t st) {
+  if (c->nowait) return 0;      // probe launch: the caller collects the flags of all slots later (csp_probe_results)
   HIPCHK(hipMemcpyAsync(c->D.info_host, c->D.info, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return *c->D.info_host;
@@ -860,7 +861,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.p_yaa, D.p_fac, D.p_faci, D.p_lfd, D.p_info, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
     for (void* p : ptrs) if (p) hipFree(p);
     if (D.info_host) hipHostFree(D.info_host);
@@ -973,6 +974,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       D.nII_total = (int64_t)large.size();
       lev3.insert(lev3.end(), large.begin(), large.end());
       if ((rc = dev_upload(&D.lev3idx, lev3, D.bytes))) return rc;
+      D.lfd_len = (int64_t)(slot + 1) * 64 * 64;
       if ((rc = dev_alloc(&D.lfd, (int64_t)(slot + 1) * 64 * 64, D.bytes))) return rc;
       D.lfd_dense = D.lfd + (int64_t)slot * 64 * 64;
     }
@@ -1299,6 +1301,70 @@ int csp_axpby(int64_t len, double a, const double* x, double b, double* y, void*
   return 0;
 }
 
+
+// ---- device-resident line search: concurrent trial factorisations ---------------------------------
+// The drivers' line searches factor X + alpha dX for a ladder of alpha (solvers.py:615-689, 928-939, 2172-2209), one
+// after the other, each followed by a read-back of the failure flag.  A trial factorisation is a chain of small
+// launches (latency bound), so K of them overlap almost perfectly on K streams -- provided they do not share scratch.
+// Slot s uses right-hand-side copy s of upd / updp / tmp and its own yaa / fac / faci / lfd / failure flag.
+int csp_probe_reserve(csp_ctx* c, int64_t K) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  if (K < 1 || K > D.max_rhs) return SMCP_EINVAL;          // upd / updp / tmp hold max_rhs copies
+  if (D.probe_K >= K) return 0;
+  HIPCHK(hipSetDevice(D.device));
+  void* old[] = {D.p_yaa, D.p_fac, D.p_faci, D.p_lfd, D.p_info};
+  for (void* p : old) if (p) (void)hipFree(p);
+  D.p_yaa = D.p_fac = D.p_faci = D.p_lfd = nullptr; D.p_info = nullptr; D.probe_K = 0;
+  const int64_t ul = std::max<int64_t>(c->S.updlen(), 1);
+  int rc;
+  if ((rc = dev_alloc(&D.p_yaa, K * ul, D.bytes))) return rc;
+  if ((rc = dev_alloc(&D.p_fac, K * ul, D.bytes))) return rc;
+  if ((rc = dev_alloc(&D.p_faci, K * ul, D.bytes))) return rc;
+  if ((rc = dev_alloc(&D.p_lfd, K * std::max<int64_t>(D.lfd_len, 1), D.bytes))) return rc;
+  if ((rc = dev_alloc(&D.p_info, K, D.bytes))) return rc;
+  D.probe_K = (int)K;
+  return 0;
+}
+// kind 0: cholesky(x), 1: completion(x), in place, on `stream`, WITHOUT waiting; slot < reserved K.
+int csp_probe_launch(csp_ctx* c, int kind, double* x, int64_t slot, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  if (slot < 0 || slot >= D.probe_K || (kind != 0 && kind != 1) || use_generic()) return SMCP_EINVAL;
+  const int64_t ul = std::max<int64_t>(c->S.updlen(), 1);
+  // the launches capture their pointer arguments when they are enqueued: shift the workspaces to the slot's copies for
+  // the duration of the (host-side) call and put everything back afterwards
+  struct Saved { double *upd, *updp, *tmp, *yaa, *fac, *faci, *lfd, *lfd_dense; int* info;
+                 const void *lkL, *lkY, *ty, *tf, *tfi; } sv =
+      {D.upd, D.updp, D.tmp, D.yaa, D.fac, D.faci, D.lfd, D.lfd_dense, D.info, D.lk_tag_L, D.lk_tag_Y, D.yaa_tag, D.fac_tag, D.faci_tag};
+  D.upd += slot * c->S.updlen();
+  D.updp += slot * c->S.updplen();
+  D.tmp += slot * D.tmplen;
+  D.yaa = D.p_yaa + slot * ul;
+  D.fac = D.p_fac + slot * ul;
+  D.faci = D.p_faci + slot * ul;
+  D.lfd = D.p_lfd + slot * std::max<int64_t>(D.lfd_len, 1);
+  D.lfd_dense = D.lfd + (D.lfd_len - 64 * 64);
+  D.info = D.p_info + slot;
+  D.yaa_tag = D.fac_tag = D.faci_tag = nullptr;
+  const bool prof = c->prof.on;
+  c->prof.on = false;
+  c->nowait = true;
+  const int rc = kind ? csp_completion(c, x, stream) : csp_cholesky(c, x, stream);
+  c->nowait = false;
+  c->prof.on = prof;
+  D.upd = sv.upd; D.updp = sv.updp; D.tmp = sv.tmp; D.yaa = sv.yaa; D.fac = sv.fac; D.faci = sv.faci;
+  D.lfd = sv.lfd; D.lfd_dense = sv.lfd_dense; D.info = sv.info;
+  D.lk_tag_L = sv.lkL; D.lk_tag_Y = sv.lkY; D.yaa_tag = sv.ty; D.fac_tag = sv.tf; D.faci_tag = sv.tfi;
+  return rc;
+}
+// failure flags of slots 0..K-1 (0 = the trial matrix is in the cone); the caller has synchronised the probes' streams
+int csp_probe_results(csp_ctx* c, int64_t K, int* out) {
+  if (int rc = ready(c)) return rc;
+  if (K < 1 || K > c->D.probe_K || !out) return SMCP_EINVAL;
+  HIPCHK(hipMemcpy(out, c->D.p_info, sizeof(int) * K, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 int csp_cache_reset(csp_ctx* c) {
   if (!c) return SMCP_EINVAL;

@@ -102,6 +102,12 @@ struct DeviceCtx {
   double* sw = nullptr;      // blklen : sqrt of the inner-product weights (Gram path)
   double* gpart = nullptr;   // partial Gram tiles
   int64_t gpart_len = 0;
+  // probe slots (csp_probe_*): K private copies of the workspaces a trial factorisation writes besides the
+  // per-right-hand-side ones (upd / updp / tmp are indexed by the slot as if it were a right-hand side)
+  int probe_K = 0;
+  int64_t lfd_len = 0;         // doubles of one lfd copy (large-front slots + the dense slot)
+  double* p_yaa = nullptr; double* p_fac = nullptr; double* p_faci = nullptr; double* p_lfd = nullptr;
+  int* p_info = nullptr;       // K device failure flags
   int64_t bytes = 0;
 };
 
@@ -163,6 +169,7 @@ struct csp_ctx {
   std::vector<int> lev_namax;   // per level: largest separator (sizes the gather launches)
   std::vector<int64_t> fam;     // per clique: family role (CSP_Q_FAMILY)
   std::vector<uint8_t> is_diag_cache;
+  bool nowait = false;                  // csp_probe_launch: factorisations return without reading the failure flag back
   double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)
   std::vector<int64_t> h_kptr;          // ns + 1 : offsets into kidx, host copy for chunk planning
   std::vector<int32_t> h_slist;

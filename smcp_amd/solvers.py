@@ -40,6 +40,8 @@ options = {
     "esd_kkt_refinement": 1, "esd_ds_from_hessian": False,
     # relaxed supernode amalgamation of deep, thin clique trees (smcp_amd.symbolic.amalgamate; not in the reference)
     "amalgamate": True,
+    # device-resident line search: the bisection probes of the feasible-start solver as concurrent trial factorisations
+    "batched_linesearch": True,
 }
 _defaults = _copy.deepcopy(options)
 
@@ -527,6 +529,7 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
     ALPHA = _opt("alpha", float, 0.0, 0.5, strict_lo=True)
     BETA = _opt("beta", float, 0.0, 1.0, strict_lo=True)
     MINSTEP = _opt("minstep", float, 0.0, strict_lo=True)
+    BATCHED = _opt("batched_linesearch", bool) and (torch.cuda.is_available() or getattr(chordal, "_probe_emulated", False))
     LIFTING = _opt("lifting", bool)
     EQUALSTEPS = _opt("equalsteps", bool)
     PREDICTION = _opt("prediction", bool)
@@ -595,7 +598,23 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
         return math.sqrt(max(dot(du, du), 0.0))
 
     def bisect(base_, d, which, a):
+        """Largest step g in [MINSTEP, 1] (to a resolution of 1/256 or finer) with base_ + g d inside the cone.
+        The reference bisects with eight trial factorisations one after the other (solvers.py:615-689); with
+        options['batched_linesearch'] the same interval is narrowed by an 8-ary search whose eight trial
+        factorisations per round run concurrently on the device (chordal.probe_cone): three rounds, 1/512."""
         lo, hi, g_ = MINSTEP, 1.0, MINSTEP
+        if BATCHED:
+            KP = 8
+            for _ in range(3):
+                pts = [lo + (hi - lo) * (k + 1) / KP for k in range(KP)]
+                ok = chordal.probe_cone(base_, d, pts, which)
+                kmax = max([k for k in range(KP) if ok[k]], default=-1)
+                if kmax >= 0:
+                    lo = g_ = pts[kmax]
+                if kmax == KP - 1:
+                    break                      # the whole interval is feasible
+                hi = pts[kmax + 1]
+            return a * g_
         for _ in range(8):
             g = 0.5 * (lo + hi)
             try:

@@ -130,6 +130,22 @@ def oracle_backend():
 
     chordal.hessian = hessian
     chordal.trsm = lambda L, B, trans="N": orc.trsm(_S(L.symb), _np(L), B.numpy(), trans)
+
+    def probe_cone(base, d, alphas, kind):          # the concurrent probes, emulated one after the other
+        out = []
+        for al in alphas:
+            t = _np(base) + al * _np(d)
+            try:
+                (orc.completion if kind == "p" else orc.cholesky)(_S(base.symb), t)
+                out.append(True)
+            except ArithmeticError:
+                out.append(False)
+        return out
+
+    saved["probe_cone"] = getattr(chordal, "probe_cone", None)
+    saved["_probe_emulated"] = getattr(chordal, "_probe_emulated", False)
+    chordal.probe_cone = probe_cone
+    chordal._probe_emulated = True
     chordal.dot = lambda X, Y: orc.dot(_S(X.symb), _np(X), _np(Y))
     chordal.logdiagsum = lambda X: orc.logdiagsum(_S(X.symb), _np(X))
     kkt.KKTSystem = OracleKKT

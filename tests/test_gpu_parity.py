@@ -379,3 +379,39 @@ def test_kkt_solve_at_ill_conditioned_scaling_points(spread, tol):
 
     (g1, g2), (o1, o2) = res(xg, yg), res(xr, yr)
     assert g1 <= 10 * o1 + 1e-12 and g2 <= 10 * o2 + 1e-10
+
+
+@pytest.mark.parametrize("name", ["nested_mid", "arrow_big", "band", "fam_odd"])
+def test_concurrent_cone_probes_match_sequential_factorisations(name):
+    """Device-resident line search (csp_probe_*): eight trial factorisations on eight streams with private workspace
+    slots give the same in-cone / out-of-cone answers as eight factorisations one after the other, for both cones
+    (cholesky: K_V, completion: C_V), on LDS-class and large fronts; the main context's caches are untouched."""
+    symb, S, A, msk = setup(name, 51)
+    symb.device_init(0, 8)
+    X = dev(symb, A)
+    Dm = dev(symb, problems.random_factor_blkval(symb, 52))
+    chordal.llt(Dm)
+    Dm *= -1.0
+    als = [0.02 * 2 ** k for k in range(8)]
+    # a cached (L, Y) pair of the main context must survive the probes
+    Lc = X.copy()
+    chordal.cholesky(Lc)
+    Yc = Lc.copy()
+    chordal.projected_inverse(Yc)
+    U0 = np.random.default_rng(53).standard_normal(symb.blklen) * msk
+    Ua = dev(symb, U0)
+    chordal.hessian(Lc, Yc, Ua, adj=None, inv=False)
+    for kind, op in (("d", chordal.cholesky), ("p", chordal.completion)):
+        got = chordal.probe_cone(X, Dm, als, kind)
+        want = []
+        for al in als:
+            T = X + Dm * al
+            try:
+                op(T)
+                want.append(True)
+            except ArithmeticError:
+                want.append(False)
+        assert got == want and want[0] and not want[-1]
+    Ub = dev(symb, U0)
+    chordal.hessian(Lc, Yc, Ub, adj=None, inv=False)
+    assert rel(host(Ub)[msk], host(Ua)[msk]) < 1e-13
