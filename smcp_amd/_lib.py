@@ -42,6 +42,7 @@ SIGNATURES = {
     "csp_probe_reserve": (ctypes.c_int, [c_vp, c_i64]),
     "csp_probe_launch": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp]),
     "csp_probe_results": (ctypes.c_int, [c_vp, c_i64, c_vp]),
+    "csp_probe_run": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "csp_profile_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "csp_profile_kinds": (c_i64, []),
     "csp_profile_filter": (ctypes.c_int, [c_vp, ctypes.c_int]),

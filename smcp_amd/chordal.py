@@ -122,20 +122,17 @@ def probe_cone(base, d, alphas, kind):
         symb.device_init(symb._device, K)
     L = _lib.lib()
     _chk(L.csp_probe_reserve(symb.handle, K), "csp_probe_reserve")
-    main = torch.cuda.current_stream()
     al = torch.as_tensor(list(alphas), dtype=torch.float64, device=base.blkval.device)
-    T = base.blkval.unsqueeze(0) + al.unsqueeze(1) * d.blkval.unsqueeze(0)        # (K, blklen), one launch
-    while len(_probe_streams) < K:
-        _probe_streams.append(torch.cuda.Stream())
-    k_id = 1 if kind == "p" else 0
-    for k in range(K):
-        s = _probe_streams[k]
-        s.wait_stream(main)
-        rc = L.csp_probe_launch(symb.handle, k_id, T[k].data_ptr(), k, s.cuda_stream)
-        if rc < 0:
-            raise RuntimeError("csp_probe_launch failed (%d)" % rc)
-    for k in range(K):
-        _probe_streams[k].synchronize()
+    # persistent trial buffer per pattern: its address is part of the key of the captured launch sequences
+    T = symb.__dict__.get("_probe_T")
+    if T is None or T.shape[0] < K or T.device != base.blkval.device:
+        T = torch.empty((max(K, 8), symb.blklen), dtype=torch.float64, device=base.blkval.device)
+        symb.__dict__["_probe_T"] = T
+    Tk = T[:K]
+    torch.mul(al.unsqueeze(1), d.blkval.unsqueeze(0), out=Tk)
+    Tk.add_(base.blkval.unsqueeze(0))
     out = (ctypes.c_int * K)()
-    _chk(L.csp_probe_results(symb.handle, K, out), "csp_probe_results")
+    rc = L.csp_probe_run(symb.handle, 1 if kind == "p" else 0, K, Tk.data_ptr(), T.stride(0), _stream(), out)
+    if rc < 0:
+        raise RuntimeError("csp_probe_run failed (%d)" % rc)
     return [out[k] == 0 for k in range(K)]

@@ -108,6 +108,16 @@ struct DeviceCtx {
   int64_t lfd_len = 0;         // doubles of one lfd copy (large-front slots + the dense slot)
   double* p_yaa = nullptr; double* p_fac = nullptr; double* p_faci = nullptr; double* p_lfd = nullptr;
   int* p_info = nullptr;       // K device failure flags
+  // csp_probe_run: one stream and one captured launch sequence (hipGraph) per (cone, slot); a graph is replayed as
+  // long as the trial buffer and the workspaces it was captured with are unchanged (ws_gen)
+  static constexpr int PROBE_MAX = 16;
+  hipStream_t p_stream[PROBE_MAX] = {};
+  hipGraphExec_t p_graph[2][PROBE_MAX] = {};
+  const void* p_graph_x[2][PROBE_MAX] = {};
+  int64_t p_graph_gen[2][PROBE_MAX] = {};
+  bool p_warm[2] = {false, false};
+  hipEvent_t p_ev = nullptr;
+  int64_t ws_gen = 0;          // bumped whenever csp_device_init (re)allocates workspaces
   int64_t bytes = 0;
 };
 
