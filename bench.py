@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="synth50k")
+    ap.add_argument("--kktsolver", default="chol", choices=("chol", "qr"),
+                    help="'qr': the step factors with kkt_qr (Cholesky-QR of the swept stack) instead of kkt_chol; one GPU")
     ap.add_argument("--m", type=int, default=None)
     ap.add_argument("--max-rhs", type=int, default=None)
     ap.add_argument("--cpu-cols", type=int, default=64, help="Schur columns timed on the CPU oracle (at least one per thread)")
@@ -117,7 +119,7 @@ def main():
     per_rhs = 8 * (U + 3 * B)
     max_rhs = args.max_rhs or int(max(1, min(m, (48 << 30) // per_rhs)))
     cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=1)
-    kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs)
+    kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs, tnzcols=0.0 if args.kktsolver == "qr" else None)
     part = None
     if world > 1 and args.shard == "subtree":
         part = kkt.set_partition(dist.group.WORLD)   # subtrees -> ranks, replicated top, boundary exchange lists
@@ -148,11 +150,14 @@ def main():
         chk(lib.csp_cholesky(h, L.blkval.data_ptr(), st()), "cholesky")
         Y.blkval.copy_(L.blkval)
         chk(lib.csp_projected_inverse(h, Y.blkval.data_ptr(), st()), "projected_inverse")
+        bx.blkval.copy_(bx0)
+        by.copy_(by0)
+        if args.kktsolver == "qr":
+            kkt.factor_qr(L, Y, dist.group.WORLD if world > 1 else None)(bx, by, 1.0)
+            return
         # Schur complement: this rank's columns + one RCCL all-reduce (smcp_amd.kkt.ShardedSchur), then potrf
         kkt.build_schur(L, Y, dist.group.WORLD if world > 1 else None)
         kkt._potrf()
-        bx.blkval.copy_(bx0)
-        by.copy_(by0)
         chk(lib.kkt_solve(h, L.blkval.data_ptr(), Y.blkval.data_ptr(), H.data_ptr(), m, 1.0,
                           bx.blkval.data_ptr(), by.data_ptr(), st()), "solve")
 
@@ -371,7 +376,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": label, "n": symb.n, "cliques": symb.Nsn, "m": m, "blkval_doubles": int(B),
+            "config": {"workload": label, "kktsolver": args.kktsolver, "n": symb.n, "cliques": symb.Nsn, "m": m, "blkval_doubles": int(B),
                        "update_doubles": int(U), "rhs_per_sweep": max_rhs,
                        "parallelism": ("single" if world == 1 else
                                        ("subtree-sharded Gram + boundary exchange/%d" % world if part is not None

@@ -129,6 +129,24 @@ int dense_potrs(csp_ctx* ctx, const double* A, int64_t n, int64_t lda, double* B
 int kkt_solve(csp_ctx* ctx, const double* L, const double* Y, const double* H, int64_t ldh,
               double kk, double* bx, double* by, void* stream);
 
+/* kkt_qr (solvers.py:413-475 feas, 1843-1905 esd): the QR-based KKT solver.  kkt_qr_factor builds the stack of
+ * half-Hessian images of ALL m constraints (call kkt_set_tnzcols(ctx, 0) before kkt_set_constraints: the reference
+ * does not split off column-sparse constraints on this path, solvers.py:242,551-556) and factors it, At = Q R, by
+ * Cholesky-QR iterations on the device (csrc/kkt_qr.hip; a shifted first pass when chol(At^T At) breaks down).  Q
+ * (orthonormal in the Schur complement's inner product) stays on the device in place of the stack, R^T as an m x m
+ * lower-triangular matrix.  *passes (optional) receives the number of passes taken, *shift the relative shift of
+ * the first pass (0: none).  Returns 0, a negative error, or j+1 > 0 when chol(Y_AA) of a clique or the Gram
+ * matrix is not positive definite (lapack.geqrf's ArithmeticError at solvers.py:425-428 has no counterpart: a
+ * rank-deficient stack shows up here).  m <= 320 in this build (SMCP_ENOMEM beyond).
+ * kkt_qr_solve is its solve_ closure (solvers.py:430-471): overwrites bx (blkval) with x and by (length m) with y;
+ * valid until the next call that rewrites the stack (kkt_qr_factor, kkt_schur_*, kkt_solve, kkt_gram_*). */
+int kkt_qr_factor(csp_ctx* ctx, const double* L, const double* Y, int64_t* passes, double* shift, void* stream);
+int kkt_qr_solve(csp_ctx* ctx, const double* L, const double* Y, double kk, double* bx, double* by, void* stream);
+/* test hook: Rt_host (m*m doubles, host, optional) <- R^T (lower, column-major); G_dev (m*m doubles, device,
+ * optional) <- Gram matrix of the current stack in the weighted inner product (Q^T Q; the identity after a
+ * factorisation).  Synchronises the stream. */
+int kkt_qr_inspect(csp_ctx* ctx, double* Rt_host, double* G_dev, void* stream);
+
 /* ---- subtree-sharded multi-GPU Schur complement (Gram formulation) ---------------------------
  * The elimination tree is cut into subtrees owned by single ranks plus a replicated top
  * (owner[k] = rank, or -1 for the top).  Per solve: kkt_gram_prepare; for every chunk of right-hand

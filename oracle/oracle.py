@@ -278,6 +278,49 @@ class KKT:
         x *= 1.0 / kk
         return x, y
 
+    # ---- kkt_qr (solvers.py:413-475): QR of the stack of half-Hessian images ------------------------------
+    def _svec_scale(self):
+        """Per blkval position: 0 above the diagonal of a clique's diagonal block (not an entry of the lower
+        triangle), 1/sqrt(2) on the diagonal (solvers.py:420), 1 below it."""
+        S = self.S
+        sc = np.zeros(S.blklen)
+        for k, nn, rows in S._iter():
+            nf = len(rows)
+            i, j = np.meshgrid(np.arange(nf), np.arange(nn), indexing="ij")
+            blk = np.where(i > j, 1.0, np.where(i == j, 1.0 / np.sqrt(2.0), 0.0))
+            sc[S.blkptr[k]:S.blkptr[k] + nf * nn] = blk.reshape(-1, order="F")
+        return sc
+
+    def qr_factor(self, L, Y):
+        """kkt_qr's factorisation (solvers.py:414-428): At[:, j] = svec(G(A_j)) with the diagonal entries scaled by
+        1/sqrt(2), then lapack.geqrf -- here numpy's Householder QR (LAPACK geqrf + orgqr), thin form."""
+        sc = self._svec_scale()
+        At = np.zeros((self.S.blklen, self.m))
+        for j in range(self.m):
+            u = self.constraint(j)
+            hessian(self.S, L, Y, u, adj=False, inv=False)
+            At[:, j] = sc * u
+        Q, R = np.linalg.qr(At, mode="reduced")
+        return dict(Q=Q, R=R, sc=sc)
+
+    def qr_solve(self, L, Y, F, bx, by, kk):
+        """solve_ of kkt_qr (solvers.py:430-471), statement by statement."""
+        import scipy.linalg as sla
+        Q, R, sc = F["Q"], F["R"], F["sc"]
+        r1 = bx.copy()
+        hessian(self.S, L, Y, r1, adj=False, inv=False)
+        r1 = sc * r1                                        # spmatrix(...).V, r1[Id] /= sqrt(2)
+        x = Q.T @ r1                                        # ormqr(trans='T'), x[m:] = 0
+        r2 = sla.solve_triangular(R, by, trans="T")         # trtrs(At[:m,:], r2, uplo='U', trans='T')
+        x = x + 0.5 * kk * r2
+        y = sla.solve_triangular(R, x)                      # trtrs(At[:m,:], y, uplo='U')
+        v = Q @ x - r1                                      # ormqr; Vp.V = x - r1
+        # scal_diag(Vp, Id, sqrt(2)) undoes the diagonal scaling: v / sc (off the diagonal sc = 1)
+        xo = np.where(sc > 0, v / np.where(sc > 0, sc, 1.0), 0.0)
+        hessian(self.S, L, Y, xo, adj=True, inv=False)
+        xo *= 1.0 / kk
+        return xo, y
+
     def residual(self, L, Y, x, y, bx, by, kk):
         """kkt_res (solvers.py:401-411): r = -kk*W^-1 x + Aadj(y) - bx ; Amap(x) - by."""
         r = x.copy()

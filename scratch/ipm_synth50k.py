@@ -6,7 +6,8 @@ import numpy as np, scipy.sparse as sp, torch
 from smcp_amd import chordal, problems, solvers
 from smcp_amd.cspmatrix import cspmatrix
 from smcp_amd.symbolic import Symbolic
-small = len(sys.argv) > 1 and sys.argv[1] == "small"
+small = "small" in sys.argv[1:]
+kktsolver = "qr" if "qr" in sys.argv[1:] else "chol"
 pat = problems.nested_block_arrow_pattern(nsub=2, nmid=6) if small else problems.nested_block_arrow_pattern()
 n, cp, ri = pat
 m = 100
@@ -39,7 +40,7 @@ A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows).astype(np.int64),
 print("problem built in %.1f s: n=%d |V|=%d m=%d nnz(A_i)=%d" % (time.time() - t0, n, nv, m, per), flush=True)
 solvers.options.update(show_progress=True, maxiters=100)
 t0 = time.time()
-sol = solvers.chordalsolver_feas(A, b, primalstart={"x": X0}, dualstart={"y": y0, "s": S0}, scaling="dual")
+sol = solvers.chordalsolver_feas(A, b, primalstart={"x": X0}, dualstart={"y": y0, "s": S0}, scaling="dual", kktsolver=kktsolver)
 dt = time.time() - t0
-print("status", sol["status"], "iterations", sol["iterations"], "pobj %.8g dobj %.8g gap %.2e" % (sol["primal objective"], sol["dual objective"], sol["gap"]),
+print("kktsolver", kktsolver, "status", sol["status"], "iterations", sol["iterations"], "pobj %.8g dobj %.8g gap %.2e" % (sol["primal objective"], sol["dual objective"], sol["gap"]),
       "total %.2f s, %.3f s/iteration (incl. symbolic setup)" % (dt, dt / max(1, sol["iterations"])), "dimacs", ["%.1e" % v for v in sol["dimacs"]])

@@ -57,6 +57,9 @@ SIGNATURES = {
     "dense_potrf": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "dense_potrs": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "kkt_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, c_vp, c_vp, c_vp]),
+    "kkt_qr_factor": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "kkt_qr_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_double, c_vp, c_vp, c_vp]),
+    "kkt_qr_inspect": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
 }
 
 _lib = None

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsmcp_amd.so")
 SOURCES = ["capi.hip", "symbolic.cpp"]
-DEPS = ["front_large.hip", "front_mfma.hip", "capi.hip", "kkt.hip", "front_generic.hip", "wgblas.hpp", "context.hpp", "symbolic.cpp",
+DEPS = ["front_large.hip", "front_mfma.hip", "capi.hip", "kkt.hip", "kkt_qr.hip", "front_generic.hip", "wgblas.hpp", "context.hpp", "symbolic.cpp",
         "symbolic.hpp", "../../include/smcp_amd.h"]
 
 

@@ -46,7 +46,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -63,7 +63,8 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_factor_inverse", "k_hess_down_inv_mfma<true>", "k_hess_down_inv_mfma<false>", "k_hess_up_inv_mfma<true>",
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
-  "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam"};
+  "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small"};
 
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
@@ -862,7 +863,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   if (D.device >= 0) {
     hipSetDevice(D.device);
     void* ptrs[] = {D.p_yaa, D.p_fac, D.p_faci, D.p_lfd, D.p_info, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
-                    D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack};
+                    D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws};
     for (void* p : ptrs) if (p) hipFree(p);
     if (D.info_host) hipHostFree(D.info_host);
     for (int q = 0; q < 2; ++q)
@@ -1477,3 +1478,4 @@ const char* csp_profile_kernel_name(int kid) { return (kid >= 0 && kid < KID_COU
 }  // extern "C"
 
 #include "kkt.hip"
+#include "kkt_qr.hip"

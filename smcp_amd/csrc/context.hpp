@@ -102,6 +102,12 @@ struct DeviceCtx {
   double* sw = nullptr;      // blklen : sqrt of the inner-product weights (Gram path)
   double* gpart = nullptr;   // partial Gram tiles
   int64_t gpart_len = 0;
+  // kkt_qr (csrc/kkt_qr.hip): m x m work matrices, the inverse of the triangular factor, G(bx) and reduction scratch;
+  // the orthonormal factor Q itself overwrites ustack
+  double* qr_ws = nullptr;
+  int64_t qr_len = 0;
+  bool qr_valid = false;       // ustack holds Q and qr_ws the factor for the matrices (qr_L, qr_Y)
+  const void* qr_L = nullptr; const void* qr_Y = nullptr;
   // probe slots (csp_probe_*): K private copies of the workspaces a trial factorisation writes besides the
   // per-right-hand-side ones (upd / updp / tmp are indexed by the slot as if it were a right-hand side)
   int probe_K = 0;

@@ -309,6 +309,8 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   D.vbuf = D.hd = nullptr;
   D.kc_ptr = D.kc_off = nullptr; D.kc_val = nullptr;
   D.md = D.ns = D.vcols = 0;
+  if (D.qr_ws) { hipFree(D.qr_ws); D.bytes -= D.qr_len * 8; D.qr_ws = nullptr; D.qr_len = 0; }
+  D.qr_valid = false;
   const int64_t nnz = cptr[m];
   // diagonal flags: position -> is it a diagonal entry of its NN block?
   std::vector<double> w(nnz);
@@ -591,6 +593,7 @@ static bool use_gram() {
 static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_t st) {
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
+  D.qr_valid = false;      // the stack is about to be rewritten
   prepare_yaa(c, Y, true, st);
   prep_lk_cached(c, L, Y, st);
   if (!D.kc_ptr) {   // the sweeps read their input from the stack: clear it and scatter the constraints into it
@@ -746,6 +749,7 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
   const int64_t m = D.m, bl = c->S.blklen();
   if (!m || ldh < m || j0 < 0 || j1 > m || j0 > j1) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  D.qr_valid = false;
   if (j0 == 0 && j1 == m && use_gram()) return schur_gram(c, L, Y, H, ldh, st);
   prepare_yaa(c, Y, false, st);
   if (!use_generic()) prep_lk_cached(c, L, Y, st);
@@ -774,6 +778,7 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   const int64_t m = D.m, bl = c->S.blklen();
   if (!m) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  D.qr_valid = false;          // r1 below overwrites the first row of the stack
   double* r1 = D.ustack;       // blkval-sized temporaries
   double* ytmp = D.red + 600;  // (m <= 400 fits; larger m uses the tail of ustack)
   if (m > 400) {

@@ -1,0 +1,370 @@
+// kkt_qr: the QR-based KKT solver of the reference (src/python/solvers.py:413-475 and 1843-1905) on the device.
+//
+// The reference stacks the half-Hessian images svec(G(A_j)) of all m constraints into a |V| x m matrix At, takes its
+// Householder QR (lapack.geqrf) and solves the KKT system through Q and R instead of the Cholesky factor of the
+// Schur complement H = At^T At, which squares the condition number.  Here the stack is what the Gram formulation of
+// kkt_chol already builds (one leaves->root sweep per constraint, D.ustack: row j = G(A_j) in blkval layout), and
+// the QR is computed where the chip is fast, as Cholesky-QR iterations on the MFMA SYRK of the Gram path:
+//
+//     G = W^T W (weighted: H's inner product),  R_p = chol(G)^T,  W <- W R_p^-1,  R <- R_p R      (one pass)
+//
+// Two passes (CholeskyQR2) give Q orthonormal to rounding when kappa(At) < ~1e8.  When chol(G) breaks down -- the
+// regime where kkt_chol fails -- the first pass is repeated with a shifted Gram matrix G + s I (shifted CholeskyQR3,
+// Fukaya et al., SIAM J. Sci. Comput. 42 (2020)): the shift makes the factorisation go through, the pass still
+// reduces the condition number to where two plain passes finish the job.  Q is kept explicitly (it overwrites the
+// stack), R as its lower-triangular transpose; solve_ applies Q^T, R^-T, R^-1 and Q exactly where the reference
+// applies ormqr / trtrs (solvers.py:443-459).  Normalisation: the reference scales the diagonal entries by
+// 1/sqrt(2) and stores off-diagonal entries once, so its R^T R = H / 2; here the inner product carries the weights
+// (1 on the diagonal, 2 below it), R^T R = H, and the 0.5 of solvers.py:453 disappears.
+
+namespace {
+
+constexpr int QR_JB = 8;       // rows of the stack per register block of k_stack_trsm
+
+// W <- W * R^-1 in place BY SUBSTITUTION (multiplying by an explicit inverse would leave Q R = At only to
+// kappa(R) * eps, which is exactly what the QR path is there to avoid).  W is the m x len stack (row j at W + j * ldw);
+// Rp the upper-triangular factor, row-major with leading dimension ldr = 8 * nblk, reciprocals on its diagonal,
+// padded with a unit diagonal.
+// One workgroup = 64 stack positions (one per lane) x 4 waves; the m rows are cut into blocks of 8 dealt cyclically to
+// the waves, and every wave keeps ITS blocks of the 64 columns in registers for the whole kernel (NBW blocks = 8 NBW
+// accumulators).  Right-looking: for block J = 0, 1, ... its owner finishes it (8-step substitution with the
+// diagonal block, in registers), stores the rows and broadcasts them through LDS; every wave then subtracts their
+// contribution from its own later blocks (64 FMAs per block pair, the entries of R wave-uniform scalar loads).
+// LDS carries only the 8 finished rows (double buffered: one barrier per block step).
+template <int NBW>
+__global__ void __launch_bounds__(256) k_stack_trsm(double* W, int64_t ldw, int64_t len, int m, const double* __restrict__ Rp,
+                                                    int ldr, int fake) {
+  __shared__ double sq[2][QR_JB][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  const bool in = p < len;
+  const int nblk = ldr / QR_JB;
+  double acc[NBW][QR_JB];
+#pragma unroll
+  for (int s = 0; s < NBW; ++s) {
+    const int K = s * 4 + wave;
+#pragma unroll
+    for (int jj = 0; jj < QR_JB; ++jj) {
+      const int row = K * QR_JB + jj;
+      acc[s][jj] = (in && row < m) ? W[(int64_t)row * ldw + p] : 0.0;
+    }
+  }
+  for (int J = 0; J < nblk; ++J) {
+    const int j0 = J * QR_JB, buf = J & 1;
+    if ((J & 3) == wave) {
+      const int sJ = J >> 2;
+#pragma unroll
+      for (int s = 0; s < NBW; ++s)
+        if (s == sJ) {
+          double q[QR_JB];
+#pragma unroll
+          for (int jj = 0; jj < QR_JB; ++jj) {
+            double v = acc[s][jj];
+#pragma unroll
+            for (int ii = 0; ii < jj; ++ii) v -= q[ii] * Rp[(int64_t)(j0 + ii) * ldr + j0 + jj];
+            q[jj] = v * Rp[(int64_t)(j0 + jj) * ldr + j0 + jj];     // the packed diagonal holds reciprocals
+          }
+#pragma unroll
+          for (int jj = 0; jj < QR_JB; ++jj) {
+            sq[buf][jj][lane] = q[jj];
+            if (in && j0 + jj < m) W[(int64_t)(j0 + jj) * ldw + p] = q[jj];
+          }
+        }
+    }
+    __syncthreads();
+    if (J + 1 >= nblk) break;
+    double q[QR_JB];
+#pragma unroll
+    for (int ii = 0; ii < QR_JB; ++ii) q[ii] = sq[buf][ii][lane];
+#pragma unroll
+    for (int s = 0; s < NBW; ++s) {
+      const int K = s * 4 + wave;
+      if (K > J && K < nblk) {
+        const double* r = fake ? Rp : Rp + (int64_t)j0 * ldr + K * QR_JB;
+        // two halves of four rows of R: 32 wave-uniform doubles (64 SGPRs) in flight at a time -- all 64 at once
+        // overflow the scalar register file and the spills land in the inner loop
+#pragma unroll
+        for (int ii = 0; ii < QR_JB / 2; ++ii)
+#pragma unroll
+          for (int kk = 0; kk < QR_JB; ++kk) acc[s][kk] -= q[ii] * r[(int64_t)ii * ldr + kk];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ii = QR_JB / 2; ii < QR_JB; ++ii)
+#pragma unroll
+          for (int kk = 0; kk < QR_JB; ++kk) acc[s][kk] -= q[ii] * r[(int64_t)ii * ldr + kk];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+// Rp (row-major upper, ldr x ldr, RECIPROCALS on the diagonal, unit diagonal in the padding) <- transpose of the lower
+// Cholesky factor T (m x m)
+__global__ void k_qr_pack(const double* T, int m, int64_t ldt, double* Rp, int ldr) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ldr * ldr; e += gridDim.x * blockDim.x) {
+    const int i = e / ldr, j = e % ldr;
+    Rp[e] = (i < m && j < m) ? (j > i ? T[j + (int64_t)i * ldt] : (j == i ? 1.0 / T[i + (int64_t)i * ldt] : 0.0)) : (i == j ? 1.0 : 0.0);
+  }
+}
+
+// r <- sw^2 * r  (the inner-product weights, folded into the vector once)
+__global__ void k_weight_vec(const double* __restrict__ sw, double* r, int64_t len) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < len; p += (int64_t)gridDim.x * 256) r[p] *= sw[p] * sw[p];
+}
+// part[j * nchunk + c] = sum over the c-th chunk of Q[j] * rw for the four rows j = 4 blockIdx.y .. (rw = weighted r:
+// inner products of the rows of Q with r; four rows share every load of rw)
+constexpr int QR_DROWS = 4;
+__global__ void __launch_bounds__(256) k_stack_dots(const double* __restrict__ Q, int64_t ldq, int64_t len, int m,
+                                                    const double* __restrict__ rw, int64_t chunk, double* part, int nchunk) {
+  __shared__ double red[4][QR_DROWS];
+  const int j0 = blockIdx.y * QR_DROWS;
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(len, lo + chunk);
+  double acc[QR_DROWS];
+#pragma unroll
+  for (int t = 0; t < QR_DROWS; ++t) acc[t] = 0.0;
+  for (int64_t p = lo + threadIdx.x; p < hi; p += 256) {
+    const double w = rw[p];
+#pragma unroll
+    for (int t = 0; t < QR_DROWS; ++t)
+      if (j0 + t < m) acc[t] += w * Q[(int64_t)(j0 + t) * ldq + p];
+  }
+#pragma unroll
+  for (int t = 0; t < QR_DROWS; ++t) {
+    double a = acc[t];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < QR_DROWS && j0 + threadIdx.x < m)
+    part[(int64_t)(j0 + threadIdx.x) * nchunk + blockIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// out[j] = sum_c part[j * nchunk + c]  (fixed order: deterministic)
+__global__ void k_rows_sum(const double* part, int nchunk, double* out) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  double acc = 0.0;
+  for (int c = lane; c < nchunk; c += 64) acc += part[(int64_t)j * nchunk + c];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) out[j] = acc;
+}
+// out = sum_j v[j] Q[j] - r   (out may alias r)
+__global__ void __launch_bounds__(256) k_stack_comb(const double* __restrict__ Q, int64_t ldq, int64_t len, int m,
+                                                    const double* __restrict__ v, const double* r, double* out) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < len; p += (int64_t)gridDim.x * 256) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int j = 0;
+    for (; j + 4 <= m; j += 4) {
+      a0 += v[j] * Q[(int64_t)j * ldq + p];
+      a1 += v[j + 1] * Q[(int64_t)(j + 1) * ldq + p];
+      a2 += v[j + 2] * Q[(int64_t)(j + 2) * ldq + p];
+      a3 += v[j + 3] * Q[(int64_t)(j + 3) * ldq + p];
+    }
+    for (; j < m; ++j) a0 += v[j] * Q[(int64_t)j * ldq + p];
+    out[p] = ((a0 + a1) + (a2 + a3)) - r[p];
+  }
+}
+
+// ---- m x m helpers (small: one or a few workgroups) ------------------------------------------------------------
+// T = A * B for lower-triangular A, B (column-major m x m): T(i, j) = sum_{k = j..i} A(i, k) B(k, j)
+__global__ void k_qr_lower_mul(const double* A, const double* B, int m, int64_t ld, double* T) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m * m; e += gridDim.x * blockDim.x) {
+    const int i = e % m, j = e / m;
+    double acc = 0.0;
+    for (int k = j; k <= i; ++k) acc += A[i + (int64_t)k * ld] * B[k + (int64_t)j * ld];
+    T[i + (int64_t)j * ld] = acc;
+  }
+}
+// b <- L^-1 b (trans 0) or L^-T b (trans 1), one workgroup
+__global__ void __launch_bounds__(256) k_qr_trsv(const double* L, int m, int64_t ldl, double* b, int trans) {
+  if (trans) wg::trsm_llT(m, 1, L, ldl, b, m);
+  else wg::trsm_llN(m, 1, L, ldl, b, m);
+}
+// A += (rel * trace(A)) I, one workgroup
+__global__ void __launch_bounds__(256) k_qr_shift(double* A, int m, int64_t lda, double rel) {
+  __shared__ double red[4];
+  double t = 0.0;
+  for (int i = threadIdx.x; i < m; i += 256) t += A[i + (int64_t)i * lda];
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  const double s = rel * ((red[0] + red[1]) + (red[2] + red[3]));
+  for (int i = threadIdx.x; i < m; i += 256) A[i + (int64_t)i * lda] += s;
+}
+
+// out[0] = max |A - I| over the lower triangle (one workgroup): how far the stack is from orthonormal
+__global__ void __launch_bounds__(256) k_qr_deviation(const double* A, int m, int64_t lda, double* out) {
+  __shared__ double red[4];
+  double t = 0.0;
+  for (int e = threadIdx.x; e < m * m; e += 256) {
+    const int i = e % m, j = e / m;
+    if (i >= j) t = fmax(t, fabs(A[i + (int64_t)j * lda] - (i == j ? 1.0 : 0.0)));
+  }
+  for (int off = 32; off > 0; off >>= 1) t = fmax(t, __shfl_down(t, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+constexpr int64_t QR_DOT_CHUNK = 16384;
+
+int qr_alloc(csp_ctx* c) {
+  DeviceCtx& D = c->D;
+  const int64_t m = D.m, bl = c->S.blklen();
+  const int64_t ldr = (m + QR_JB - 1) / QR_JB * QR_JB;
+  const int64_t nchunk = (bl + QR_DOT_CHUNK - 1) / QR_DOT_CHUNK;
+  // G | T | Lc | scratch (m x m each), Rp (ldr x ldr: the packed factor of the pass), r1 (bl), part (m * nchunk), xm, r2 (m each)
+  const int64_t need = 4 * m * m + ldr * ldr + bl + m * nchunk + 2 * m + bl;     // ... and the weighted copy of r1 at the end
+  if (D.qr_ws && D.qr_len >= need) return 0;
+  if (D.qr_ws) { HIPCHK(hipFree(D.qr_ws)); D.bytes -= D.qr_len * 8; D.qr_ws = nullptr; }
+  if (int rc = dev_alloc(&D.qr_ws, need, D.bytes)) return rc;
+  D.qr_len = need;
+  HIPCHK(hipMemset(D.qr_ws, 0, sizeof(double) * need));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_out, double* shift_out, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  const int64_t m = D.m, bl = c->S.blklen();
+  if (!m || use_generic()) return SMCP_EINVAL;
+  if (D.ns) return SMCP_EINVAL;                 // every constraint must be swept (kkt_set_tnzcols(0) before the constraints)
+  if (D.max_rhs < 1 || D.ustack_cols < m) return SMCP_EINVAL;
+  if (m > 320) return SMCP_ENOMEM;              // k_stack_trsm keeps m / 4 rows per wave in registers: m <= 320 in this build
+  hipStream_t st = (hipStream_t)stream;
+  D.qr_valid = false;
+  if (int rc = qr_alloc(c)) return rc;
+  const int64_t ldr = (m + QR_JB - 1) / QR_JB * QR_JB;
+  double* G = D.qr_ws;
+  double* T = G + m * m;
+  double* Lc = T + m * m;
+  double* S2 = Lc + m * m;
+  double* X = S2 + m * m;
+  // the stack of half-Hessian images, exactly as the Gram formulation of kkt_chol builds it
+  if (int rc = gram_prepare(c, L, Y, st)) return rc;
+  for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
+    int nr = (int)std::min(D.max_rhs, m - jb);
+    hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st, 0, D.kc_ptr ? jb : -1);
+  }
+  static int npass_env = -1;
+  if (npass_env < 0) { const char* e = getenv("SMCP_QR_PASSES"); npass_env = e ? std::max(1, atoi(e)) : 0; }
+  int npass = npass_env ? npass_env : 2;
+  double shift = 0.0;
+  const int64_t range[2] = {0, bl};
+  for (int pass = 0; pass < npass; ++pass) {
+    if (int rc = gram_accumulate(c, 1, range, G, m, st)) return rc;
+    if (pass == 0) { if (int f = fetch_info(c, st)) return f; }     // chol(Y_AA) failure inside the sweeps
+    if (pass > 0 && pass == npass - 1 && !npass_env && npass < 5) {
+      // last planned pass: its Gram matrix tells how orthonormal the previous pass left the stack; this pass squares
+      // that deviation, so one more is planned when it would not reach rounding level
+      double dev = 0.0;
+      launch(c, KID_qr_small, k_qr_deviation, dim3(1), dim3(256), st, (const double*)G, (int)m, m, S2);
+      HIPCHK(hipMemcpyAsync(&dev, S2, sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (!(dev < 1e-4)) ++npass;
+    }
+    int tries = 0;
+    for (;;) {
+      HIPCHK(hipMemcpyAsync(T, G, sizeof(double) * m * m, hipMemcpyDeviceToDevice, st));
+      if (shift > 0.0) launch(c, KID_qr_small, k_qr_shift, dim3(1), dim3(256), st, T, (int)m, m, shift);
+      const int rc = dense_potrf(c, T, m, m, stream);
+      if (rc == 0) break;
+      if (rc < 0) return rc;
+      // breakdown: shift (relative to the trace, which bounds ||At||_2^2 from above) and, on the first pass, plan the
+      // two clean-up passes of shifted CholeskyQR3
+      if (++tries > 8) return rc;
+      shift = shift > 0.0 ? shift * 100.0 : 1e-15 * (double)m;
+      if (!npass_env) npass = std::max(npass, pass + 3);
+    }
+    if (pass > 0) shift = 0.0;       // later passes see a well-conditioned stack; a shift there would only be a rescue
+    launch(c, KID_qr_small, k_qr_pack, dim3((unsigned)std::min<int64_t>(256, (ldr * ldr + 255) / 256)), dim3(256), st,
+           (const double*)T, (int)m, m, X, (int)ldr);
+    {
+      const dim3 grid((unsigned)((bl + 63) / 64)), blk(256);
+      const int nbw = (int)((ldr / QR_JB + 3) / 4);
+      static int fake = -1;     // timing experiment only: every update reads the same 8 x 8 block of R
+      if (fake < 0) { const char* e = getenv("SMCP_QR_FAKE"); fake = e ? atoi(e) : 0; }
+#define SMCP_TRSM_CASE(N) case N: launch(c, KID_qr_rmul, k_stack_trsm<N>, grid, blk, st, D.ustack, bl, bl, (int)m, (const double*)X, (int)ldr, fake); break;
+      switch (nbw) {
+        SMCP_TRSM_CASE(1) SMCP_TRSM_CASE(2) SMCP_TRSM_CASE(3) SMCP_TRSM_CASE(4) SMCP_TRSM_CASE(5)
+        SMCP_TRSM_CASE(6) SMCP_TRSM_CASE(7) SMCP_TRSM_CASE(8) SMCP_TRSM_CASE(9) SMCP_TRSM_CASE(10)
+        default: return SMCP_ENOMEM;
+      }
+#undef SMCP_TRSM_CASE
+    }
+    if (pass == 0) {
+      HIPCHK(hipMemcpyAsync(Lc, T, sizeof(double) * m * m, hipMemcpyDeviceToDevice, st));
+    } else {
+      launch(c, KID_qr_small, k_qr_lower_mul, dim3((unsigned)std::min<int64_t>(256, (m * m + 255) / 256)), dim3(256), st,
+             (const double*)Lc, (const double*)T, (int)m, m, S2);
+      HIPCHK(hipMemcpyAsync(Lc, S2, sizeof(double) * m * m, hipMemcpyDeviceToDevice, st));
+    }
+    if (pass == 0 && shift_out) *shift_out = shift;
+  }
+  HIPCHK(hipGetLastError());
+  if (passes_out) *passes_out = npass;
+  D.qr_valid = true;
+  D.qr_L = L; D.qr_Y = Y;
+  return 0;
+}
+
+int kkt_qr_solve(csp_ctx* c, const double* L, const double* Y, double kk, double* bx, double* by, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  const int64_t m = D.m, bl = c->S.blklen();
+  if (!m || !D.qr_valid || D.qr_L != L || D.qr_Y != Y) return SMCP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ldr = (m + QR_JB - 1) / QR_JB * QR_JB;
+  const int nchunk = (int)((bl + QR_DOT_CHUNK - 1) / QR_DOT_CHUNK);
+  double* Lc = D.qr_ws + 2 * m * m;
+  double* r1 = D.qr_ws + 4 * m * m + ldr * ldr;
+  double* part = r1 + bl;
+  double* xm = part + m * nchunk;
+  double* r2 = xm + m;
+  if (!(D.yaa_tag == Y && D.yaa_tag)) prepare_yaa(c, Y, false, st);
+  prep_lk_cached(c, L, Y, st);
+  HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
+  hessian_impl(c, L, r1, 1, bl, 0, 0, st);                                   // r1 = G(bx)           (solvers.py:444-447)
+  // x = Q^T r1 in the weighted inner product (solvers.py:449-450); rw = sw^2 r1 in the partial-sum scratch's tail
+  double* rw = D.qr_ws + D.qr_len - bl;
+  HIPCHK(hipMemcpyAsync(rw, r1, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
+  launch(c, KID_qr_small, k_weight_vec, dim3((unsigned)std::min<int64_t>(2048, (bl + 255) / 256)), dim3(256), st, (const double*)D.sw, rw, bl);
+  launch(c, KID_qr_dots, k_stack_dots, dim3((unsigned)nchunk, (unsigned)((m + QR_DROWS - 1) / QR_DROWS)), dim3(256), st,
+         (const double*)D.ustack, bl, bl, (int)m, (const double*)rw, QR_DOT_CHUNK, part, nchunk);
+  launch(c, KID_qr_small, k_rows_sum, dim3((unsigned)m), dim3(64), st, (const double*)part, nchunk, xm);   // x = Q^T r1  (449-450)
+  HIPCHK(hipMemcpyAsync(r2, by, sizeof(double) * m, hipMemcpyDeviceToDevice, st));
+  launch(c, KID_qr_small, k_qr_trsv, dim3(1), dim3(256), st, (const double*)Lc, (int)m, m, r2, 0);        // r2 = R^-T by (452)
+  launch(c, KID_vec_axpby, k_vec_axpby, dim3((unsigned)((m + 255) / 256)), dim3(256), st, m, kk, (const double*)r2, 1.0, xm);  // (453)
+  HIPCHK(hipMemcpyAsync(by, xm, sizeof(double) * m, hipMemcpyDeviceToDevice, st));
+  launch(c, KID_qr_small, k_qr_trsv, dim3(1), dim3(256), st, (const double*)Lc, (int)m, m, by, 1);        // y = R^-1 x  (454-455)
+  launch(c, KID_qr_comb, k_stack_comb, dim3((unsigned)std::min<int64_t>(65535, (bl + 255) / 256)), dim3(256), st,
+         (const double*)D.ustack, bl, bl, (int)m, (const double*)xm, (const double*)r1, bx);                // Q x - r1    (457-458)
+  hessian_impl(c, L, bx, 1, bl, 1, 0, st);                                                                  // G^T         (461)
+  launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 0.0, (const double*)nullptr, 1.0 / kk, bx);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// test hook: copies the composite factor (lower m x m, R^T) to the host and the Gram matrix of the current stack
+// (Q^T Q in the weighted inner product, = I after a factorisation) into G (device, m x m)
+int kkt_qr_inspect(csp_ctx* c, double* Rt_host, double* G_dev, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  if (!D.m || !D.qr_valid) return SMCP_EINVAL;
+  const int64_t m = D.m;
+  hipStream_t st = (hipStream_t)stream;
+  if (G_dev) {
+    const int64_t range[2] = {0, c->S.blklen()};
+    if (int rc = gram_accumulate(c, 1, range, G_dev, m, st)) return rc;
+  }
+  if (Rt_host) {
+    HIPCHK(hipMemcpyAsync(Rt_host, D.qr_ws + 2 * m * m, sizeof(double) * m * m, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // extern "C"

@@ -3,6 +3,8 @@
 Python-side mirror of the closures at src/python/solvers.py:369-386 and 477-541; all
 arithmetic is done by the C-ABI entry points ``kkt_*`` (include/smcp_amd.h).
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -206,3 +208,35 @@ class KKTSystem(ShardedSchur):
             return bx, by
 
         return solve_
+
+    def factor_qr(self, L, Y, group=None):
+        """kkt_qr(L, Y) (solvers.py:413-475): QR factorisation of the stack of half-Hessian images of the
+        constraints (csrc/kkt_qr.hip); returns solve_(bx, by, kk).  The system must have been created with
+        tnzcols = 0 (every constraint swept).  Not sharded: one GPU."""
+        if group is not None:
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_world_size(group) > 1:
+                raise NotImplementedError("kktsolver='qr' runs on one GPU (the Q factor is not sharded)")
+        sync_cache(self.symb, L, Y)
+        passes = ctypes.c_int64(0)
+        shift = ctypes.c_double(0.0)
+        _chk(_lib.lib().kkt_qr_factor(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), ctypes.addressof(passes),
+                                      ctypes.addressof(shift), _stream()), "kkt_qr_factor")
+        self.qr_passes, self.qr_shift = passes.value, shift.value
+
+        def solve_(bx, by, kk):
+            """Overwrites bx (cspmatrix) with x and by (device vector) with y."""
+            sync_cache(self.symb, L, Y)
+            bx.touched()
+            _chk(_lib.lib().kkt_qr_solve(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), float(kk),
+                                         bx.blkval.data_ptr(), by.data_ptr(), _stream()), "kkt_qr_solve")
+            return bx, by
+
+        return solve_
+
+    def qr_inspect(self):
+        """(R^T as a host array, Q^T Q as a device tensor) of the last factor_qr -- test hook."""
+        Rt = np.zeros((self.m, self.m), order="F")
+        G = torch.zeros((self.m, self.m), dtype=torch.float64, device=self.dev)
+        _chk(_lib.lib().kkt_qr_inspect(self.symb.handle, Rt.ctypes.data, G.data_ptr(), _stream()), "kkt_qr_inspect")
+        return Rt, G

@@ -126,7 +126,11 @@ class _Problem:
             raise TypeError("tnzcols must be a float between 0.0 and 1.0")
         if tnz > 1 or tnz < 0:
             raise ValueError("tnzcols must be between 0.0 and 1.0")
-        self.kkt = KKTSystem(symb, cptr, pos[colptr[1]:], vals[colptr[1]:], tnzcols=tnz)
+        self._con = (cptr, pos[colptr[1]:], vals[colptr[1]:])
+        self._tnz_user = tnz
+        self._tnz = tnz
+        self.kktsolver = "chol"
+        self.kkt = KKTSystem(symb, *self._con, tnzcols=tnz)
         self.C = cspmatrix(symb, torch.from_numpy(h).to(self.dev))
         self.b = torch.from_numpy(b.copy()).to(self.dev)
         self.bh = b
@@ -148,6 +152,21 @@ class _Problem:
         """cspmatrix of a symmetric scipy/numpy matrix given in ORIGINAL coordinates (start points)."""
         M = sp.tril(sp.coo_matrix(M)).tocoo()
         return cspmatrix.from_entries(self.symb, M.row, M.col, M.data, device=self.dev)
+
+    def use_kktsolver(self, name):
+        """'chol' (kkt_chol, solvers.py:477-541) or 'qr' (kkt_qr, solvers.py:413-475).  The QR path sweeps every
+        constraint -- the reference only splits off column-sparse constraints for 'chol' (solvers.py:242, 355) --
+        so the constraint classification is redone with tnzcols = 0 when the solver changes."""
+        if name not in ("chol", "qr"):
+            raise ValueError("Unknown 'kktsolver'.")
+        want = 0.0 if name == "qr" else self._tnz_user
+        if want != self._tnz:
+            self.kkt = KKTSystem(self.symb, *self._con, tnzcols=want)
+            self._tnz = want
+        self.kktsolver = name
+
+    def factor(self, L, Y):
+        return self.kkt.factor_qr(L, Y) if self.kktsolver == "qr" else self.kkt.factor(L, Y)
 
     def Amap(self, X):
         return self.kkt.amap(X)
@@ -192,10 +211,11 @@ def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", 
     DS_HESS = _opt("esd_ds_from_hessian", bool)
     if scaling not in ("primal", "dual"):
         raise ValueError("scaling must be 'primal' or 'dual'")
-    if kktsolver != "chol":
-        raise NotImplementedError("kktsolver='qr' (solvers.py:413-475) is out of scope of this build; use 'chol'")
+    if kktsolver not in ("chol", "qr"):
+        raise ValueError("Unknown 'kktsolver'.")
 
     P = A if isinstance(A, _Problem) else _Problem(A, b, p)
+    P.use_kktsolver(kktsolver)
     n, m, C, bv = P.n, P.m, P.C, P.b
     Amap, Aadj = P.Amap, P.Aadj
     dot = chordal.dot
@@ -451,7 +471,7 @@ def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", 
             status = "unknown"
             break
         try:
-            f = P.kkt.factor(L, Y)
+            f = P.factor(L, Y)
         except ArithmeticError:
             status = "unknown"
             break
@@ -539,10 +559,11 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
         raise NotImplementedError("options['eta'] (Omega-neighbourhood line search, solvers.py:665-689) is not built")
     if scaling not in ("primal", "dual"):
         raise ValueError("scaling must be 'primal' or 'dual'")
-    if kktsolver != "chol":
-        raise NotImplementedError("kktsolver='qr' (solvers.py:413-475) is out of scope of this build; use 'chol'")
+    if kktsolver not in ("chol", "qr"):
+        raise ValueError("Unknown 'kktsolver'.")
 
     P = A if isinstance(A, _Problem) else _Problem(A, b, p)
+    P.use_kktsolver(kktsolver)
     n, m, C, bv = P.n, P.m, P.C, P.b
     Amap, Aadj, dot = P.Amap, P.Aadj, chordal.dot
     resy0 = max(1.0, _nrm2(bv))
@@ -560,7 +581,7 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
         return Lt
 
     def factor(L, Y):
-        st.update(L=L, Y=Y, f=P.kkt.factor(L, Y))
+        st.update(L=L, Y=Y, f=P.factor(L, Y))
 
     def kk_of(tt):
         return 1.0 / tt if st["scaling"] == "primal" else tt

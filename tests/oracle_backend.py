@@ -112,6 +112,17 @@ class OracleKKT(kkt.ShardedSchur):
 
         return solve_
 
+    def factor_qr(self, L, Y, group=None):
+        F = self.K.qr_factor(_np(L), _np(Y))
+
+        def solve_(bx, by, kk):
+            x, y = self.K.qr_solve(_np(L), _np(Y), F, _np(bx).copy(), by.numpy().copy(), kk)
+            bx.blkval.copy_(torch.from_numpy(x))
+            by.copy_(torch.from_numpy(y))
+            return bx, by
+
+        return solve_
+
 
 @contextlib.contextmanager
 def oracle_backend():

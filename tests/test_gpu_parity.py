@@ -415,3 +415,104 @@ def test_concurrent_cone_probes_match_sequential_factorisations(name):
     Ub = dev(symb, U0)
     chordal.hessian(Lc, Yc, Ub, adj=None, inv=False)
     assert rel(host(Ub)[msk], host(Ua)[msk]) < 1e-13
+
+
+def _kkt_qr_case(name, m, seed, density=0.05):
+    symb, S, A, msk = setup(name, seed)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=seed + 2)
+    return symb, S, msk, L, Yh, cptr, cidx, cval
+
+
+@pytest.mark.parametrize("name", ["arrow", "rand2", "nested_mid", "fam_max", "fam_nine", "nested", "band"])
+def test_kkt_qr_factor_and_solve(name):
+    """kkt_qr (solvers.py:413-475) on the device against its restatement around the oracle (Householder QR of the
+    same stack): R up to the svec normalisation, Q orthonormal, (x, y) and the reference's DEBUG residuals."""
+    m = 7
+    symb, S, msk, L, Yh, cptr, cidx, cval = _kkt_qr_case(name, m, 21)
+    rng = np.random.default_rng(22)
+    K = orc.KKT(S, cptr, cidx, cval)
+    F = K.qr_factor(L, Yh)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=3, tnzcols=0.0)
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    solve = sys.factor_qr(Ld, Yd)
+    assert sys.qr_passes == 2 and sys.qr_shift == 0.0
+    Rt, G = sys.qr_inspect()
+    assert np.abs(G.cpu().numpy() - np.eye(m)).max() < 1e-13
+    # R^T R = At^T At: the device's inner product carries the weights, the reference's svec scaling halves it
+    assert rel(np.tril(Rt) @ np.tril(Rt).T, 2.0 * F["R"].T @ F["R"]) < 1e-11
+    # R itself (positive diagonal on both sides after fixing the signs of the Householder factor)
+    Rref = F["R"] * np.sign(np.diag(F["R"]))[:, None] * np.sqrt(2.0)
+    assert rel(np.tril(Rt).T, Rref) < 1e-9
+    bx = rng.standard_normal(symb.blklen) * msk
+    by = rng.standard_normal(m)
+    for kk in (1.0, 0.25):
+        xr, yr = K.qr_solve(L, Yh, F, bx, by, kk)
+        bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+        solve(bxd, byd, kk)
+        assert rel(host(bxd)[msk], xr[msk]) < 1e-9
+        assert rel(byd.cpu().numpy(), yr) < 1e-9
+        r, rr = K.residual(L, Yh, host(bxd) * msk, byd.cpu().numpy(), bx, by, kk)
+        assert np.sqrt(orc.dot(S, r, r)) / max(1, np.sqrt(orc.dot(S, bx, bx))) < 1e-10
+        assert np.linalg.norm(rr) / max(1, np.linalg.norm(by)) < 1e-10
+    # the chol-based solver on the same system afterwards (it rewrites the stack): the QR closure must refuse
+    sys.factor(Ld, Yd)
+    with pytest.raises(Exception):
+        solve(dev(symb, bx), torch.from_numpy(by.copy()).cuda(), 1.0)
+
+
+def test_kkt_qr_many_constraints():
+    """m = 150 constraints (more than one 128-column Gram block, 19 accumulator blocks in k_stack_rmul)."""
+    m = 150
+    symb, S, msk, L, Yh, cptr, cidx, cval = _kkt_qr_case("nested_mid", m, 31, density=0.02)
+    rng = np.random.default_rng(32)
+    K = orc.KKT(S, cptr, cidx, cval)
+    F = K.qr_factor(L, Yh)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=16, tnzcols=0.0)
+    solve = sys.factor_qr(dev(symb, L), dev(symb, Yh))
+    Rt, G = sys.qr_inspect()
+    assert np.abs(G.cpu().numpy() - np.eye(m)).max() < 1e-12
+    bx = rng.standard_normal(symb.blklen) * msk
+    by = rng.standard_normal(m)
+    xr, yr = K.qr_solve(L, Yh, F, bx, by, 0.5)
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    solve(bxd, byd, 0.5)
+    assert rel(host(bxd)[msk], xr[msk]) < 1e-8
+    assert rel(byd.cpu().numpy(), yr) < 1e-8
+
+
+def test_kkt_qr_nearly_dependent_constraints():
+    """Two constraints that differ by 1e-9 of a third: kappa(At) ~ 1e9, chol(At^T At) is at the edge of breakdown.
+    The QR path must still deliver the residuals of the reference's DEBUG check; the Householder restatement is
+    the yardstick for the solution."""
+    m = 6
+    symb, S, msk, L, Yh, cptr, cidx, cval = _kkt_qr_case("nested_mid", m + 1, 41, density=0.05)
+    K0 = orc.KKT(S, cptr, cidx, cval)
+    dense = np.stack([K0.constraint(j) for j in range(m + 1)])
+    dense[1] = dense[0] + 1e-9 * dense[m]         # the perturbation is independent of the other constraints
+    cptr2, cidx2, cval2 = [0], [], []
+    for j in range(m):
+        nz = np.flatnonzero(dense[j])
+        cidx2.extend(nz.tolist()); cval2.extend(dense[j][nz].tolist()); cptr2.append(len(cidx2))
+    cptr2, cidx2, cval2 = np.array(cptr2), np.array(cidx2), np.array(cval2)
+    K = orc.KKT(S, cptr2, cidx2, cval2)
+    F = K.qr_factor(L, Yh)
+    assert np.linalg.cond(F["R"]) > 1e8
+    sys = KKTSystem(symb, cptr2, cidx2, cval2, max_rhs=4, tnzcols=0.0)
+    solve = sys.factor_qr(dev(symb, L), dev(symb, Yh))
+    Rt, G = sys.qr_inspect()
+    assert np.abs(G.cpu().numpy() - np.eye(m)).max() < 1e-10
+    rng = np.random.default_rng(42)
+    bx = rng.standard_normal(symb.blklen) * msk
+    by = rng.standard_normal(m) * 0.0          # consistent right-hand side: A x = 0
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    solve(bxd, byd, 1.0)
+    x, y = host(bxd) * msk, byd.cpu().numpy()
+    r, rr = K.residual(L, Yh, x, y, bx, by, 1.0)
+    assert np.sqrt(orc.dot(S, r, r)) / max(1, np.sqrt(orc.dot(S, bx, bx))) < 1e-6
+    assert np.linalg.norm(rr) < 1e-6
+    xr, yr = K.qr_solve(L, Yh, F, bx, by, 1.0)
+    assert rel(x[msk], xr[msk]) < 1e-5          # x is well determined even though y is not

@@ -241,3 +241,21 @@ def test_one_by_one_sdp():
 
     sol = One().solve_esd()
     assert sol["status"] == "optimal" and abs(sol["primal objective"] - 6.0) < 1e-5 and abs(sol["dual objective"] - 6.0) < 1e-5
+
+
+@pytest.mark.gpu
+def test_kktsolver_qr_on_device_matches_chol():
+    from smcp_amd import base
+    """kktsolver='qr' end to end on the device (feasible-start and embedding drivers, a problem with column-sparse
+    constraints so that the constraint classification has to be redone): same optimum and iteration count as
+    'chol', primal feasibility at least as good."""
+    P = base.band_SDP(60, 20, 3, seed=5)
+    fc = P.solve_feas(kktsolver="chol")
+    fq = P.solve_feas(kktsolver="qr")
+    eq = P.solve_esd(kktsolver="qr")
+    for sol in (fc, fq, eq):
+        assert sol["status"] == "optimal"
+    assert abs(fq["primal objective"] - fc["primal objective"]) < 1e-6 * (1 + abs(fc["primal objective"]))
+    assert abs(eq["primal objective"] - fc["primal objective"]) < 1e-5 * (1 + abs(fc["primal objective"]))
+    assert abs(fq["iterations"] - fc["iterations"]) <= 1
+    assert fq["primal infeasibility"] < 1e-8

@@ -209,3 +209,20 @@ def test_nonchordal_embedding_maxcut_small():
     assert np.linalg.norm(np.diag(sol["y"]) + S - C) < 1e-7 * (1 + np.abs(C).max())
     assert np.linalg.eigvalsh(S).min() > -1e-8
     assert abs(np.sum(C * X) - sol["y"].sum()) < 1e-5 * (1 + abs(sol["y"].sum()))
+
+
+def test_kktsolver_qr_both_drivers():
+    """kktsolver='qr' (solvers.py:413-475, 551-556): same optimum as 'chol' from both drivers; unknown names are
+    rejected with the reference's message (solvers.py:561)."""
+    P = base.band_SDP(40, 12, 2, seed=3)
+    with oracle_backend():
+        fc = P.solve_feas(kktsolver="chol")
+        fq = P.solve_feas(kktsolver="qr")
+        eq = P.solve_esd(kktsolver="qr")
+        with pytest.raises(ValueError, match="Unknown 'kktsolver'"):
+            P.solve_feas(kktsolver="lu")
+    for sol in (fc, fq, eq):
+        assert sol["status"] == "optimal"
+    assert abs(fq["primal objective"] - fc["primal objective"]) < 1e-5 * (1 + abs(fc["primal objective"]))
+    assert abs(eq["primal objective"] - fc["primal objective"]) < 1e-5 * (1 + abs(fc["primal objective"]))
+    assert fq["iterations"] == fc["iterations"]

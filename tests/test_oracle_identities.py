@@ -167,3 +167,35 @@ def test_kkt_solve_residuals(name):
         r, rr = K.residual(L, Y, x, y, bx, by, kk)
         assert np.sqrt(orc.dot(S, r, r)) / max(1, np.sqrt(orc.dot(S, bx, bx))) < 1e-10
         assert np.linalg.norm(rr) / max(1, np.linalg.norm(by)) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["arrow", "rand2"])
+def test_kkt_qr_restatement(name):
+    """kkt_qr (solvers.py:413-475) restated around the oracle: R^T R = H / 2 (the svec scaling of solvers.py:420),
+    the solution agrees with kkt_chol's and passes the reference's DEBUG residual check (solvers.py:465-469)."""
+    from smcp_amd import problems
+    pat, symb, S = make(name)
+    rng = np.random.default_rng(17)
+    A, _ = random_spd_on_V(S, 17)
+    L = S.project(A)
+    orc.cholesky(S, L)
+    Y = L.copy()
+    orc.projected_inverse(S, Y)
+    m = 5
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.2, seed=13)
+    K = orc.KKT(S, cptr, cidx, cval)
+    H = K.schur_factor(L, Y)
+    Hl = np.tril(H)
+    F = K.qr_factor(L, Y)
+    assert rel(F["R"].T @ F["R"], 0.5 * (Hl @ Hl.T)) < 1e-10
+    bxd = rng.standard_normal((S.n, S.n))
+    bx = S.project(proj(S, bxd + bxd.T))
+    by = rng.standard_normal(m)
+    for kk in (1.0, 0.37):
+        xc, yc = K.solve(L, Y, H, bx, by, kk)
+        x, y = K.qr_solve(L, Y, F, bx, by, kk)
+        assert rel(y, yc) < 1e-10
+        assert rel(x, xc) < 1e-10
+        r, rr = K.residual(L, Y, x, y, bx, by, kk)
+        assert np.sqrt(orc.dot(S, r, r)) / max(1, np.sqrt(orc.dot(S, bx, bx))) < 1e-10
+        assert np.linalg.norm(rr) / max(1, np.linalg.norm(by)) < 1e-10
