@@ -333,7 +333,8 @@ def main():
 
     # ---------------- CPU baseline: the oracle on a bounded sample (rank 0, N = 1 only) --------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    # (the oracle leg times the reference's default kkt_chol path and needs the factored H: not run for --kktsolver qr)
+    if rank == 0 and world == 1 and not args.no_cpu and args.kktsolver == "chol":
         from oracle import oracle as orc
         So = orc.Sym(symb)
         K = orc.KKT(So, cptr, cidx, cval)
