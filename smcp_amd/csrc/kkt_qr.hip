@@ -25,75 +25,205 @@ constexpr int QR_JB = 8;       // rows of the stack per register block of k_stac
 // kappa(R) * eps, which is exactly what the QR path is there to avoid).  W is the m x len stack (row j at W + j * ldw);
 // Rp the upper-triangular factor, row-major with leading dimension ldr = 8 * nblk, reciprocals on its diagonal,
 // padded with a unit diagonal.
-// One workgroup = 64 stack positions (one per lane) x 4 waves; the m rows are cut into blocks of 8 dealt cyclically to
-// the waves, and every wave keeps ITS blocks of the 64 columns in registers for the whole kernel (NBW blocks = 8 NBW
+// One workgroup = 64 P stack positions (P per lane) x 8 waves; the m rows are cut into blocks of 8 dealt cyclically to
+// the waves, and every wave keeps ITS blocks of the columns in registers for the whole kernel (NBW blocks = 8 NBW P
 // accumulators).  Right-looking: for block J = 0, 1, ... its owner finishes it (8-step substitution with the
 // diagonal block, in registers), stores the rows and broadcasts them through LDS; every wave then subtracts their
-// contribution from its own later blocks (64 FMAs per block pair, the entries of R wave-uniform scalar loads).
+// contribution from its own later blocks (64 P FMAs per block pair).  The entries of R are wave-uniform scalar loads
+// and they are what bounds the kernel: R (m^2 doubles) does not fit the 16 KB scalar cache and the workgroups of a CU
+// walk it at different phases, so P positions per lane (P = 4 for m <= 128, else 2) divide that traffic by P and the
+// eight-wave workgroups halve the number of phases per CU (1.72 ms -> see DESIGN for one pass on synth50k).
 // LDS carries only the 8 finished rows (double buffered: one barrier per block step).
-template <int NBW>
-__global__ void __launch_bounds__(256) k_stack_trsm(double* W, int64_t ldw, int64_t len, int m, const double* __restrict__ Rp,
-                                                    int ldr, int fake) {
-  __shared__ double sq[2][QR_JB][64];
+template <int NBW, int P, int QR_NW>
+__global__ void __launch_bounds__(64 * QR_NW) k_stack_trsm(double* W, int64_t ldw, int64_t len, int m,
+                                                           const double* __restrict__ Rp, int ldr, int fake) {
+  __shared__ double sq[2][QR_JB][64 * P];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
-  const bool in = p < len;
+  const int64_t p0 = (int64_t)blockIdx.x * (64 * P) + lane;       // this lane's positions: p0 + 64 t
   const int nblk = ldr / QR_JB;
-  double acc[NBW][QR_JB];
+  double acc[NBW][QR_JB][P];
 #pragma unroll
   for (int s = 0; s < NBW; ++s) {
-    const int K = s * 4 + wave;
+    const int K = s * QR_NW + wave;
 #pragma unroll
     for (int jj = 0; jj < QR_JB; ++jj) {
       const int row = K * QR_JB + jj;
-      acc[s][jj] = (in && row < m) ? W[(int64_t)row * ldw + p] : 0.0;
+#pragma unroll
+      for (int t = 0; t < P; ++t) acc[s][jj][t] = (row < m && p0 + 64 * t < len) ? W[(int64_t)row * ldw + p0 + 64 * t] : 0.0;
     }
   }
   for (int J = 0; J < nblk; ++J) {
     const int j0 = J * QR_JB, buf = J & 1;
-    if ((J & 3) == wave) {
-      const int sJ = J >> 2;
+    if ((J & (QR_NW - 1)) == wave) {
+      const int sJ = J / QR_NW;
 #pragma unroll
       for (int s = 0; s < NBW; ++s)
         if (s == sJ) {
-          double q[QR_JB];
+          double q[QR_JB][P];
 #pragma unroll
           for (int jj = 0; jj < QR_JB; ++jj) {
-            double v = acc[s][jj];
+            const double rinv = Rp[(int64_t)(j0 + jj) * ldr + j0 + jj];     // the packed diagonal holds reciprocals
 #pragma unroll
-            for (int ii = 0; ii < jj; ++ii) v -= q[ii] * Rp[(int64_t)(j0 + ii) * ldr + j0 + jj];
-            q[jj] = v * Rp[(int64_t)(j0 + jj) * ldr + j0 + jj];     // the packed diagonal holds reciprocals
+            for (int t = 0; t < P; ++t) {
+              double v = acc[s][jj][t];
+#pragma unroll
+              for (int ii = 0; ii < jj; ++ii) v -= q[ii][t] * Rp[(int64_t)(j0 + ii) * ldr + j0 + jj];
+              q[jj][t] = v * rinv;
+            }
           }
 #pragma unroll
-          for (int jj = 0; jj < QR_JB; ++jj) {
-            sq[buf][jj][lane] = q[jj];
-            if (in && j0 + jj < m) W[(int64_t)(j0 + jj) * ldw + p] = q[jj];
-          }
+          for (int jj = 0; jj < QR_JB; ++jj)
+#pragma unroll
+            for (int t = 0; t < P; ++t) {
+              sq[buf][jj][lane + 64 * t] = q[jj][t];
+              if (j0 + jj < m && p0 + 64 * t < len) W[(int64_t)(j0 + jj) * ldw + p0 + 64 * t] = q[jj][t];
+            }
         }
     }
     __syncthreads();
     if (J + 1 >= nblk) break;
-    double q[QR_JB];
-#pragma unroll
-    for (int ii = 0; ii < QR_JB; ++ii) q[ii] = sq[buf][ii][lane];
 #pragma unroll
     for (int s = 0; s < NBW; ++s) {
-      const int K = s * 4 + wave;
+      const int K = s * QR_NW + wave;
       if (K > J && K < nblk) {
         const double* r = fake ? Rp : Rp + (int64_t)j0 * ldr + K * QR_JB;
         // two halves of four rows of R: 32 wave-uniform doubles (64 SGPRs) in flight at a time -- all 64 at once
         // overflow the scalar register file and the spills land in the inner loop
 #pragma unroll
-        for (int ii = 0; ii < QR_JB / 2; ++ii)
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-          for (int kk = 0; kk < QR_JB; ++kk) acc[s][kk] -= q[ii] * r[(int64_t)ii * ldr + kk];
-        __builtin_amdgcn_sched_barrier(0);
+          for (int ii = h * (QR_JB / 2); ii < (h + 1) * (QR_JB / 2); ++ii) {
+            double q[P];
 #pragma unroll
-        for (int ii = QR_JB / 2; ii < QR_JB; ++ii)
+            for (int t = 0; t < P; ++t) q[t] = sq[buf][ii][lane + 64 * t];
 #pragma unroll
-          for (int kk = 0; kk < QR_JB; ++kk) acc[s][kk] -= q[ii] * r[(int64_t)ii * ldr + kk];
-        __builtin_amdgcn_sched_barrier(0);
+            for (int kk = 0; kk < QR_JB; ++kk) {
+              const double rv = r[(int64_t)ii * ldr + kk];
+#pragma unroll
+              for (int t = 0; t < P; ++t) acc[s][kk][t] -= q[t] * rv;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+}
+// The same substitution with the block updates on the matrix cores (v_mfma_f64_16x16x4: twice the vector fp64 rate,
+// and the entries of R become a VECTOR operand, 16 consecutive doubles of a row per load, pipelined under vmcnt --
+// the scalar loads of k_stack_trsm cannot be: they return out of order, so every wait is a wait for all of them).
+// One workgroup = 64 stack positions x 4 waves; the rows are cut into blocks of 16 dealt cyclically to the waves;
+// a wave keeps its blocks as MFMA accumulators D[position][row] (4 position groups of 16 x NB blocks x 4 registers).
+// Block step J: the owner spills its block through LDS into "lane = position" form, every lane runs the 16-step
+// substitution of its position in registers (diagonal block of R: wave-uniform loads, reciprocals precomputed),
+// stores the finished rows (coalesced) and leaves them in LDS; after the barrier every wave subtracts
+// Q_J R[J, K] from its later blocks K: per block pair 4 k-steps x 4 position groups = 16 MFMAs, the R operand of a
+// k-step loaded once and shared by the four groups.  Rp: ldr a multiple of 16 here.
+constexpr int QR_MB = 16;
+template <int NB>
+__global__ void __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 2 ? 3 : 2))) k_stack_trsm_mfma(double* W, int64_t ldw, int64_t len, int m,
+                                                         const double* __restrict__ Rp, int ldr) {
+  __shared__ double sT[QR_MB][64 + 1];          // the owner's block, [row][position]
+  __shared__ double sQ[2][QR_MB][64];           // finished rows of the block step, double buffered
+  __shared__ double sR[2][QR_MB][QR_MB + 1];    // diagonal block of R of the block step (reciprocals on its diagonal)
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  const int nblk = ldr / QR_MB;
+  d4 D[NB][4];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    const int K = s * 4 + wave;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = K * QR_MB + kq + 4 * r;
+        const int64_t p = p0 + 16 * g + l15;
+        D[s][g][r] = (row < m && p < len) ? W[(int64_t)row * ldw + p] : 0.0;
+      }
+  }
+  // diagonal block of R for block step J: fetched by its owner-to-be one step ahead (vector loads, 4 entries per lane)
+  // into sR[J & 1]; written and read by the same wave
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = lane + 64 * t;
+      sR[0][e >> 4][e & 15] = Rp[(int64_t)(e >> 4) * ldr + (e & 15)];
+    }
+  }
+  for (int J = 0; J < nblk; ++J) {
+    const int j0 = J * QR_MB, buf = J & 1;
+    // R operands of this step's updates: they do not depend on the rows being finished, so the loads go out before
+    // the owner's substitution and the barrier
+    double b[NB][4];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      const int K = s * 4 + wave;
+      if (K > J && K < nblk) {
+        const double* r = Rp + (int64_t)(j0 + kq) * ldr + K * QR_MB + l15;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) b[s][st] = r[(int64_t)(4 * st) * ldr];
+      } else {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) b[s][st] = 0.0;
+      }
+    }
+    if ((J & 3) == wave) {
+      const int sJ = J >> 2;
+#pragma unroll
+      for (int s = 0; s < NB; ++s)
+        if (s == sJ) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sT[kq + 4 * r][16 * g + l15] = D[s][g][r];
+        }
+      // same wave wrote and reads: the LDS operations of a wave are executed in order.  Substitution of this lane's
+      // position in registers
+      const int64_t p = p0 + lane;
+      double v[QR_MB];
+#pragma unroll
+      for (int jj = 0; jj < QR_MB; ++jj) v[jj] = sT[jj][lane];
+#pragma unroll
+      for (int jj = 0; jj < QR_MB; ++jj) {          // right-looking: 15 - jj independent updates per finished entry
+        const double qv = v[jj] * sR[buf][jj][jj];  // reciprocal
+#pragma unroll
+        for (int kk = jj + 1; kk < QR_MB; ++kk) v[kk] -= qv * sR[buf][jj][kk];
+        sQ[buf][jj][lane] = qv;
+        __builtin_amdgcn_sched_barrier(0);          // one row of R in flight at a time
+      }
+      if (p < len) {
+        double* wp = W + (int64_t)j0 * ldw + p;
+#pragma unroll 4
+        for (int jj = 0; jj < QR_MB; ++jj)
+          if (j0 + jj < m) wp[(int64_t)jj * ldw] = sQ[buf][jj][lane];
+      }
+    }
+    __syncthreads();
+    if (J + 1 >= nblk) break;
+    if (((J + 1) & 3) == wave) {
+      const int jn = j0 + QR_MB;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int e = lane + 64 * t;
+        sR[(J + 1) & 1][e >> 4][e & 15] = Rp[(int64_t)(jn + (e >> 4)) * ldr + jn + (e & 15)];
+      }
+    }
+    double aq[4][4];                              // -Q_J as the A operand: [position group][k-step]
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) aq[g][st] = -sQ[buf][kq + 4 * st][16 * g + l15];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      const int K = s * 4 + wave;
+      if (K > J && K < nblk) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) D[s][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[s][st], aq[g][st], D[s][g], 0, 0, 0);
       }
     }
   }
@@ -210,7 +340,7 @@ constexpr int64_t QR_DOT_CHUNK = 16384;
 int qr_alloc(csp_ctx* c) {
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
-  const int64_t ldr = (m + QR_JB - 1) / QR_JB * QR_JB;
+  const int64_t ldr = (m + QR_MB - 1) / QR_MB * QR_MB;
   const int64_t nchunk = (bl + QR_DOT_CHUNK - 1) / QR_DOT_CHUNK;
   // G | T | Lc | scratch (m x m each), Rp (ldr x ldr: the packed factor of the pass), r1 (bl), part (m * nchunk), xm, r2 (m each)
   const int64_t need = 4 * m * m + ldr * ldr + bl + m * nchunk + 2 * m + bl;     // ... and the weighted copy of r1 at the end
@@ -233,11 +363,11 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
   if (!m || use_generic()) return SMCP_EINVAL;
   if (D.ns) return SMCP_EINVAL;                 // every constraint must be swept (kkt_set_tnzcols(0) before the constraints)
   if (D.max_rhs < 1 || D.ustack_cols < m) return SMCP_EINVAL;
-  if (m > 320) return SMCP_ENOMEM;              // k_stack_trsm keeps m / 4 rows per wave in registers: m <= 320 in this build
+  if (m > 320) return SMCP_ENOMEM;              // k_stack_trsm keeps m / 8 rows per wave in registers: m <= 320 in this build
   hipStream_t st = (hipStream_t)stream;
   D.qr_valid = false;
   if (int rc = qr_alloc(c)) return rc;
-  const int64_t ldr = (m + QR_JB - 1) / QR_JB * QR_JB;
+  const int64_t ldr8 = (m + QR_JB - 1) / QR_JB * QR_JB, ldr16 = (m + QR_MB - 1) / QR_MB * QR_MB;
   double* G = D.qr_ws;
   double* T = G + m * m;
   double* Lc = T + m * m;
@@ -279,18 +409,41 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
       shift = shift > 0.0 ? shift * 100.0 : 1e-15 * (double)m;
       if (!npass_env) npass = std::max(npass, pass + 3);
     }
-    if (pass > 0) shift = 0.0;       // later passes see a well-conditioned stack; a shift there would only be a rescue
+    if (pass == 0 && shift_out) *shift_out = shift;
+    shift = 0.0;                     // the next pass sees a better-conditioned stack and starts unshifted again
+    static int fake = -1;      // timing experiment only, vector-FMA kernel (SMCP_QR_FAKE=1: every update reads the same block of R)
+    if (fake < 0) { const char* e = getenv("SMCP_QR_FAKE"); fake = e ? atoi(e) : 0; }
+    static int vfma = -1;      // SMCP_QR_TRSM=fma: the vector-FMA kernel (k_stack_trsm) instead of the MFMA one
+    if (vfma < 0) { const char* e = getenv("SMCP_QR_TRSM"); vfma = (e && e[0] == 'f') ? 1 : 0; }
+    const int64_t ldr = vfma ? ldr8 : ldr16;
     launch(c, KID_qr_small, k_qr_pack, dim3((unsigned)std::min<int64_t>(256, (ldr * ldr + 255) / 256)), dim3(256), st,
            (const double*)T, (int)m, m, X, (int)ldr);
-    {
+    if (!vfma) {
       const dim3 grid((unsigned)((bl + 63) / 64)), blk(256);
-      const int nbw = (int)((ldr / QR_JB + 3) / 4);
-      static int fake = -1;     // timing experiment only: every update reads the same 8 x 8 block of R
-      if (fake < 0) { const char* e = getenv("SMCP_QR_FAKE"); fake = e ? atoi(e) : 0; }
-#define SMCP_TRSM_CASE(N) case N: launch(c, KID_qr_rmul, k_stack_trsm<N>, grid, blk, st, D.ustack, bl, bl, (int)m, (const double*)X, (int)ldr, fake); break;
-      switch (nbw) {
+      const int nb = (int)((ldr / QR_MB + 3) / 4);
+#define SMCP_TRSM_CASE(N) case N: launch(c, KID_qr_rmul, k_stack_trsm_mfma<N>, grid, blk, st, D.ustack, bl, bl, (int)m, (const double*)X, (int)ldr); break;
+      switch (nb) {
         SMCP_TRSM_CASE(1) SMCP_TRSM_CASE(2) SMCP_TRSM_CASE(3) SMCP_TRSM_CASE(4) SMCP_TRSM_CASE(5)
-        SMCP_TRSM_CASE(6) SMCP_TRSM_CASE(7) SMCP_TRSM_CASE(8) SMCP_TRSM_CASE(9) SMCP_TRSM_CASE(10)
+        default: return SMCP_ENOMEM;
+      }
+#undef SMCP_TRSM_CASE
+    } else {
+      static int nwv = -1, pv = -1;     // SMCP_QR_NW = 4 | 8 waves per workgroup, SMCP_QR_P = 1 | 2 | 4 positions per lane
+      if (nwv < 0) { const char* e = getenv("SMCP_QR_NW"); nwv = (e && e[0] == '8') ? 8 : 4; }
+      if (pv < 0) { const char* e = getenv("SMCP_QR_P"); pv = e ? atoi(e) : 1; }
+      const int nbw = (int)((ldr / QR_JB + nwv - 1) / nwv);
+      int P = pv;
+      if (nbw * P > 10) P = nbw > 5 ? 1 : 2;        // register budget: 8 NBW P accumulators per lane
+      const dim3 grid((unsigned)((bl + 64 * P - 1) / (64 * P))), blk(64 * nwv);
+#define SMCP_TRSM_CASE(N, PP, NWV) case (N * 8 + PP) * 16 + NWV: launch(c, KID_qr_rmul, k_stack_trsm<N, PP, NWV>, grid, blk, st, D.ustack, bl, bl, (int)m, (const double*)X, (int)ldr, fake); break;
+      switch ((nbw * 8 + P) * 16 + nwv) {
+        SMCP_TRSM_CASE(1, 1, 4) SMCP_TRSM_CASE(2, 1, 4) SMCP_TRSM_CASE(3, 1, 4) SMCP_TRSM_CASE(4, 1, 4) SMCP_TRSM_CASE(5, 1, 4)
+        SMCP_TRSM_CASE(6, 1, 4) SMCP_TRSM_CASE(7, 1, 4) SMCP_TRSM_CASE(8, 1, 4) SMCP_TRSM_CASE(9, 1, 4) SMCP_TRSM_CASE(10, 1, 4)
+        SMCP_TRSM_CASE(1, 2, 4) SMCP_TRSM_CASE(2, 2, 4) SMCP_TRSM_CASE(3, 2, 4) SMCP_TRSM_CASE(4, 2, 4) SMCP_TRSM_CASE(5, 2, 4)
+        SMCP_TRSM_CASE(1, 4, 4) SMCP_TRSM_CASE(2, 4, 4)
+        SMCP_TRSM_CASE(1, 1, 8) SMCP_TRSM_CASE(2, 1, 8) SMCP_TRSM_CASE(3, 1, 8) SMCP_TRSM_CASE(4, 1, 8) SMCP_TRSM_CASE(5, 1, 8)
+        SMCP_TRSM_CASE(1, 2, 8) SMCP_TRSM_CASE(2, 2, 8) SMCP_TRSM_CASE(3, 2, 8) SMCP_TRSM_CASE(4, 2, 8) SMCP_TRSM_CASE(5, 2, 8)
+        SMCP_TRSM_CASE(1, 4, 8) SMCP_TRSM_CASE(2, 4, 8)
         default: return SMCP_ENOMEM;
       }
 #undef SMCP_TRSM_CASE
@@ -302,7 +455,6 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
              (const double*)Lc, (const double*)T, (int)m, m, S2);
       HIPCHK(hipMemcpyAsync(Lc, S2, sizeof(double) * m * m, hipMemcpyDeviceToDevice, st));
     }
-    if (pass == 0 && shift_out) *shift_out = shift;
   }
   HIPCHK(hipGetLastError());
   if (passes_out) *passes_out = npass;
@@ -317,7 +469,7 @@ int kkt_qr_solve(csp_ctx* c, const double* L, const double* Y, double kk, double
   const int64_t m = D.m, bl = c->S.blklen();
   if (!m || !D.qr_valid || D.qr_L != L || D.qr_Y != Y) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t ldr = (m + QR_JB - 1) / QR_JB * QR_JB;
+  const int64_t ldr = (m + QR_MB - 1) / QR_MB * QR_MB;
   const int nchunk = (int)((bl + QR_DOT_CHUNK - 1) / QR_DOT_CHUNK);
   double* Lc = D.qr_ws + 2 * m * m;
   double* r1 = D.qr_ws + 4 * m * m + ldr * ldr;
