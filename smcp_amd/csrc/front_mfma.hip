@@ -1312,8 +1312,15 @@ __global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* 
   if (tn * 16 >= nj || (diag && tm < tn)) return;
   const int idx = threadIdx.x;          // element within the tile (column-major 16 x 16)
   const double* p = partial + (int64_t)blockIdx.y * nchunk * (int64_t)(64 * 256) + (int64_t)t * 256 + idx;
-  double s = 0.0;
-  for (int c = 0; c < nchunk; ++c) s += p[(int64_t)c * (64 * 256)];
+  // eight independent partial sums (eight loads in flight; the order of the additions is fixed: deterministic)
+  double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int c = 0;
+  for (; c + 8 <= nchunk; c += 8) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s8[q] += p[(int64_t)(c + q) * (64 * 256)];
+  }
+  for (; c < nchunk; ++c) s8[0] += p[(int64_t)c * (64 * 256)];
+  const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   const int i = ci0 + tm * 16 + (idx & 15), j = cj0 + tn * 16 + (idx >> 4);
   if (i < ci0 + ni && j < cj0 + nj) {
     H[i + (int64_t)j * ldh] = s;
