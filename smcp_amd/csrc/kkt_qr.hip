@@ -110,8 +110,8 @@ __global__ void __launch_bounds__(64 * QR_NW) k_stack_trsm(double* W, int64_t ld
     }
   }
 }
-// The same substitution with the block updates on the matrix cores (v_mfma_f64_16x16x4: twice the vector fp64 rate,
-// and the entries of R become a VECTOR operand, 16 consecutive doubles of a row per load, pipelined under vmcnt --
+// The same substitution with the block updates on the matrix cores (v_mfma_f64_16x16x4: the same peak as the vector
+// fp64 pipe on gfx950, but the entries of R become a VECTOR operand, 16 consecutive doubles of a row per load, pipelined under vmcnt --
 // the scalar loads of k_stack_trsm cannot be: they return out of order, so every wait is a wait for all of them).
 // One workgroup = 64 stack positions x 4 waves; the rows are cut into blocks of 16 dealt cyclically to the waves;
 // a wave keeps its blocks as MFMA accumulators D[position][row] (4 position groups of 16 x NB blocks x 4 registers).
