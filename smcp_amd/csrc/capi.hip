@@ -863,8 +863,10 @@ void csp_symbolic_destroy(csp_ctx* c) {
   if (D.device >= 0) {
     hipSetDevice(D.device);
     void* ptrs[] = {D.p_yaa, D.p_fac, D.p_faci, D.p_lfd, D.p_info, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
-                    D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws};
+                    D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
+                    D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (int set = 1; set <= 2; ++set) if (c->sets[set].lev2) hipFree(c->sets[set].lev2);
     if (D.info_host) hipHostFree(D.info_host);
     for (int q = 0; q < 2; ++q)
       for (int k = 0; k < DeviceCtx::PROBE_MAX; ++k)

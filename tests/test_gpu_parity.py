@@ -516,3 +516,29 @@ def test_kkt_qr_nearly_dependent_constraints():
     assert np.linalg.norm(rr) < 1e-6
     xr, yr = K.qr_solve(L, Yh, F, bx, by, 1.0)
     assert rel(x[msk], xr[msk]) < 1e-5          # x is well determined even though y is not
+
+
+def test_context_destroy_releases_device_memory():
+    """csp_symbolic_destroy frees every device array of a context (workspaces, constraint tables, probe slots, the QR
+    workspace): creating and dropping contexts does not shrink the free device memory."""
+    import gc
+
+    def cycle():
+        symb, S, msk, L, Yh, cptr, cidx, cval = _kkt_qr_case("nested_mid", 12, 51, density=0.05)
+        sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=8, tnzcols=0.0)
+        Ld, Yd = dev(symb, L), dev(symb, Yh)
+        sys.factor(Ld, Yd)
+        sys.factor_qr(Ld, Yd)
+        Ad = dev(symb, S.project(np.eye(symb.n)))
+        chordal.probe_cone(Ad, Ad, np.linspace(0.0, 0.1, 8), "d")        # reserves the probe slots and streams
+        del sys, Ld, Yd, symb
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    cycle()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(4):
+        cycle()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (32 << 20), (free0, free1)
