@@ -182,7 +182,7 @@ int csp_probe_launch(csp_ctx* ctx, int kind, double* x, int64_t slot, void* stre
 int csp_probe_results(csp_ctx* ctx, int64_t K, int* out);
 /* The three calls above in one: trial matrices T + k*ldT (k < K <= 16, written on producer_stream) are factored in place
  * on K library-owned streams (SMCP_PROBE_GRAPH=1: after the first run per cone the launch sequence of every slot is
- * replayed from a captured hipGraph -- experimental).  Returns when all probes are done; out[k] as csp_probe_results. */
+ * replayed from a captured hipGraph).  Returns when all probes are done; out[k] as csp_probe_results. */
 int csp_probe_run(csp_ctx* ctx, int kind, int64_t K, double* T, int64_t ldT, void* producer_stream, int* out);
 
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */

@@ -573,6 +573,16 @@ void lf_factor_inverse(csp_ctx* c, const MfmaArgs& a, int cnt, hipStream_t st) {
   }
 }
 
+// In probe mode (c->nowait: the launch sequence may be under stream capture) the failure flag is cleared and the
+// separator blocks are copied by kernels rather than by memset / memcpy nodes
+__global__ void k_zero_flag(int* p) { *p = 0; }
+__global__ void k_copy_doubles(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) dst[e] = src[e];
+}
+inline hipError_t zero_flag(csp_ctx* c, hipStream_t st) {
+  if (c->nowait) { hipLaunchKernelGGL(k_zero_flag, dim3(1), dim3(1), 0, st, c->D.info); return hipGetLastError(); }
+  return hipMemsetAsync(c->D.info, 0, sizeof(int), st);
+}
 // yaa <- separator blocks of Y; fac <- their Cholesky factors (need_fac); faci <- inverses of those (need_inv).
 // Each stage is skipped when the cache already holds it for the matrix at this address (see invalidate_tags).
 int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool need_inv) {
@@ -587,7 +597,11 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
   const bool fast = !use_generic() && use_large();
   if (need_fac && c->D.fac_tag != Y) {
     if (fast) {
-      (void)hipMemcpyAsync(c->D.fac, c->D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st);
+      if (c->nowait)
+        hipLaunchKernelGGL(k_copy_doubles, dim3((unsigned)std::min<int64_t>(1024, (c->S.updlen() + 255) / 256 + 1)), dim3(256), 0, st,
+                           (const double*)c->D.yaa, c->D.fac, c->S.updlen());
+      else
+        (void)hipMemcpyAsync(c->D.fac, c->D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st);
       MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
       for (int64_t l = 0; l < c->S.nlev; ++l)
         for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
@@ -1106,7 +1120,7 @@ int csp_cholesky(csp_ctx* c, double* x, void* stream) {
   invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
-  HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
+  HIPCHK(zero_flag(c, st));
   if (!use_generic()) {
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
     a0.LK = nullptr;
@@ -1185,7 +1199,7 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
   invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
-  HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
+  HIPCHK(zero_flag(c, st));
   if (!use_generic()) {
     // clique-local given chol(X_AA) and its inverse of every clique (taken from the input before it is overwritten)
     prepare_yaa(c, x, true, st, true);
@@ -1239,7 +1253,7 @@ int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t
   hipStream_t st = (hipStream_t)stream;
   bool need_fac = !(adj == 2 && inv == 0);
   invalidate_tags(c, U);
-  HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
+  HIPCHK(zero_flag(c, st));
   const bool refactor = need_fac && (cache_off() || c->D.fac_tag != Y);
   prepare_yaa(c, Y, need_fac, st, inv && !use_generic());
   if (!inv && !use_generic()) prep_lk_cached(c, L, Y, st);
@@ -1391,10 +1405,11 @@ int csp_probe_run(csp_ctx* c, int kind, int64_t K, double* T, int64_t ldT, void*
   for (int k = 0; k < K; ++k)
     if (!D.p_stream[k]) HIPCHK(hipStreamCreateWithFlags(&D.p_stream[k], hipStreamNonBlocking));
   HIPCHK(hipEventRecord(D.p_ev, (hipStream_t)producer_stream));
-  // Graph replay is OPT-IN (SMCP_PROBE_GRAPH=1): it saves 15-25 % of the launch time of a round, but inside whole
-  // interior-point runs (alternating cones on the same slots) one slot per cone came back with a spurious failure flag
-  // (scratch/probe_ipm_verify.py) although isolated calls agree with sequential factorisations; until that is
-  // understood the probes are launched plainly.
+  // Graph replay is opt-in (SMCP_PROBE_GRAPH=1).  It is correct only because the probe path clears its failure flag and
+  // copies the separator blocks with KERNELS (zero_flag, k_copy_doubles): with hipMemsetAsync / hipMemcpyAsync captured as
+  // memset / memcpy nodes, graphs of different slots replayed concurrently came back with spurious failure flags (74 of
+  // 92 rounds of scratch/probe_ipm_verify.py; 0 of 92 with kernel nodes only).  The gain is within noise on the cases
+  // measured (band n = 200: 0.31 vs 0.33 s per solve, synth50k 2.2 s either way), hence not the default.
   static int nograph = -1;
   if (nograph < 0) { const char* e = getenv("SMCP_PROBE_GRAPH"); nograph = (e && e[0] == '1') ? 0 : 1; }
   const bool use_graph = !nograph && D.p_warm[kind];
