@@ -484,15 +484,17 @@ def test_kkt_qr_many_constraints():
     assert rel(byd.cpu().numpy(), yr) < 1e-8
 
 
-def test_kkt_qr_nearly_dependent_constraints():
-    """Two constraints that differ by 1e-9 of a third: kappa(At) ~ 1e9, chol(At^T At) is at the edge of breakdown.
-    The QR path must still deliver the residuals of the reference's DEBUG check; the Householder restatement is
-    the yardstick for the solution."""
+@pytest.mark.parametrize("eps,shifted", [(1e-9, False), (1e-13, True)])
+def test_kkt_qr_nearly_dependent_constraints(eps, shifted):
+    """Two constraints that differ by eps times a third, independent one: kappa(At) ~ 2 / eps.  At 1e-9 chol(At^T At)
+    still goes through and a third pass is planned from the deviation of the second Gram matrix; at 1e-13 it breaks
+    down and the first pass is repeated on the shifted Gram matrix (shifted CholeskyQR3).  Either way the QR path must
+    deliver the residuals of the reference's DEBUG check; the Householder restatement is the yardstick."""
     m = 6
     symb, S, msk, L, Yh, cptr, cidx, cval = _kkt_qr_case("nested_mid", m + 1, 41, density=0.05)
     K0 = orc.KKT(S, cptr, cidx, cval)
     dense = np.stack([K0.constraint(j) for j in range(m + 1)])
-    dense[1] = dense[0] + 1e-9 * dense[m]         # the perturbation is independent of the other constraints
+    dense[1] = dense[0] + eps * dense[m]         # the perturbation is independent of the other constraints
     cptr2, cidx2, cval2 = [0], [], []
     for j in range(m):
         nz = np.flatnonzero(dense[j])
@@ -511,11 +513,14 @@ def test_kkt_qr_nearly_dependent_constraints():
     bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
     solve(bxd, byd, 1.0)
     x, y = host(bxd) * msk, byd.cpu().numpy()
-    r, rr = K.residual(L, Yh, x, y, bx, by, 1.0)
-    assert np.sqrt(orc.dot(S, r, r)) / max(1, np.sqrt(orc.dot(S, bx, bx))) < 1e-6
-    assert np.linalg.norm(rr) < 1e-6
+    assert (sys.qr_shift > 0.0) == shifted and sys.qr_passes == 3
+    res = lambda xx, yy: (np.sqrt(orc.dot(S, *(2 * [K.residual(L, Yh, xx, yy, bx, by, 1.0)[0]]))) / max(1, np.sqrt(orc.dot(S, bx, bx))),
+                          np.linalg.norm(K.residual(L, Yh, xx, yy, bx, by, 1.0)[1]))
     xr, yr = K.qr_solve(L, Yh, F, bx, by, 1.0)
-    assert rel(x[msk], xr[msk]) < 1e-5          # x is well determined even though y is not
+    (r1, r2), (o1, o2) = res(x, y), res(xr, yr)
+    # the achievable residual grows with |y| ~ kappa; the Householder solution of the same system is the measure
+    assert r1 < max(1e-8, 3 * o1) and r2 < 1e-10
+    assert rel(x[msk], xr[msk]) < max(1e-7, 20 * o1)     # x is well determined even though y is not
 
 
 def test_context_destroy_releases_device_memory():
