@@ -177,7 +177,11 @@ __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u,
   const double* ubase = a.t.updp + (int64_t)r * a.t.updplen;
   // packed column start minus the column index: T[cb(j) + i] = front(i, j), i >= j
   auto cb = [nf](int j) { return j * nf - ((j * (j - 1)) >> 1) - j; };
-  for (int q = wave; q < nch; q += nw) {
+  // fewer children than waves: `parts` waves share a child and take its column batches round-robin (eight children
+  // on sixteen waves left half of the workgroup idle)
+  const int parts = nch < nw ? max(1, nw / nch) : 1;
+  const int part = parts > 1 ? wave / nch : 0;
+  for (int q = parts > 1 ? wave % nch : wave; q < nch && part < parts; q += nw) {
     const int nac = sCn[q];
     const int32_t* rel = a.t.relidx + sCr[q];
     const double* Uc = ubase + sCu[q];
@@ -200,9 +204,10 @@ __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u,
         }
       }
     };
-    fetch(0, cur);
-    for (int j0 = 0; j0 < nac; j0 += CB) {
-      if (j0 + CB < nac) fetch(j0 + CB, nxt);
+    const int jstep = CB * parts;
+    fetch(CB * part, cur);
+    for (int j0 = CB * part; j0 < nac; j0 += jstep) {
+      if (j0 + jstep < nac) fetch(j0 + jstep, nxt);
 #pragma unroll
       for (int x = 0; x < CB; ++x) {
         const int j = j0 + x;
