@@ -152,6 +152,55 @@ __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
 __device__ inline double col_at(const double* Uc, int nac, int i, int j) { return Uc[pk_col(j, nac) - j + i]; }
 constexpr int LF_ALDS_MAXNF = 198;
 __host__ __device__ inline int lf_alds_doubles(int nf) { return nf * (nf + 1) / 2; }
+// One child of k_lf_assemble_lds: lane l owns row l (and, TWO, row l + 64) of the child's packed update matrix
+// (separators of up to 128 rows; longer ones finish with a plain loop); each wave load is one contiguous run of a packed
+// column.  CB columns are fetched per batch and the next batch is in flight while the current one is added into the
+// front (LDS atomics: several waves may hit one front column).  Children with at most 64 rows take 16 columns per
+// batch with one row per lane -- the same number of loads in flight, half the latency steps.
+template <int CB, bool TWO>
+__device__ inline void lf_add_child(double* T, int nf, const double* Uc, const int32_t* rel, int nac, int lane, int part, int parts) {
+  auto cb = [nf](int j) { return j * nf - ((j * (j - 1)) >> 1) - j; };
+  constexpr int NR = TWO ? 2 : 1;
+  const int iA = lane, iB = lane + 64;
+  const int rA = iA < nac ? rel[iA] : 0, rB = (TWO && iB < nac) ? rel[iB] : 0;
+  double cur[CB][NR], nxt[CB][NR];
+  auto fetch = [&](int j0, double (&v)[CB][NR]) {
+#pragma unroll
+    for (int x = 0; x < CB; ++x) {
+      const int j = j0 + x;
+#pragma unroll
+      for (int h = 0; h < NR; ++h) v[x][h] = 0.0;
+      if (j < nac) {
+        const double* col = Uc + pk_col(j, nac) - j;               // col[i] = U_c(i, j), i >= j
+        if (iA >= j && iA < nac) v[x][0] = col[iA];
+        if (TWO && iB >= j && iB < nac) v[x][NR - 1] = col[iB];
+      }
+    }
+  };
+  const int jstep = CB * parts;
+  fetch(CB * part, cur);
+  for (int j0 = CB * part; j0 < nac; j0 += jstep) {
+    if (j0 + jstep < nac) fetch(j0 + jstep, nxt);
+#pragma unroll
+    for (int x = 0; x < CB; ++x) {
+      const int j = j0 + x;
+      if (j < nac) {
+        const int cj = j < 64 ? __builtin_amdgcn_readlane(rA, j & 63) : (j < 128 ? __builtin_amdgcn_readlane(rB, j & 63) : rel[j]);
+        const int cbj = cb(cj);
+        if (iA >= j && iA < nac) unsafeAtomicAdd(&T[cbj + rA], cur[x][0]);
+        if (TWO) {
+          if (iB >= j && iB < nac) unsafeAtomicAdd(&T[cbj + rB], cur[x][NR - 1]);
+          for (int i = lane + 128; i < nac; i += 64)                 // separators beyond 128 rows (rare)
+            if (i >= j) unsafeAtomicAdd(&T[cbj + rel[i]], col_at(Uc, nac, i, j));
+        }
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < CB; ++x)
+#pragma unroll
+      for (int h = 0; h < NR; ++h) cur[x][h] = nxt[x][h];
+  }
+}
 __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u, int64_t ldu, int sgn) {
   extern __shared__ __attribute__((aligned(16))) double T[];
   const int k = a.t.lev[blockIdx.x];
@@ -185,44 +234,8 @@ __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u,
     const int nac = sCn[q];
     const int32_t* rel = a.t.relidx + sCr[q];
     const double* Uc = ubase + sCu[q];
-    // lane l owns rows l and l + 64 of the child (separators of up to 128 rows; longer ones finish with a plain
-    // loop): each wave load is one contiguous run of a packed column.  Eight columns are fetched per batch and the
-    // next batch is in flight while the current one is added into the front.
-    const int iA = lane, iB = lane + 64;
-    const int rA = iA < nac ? rel[iA] : 0, rB = iB < nac ? rel[iB] : 0;
-    constexpr int CB = 8;
-    double cur[CB][2], nxt[CB][2];
-    auto fetch = [&](int j0, double (&v)[CB][2]) {
-#pragma unroll
-      for (int x = 0; x < CB; ++x) {
-        const int j = j0 + x;
-        v[x][0] = v[x][1] = 0.0;
-        if (j < nac) {
-          const double* col = Uc + pk_col(j, nac) - j;               // col[i] = U_c(i, j), i >= j
-          if (iA >= j && iA < nac) v[x][0] = col[iA];
-          if (iB >= j && iB < nac) v[x][1] = col[iB];
-        }
-      }
-    };
-    const int jstep = CB * parts;
-    fetch(CB * part, cur);
-    for (int j0 = CB * part; j0 < nac; j0 += jstep) {
-      if (j0 + jstep < nac) fetch(j0 + jstep, nxt);
-#pragma unroll
-      for (int x = 0; x < CB; ++x) {
-        const int j = j0 + x;
-        if (j < nac) {
-          const int cj = j < 64 ? __builtin_amdgcn_readlane(rA, j & 63) : (j < 128 ? __builtin_amdgcn_readlane(rB, j & 63) : rel[j]);
-          const int cbj = cb(cj);
-          if (iA >= j && iA < nac) unsafeAtomicAdd(&T[cbj + rA], cur[x][0]);
-          if (iB >= j && iB < nac) unsafeAtomicAdd(&T[cbj + rB], cur[x][1]);
-          for (int i = lane + 128; i < nac; i += 64)                 // separators beyond 128 rows (rare)
-            if (i >= j) unsafeAtomicAdd(&T[cbj + rel[i]], col_at(Uc, nac, i, j));
-        }
-      }
-#pragma unroll
-      for (int x = 0; x < CB; ++x) { cur[x][0] = nxt[x][0]; cur[x][1] = nxt[x][1]; }
-    }
+    if (nac <= 64) lf_add_child<16, false>(T, nf, Uc, rel, nac, lane, part, parts);
+    else lf_add_child<8, true>(T, nf, Uc, rel, nac, lane, part, parts);
   }
   __syncthreads();
   double* P = u + (int64_t)r * ldu + d.blk;
