@@ -19,8 +19,10 @@ __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0
                                    double* sA, double* sB) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4, wm = wave & 1, wn = wave >> 1;
-  for (int k0 = 0; k0 < Kd; k0 += LKC) {
-    double va[4], vb[4];
+  // the operands of slice k0 + LKC are fetched into registers while the MFMAs of slice k0 run (the products here
+  // are short -- K = 64 is four slices -- so an exposed memory latency per slice is most of a tile's time)
+  double va[4], vb[4];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + 256 * u;
@@ -29,6 +31,9 @@ __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0
       const int kb = e & 15, j = e >> 4;
       vb[u] = (n0 + j < N && k0 + kb < Kd) ? lb(k0 + kb, n0 + j) : 0.0;
     }
+  };
+  if (Kd > 0) fetch(0);
+  for (int k0 = 0; k0 < Kd; k0 += LKC) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -37,6 +42,7 @@ __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0
       sB[(e & 15) + (e >> 4) * LSB] = vb[u];
     }
     __syncthreads();
+    if (k0 + LKC < Kd) fetch(k0 + LKC);
 #pragma unroll
     for (int ks = 0; ks < LKC / 4; ++ks) {
       const int kk = 4 * ks + kq;
