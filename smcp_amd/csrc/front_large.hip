@@ -14,9 +14,12 @@ constexpr int LSA = LT + 1, LSB = LKC + 1;
 
 // acc (2x2 MFMA tiles per wave, waves arranged 2x2 over the 64x64 tile) += A[m0.., :] * B[:, n0..]
 // la(m, k) / lb(k, n): element loaders (global memory, any layout / symmetry); out-of-range -> 0.
+// The products run over k in [kbeg, Kd): a caller whose operand is triangular passes the range where it is nonzero
+// (kbeg is rounded down to a slice boundary; Li is stored with explicit zeros above its diagonal, so the bounds only
+// skip slices of zeros -- half of T = Li F_NN, G = X Li^T ... on a big front).
 template <class LA, class LB>
 __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0, int n0, LA la, LB lb,
-                                   double* sA, double* sB) {
+                                   double* sA, double* sB, int kbeg = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4, wm = wave & 1, wn = wave >> 1;
   // the operands of slice k0 + LKC are fetched into registers while the MFMAs of slice k0 run (the products here
@@ -32,8 +35,9 @@ __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0
       vb[u] = (n0 + j < N && k0 + kb < Kd) ? lb(k0 + kb, n0 + j) : 0.0;
     }
   };
-  if (Kd > 0) fetch(0);
-  for (int k0 = 0; k0 < Kd; k0 += LKC) {
+  const int kfirst = (kbeg / LKC) * LKC;
+  if (kfirst < Kd) fetch(kfirst);
+  for (int k0 = kfirst; k0 < Kd; k0 += LKC) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -361,7 +365,7 @@ __global__ void __launch_bounds__(256) k_lf_up1(MfmaArgs a, double* u, int64_t l
   } else {
     const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
     const double* Li = c.Li;
-    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; }, fsym, sA, sB);
+    gemm_tile64(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; }, fsym, sA, sB);   // Li(m, k) = 0 for k > m
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
   }
@@ -401,15 +405,15 @@ __global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t l
       });
   } else if (t < nU + nG) {
     const int tt = t - nU, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
-    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; },
-                [=](int kk, int n) { return Li[n + (int64_t)kk * nf]; }, sA, sB);
+    gemm_tile64(acc, na, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; },
+                [=](int kk, int n) { return Li[n + (int64_t)kk * nf]; }, sA, sB);      // Li(n, k) = 0 for k > n
     double* G = c.G;
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { G[m + (int64_t)n * na] = v; });
   } else {
     int tm, tn;
     lower_pair(t - nU - nG, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return T[m + (int64_t)kk * nn]; },
+    gemm_tile64(acc, nn, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return T[m + (int64_t)kk * nn]; },
                 [=](int kk, int n) { return Li[n + (int64_t)kk * nf]; }, sA, sB);
     double* Pw = c.P;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
@@ -453,13 +457,13 @@ __global__ void __launch_bounds__(256) k_lf_down1(MfmaArgs a, double* u, int64_t
   tile64_zero(acc);
   if (t < nE) {
     const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
-    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, li, sA, sB);
+    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, li, sA, sB, n0);   // Li(k, n) = 0 for k < n
     double* E = c.E;
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = v; });
   } else {
     const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
     gemm_tile64(acc, nn, nn, nn, m0, n0,
-                [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : P[kk + (int64_t)m * nf]; }, li, sA, sB);
+                [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : P[kk + (int64_t)m * nf]; }, li, sA, sB, n0);
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
   }
@@ -502,7 +506,7 @@ __global__ void __launch_bounds__(256) k_lf_down3(MfmaArgs a, double* u, int64_t
   d4 acc[2][2];
   tile64_zero(acc);
   gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
-              [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB);
+              [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB, m0);                 // Li(k, m) = 0 for k < m
   gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -K[kk + (int64_t)m * nf]; },
               [=](int kk, int n) { return D[kk + (int64_t)n * na]; }, sA, sB);
   gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -D[kk + (int64_t)m * na]; },
@@ -547,7 +551,7 @@ __global__ void __launch_bounds__(256) k_lf_pinv2(MfmaArgs a, double* x) {
     d4 acc[2][2];
     tile64_zero(acc);
     gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
-                [=](int kk, int n) { return Li[kk + (int64_t)n * nf]; }, sA, sB);
+                [=](int kk, int n) { return Li[kk + (int64_t)n * nf]; }, sA, sB, max(m0, n0));
     gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return K[kk + (int64_t)m * nf]; },
                 [=](int kk, int n) { return E[kk + (int64_t)n * na]; }, sA, sB);
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
@@ -787,7 +791,7 @@ __global__ void __launch_bounds__(256) k_lf_prep_s(MfmaArgs a, const double* L, 
   d4 acc[2][2];
   tile64_zero(acc);
   gemm_tile64(acc, w, ib, ib, 0, n0, [=](int m, int kk) { return Lk[(ib + m) + (int64_t)kk * nf]; },
-              [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB);
+              [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB, n0);
   tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { S[s0 + m * sm + n * sn] = v; });
 }
 __global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L, double* LK, int ib, int mode) {
@@ -840,7 +844,7 @@ __global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, 
   d4 acc[2][2];
   tile64_zero(acc);
   gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return Lk[(nn + m) + (int64_t)kk * nf]; },
-              [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB);
+              [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB, n0);
   tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Kk[m + (int64_t)n * nf] = v; });
 }
 
