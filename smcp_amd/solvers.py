@@ -555,8 +555,11 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
     PREDICTION = _opt("prediction", bool)
     STEP = _opt("step", float, 0.0, 1.0, strict_lo=True)
     t = float(_opt("t0", float, 0.0, strict_lo=True))
-    if options.get("eta") is not None:
-        raise NotImplementedError("options['eta'] (Omega-neighbourhood line search, solvers.py:665-689) is not built")
+    ETA = options.get("eta")
+    if ETA is not None:                              # solvers.py:132-136
+        if type(ETA) is not float or ETA <= 0.0:
+            raise TypeError("options['eta'] must be a positive float")
+        ETATOL = 0.10 * ETA
     if scaling not in ("primal", "dual"):
         raise ValueError("scaling must be 'primal' or 'dual'")
     if kktsolver not in ("chol", "qr"):
@@ -645,6 +648,30 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
                 hi = g
                 g_ = lo
         return a * g_
+
+    def linesearch_omega(X, dx, S, ds, eta):
+        """Bisection on the step that keeps Omega(X, S) = phi_p(X) + phi_d(S) + n log(<X, S> / n) + n within ETATOL of
+        eta (options['eta']; solvers.py:386-394, 662-689): one common primal/dual step."""
+        lo, hi, g_ = MINSTEP, 1.0, None
+        for _ in range(8):
+            g = 0.5 * (lo + hi)
+            Xt, St = X + dx * g, S + ds * g
+            try:
+                Lt = in_cone(Xt, "p")                # Cholesky factor of the inverse of the completion of Xt
+                Lst = in_cone(St, "d")
+                gapt = dot(St, Xt)
+                g_ = g
+                Ot = 2.0 * chordal.logdiagsum(Lt) - 2.0 * chordal.logdiagsum(Lst) + n * math.log(gapt / n)
+                if Ot - eta > ETATOL:
+                    hi = g
+                elif Ot - eta < -ETATOL:
+                    lo = g
+                else:
+                    break
+            except (ArithmeticError, ValueError):    # outside a cone (or a non-positive gap)
+                hi = g
+                g_ = None
+        return g_ if g_ else lo
 
     def backtrack_primal(X, dx, tt, ntd):
         """Damped centering step on X (solvers.py:928-939)."""
@@ -838,13 +865,17 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
             stype = "a"
             dx, dy = solve_refined(S, bv - Amap(X), t)
             ds = Aadj(-dy)
-            pstep, dstep = bisect(X, dx, "p", STEP), bisect(S, ds, "d", STEP)
-            if EQUALSTEPS:
-                pstep = dstep = min(pstep, dstep)
+            if ETA is not None:                      # stay in the Omega-neighbourhood (solvers.py:1046-1054)
+                gam = linesearch_omega(X, dx, S, ds, ETA)
+                pstep = dstep = gam
+            else:
+                pstep, dstep = bisect(X, dx, "p", STEP), bisect(S, ds, "d", STEP)
+                if EQUALSTEPS:
+                    pstep = dstep = min(pstep, dstep)
             Xt = X + dx * pstep
             yt = y + dstep * dy
             St = S_of(yt)
-            if not PREDICTION:
+            if ETA is not None or not PREDICTION:
                 X, y, S = Xt, yt, St
             else:
                 gapt = dot(Xt, St)

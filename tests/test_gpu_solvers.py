@@ -259,3 +259,21 @@ def test_kktsolver_qr_on_device_matches_chol():
     assert abs(eq["primal objective"] - fc["primal objective"]) < 1e-5 * (1 + abs(fc["primal objective"]))
     assert abs(fq["iterations"] - fc["iterations"]) <= 1
     assert fq["primal infeasibility"] < 1e-8
+
+
+def test_omega_neighbourhood_linesearch_on_device():
+    """options['eta']: bisection on Omega(X, S) for the tangent step (solvers.py:662-689), on the device."""
+    from smcp_amd import base, solvers
+    P = base.band_SDP(60, 20, 3, seed=6)
+    saved = dict(solvers.options)
+    try:
+        solvers.options.update(show_progress=False)
+        ref = P.solve_feas()
+        solvers.options["eta"] = 5.0
+        sol = P.solve_feas()
+    finally:
+        solvers.options.clear()
+        solvers.options.update(saved)
+    assert sol["status"] == "optimal" and ref["status"] == "optimal"
+    assert abs(sol["primal objective"] - ref["primal objective"]) < 1e-5 * (1 + abs(ref["primal objective"]))
+    _certify(P, sol)

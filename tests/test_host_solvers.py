@@ -226,3 +226,18 @@ def test_kktsolver_qr_both_drivers():
     assert abs(fq["primal objective"] - fc["primal objective"]) < 1e-5 * (1 + abs(fc["primal objective"]))
     assert abs(eq["primal objective"] - fc["primal objective"]) < 1e-5 * (1 + abs(fc["primal objective"]))
     assert fq["iterations"] == fc["iterations"]
+
+
+def test_omega_neighbourhood_linesearch():
+    """options['eta'] (solvers.py:132-136, 662-689, 1046-1054): the tangent step is chosen by bisection on
+    Omega(X, S) instead of the two exact line searches; same optimum, and the option is validated as in the reference."""
+    P = base.band_SDP(40, 12, 2, seed=4)
+    with oracle_backend():
+        ref = P.solve_feas()
+        solvers.options["eta"] = 5.0
+        sol = P.solve_feas()
+        solvers.options["eta"] = 1
+        with pytest.raises(TypeError, match="positive float"):
+            P.solve_feas()
+    assert sol["status"] == "optimal" and ref["status"] == "optimal"
+    assert abs(sol["primal objective"] - ref["primal objective"]) < 1e-5 * (1 + abs(ref["primal objective"]))
