@@ -434,8 +434,10 @@ __global__ void __launch_bounds__(256) k_lf_up3(MfmaArgs a, double* u, int64_t l
   d4 acc[2][2];
   tile64_zero(acc);
   if (ymode) {
-    gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return yacc(Y, na, ymode, m, kk); },
-                [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB);
+    // ymode 2: R^T(m, k) = 0 for k < m; any other mode but 1 (symmetric Y_AA): R(m, k) = 0 for k > m
+    gemm_tile64(acc, na, nn, (ymode == 1 || ymode == 2) ? na : min(na, m0 + LT), m0, n0,
+                [=](int m, int kk) { return yacc(Y, na, ymode, m, kk); },
+                [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB, ymode == 2 ? m0 : 0);
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = v; });
   } else {
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = G[m + (int64_t)n * na]; });
