@@ -476,7 +476,9 @@ int kkt_qr_solve(csp_ctx* c, const double* L, const double* Y, double kk, double
   double* part = r1 + bl;
   double* xm = part + m * nchunk;
   double* r2 = xm + m;
-  if (!(D.yaa_tag == Y && D.yaa_tag)) prepare_yaa(c, Y, false, st);
+  // the half-Hessians below need chol(Y_AA), not only Y_AA (kkt_solve's full Hessian does with the latter): another
+  // factorisation between kkt_qr_factor and this call (a line-search completion, say) leaves the cache with its own
+  prepare_yaa(c, Y, true, st);
   prep_lk_cached(c, L, Y, st);
   HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
   hessian_impl(c, L, r1, 1, bl, 0, 0, st);                                   // r1 = G(bx)           (solvers.py:444-447)

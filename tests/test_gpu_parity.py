@@ -452,6 +452,10 @@ def test_kkt_qr_factor_and_solve(name):
     for kk in (1.0, 0.25):
         xr, yr = K.qr_solve(L, Yh, F, bx, by, kk)
         bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+        # another factorisation between factor and solve (what a line search does) must not disturb the closure: its
+        # half-Hessians need chol(Y_AA) of THIS Y, which the completion below replaces in the cache
+        other = dev(symb, Yh * (1.0 + 0.5 * kk))
+        chordal.completion(other)
         solve(bxd, byd, kk)
         assert rel(host(bxd)[msk], xr[msk]) < 1e-9
         assert rel(byd.cpu().numpy(), yr) < 1e-9

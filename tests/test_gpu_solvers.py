@@ -277,3 +277,18 @@ def test_omega_neighbourhood_linesearch_on_device():
     assert sol["status"] == "optimal" and ref["status"] == "optimal"
     assert abs(sol["primal objective"] - ref["primal objective"]) < 1e-5 * (1 + abs(ref["primal objective"]))
     _certify(P, sol)
+
+
+def test_ipm_golden_cases_on_device():
+    """The same six runs on the device: same optimum (the iterates differ in the last bits, so the step counts may
+    differ by one and the objectives by the stopping tolerance).  This test found kkt_qr_solve using a stale
+    chol(Y_AA) cache after a line-search completion (36 iterations against 34 before the fix)."""
+    from smcp_amd import solvers
+    import ipm_golden
+    saved = dict(solvers.options)
+    try:
+        solvers.options.update(show_progress=False, maxiters=100)
+        ipm_golden.check_all(iter_slack=1, obj_tol=2e-6, y_tol=2e-4)
+    finally:
+        solvers.options.clear()
+        solvers.options.update(saved)

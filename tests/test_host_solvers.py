@@ -241,3 +241,11 @@ def test_omega_neighbourhood_linesearch():
             P.solve_feas()
     assert sol["status"] == "optimal" and ref["status"] == "optimal"
     assert abs(sol["primal objective"] - ref["primal objective"]) < 1e-5 * (1 + abs(ref["primal objective"]))
+
+
+def test_ipm_golden_cases_over_the_oracle():
+    """The stored interior-point runs (tests/golden/ipm_cases.json, six seeded problems through both drivers, both
+    scalings, both KKT solvers) are reproduced by the drivers over the CPU oracle."""
+    import ipm_golden
+    with oracle_backend():
+        ipm_golden.check_all(iter_slack=0, obj_tol=1e-9, y_tol=1e-7)
