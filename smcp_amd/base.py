@@ -318,7 +318,8 @@ class pattern_SDP(SDP):
             raise ValueError("pattern_SDP needs a chordal pattern in a perfect elimination order")
 
         def posdef(sd):
-            X = cspmatrix(symb, torch.from_numpy(problems.random_factor_blkval(symb, sd)).cuda())
+            # (without a GPU the tensor stays on the host and chordal.llt fails loudly -- unless the tests' oracle backend serves it)
+            X = cspmatrix(symb, torch.from_numpy(problems.random_factor_blkval(symb, sd)).to("cuda" if torch.cuda.is_available() else "cpu"))
             chordal.llt(X)
             return sp.csc_matrix(X.spmatrix(reordered=False, symmetric=False))
 

@@ -24,17 +24,36 @@ CASES = [
     ("esd_primal", (30, 10, 2, 14), "esd", dict(scaling="primal")),
     ("esd_dual_qr", (36, 9, 3, 15), "esd", dict(scaling="dual", kktsolver="qr")),
     ("feas_lp_like", (25, 8, 0, 16), "feas_started", dict(scaling="dual")),  # bandwidth 0: every clique 1 x 1; known starts
+    # patterns with families of small fronts, fronts beyond the LDS class and a deep chain (amalgamated by default)
+    ("nested_feas_dual", ("nested", 8, 0.05, 21), "feas_started", dict(scaling="dual")),
+    ("arrow_feas_qr", ("arrow", 6, 0.05, 22), "feas_started", dict(scaling="primal", kktsolver="qr")),
+    ("chain_esd", (60, 12, 1, 23), "esd", dict(scaling="primal")),
+    ("mtxnorm_esd", ("mtxnorm", 6, 4, 24), "esd", dict(scaling="dual")),
 ]
 
 
+def build_problem(spec, base):
+    from smcp_amd import problems
+    if spec[0] == "nested":
+        pat = problems.nested_block_arrow_pattern(nsub=2, nmid=3, nleaf_per_mid=4, leaf=(3, 7), mid=(6, 20), top=(24, 40),
+                                                  root=70, seed=3)
+        return base.pattern_SDP(pat, spec[1], density=spec[2], seed=spec[3])
+    if spec[0] == "arrow":
+        return base.pattern_SDP(problems.block_arrow_pattern(5, 30, 80), spec[1], density=spec[2], seed=spec[3])
+    if spec[0] == "mtxnorm":
+        return base.mtxnorm_SDP(spec[1], spec[2], spec[1] + 2, seed=spec[3])
+    n, m, bw, seed = spec
+    return base.band_SDP(n, m, bw, seed=seed)
+
+
 def run_case(case, base, solvers):
-    name, (n, m, bw, seed), driver, kw = case
-    P = base.band_SDP(n, m, bw, seed=seed)
+    name, spec, driver, kw = case
+    P = build_problem(spec, base)
     if driver == "feas_started":
         import numpy as np
         import scipy.sparse as sp
-        kw = dict(kw, primalstart={"x": sp.csc_matrix(np.tril(P._X0))},
-                  dualstart={"y": P._y0, "s": sp.csc_matrix(np.tril(P._S0))})
+        low = lambda M: sp.csc_matrix(sp.tril(M)) if sp.issparse(M) else sp.csc_matrix(np.tril(M))
+        kw = dict(kw, primalstart={"x": low(P._X0)}, dualstart={"y": P._y0, "s": low(P._S0)})
     sol = (P.solve_esd if driver == "esd" else P.solve_feas)(**kw)
     return dict(name=name, status=sol["status"], iterations=int(sol["iterations"]),
                 pobj=float(sol["primal objective"]), dobj=float(sol["dual objective"]),

@@ -280,7 +280,7 @@ def test_omega_neighbourhood_linesearch_on_device():
 
 
 def test_ipm_golden_cases_on_device():
-    """The same six runs on the device: same optimum (the iterates differ in the last bits, so the step counts may
+    """The same ten runs on the device: same optimum (the iterates differ in the last bits, so the step counts may
     differ by one and the objectives by the stopping tolerance).  This test found kkt_qr_solve using a stale
     chol(Y_AA) cache after a line-search completion (36 iterations against 34 before the fix)."""
     from smcp_amd import solvers

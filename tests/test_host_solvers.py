@@ -244,7 +244,7 @@ def test_omega_neighbourhood_linesearch():
 
 
 def test_ipm_golden_cases_over_the_oracle():
-    """The stored interior-point runs (tests/golden/ipm_cases.json, six seeded problems through both drivers, both
+    """The stored interior-point runs (tests/golden/ipm_cases.json, ten seeded problems through both drivers, both
     scalings, both KKT solvers) are reproduced by the drivers over the CPU oracle."""
     import ipm_golden
     with oracle_backend():
