@@ -594,6 +594,9 @@ static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
   D.qr_valid = false;      // the stack is about to be rewritten
+  // the flag read after the sweeps must be theirs: a failed dense_potrf (Schur complement not positive definite) or
+  // kkt_qr_factor leaves its own behind
+  HIPCHK(zero_flag(c, st));
   prepare_yaa(c, Y, true, st);
   prep_lk_cached(c, L, Y, st);
   if (!D.kc_ptr) {   // the sweeps read their input from the stack: clear it and scatter the constraints into it
@@ -750,6 +753,7 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
   if (!m || ldh < m || j0 < 0 || j1 > m || j0 > j1) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   D.qr_valid = false;
+  HIPCHK(zero_flag(c, st));
   if (j0 == 0 && j1 == m && use_gram()) return schur_gram(c, L, Y, H, ldh, st);
   prepare_yaa(c, Y, false, st);
   if (!use_generic()) prep_lk_cached(c, L, Y, st);

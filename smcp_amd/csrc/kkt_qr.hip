@@ -384,7 +384,7 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
   int npass = npass_env ? npass_env : 2;
   double shift = 0.0;
   const int64_t range[2] = {0, bl};
-  for (int pass = 0; pass < npass; ++pass) {
+  for (int pass = 0; pass < npass && pass < 8; ++pass) {
     if (int rc = gram_accumulate(c, 1, range, G, m, st)) return rc;
     if (pass == 0) { if (int f = fetch_info(c, st)) return f; }     // chol(Y_AA) failure inside the sweeps
     if (pass > 0 && pass == npass - 1 && !npass_env && npass < 5) {
@@ -407,6 +407,9 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
       // two clean-up passes of shifted CholeskyQR3
       if (++tries > 8) return rc;
       shift = shift > 0.0 ? shift * 100.0 : 1e-15 * (double)m;
+      // a stack that still breaks down after several passes is rank deficient (more constraints than entries, exactly
+      // dependent constraints): report it like a failed Cholesky instead of shifting for ever
+      if (pass >= 4) return rc;
       if (!npass_env) npass = std::max(npass, pass + 3);
     }
     if (pass == 0 && shift_out) *shift_out = shift;

@@ -113,6 +113,8 @@ class _Problem:
             self.dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         else:
             self.dev = torch.device("cpu")   # storage only: every kernel call fails without a GPU
+        if m > symb.nnz:                              # solvers.py:351-352
+            raise ValueError("more constraints than nonzeros")
         colptr = A.indptr.astype(np.int64)
         pos = symb.index_map(I, J)
         vals = A.data.astype(np.float64)

@@ -551,3 +551,29 @@ def test_context_destroy_releases_device_memory():
         cycle()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < (32 << 20), (free0, free1)
+
+
+@pytest.mark.timeout(120)
+def test_kkt_qr_rank_deficient_stack_fails_instead_of_looping():
+    """More constraints than entries of V (20 diagonal constraints on 15 unknowns; the drivers reject such a problem
+    up front, solvers.py:351-352): the stack has rank 15, every pass breaks down again.  kkt_qr_factor must give up
+    with the failure code of a Cholesky breakdown (ArithmeticError in the shim) after a bounded number of shifted
+    passes -- it used to plan three more passes at every breakdown, for ever (found by scratch/fuzz_ipm.py)."""
+    symb, S, A, msk = setup("diag", 61)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    rng = np.random.default_rng(62)
+    m = 20
+    pos = np.flatnonzero(msk)
+    cptr = np.arange(m + 1) * len(pos)
+    cidx = np.tile(pos, m)
+    cval = rng.standard_normal(m * len(pos))
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=4, tnzcols=0.0)
+    with pytest.raises(ArithmeticError):
+        sys.factor_qr(dev(symb, L), dev(symb, Yh))
+    # the context stays usable
+    cptr2, cidx2, cval2 = problems.random_constraints(symb, 5, density=0.5, seed=63)
+    sys2 = KKTSystem(symb, cptr2, cidx2, cval2, max_rhs=4, tnzcols=0.0)
+    sys2.factor_qr(dev(symb, L), dev(symb, Yh))

@@ -249,3 +249,11 @@ def test_ipm_golden_cases_over_the_oracle():
     import ipm_golden
     with oracle_backend():
         ipm_golden.check_all(iter_slack=0, obj_tol=1e-9, y_tol=1e-7)
+
+
+def test_more_constraints_than_nonzeros_is_rejected():
+    """solvers.py:351-352: m > |V| raises before anything is factored (found by scratch/fuzz_ipm.py: such a problem
+    sent the QR factorisation of the rank-deficient stack into an endless sequence of shifted passes)."""
+    with oracle_backend():
+        with pytest.raises(ValueError, match="more constraints than nonzeros"):
+            base.band_SDP(11, 16, 0, seed=1).solve_feas()
