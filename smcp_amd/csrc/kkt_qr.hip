@@ -431,9 +431,11 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
       }
 #undef SMCP_TRSM_CASE
     } else {
-      static int nwv = -1, pv = -1;     // SMCP_QR_NW = 4 | 8 waves per workgroup, SMCP_QR_P = 1 | 2 | 4 positions per lane
-      if (nwv < 0) { const char* e = getenv("SMCP_QR_NW"); nwv = (e && e[0] == '8') ? 8 : 4; }
-      if (pv < 0) { const char* e = getenv("SMCP_QR_P"); pv = e ? atoi(e) : 1; }
+      // SMCP_QR_P=2: two positions per lane (halves the scalar loads per FMA; measured no faster).  Eight waves per
+      // workgroup and four positions per lane were measured too (1.75-2.4 ms per pass) and are not instantiated any more.
+      static int pv = -1;
+      const int nwv = 4;
+      if (pv < 0) { const char* e = getenv("SMCP_QR_P"); pv = (e && e[0] == '2') ? 2 : 1; }
       const int nbw = (int)((ldr / QR_JB + nwv - 1) / nwv);
       int P = pv;
       if (nbw * P > 10) P = nbw > 5 ? 1 : 2;        // register budget: 8 NBW P accumulators per lane
@@ -443,10 +445,6 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
         SMCP_TRSM_CASE(1, 1, 4) SMCP_TRSM_CASE(2, 1, 4) SMCP_TRSM_CASE(3, 1, 4) SMCP_TRSM_CASE(4, 1, 4) SMCP_TRSM_CASE(5, 1, 4)
         SMCP_TRSM_CASE(6, 1, 4) SMCP_TRSM_CASE(7, 1, 4) SMCP_TRSM_CASE(8, 1, 4) SMCP_TRSM_CASE(9, 1, 4) SMCP_TRSM_CASE(10, 1, 4)
         SMCP_TRSM_CASE(1, 2, 4) SMCP_TRSM_CASE(2, 2, 4) SMCP_TRSM_CASE(3, 2, 4) SMCP_TRSM_CASE(4, 2, 4) SMCP_TRSM_CASE(5, 2, 4)
-        SMCP_TRSM_CASE(1, 4, 4) SMCP_TRSM_CASE(2, 4, 4)
-        SMCP_TRSM_CASE(1, 1, 8) SMCP_TRSM_CASE(2, 1, 8) SMCP_TRSM_CASE(3, 1, 8) SMCP_TRSM_CASE(4, 1, 8) SMCP_TRSM_CASE(5, 1, 8)
-        SMCP_TRSM_CASE(1, 2, 8) SMCP_TRSM_CASE(2, 2, 8) SMCP_TRSM_CASE(3, 2, 8) SMCP_TRSM_CASE(4, 2, 8) SMCP_TRSM_CASE(5, 2, 8)
-        SMCP_TRSM_CASE(1, 4, 8) SMCP_TRSM_CASE(2, 4, 8)
         default: return SMCP_ENOMEM;
       }
 #undef SMCP_TRSM_CASE
