@@ -62,6 +62,27 @@ def lds_fits(nn, na):
     return d * 8 <= 160 * 1024 - 2048
 
 
+def self_launch(ngpus):
+    """python bench.py --gpus N without a launcher: N ranks through torch.distributed.run as a child process."""
+    import socket
+    import subprocess
+    import torch           # device_count() does not initialise the GPU on this image
+    ndev = torch.cuda.device_count()
+    if os.environ.get("SMCP_BENCH_BACKEND", "nccl") == "nccl" and ndev < ngpus:
+        print("bench.py: --gpus %d needs %d visible GPUs for one RCCL rank per GPU, found %d"
+              % (ngpus, ngpus, ndev), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +101,17 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # Not under a launcher: start the N ranks as fresh child processes (one per GPU, RCCL) BEFORE this process
+        # touches the GPU, relay rank 0's JSON line and exit with the launcher's code.  Nothing is exec'd.
+        raise SystemExit(self_launch(args.gpus))
+    if int(world_env or "1") != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s; launch with `python bench.py --gpus N` or "
+              "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world_env),
+              file=sys.stderr)
+        raise SystemExit(2)
 
     import torch
     import torch.distributed as dist
@@ -103,7 +135,6 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = _lib.lib()
 

@@ -63,7 +63,9 @@ int csp_index_map(const csp_ctx* ctx, int64_t cnt, const int64_t* I, const int64
 /* ---- device context ---------------------------------------------------------------- */
 
 /* Upload the index arrays to `device` and allocate the internal update-matrix workspace for
- * up to max_rhs simultaneous right-hand sides (>= 1).  Idempotent for the same arguments. */
+ * up to max_rhs simultaneous right-hand sides (>= 1).  Idempotent for the same arguments; a larger max_rhs
+ * grows the workspace.  One process drives ONE device: a different device for an initialised context, or for
+ * another context of the same process, returns SMCP_EINVAL (one rank per GPU is the multi-GPU model). */
 int csp_device_init(csp_ctx* ctx, int device, int64_t max_rhs);
 /* Bytes of HBM held by the context (index arrays + workspaces). */
 int64_t csp_device_bytes(const csp_ctx* ctx);

@@ -6,6 +6,8 @@ negative = diagonal block, b, then ``matno blkno i j val`` 1-based upper-triangu
 The reference draws random data from cvxopt's RNG; these generators use numpy ``default_rng``.
 """
 import math
+import os
+import re
 
 import numpy as np
 import scipy.sparse as sp
@@ -22,8 +24,78 @@ class SDP:
         self._pname = None
         self._X0 = self._y0 = self._S0 = None
         if filename is not None:
-            self._A, self._b, self._blockstruct = sdpa_read(filename)
-            self._pname = str(filename)
+            # extension dispatch of the reference (base.py:71-86): .dat-s[.bz2] -> SDPA sparse, .pkl[.bz2] -> pickle
+            filename = str(filename)
+            fp, ext = os.path.splitext(filename)
+            self._pname = fp.split("/")[-1]
+            if ext == ".dat-s":
+                self._read_sdpa(filename)
+            elif ext == ".pkl":
+                self._load(filename)
+            elif os.path.splitext(fp)[1] == ".dat-s":
+                self._pname = self._pname[:-6]
+                self._read_sdpa(filename)
+            elif os.path.splitext(fp)[1] == ".pkl":
+                self._pname = self._pname[:-4]
+                self._load(filename)
+            else:
+                raise NameError("Unknown file extension")
+
+    def __str__(self):
+        return "<SDP: n=%i, m=%i, nnz=%i> %s" % (self.n, self.m, self.nnz, self._pname)
+
+    def _read_sdpa(self, fname):
+        """SDPA sparse file -> (A, b, blockstruct), NEGATED as the reference does (base.py:177-194, neg=True):
+        an SDPA file states  max <F0,Y> s.t. <Fi,Y> = ci, so C = -F0, A_i = -F_i, b = -c."""
+        fp, ext = os.path.splitext(fname)
+        if ext == ".bz2":
+            import bz2
+            import tempfile
+            with open(fname, "rb") as fc, tempfile.NamedTemporaryFile("wb", suffix=".dat-s", delete=False) as fo:
+                fo.write(bz2.decompress(fc.read()))
+                tmp = fo.name
+            try:
+                self._A, self._b, self._blockstruct = sdpa_read(tmp, neg=True)
+            finally:
+                os.remove(tmp)
+        else:
+            self._A, self._b, self._blockstruct = sdpa_read(fname, neg=True)
+
+    def _load(self, fname):
+        """Load SDP data from a pickle written by save() (base.py:219-239; binary modes, which the reference's
+        text-mode open() breaks on Python 3)."""
+        import pickle
+        fp, ext = os.path.splitext(fname)
+        if ext == ".bz2":
+            import bz2
+            with open(fname, "rb") as f:
+                D = pickle.loads(bz2.decompress(f.read()))
+        elif ext == ".pkl":
+            with open(fname, "rb") as f:
+                D = pickle.load(f)
+        else:
+            raise IOError("unknown extension '%s' " % ext)
+        self._A, self._b = D["A"], D["b"]
+        self._X0, self._y0, self._S0 = D["X0"], D["y0"], D["S0"]
+        self._pname = D["pname"]
+        self._blockstruct = D.get("blockstruct")
+
+    def save(self, fname=None, compress=False):
+        """Save SDP data to a pickle file (base.py:241-270): fname + '.pkl' (or '.pkl.bz2')."""
+        import pickle
+        if fname is None:
+            fname = self._pname
+        fname += ".pkl.bz2" if compress else ".pkl"
+        if os.path.isfile(fname):
+            raise IOError("file %s already exists" % fname)
+        D = {"A": self._A, "b": self._b, "X0": self._X0, "y0": self._y0, "S0": self._S0, "pname": self._pname,
+             "blockstruct": self._blockstruct}
+        with open(fname, "wb") as f:
+            if compress:
+                import bz2
+                f.write(bz2.compress(pickle.dumps(D)))
+            else:
+                pickle.dump(D, f)
 
     # ---- properties (base.py:92-314) ---------------------------------------------------
     @property
@@ -160,8 +232,24 @@ class SDP:
         X = sp.csc_matrix(sol.pop("x"))[:n, :n] - s_ * eye
         return sp.csc_matrix(X), sol
 
-    def write_sdpa(self, filename):
-        sdpa_write(filename, self._A, self._b, self._blockstruct or [self.n])
+    def write_sdpa(self, fname=None, compress=False):
+        """Writes the problem to fname + '.dat-s' (base.py:196-217): negated data (neg=True, the inverse of what
+        SDP(filename) applies), refuses to overwrite, optional bz2 compression."""
+        if not self._blockstruct:
+            self._blockstruct = [self.n]
+        if fname is None:
+            fname = self._pname
+        fname = str(fname) + ".dat-s"
+        if os.path.isfile(fname):
+            raise IOError("file %s already exists" % fname)
+        if compress and os.path.isfile(fname + ".bz2"):
+            raise IOError("file %s already exists" % (fname + ".bz2"))
+        sdpa_write(fname, self._A, self._b, self._blockstruct, neg=True)
+        if compress:
+            import bz2
+            with open(fname, "rb") as fi, open(fname + ".bz2", "wb") as fo:
+                fo.write(bz2.compress(fi.read()))
+            os.remove(fname)
 
 
 def _band_entries(n, bw):
@@ -372,70 +460,106 @@ def maxcut_SDP(n=1000, nedges=5909, seed=0):
     return P
 
 
-# ---- SDPA sparse format (misc.c:139-365) ----------------------------------------------------
-def sdpa_readhead(filename):
-    """(n, m, blockstruct) from the header (misc.c:56-137)."""
+# ---- SDPA sparse format (misc.c:56-365) -----------------------------------------------------
+# A number as C's scanf("%d") / scanf("%lf") accepts it after the reference's skip of everything that is not a
+# digit or a sign (the "%*[^0-9+-]" directive at misc.c:94,176,185,205-209): SDPLIB headers such as "2 =mdim",
+# "{2, -2}" or "(1.0, 2.0)" parse because the text between the numbers is skipped, not tokenised.
+_SDPA_NUM = re.compile(r"[-+]?(?:\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?)")
+
+
+def _sdpa_numbers(filename):
+    """(m, iterator over the numbers after the line that holds m).  Leading comment lines start with '*' or '"'
+    (misc.c:76-82, 158-164); m is the first integer of the first other line, the rest of that line is dropped."""
     with open(filename) as f:
-        toks = _sdpa_tokens(f)
-        m = int(next(toks))
-        nb = int(next(toks))
-        bs = [int(float(next(toks))) for _ in range(nb)]
+        text = f.read()
+    pos = 0
+    m = None
+    while pos < len(text):
+        end = text.find("\n", pos)
+        end = len(text) if end < 0 else end
+        line = text[pos:end]
+        pos = end + 1
+        if line[:1] in ('*', '"'):
+            continue
+        mt = re.match(r"\s*([-+]?\d+)", line)
+        if mt is None:
+            raise ValueError("SDPA file %s: expected the number of constraints, got %r" % (filename, line[:40]))
+        m = int(mt.group(1))
+        break
+    if m is None:
+        raise ValueError("SDPA file %s: no header" % filename)
+    return m, (mt.group(0) for mt in _SDPA_NUM.finditer(text, pos))
+
+
+def _sdpa_int(tok):
+    return int(float(tok))
+
+
+def sdpa_readhead(filename):
+    """(n, m, blockstruct) from the header (misc.c:56-103)."""
+    m, toks = _sdpa_numbers(filename)
+    nb = _sdpa_int(next(toks))
+    bs = [_sdpa_int(next(toks)) for _ in range(nb)]
     return sum(abs(x) for x in bs), m, bs
 
 
-def _sdpa_tokens(f):
-    for line in f:
-        s = line.strip()
-        if not s or s[0] in '*"':
-            continue
-        for ch in "{}(),":
-            s = s.replace(ch, " ")
-        for t in s.split():
-            yield t
-
-
 def sdpa_read(filename, neg=False):
-    """Returns (A, b, blockstruct): A is n^2 x (m+1) CSC with columns vec(lower triangles); the
-    SDPA entry (i, j) of block k lands at row (off+j-1) + n*(off+i-1)... i.e. the lower-triangular
-    position of the symmetric entry (misc.c:205-237).  neg=True negates b and A (misc.c:192-193,223-224)."""
-    with open(filename) as f:
-        toks = _sdpa_tokens(f)
-        m = int(next(toks))
-        nb = int(next(toks))
-        bs = [int(float(next(toks))) for _ in range(nb)]
-        offs = np.concatenate([[0], np.cumsum([abs(x) for x in bs])])
+    """Returns (A, b, blockstruct): A is n^2 x (m+1) CSC with columns vec(lower triangles); the SDPA entry
+    ``matno blkno i j val`` (1-based, upper triangle of block blkno) lands at row (off+j-1) + n (off+i-1), the
+    lower-triangular position of the symmetric entry (misc.c:205-237; an entry given in the lower triangle is
+    mirrored instead of being stored above the diagonal).  A negative block size is a diagonal block of that
+    many rows (misc.c:177-178).  Explicit zeros are dropped (misc.c:216).  neg=True negates b and A
+    (misc.c:186-187, 223-224) -- what SDP(filename) asks for, base.py:189,194.  A truncated last record ends
+    the data as the reference's break at misc.c:205-209 does."""
+    m, toks = _sdpa_numbers(filename)
+    try:
+        nb = _sdpa_int(next(toks))
+        bs = [_sdpa_int(next(toks)) for _ in range(nb)]
+        offs = np.concatenate([[0], np.cumsum([abs(x) for x in bs])]).astype(np.int64)
         n = int(offs[-1])
         b = np.array([float(next(toks)) for _ in range(m)])
-        rows, cols, vals = [], [], []
-        rest = list(toks)
-    for q in range(0, len(rest) - 4, 5):
-        mat, blk, i, j, v = int(rest[q]), int(rest[q + 1]), int(rest[q + 2]), int(rest[q + 3]), float(rest[q + 4])
-        a, c = offs[blk - 1] + i - 1, offs[blk - 1] + j - 1
-        lo, hi = min(a, c), max(a, c)
-        rows.append(hi + n * lo)
-        cols.append(mat)
-        vals.append(v)
+    except StopIteration:
+        raise ValueError("SDPA file %s: truncated header" % filename)
+    rest = list(toks)
+    nrec = len(rest) // 5
+    rec = np.array([float(t) for t in rest[:5 * nrec]]).reshape(nrec, 5)
+    mat, blk = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
+    keep = rec[:, 4] != 0.0
+    if nrec and (mat.min() < 0 or mat.max() > m or blk.min() < 1 or blk.max() > len(bs)):
+        raise ValueError("SDPA file %s: matrix or block number out of range" % filename)
+    a = offs[blk - 1] + rec[:, 2].astype(np.int64) - 1
+    c = offs[blk - 1] + rec[:, 3].astype(np.int64) - 1
+    if nrec and (np.minimum(a, c).min() < 0 or (np.maximum(a, c) >= offs[blk]).any()):
+        raise ValueError("SDPA file %s: entry outside its block" % filename)
+    lo, hi = np.minimum(a, c)[keep], np.maximum(a, c)[keep]
     sgn = -1.0 if neg else 1.0
-    A = sp.csc_matrix((sgn * np.asarray(vals), (np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64))),
-                      shape=(n * n, m + 1))
+    A = sp.csc_matrix((sgn * rec[keep, 4], (hi + n * lo, mat[keep])), shape=(n * n, m + 1))
     return A, sgn * b, bs
 
 
 def sdpa_write(filename, A, b, blockstruct, neg=False):
-    """Write the problem in SDPA sparse format (the reference opens the file with mode "r",
-    misc.c:299 -- a bug this writer does not share)."""
+    """Write the problem in SDPA sparse format with the reference's header (misc.c:303-323; the reference opens
+    the file with mode "r", misc.c:299 -- a bug this writer does not share).  Zero entries are skipped
+    (misc.c:350); values with 17 significant digits so that a write/read round trip is exact."""
     A = sp.csc_matrix(A)
     n = int(round(math.sqrt(A.shape[0])))
     m = A.shape[1] - 1
     offs = np.concatenate([[0], np.cumsum([abs(x) for x in blockstruct])])
     sgn = -1.0 if neg else 1.0
     with open(filename, "w") as f:
-        f.write("%d\n%d\n%s\n" % (m, len(blockstruct), " ".join(str(x) for x in blockstruct)))
-        f.write(" ".join(repr(float(sgn * v)) for v in np.asarray(b).reshape(-1)) + "\n")
+        f.write("* sparse SDPA data file (created by smcp_amd)\n")
+        f.write("%d = m\n%d = nBlocks\n%s\n" % (m, len(blockstruct), " ".join(str(int(x)) for x in blockstruct)))
+        f.write(" ".join("%.17g" % float(sgn * v) for v in np.asarray(b).reshape(-1)) + "\n")
         for k in range(m + 1):
             col = A[:, k].tocoo()
             order = np.argsort(col.row, kind="stable")
             for r, v in zip(col.row[order], col.data[order]):
+                if v == 0.0:
+                    continue
                 i, j = r % n, r // n            # i >= j (lower); SDPA wants upper: (j, i)
+                if j > i:
+                    i, j = j, i
                 blk = int(np.searchsorted(offs, j, side="right"))
-                f.write("%d %d %d %d %r\n" % (k, blk, j - offs[blk - 1] + 1, i - offs[blk - 1] + 1, float(sgn * v)))
+                if i >= offs[blk]:
+                    raise ValueError("sdpa_write: entry (%d, %d) lies outside the diagonal blocks" % (i, j))
+                f.write("%d %d %d %d %.17g\n" % (k, blk, j - offs[blk - 1] + 1, i - offs[blk - 1] + 1, float(sgn * v)))

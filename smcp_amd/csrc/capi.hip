@@ -66,12 +66,29 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
   "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small"};
 
+// A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
+// record the first failure in the context and every entry point ends with end_call(), which returns it.
+inline void note_launch(csp_ctx* c, int kid) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess && !c->launch_err) {
+    c->launch_err = (int)e;
+    fprintf(stderr, "smcp_amd: launch of %s failed: %s\n", (kid >= 0 && kid < KID_COUNT) ? KID_NAMES[kid] : "?", hipGetErrorString(e));
+  }
+}
+inline hipError_t end_call(csp_ctx* c) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && c->launch_err) e = c->launch_err > 0 ? (hipError_t)c->launch_err : hipErrorLaunchFailure;
+  c->launch_err = 0;
+  return e;
+}
+
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
   Profiler& P = c->prof;
   const bool timed = P.want(kid);
   if (timed) (void)hipEventRecord(P.next(), st);
   hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
+  note_launch(c, kid);
   if (timed) {
     (void)hipEventRecord(P.next(), st);
     P.kids.push_back(kid);
@@ -83,6 +100,7 @@ inline void launch(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, hipStream
   const bool timed = P.want(kid);
   if (timed) (void)hipEventRecord(P.next(), st);
   hipLaunchKernelGGL(kern, grid, block, 0, st, args...);
+  note_launch(c, kid);
   if (timed) {
     (void)hipEventRecord(P.next(), st);
     P.kids.push_back(kid);
@@ -135,6 +153,7 @@ int ready(csp_ctx* c) {
 
 // read back the device failure flag (synchronises the stream)
 int fetch_info(csp_ctx* c, hipStream_t st) {
+  if (c->launch_err) { c->launch_err = 0; return SMCP_EHIP; }
   if (c->nowait) return 0;      // probe launch: the caller collects the flags of all slots later (csp_probe_results)
   HIPCHK(hipMemcpyAsync(c->D.info_host, c->D.info, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -521,7 +540,12 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         if (a.level > 0) {
           MfmaArgs af = a;
           af.t.lev = a.t.lev + (cnt - nS);
-          if (!try_fam(c, af, nS, nrhs, U, ldu, st)) fprintf(stderr, "smcp_amd: family kernel launch failed\n");
+          if (!try_fam(c, af, nS, nrhs, U, ldu, st)) {
+            // the level-0 members were skipped for this kernel: without it their panels and the parents' updates
+            // would be missing, so the call must fail (end_call returns SMCP_EHIP)
+            fprintf(stderr, "smcp_amd: family kernel not launchable (LDS budget or attribute)\n");
+            if (!c->launch_err) c->launch_err = -1;
+          }
         }
         cnt -= nS;
         if (cnt == 0) return;
@@ -952,6 +976,13 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
   DeviceCtx& D = c->D;
   const Symbolic& S = c->S;
   if (D.device == device && D.max_rhs >= max_rhs) return 0;
+  // One process drives one GPU (one rank per GPU under torch.distributed): the launch helpers cache function
+  // attributes, occupancy and the CU count per process, and a context's buffers live on the device it was
+  // first initialised on.  A second device -- for this context or for another one of this process -- is refused.
+  static int bound_device = -1;
+  if (D.device >= 0 && D.device != device) return SMCP_EINVAL;
+  if (bound_device >= 0 && bound_device != device) return SMCP_EINVAL;
+  bound_device = device;
   HIPCHK(hipSetDevice(device));
   if (D.device < 0) {
     std::vector<CliqueDesc> cl(S.nsn);
@@ -1135,7 +1166,7 @@ int csp_cholesky(csp_ctx* c, double* x, void* stream) {
     a.lev = lev;
     launch(c, KID_chol_level, k_chol_level, dim3(cnt), dim3(NT), st, a, x);
   });
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return fetch_info(c, st);
 }
 
@@ -1165,7 +1196,7 @@ int csp_llt(csp_ctx* c, double* x, void* stream) {
     a.lev = lev;
     launch(c, KID_llt_level, k_llt_level, dim3(cnt), dim3(NT), st, a, x);
   });
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 
@@ -1190,7 +1221,7 @@ int csp_projected_inverse(csp_ctx* c, double* x, void* stream) {
     a.lev = lev;
     launch(c, KID_pinv_level, k_pinv_level, dim3(cnt), dim3(NT), st, a, x);
   });
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 
@@ -1242,7 +1273,7 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
     gather_all(c, x, 0, 1, c->D.upd, st);
     launch(c, KID_completion_all, k_completion_all, dim3((int)c->S.nsn), dim3(NT), st, a, x);
   }
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return fetch_info(c, st);
 }
 
@@ -1261,7 +1292,7 @@ int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t
     int64_t nr = std::min(c->D.max_rhs, nrhs - r0);
     hessian_impl(c, L, U + r0 * ldu, nr, ldu, adj, inv, st);
   }
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   if (refactor) {
     int rc = fetch_info(c, st);
     if (rc) c->D.fac_tag = c->D.faci_tag = nullptr;
@@ -1287,7 +1318,7 @@ int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, 
       launch(c, KID_trsm_bwd_level, k_trsm_bwd_level, dim3(cnt, (unsigned)((nrhs + TRSM_CB - 1) / TRSM_CB)), dim3(NT), st, a, L, B, (int)nrhs, ldb, c->D.rowidx);
     });
   }
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 
@@ -1300,7 +1331,7 @@ static int reduce_impl(csp_ctx* c, const double* X, const double* Y, int mode, d
     launch(c, KID_reduce_cliques, k_reduce_cliques, dim3(nb), dim3(NT), st, c->D.cl, (int)c->S.nsn, X, Y, mode, c->D.red);
   }
   launch(c, KID_reduce_final, k_reduce_final, dim3(1), dim3(NT), st, c->D.red, nb, c->D.red + 512);
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   double* h = (double*)(c->D.info_host + 2);
   HIPCHK(hipMemcpyAsync(h, c->D.red + 512, sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

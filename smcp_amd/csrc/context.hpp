@@ -185,6 +185,7 @@ struct csp_ctx {
   std::vector<int> lev_namax;   // per level: largest separator (sizes the gather launches)
   std::vector<int64_t> fam;     // per clique: family role (CSP_Q_FAMILY)
   std::vector<uint8_t> is_diag_cache;
+  int launch_err = 0;                   // first failed kernel launch of the running call (launch helpers); read by end_call
   bool nowait = false;                  // csp_probe_launch: factorisations return without reading the failure flag back
   double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)
   std::vector<int64_t> h_kptr;          // ns + 1 : offsets into kidx, host copy for chunk planning

@@ -466,7 +466,7 @@ int kkt_amap(csp_ctx* c, const double* X, double* y, void* stream) {
   if (int rc = ready(c)) return rc;
   if (!c->D.m) return SMCP_EINVAL;
   amap_impl(c, X, 0, 1, y, 0, (hipStream_t)stream);
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 
@@ -474,7 +474,7 @@ int kkt_aadj(csp_ctx* c, const double* y, double* X, void* stream) {
   if (int rc = ready(c)) return rc;
   if (!c->D.m) return SMCP_EINVAL;
   if (int rc = aadj_impl(c, y, X, (hipStream_t)stream)) return rc;
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 
@@ -487,7 +487,7 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
   if (oldp < 0) { const char* e = getenv("SMCP_POTRF_OLD"); oldp = (e && e[0] == '1') ? 1 : 0; }
   if (oldp) {
     launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
-    HIPCHK(hipGetLastError());
+    HIPCHK(end_call(c));
     return fetch_info(c, st);
   }
   if (!use_generic() && n <= 2 * LB) {
@@ -533,7 +533,7 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
       }
     }
   }
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   int rc = fetch_info(c, st);
   if (!rc && !use_generic()) { c->D.hinv_tag = A; c->D.hinv_n = n; }
   return rc;
@@ -577,7 +577,7 @@ int dense_potrs(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, 
                 void* stream) {
   if (int rc = ready(c)) return rc;
   if (int rc = potrs_impl(c, A, n, lda, B, nrhs, ldb, (hipStream_t)stream)) return rc;
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 
@@ -605,7 +605,7 @@ static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_
       launch(c, KID_scatter_constraints, k_scatter_constraints, dim3(8, (unsigned)std::min<int64_t>(65535, m - jb)),
              dim3(256), st, jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
   }
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 // H = sum over the given blkval ranges of G^T W G (ranges: host array of nranges (begin, end) pairs)
@@ -675,7 +675,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     coff += nc;
   }
   launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 
@@ -740,7 +740,7 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
            (const int64_t*)dvoff, (const int32_t*)D.s_rloc, (const int32_t*)D.s_cloc, (const double*)D.vbuf, n, H, ldh);
     q0 = q1;
   }
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   if (md) { if (int f = fetch_info(c, st)) return f; }
   return 0;
 }
@@ -766,7 +766,7 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
     // H[:, jb+r] = Amap(W(A_{jb+r}))  (full column; H is symmetric)
     amap_impl(c, D.ustack, bl, nr, H + jb * ldh, ldh, st);
   }
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 
@@ -801,7 +801,7 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 1.0, (const double*)r1, -1.0, bx);  // bx = Aadj(y) - bx
   hessian_impl(c, L, bx, 1, bl, 2, 0, st);
   launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 0.0, (const double*)nullptr, 1.0 / kk, bx);
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 
@@ -833,7 +833,7 @@ int kkt_gram_sweep(csp_ctx* c, int set, int64_t j0, int64_t j1, void* stream) {
   if (set && !c->sets[set].lev2) return SMCP_EINVAL;
   const int64_t bl = c->S.blklen();
   hess_up_fast(c, D.ustack + j0 * bl, (int)(j1 - j0), bl, D.fac, 2, (hipStream_t)stream, set, D.kc_ptr ? j0 : -1);
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 int kkt_gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, void* stream) {

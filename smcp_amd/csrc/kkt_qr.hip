@@ -457,7 +457,7 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
       HIPCHK(hipMemcpyAsync(Lc, S2, sizeof(double) * m * m, hipMemcpyDeviceToDevice, st));
     }
   }
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   if (passes_out) *passes_out = npass;
   D.qr_valid = true;
   D.qr_L = L; D.qr_Y = Y;
@@ -499,7 +499,7 @@ int kkt_qr_solve(csp_ctx* c, const double* L, const double* Y, double kk, double
          (const double*)D.ustack, bl, bl, (int)m, (const double*)xm, (const double*)r1, bx);                // Q x - r1    (457-458)
   hessian_impl(c, L, bx, 1, bl, 1, 0, st);                                                                  // G^T         (461)
   launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 0.0, (const double*)nullptr, 1.0 / kk, bx);
-  HIPCHK(hipGetLastError());
+  HIPCHK(end_call(c));
   return 0;
 }
 

@@ -4,6 +4,7 @@ Python-side mirror of the closures at src/python/solvers.py:369-386 and 477-541;
 arithmetic is done by the C-ABI entry points ``kkt_*`` (include/smcp_amd.h).
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -128,28 +129,50 @@ class KKTSystem(ShardedSchur):
             if not torch.cuda.is_available():
                 raise RuntimeError("smcp_amd needs an MI355X (HIP) device; there is no CPU fallback")
             symb.device_init(torch.cuda.current_device(), max_rhs)
-        cptr = np.ascontiguousarray(cptr, dtype=np.int64)
-        cidx = np.ascontiguousarray(cidx, dtype=np.int64)
-        cval = np.ascontiguousarray(cval, dtype=np.float64)
-        if tnzcols is not None:
-            _chk(_lib.lib().kkt_set_tnzcols(symb.handle, float(tnzcols)), "kkt_set_tnzcols")
-        _chk(_lib.lib().kkt_set_constraints(symb.handle, self.m, cptr.ctypes.data, cidx.ctypes.data,
-                                            cval.ctypes.data), "kkt_set_constraints")
+        self._con = (np.ascontiguousarray(cptr, dtype=np.int64), np.ascontiguousarray(cidx, dtype=np.int64),
+                     np.ascontiguousarray(cval, dtype=np.float64))
+        self._tnzcols = 0.1 if tnzcols is None else float(tnzcols)      # the reference's default (solvers.py:31)
         self.dev = torch.device("cuda", symb._device)
         self.H = torch.zeros((self.m, self.m), dtype=torch.float64, device=self.dev)
+        self._install()
+
+    # The constraint set (entry lists, classification, the swept stack / Q of kkt_qr) lives in the Symbolic's native
+    # context, ONE set per context.  Each KKTSystem keeps its own host copy and re-installs it when another system
+    # built on the same Symbolic has taken the context over, so two systems never run on each other's constraints;
+    # state that cannot be re-created (the Q factor of factor_qr) is refused once the context has changed hands.
+    def _install(self):
+        lib = _lib.lib()
+        cptr, cidx, cval = self._con
+        _chk(lib.kkt_set_tnzcols(self.symb.handle, self._tnzcols), "kkt_set_tnzcols")
+        _chk(lib.kkt_set_constraints(self.symb.handle, self.m, cptr.ctypes.data, cidx.ctypes.data, cval.ctypes.data),
+             "kkt_set_constraints")
+        d = self.symb.__dict__
+        d["_kkt_epoch"] = d.get("_kkt_epoch", 0) + 1
+        d["_kkt_owner"] = weakref.ref(self)
+        self._epoch = d["_kkt_epoch"]
+
+    def _own(self):
+        o = self.symb.__dict__.get("_kkt_owner")
+        if o is None or o() is not self:
+            self._install()
+            if self.partition is not None and getattr(self, "_part_rank", None) is not None:
+                self._apply_partition(self.partition, self._part_rank)
 
     def amap(self, X):
+        self._own()
         y = torch.empty(self.m, dtype=torch.float64, device=self.dev)
         _chk(_lib.lib().kkt_amap(self.symb.handle, X.blkval.data_ptr(), y.data_ptr(), _stream()), "kkt_amap")
         return y
 
     def aadj(self, y):
+        self._own()
         X = cspmatrix(self.symb, torch.empty(self.symb.blklen, dtype=torch.float64, device=self.dev))
         X.touched()
         _chk(_lib.lib().kkt_aadj(self.symb.handle, y.data_ptr(), X.blkval.data_ptr(), _stream()), "kkt_aadj")
         return X
 
     def _columns(self, L, Y, j0, j1):
+        self._own()
         sync_cache(self.symb, L, Y)
         _chk(_lib.lib().kkt_schur_columns(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(),
                                           self.H.data_ptr(), self.m, int(j0), int(j1), _stream()), "kkt_schur_columns")
@@ -159,6 +182,7 @@ class KKTSystem(ShardedSchur):
 
     # ---- subtree-sharded Gram path (C-ABI: csp_set_partition, kkt_gram_*, csp_exchange_copy)
     def _apply_partition(self, P, rank):
+        self._part_rank = int(rank)
         owner = np.ascontiguousarray(P.owner, dtype=np.int32)
         _chk(_lib.lib().csp_set_partition(self.symb.handle, owner.ctypes.data, int(rank)), "csp_set_partition")
 
@@ -166,6 +190,7 @@ class KKTSystem(ShardedSchur):
         return int(self.symb._max_rhs)
 
     def _gram_prepare(self, L, Y):
+        self._own()
         sync_cache(self.symb, L, Y)
         _chk(_lib.lib().kkt_gram_prepare(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), _stream()),
              "kkt_gram_prepare")
@@ -200,6 +225,7 @@ class KKTSystem(ShardedSchur):
 
         def solve_(bx, by, kk):
             """Overwrites bx (cspmatrix) with x and by (device vector) with y."""
+            self._own()
             sync_cache(self.symb, L, Y)
             bx.touched()
             _chk(_lib.lib().kkt_solve(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(),
@@ -217,15 +243,20 @@ class KKTSystem(ShardedSchur):
             import torch.distributed as dist
             if dist.is_initialized() and dist.get_world_size(group) > 1:
                 raise NotImplementedError("kktsolver='qr' runs on one GPU (the Q factor is not sharded)")
+        self._own()
         sync_cache(self.symb, L, Y)
         passes = ctypes.c_int64(0)
         shift = ctypes.c_double(0.0)
         _chk(_lib.lib().kkt_qr_factor(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), ctypes.addressof(passes),
                                       ctypes.addressof(shift), _stream()), "kkt_qr_factor")
         self.qr_passes, self.qr_shift = passes.value, shift.value
+        epoch = self.symb.__dict__["_kkt_epoch"]
 
         def solve_(bx, by, kk):
             """Overwrites bx (cspmatrix) with x and by (device vector) with y."""
+            if self.symb.__dict__.get("_kkt_epoch") != epoch:
+                raise RuntimeError("the Q factor of this kkt_qr factorisation is gone: another KKTSystem has used "
+                                   "the same Symbolic since factor_qr; factor again")
             sync_cache(self.symb, L, Y)
             bx.touched()
             _chk(_lib.lib().kkt_qr_solve(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), float(kk),

@@ -1059,27 +1059,58 @@ def lp(c, G, h, kktsolver="chol"):
     return conelp(c, G, h, {"l": G.shape[0], "q": [], "s": []}, kktsolver=kktsolver)
 
 
+def _split_cone_parts(sol, Nl, sizes, tail_z, tail_s, square):
+    """Replaces sol['z'] / sol['s'] by the per-cone pieces the reference's socp / sdp return
+    (solvers.py:2626-2648, 2672-2697): 'zl', 'sl' (None without a linear part) and one entry per cone."""
+    z, s_ = sol.pop("z"), sol.pop("s")
+    if Nl:
+        sol["zl"] = None if z is None else z[:Nl]
+        sol["sl"] = None if s_ is None else s_[:Nl]
+    else:
+        sol["zl"] = sol["sl"] = None
+    N = Nl
+    zs, ss = [], []
+    for ns in sizes:
+        ln = ns * ns if square else ns
+        for v, out in ((z, zs), (s_, ss)):
+            if v is None:
+                out.append(None)
+            else:
+                u = v[N:N + ln]
+                out.append(u.reshape((ns, ns), order="F") if square else u)
+        N += ln
+    sol[tail_z], sol[tail_s] = zs, ss
+    return sol
+
+
 def socp(c, Gl=None, hl=None, Gq=None, hq=None, kktsolver="chol"):
-    """Second-order cone program front end (solvers.py:2608-2650; the reference's dims['l'].append bug,
-    SURVEY App. C, is not reproduced)."""
+    """Second-order cone program front end (solvers.py:2608-2650): returns 'x', 'zl', 'sl' and the lists 'zq', 'sq'
+    in place of 'z', 's'.  The reference's dims['l'].append on an int is not reproduced."""
+    if Gq is None or hq is None:
+        raise ValueError("'Gq' and 'hq' cannot be zero")
     Gs, hs, dims = [], [], {"l": 0, "q": [], "s": []}
-    if Gl is not None:
+    if Gl is not None and hl is not None:
         Gl = sp.csc_matrix(Gl)
         Gs.append(Gl); hs.append(np.asarray(hl, dtype=np.float64).reshape(-1)); dims["l"] = Gl.shape[0]
-    for Gk, hk in zip(Gq or [], hq or []):
+    for Gk, hk in zip(Gq, hq):
         Gk = sp.csc_matrix(Gk)
         Gs.append(Gk); hs.append(np.asarray(hk, dtype=np.float64).reshape(-1)); dims["q"].append(Gk.shape[0])
-    return conelp(c, sp.vstack(Gs), np.concatenate(hs), dims, kktsolver=kktsolver)
+    sol = conelp(c, sp.vstack(Gs), np.concatenate(hs), dims, kktsolver=kktsolver)
+    return _split_cone_parts(sol, dims["l"], dims["q"], "zq", "sq", square=False)
 
 
 def sdp(c, Gl=None, hl=None, Gs=None, hs=None, kktsolver="chol"):
-    """SDP front end: Gs[k] has ns^2 rows (column-major vec), hs[k] is ns x ns (solvers.py:2651-2699)."""
+    """SDP front end: Gs[k] has ns^2 rows (column-major vec), hs[k] is ns x ns (solvers.py:2651-2699); returns 'x',
+    'zl', 'sl' and the lists 'zs', 'ss' of ns x ns matrices in place of 'z', 's'."""
+    if Gs is None or hs is None:
+        raise ValueError("'Gs' and 'hs' cannot be zero")
     Gall, hall, dims = [], [], {"l": 0, "q": [], "s": []}
-    if Gl is not None:
+    if Gl is not None and hl is not None:
         Gl = sp.csc_matrix(Gl)
         Gall.append(Gl); hall.append(np.asarray(hl, dtype=np.float64).reshape(-1)); dims["l"] = Gl.shape[0]
-    for Gk, hk in zip(Gs or [], hs or []):
+    for Gk, hk in zip(Gs, hs):
         Gk = sp.csc_matrix(Gk)
         ns = int(round(math.sqrt(Gk.shape[0])))
         Gall.append(Gk); hall.append(np.asarray(hk, dtype=np.float64).reshape(-1, order="F")); dims["s"].append(ns)
-    return conelp(c, sp.vstack(Gall), np.concatenate(hall), dims, kktsolver=kktsolver)
+    sol = conelp(c, sp.vstack(Gall), np.concatenate(hall), dims, kktsolver=kktsolver)
+    return _split_cone_parts(sol, dims["l"], dims["s"], "zs", "ss", square=True)

@@ -19,7 +19,9 @@ TOL = 1e-10
 
 
 def rel(a, b):
-    return np.linalg.norm(a - b) / max(1.0, np.linalg.norm(b))
+    """relative error in the 2-norm (absolute only when the expected output is exactly zero)"""
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / nb if nb > 0 else np.linalg.norm(a)
 
 
 def dev(symb, x):
@@ -134,7 +136,7 @@ def test_hessian(name, adj, inv):
     assert rel(host(one)[msk], ref[0][msk]) < 1e-9
 
 
-@pytest.mark.parametrize("name", ["band", "arrow", "rand2", "nested"])
+@pytest.mark.parametrize("name", ["band", "arrow", "rand2", "nested", "arrow_big", "dense200", "arrow_thin", "nested_mid", "diag"])
 def test_trsm(name):
     symb, S, A, msk = setup(name, 5)
     rng = np.random.default_rng(6)
@@ -183,6 +185,41 @@ def test_kkt_factor_and_solve(name):
         r, rr = K.residual(L, Yh, host(bxd) * msk, byd.cpu().numpy(), bx, by, kk)
         assert np.sqrt(orc.dot(S, r, r)) / max(1, np.sqrt(orc.dot(S, bx, bx))) < 1e-10
         assert np.linalg.norm(rr) / max(1, np.linalg.norm(by)) < 1e-10
+
+
+def test_two_kkt_systems_on_one_symbolic_do_not_share_constraints():
+    """The constraint set lives in the Symbolic's native context; a KKTSystem re-installs its own set when another
+    system has used the context in between (the first system silently ran on the second one's constraints).
+    The Q factor of kkt_qr cannot be re-created and is refused instead."""
+    symb, S, A, msk = setup("nested_mid", 21)
+    rng = np.random.default_rng(22)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    cons = [problems.random_constraints(symb, m, density=0.05, seed=sd) for m, sd in ((5, 23), (8, 24))]
+    Ks = [orc.KKT(S, *c) for c in cons]
+    Hs = [K.schur_factor(L, Yh) for K in Ks]
+    sys0 = KKTSystem(symb, *cons[0], max_rhs=4)
+    solve0 = sys0.factor(Ld, Yd)
+    sys1 = KKTSystem(symb, *cons[1], max_rhs=4)            # takes the context over
+    solve1 = sys1.factor(Ld, Yd)
+    x = rng.standard_normal(symb.blklen) * msk
+    for sy, K, H, solve in ((sys0, Ks[0], Hs[0], solve0), (sys1, Ks[1], Hs[1], solve1), (sys0, Ks[0], Hs[0], solve0)):
+        assert rel(sy.amap(dev(symb, x)).cpu().numpy(), K.amap(x)) < TOL
+        y = rng.standard_normal(sy.m)
+        assert rel(host(sy.aadj(torch.from_numpy(y).cuda()))[msk], K.aadj(y)[msk]) < TOL
+        bx, by = rng.standard_normal(symb.blklen) * msk, rng.standard_normal(sy.m)
+        xr, yr = K.solve(L, Yh, H, bx, by, 1.0)
+        bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+        solve(bxd, byd, 1.0)
+        assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+    q0 = KKTSystem(symb, *cons[0], max_rhs=4, tnzcols=0.0)
+    qsolve = q0.factor_qr(Ld, Yd)
+    sys1.amap(dev(symb, x))                                # another system uses the context: Q is gone
+    with pytest.raises(RuntimeError, match="factor again"):
+        qsolve(dev(symb, x), torch.zeros(q0.m, dtype=torch.float64, device="cuda"), 1.0)
 
 
 @pytest.mark.parametrize("n", [5, 64, 130, 517])

@@ -129,18 +129,6 @@ def test_lp_against_scipy():
     assert abs(c @ sol["x"] - ref.fun) < 1e-5 * (1 + abs(ref.fun))
 
 
-def test_sdpa_roundtrip(tmp_path):
-    from smcp_amd import base
-    P = base.band_SDP(12, 4, 2, seed=3)
-    fn = tmp_path / "p.dat-s"
-    P.write_sdpa(str(fn))
-    Q = base.SDP(str(fn))
-    assert Q.n == P.n and Q.m == P.m
-    assert abs(sp.csc_matrix(Q.A) - sp.csc_matrix(P.A)).max() < 1e-14
-    assert np.allclose(Q.b, P.b)
-    assert base.sdpa_readhead(str(fn)) == (12, 4, [12])
-
-
 def test_maxcut_config4_shape():
     """BASELINE config 4 at test size: max-cut SDP on a random non-chordal graph (n = 300, 900 edges; the
     full G51-sized instance n = 1000 / 5909 edges runs in scratch/maxcut.py: optimal in 31 iterations).
@@ -292,3 +280,15 @@ def test_ipm_golden_cases_on_device():
     finally:
         solvers.options.clear()
         solvers.options.update(saved)
+
+
+def test_socp_and_sdp_front_ends_on_device():
+    """solvers.socp / solvers.sdp (solvers.py:2608-2699) return the reference's split keys; same cases and
+    independent checks as the CPU suite (tests/test_host_solvers.py), here on the HIP path."""
+    from smcp_amd import solvers
+    from tests import test_host_solvers as th
+    solvers.options.update(show_progress=False, maxiters=100)
+    case = th._socp_case()
+    th.check_socp_solution(solvers.socp(*case), *case)
+    case = th._sdp_case()
+    th.check_sdp_solution(solvers.sdp(*case), *case)

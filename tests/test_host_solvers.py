@@ -257,3 +257,73 @@ def test_more_constraints_than_nonzeros_is_rejected():
     with oracle_backend():
         with pytest.raises(ValueError, match="more constraints than nonzeros"):
             base.band_SDP(11, 16, 0, seed=1).solve_feas()
+
+
+def _socp_case():
+    """minimize c'x  s.t.  ||x||_2 <= 1,  x_0 >= -0.3:  cone rows s = h - Gx with s = (1, x) in the second-order cone."""
+    c = np.array([1.0, -2.0, 0.5])
+    Gl, hl = np.array([[-1.0, 0.0, 0.0]]), np.array([0.3])
+    Gq = [np.vstack([np.zeros((1, 3)), -np.eye(3)])]
+    hq = [np.array([1.0, 0.0, 0.0, 0.0])]
+    return c, Gl, hl, Gq, hq
+
+
+def check_socp_solution(sol, c, Gl, hl, Gq, hq):
+    from scipy.optimize import minimize
+    ref = minimize(lambda x: c @ x, np.zeros(3), jac=lambda x: c, method="SLSQP",
+                   constraints=[{"type": "ineq", "fun": lambda x: 1.0 - x @ x},
+                                {"type": "ineq", "fun": lambda x: x[0] + 0.3}], options={"ftol": 1e-12})
+    assert sol["status"] == "optimal"
+    assert "s" not in sol and "z" not in sol                       # solvers.py:2646-2647
+    x = sol["x"]
+    assert abs(c @ x - ref.fun) < 1e-5 and np.allclose(x, ref.x, atol=1e-4)
+    assert sol["sl"].shape == (1,) and sol["zl"].shape == (1,)
+    assert len(sol["sq"]) == 1 and len(sol["zq"]) == 1 and sol["sq"][0].shape == (4,)
+    assert np.allclose(sol["sl"], hl - Gl @ x, atol=1e-6)
+    assert np.allclose(sol["sq"][0], hq[0] - Gq[0] @ x, atol=1e-6)
+    zq, zl = sol["zq"][0], sol["zl"]
+    assert zq[0] >= np.linalg.norm(zq[1:]) - 1e-7 and zl[0] >= -1e-7
+    assert np.allclose(Gl.T @ zl + Gq[0].T @ zq + c, 0.0, atol=1e-6)      # dual feasibility G'z + c = 0
+
+
+def test_socp_front_end_returns_reference_keys():
+    """solvers.socp (solvers.py:2608-2650): 'zl','sl','zq','sq' instead of 'z','s'; checked against SLSQP."""
+    case = _socp_case()
+    with oracle_backend():
+        sol = solvers.socp(*case)
+        with pytest.raises(ValueError, match="'Gq' and 'hq' cannot be zero"):
+            solvers.socp(case[0], case[1], case[2])
+    check_socp_solution(sol, *case)
+
+
+def _sdp_case():
+    """maximize t  s.t.  M - t I >= 0, t <= 10:  optimum lambda_min(M)."""
+    M = np.array([[4.0, 1.0, 0.0], [1.0, 3.0, -1.0], [0.0, -1.0, 2.0]])
+    c = np.array([-1.0])
+    Gl, hl = np.array([[1.0]]), np.array([10.0])
+    Gs, hs = [np.eye(3).reshape(-1, 1)], [M]
+    return c, Gl, hl, Gs, hs
+
+
+def check_sdp_solution(sol, c, Gl, hl, Gs, hs):
+    assert sol["status"] == "optimal"
+    assert "s" not in sol and "z" not in sol                       # solvers.py:2695-2696
+    lam = np.linalg.eigvalsh(hs[0]).min()
+    t = sol["x"][0]
+    assert abs(t - lam) < 1e-5
+    ss, zs = sol["ss"][0], sol["zs"][0]
+    assert ss.shape == (3, 3) and zs.shape == (3, 3)
+    assert np.allclose(ss, hs[0] - t * np.eye(3), atol=1e-5)
+    assert np.linalg.eigvalsh(zs).min() > -1e-7 and abs(np.trace(zs) + sol["zl"][0] - 1.0) < 1e-6
+    assert abs(np.sum(zs * ss)) < 1e-4
+    assert abs(sol["sl"][0] - (10.0 - t)) < 1e-5
+
+
+def test_sdp_front_end_returns_reference_keys():
+    """solvers.sdp (solvers.py:2651-2699): 'zl','sl' and ns x ns 'zs','ss' instead of 'z','s'."""
+    case = _sdp_case()
+    with oracle_backend():
+        sol = solvers.sdp(*case)
+        with pytest.raises(ValueError, match="'Gs' and 'hs' cannot be zero"):
+            solvers.sdp(case[0], case[1], case[2])
+    check_sdp_solution(sol, *case)
