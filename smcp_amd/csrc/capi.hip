@@ -17,6 +17,7 @@
 #include "front_inv.hip"
 #include "front_n16.hip"
 #include "front_fam.hip"
+#include "front_fam2.hip"
 
 using namespace smcp;
 
@@ -46,7 +47,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -64,7 +65,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -229,7 +230,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.dn = 0; a.dld = 0;
   a.kc_ptr = nullptr; a.kc_off = nullptr; a.kc_val = nullptr; a.kc_ids = nullptr;
   a.kc_stride = 0; a.kc_j0 = 0;
-  a.level = 0; a.nS = 0; a.famna = a.fampan = a.fampk = a.famcna = 0;
+  a.level = 0; a.nS = 0; a.famna = a.fampan = a.fampk = a.famcna = a.famnn = a.famcnn = 0;
   return a;
 }
 
@@ -251,7 +252,7 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f, int set = 0) {
     a.panmax = L.panmaxI;
     a.pkmax = L.pkmaxI;
     a.plansum = L.plansumI;
-    a.level = (int)l; a.nS = (int)L.nS; a.famna = L.famna; a.fampan = L.fampan; a.fampk = L.fampk; a.famcna = L.famcna;
+    a.level = (int)l; a.nS = (int)L.nS; a.famna = L.famna; a.fampan = L.fampan; a.fampk = L.fampk; a.famcna = L.famcna; a.famnn = L.famnn; a.famcnn = L.famcnn;
     size_t lds = (size_t)mfma_lds_doubles(L.nnmaxI, L.namaxI) * sizeof(double);
     f(true, a, (int)L.nI, lds, lds > 48 * 1024 ? 512 : 256);
   }
@@ -506,7 +507,77 @@ bool try_fam_sp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int
   }
   return false;
 }
+// sparse-input family kernel (front_fam2.hip): R^T scaling (the Gram sweeps), entry lists short on average, the
+// children's constants within the LDS budget; false = not applicable (the caller falls back to k_hess_up_fam)
+template <int NAT, int KSN>
+bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  const int cnn = std::max(1, a.famcnn), csa = 16 * std::max(1, (a.famcna + 15) / 16);
+  const int64_t lim = (160 * 1024 - 1024) / 8;                          // doubles of LDS a workgroup may use
+  const int64_t fixed = fam2_layout<NAT>(cnn, csa).oTab;
+  if (fixed + fam2_tail_doubles(4, 9) + 64 > lim) return false;          // room for a table of four passes at least
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k_fam_sparse<NAT, KSN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)k_fam2_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    attr = true;
+  }
+  const int64_t need = (int64_t)cnt * fam2_const_doubles(cnn, csa);
+  if (D.famc_len < need) {
+    if (D.famc) { if (hipFree(D.famc) != hipSuccess) return false; D.bytes -= D.famc_len * 8; }
+    D.famc = nullptr; D.famc_len = 0;
+    if (dev_alloc(&D.famc, need, D.bytes)) return false;
+    D.famc_len = need;
+  }
+  static int ncu = 0;
+  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  // one workgroup per CU (LDS), two right-hand sides in flight per workgroup: split the right-hand sides so that the
+  // grid fills whole rounds; set-up ~ 4 passes
+  int g = 1;
+  int64_t best = -1;
+  for (int gc = 1; gc <= std::min(nrhs, 32); ++gc) {
+    const int64_t rounds = ((int64_t)cnt * gc + ncu - 1) / ncu;
+    const int64_t passes = (nrhs + gc - 1) / gc;
+    const int64_t cost = rounds * ((passes + 1) / 2 + 4);
+    if (best < 0 || cost < best) { best = cost; g = gc; }
+  }
+  // entry table: all the passes of a workgroup if the LDS left over allows (one double per (pass, member) pair, 1.5 per
+  // staged entry, sized for twice the average list length), otherwise epochs of fewer passes
+  // entry table: all the passes of a workgroup if the LDS left over allows (one double per (pass, member) pair, two per
+  // staged entry, sized for 1.5 x the average list length), otherwise epochs of fewer passes
+  const int passes = (nrhs + g - 1) / g;
+  const double avg = 9.0 * (double)D.cnnz / ((double)c->S.nsn * (double)std::max<int64_t>(1, D.m));   // entries per (family, rhs)
+  int tabpasses = std::min(passes, 113);
+  while (tabpasses > 4 && fixed + fam2_tail_doubles(tabpasses, 9) + (int64_t)(1.5 * avg * tabpasses) + 8 > lim) tabpasses = (tabpasses + 1) / 2;
+  const int64_t left = lim - fixed - fam2_tail_doubles(tabpasses, 9) - 4;
+  const int ecap = (int)std::max<int64_t>(0, (left * 2) / 3 - 2);
+  if (9 * D.kc_maxlist > ecap) return false;      // the entries of one pass must fit the staging area (the kernel sizes its epochs itself)
+  launch_lds(c, KID_fam2_prep, k_fam2_prep, dim3(cnt), dim3(512), (size_t)8 * fam2_child_layout(cnn, csa).cstride * sizeof(double), st,
+             a, D.famc, cnn, csa);
+  MfmaArgs a2 = a;
+  { static int stag = -1; if (stag < 0) { const char* e = getenv("SMCP_FAM2_STAG"); stag = e ? atoi(e) : 0; } a2.dn = stag; }
+  launch_lds(c, KID_hess_up_fam, k_fam_sparse<NAT, KSN>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a2, U, ldu,
+             (const double*)D.famc, cnn, csa, (const int32_t*)D.kc_ij, tabpasses, ecap);
+  return true;
+}
+bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("SMCP_FAM2"); off = (e && e[0] == '0') ? 1 : 0; }
+  if (off || !a.kc_ptr || !c->D.kc_ij || a.ymode != 2 || !a.ysc) return false;
+  // short lists only: the children's sweep costs O(entries) here, the dense MFMA sweep of k_hess_up_fam does not
+  if (c->D.cnnz > (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m)) return false;
+  const int nat = std::max(1, (a.famna + 15) / 16);
+  const bool k2 = a.famnn <= 8;
+  switch (nat) {
+    case 1: return k2 ? launch_fam2<1, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<1, 4>(c, a, cnt, nrhs, U, ldu, st);
+    case 2: return k2 ? launch_fam2<2, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<2, 4>(c, a, cnt, nrhs, U, ldu, st);
+    case 3: return k2 ? launch_fam2<3, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<3, 4>(c, a, cnt, nrhs, U, ldu, st);
+    case 4: return k2 ? launch_fam2<4, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<4, 4>(c, a, cnt, nrhs, U, ldu, st);
+  }
+  return false;
+}
 bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  if (try_fam2(c, a, cnt, nrhs, U, ldu, st)) return true;
   return a.kc_ptr ? try_fam_sp<true>(c, a, cnt, nrhs, U, ldu, st) : try_fam_sp<false>(c, a, cnt, nrhs, U, ldu, st);
 }
 
@@ -818,21 +889,24 @@ void classify_levels(const Symbolic& S, Keep keep, std::vector<LevelClass>& lvl,
   if (!fam_off())
     for (int64_t l = 1; l < S.nlev; ++l) {
       std::vector<int64_t> cand;
-      int famna = 0, fampan = 0, fampk = 0, famcna = 0;
+      int famna = 0, fampan = 0, fampk = 0, famcna = 0, famnn = 0, famcnn = 0;
       for (int64_t q = S.levptr[l]; q < S.levptr[l + 1]; ++q) {
         const int64_t k = S.levidx[q];
         if (!keep(k) || !small(k) || S.nn(k) > 16 || S.na(k) > 64) continue;
         const int64_t nch = S.chptr[k + 1] - S.chptr[k];
         if (nch < 1 || nch > 8) continue;
         bool ok = true;
-        int cna = 0;
+        int cna = 0, cnn = 0;
         for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1] && ok; ++q2) {
           const int64_t ch = S.chidx[q2];
           ok = keep(ch) && S.chptr[ch + 1] == S.chptr[ch] && small(ch) && S.nn(ch) <= 16 && S.na(ch) <= 32 && S.na(ch) >= 1;
           cna = std::max<int>(cna, (int)S.na(ch));
+          cnn = std::max<int>(cnn, (int)S.nn(ch));
         }
         if (!ok) continue;
         cand.push_back(k);
+        famnn = std::max<int>(famnn, (int)S.nn(k));
+        famcnn = std::max(famcnn, cnn);
         famna = std::max<int>(famna, (int)S.na(k));
         fampan = std::max<int>(fampan, (int)(S.nf(k) * S.nn(k)));
         fampk = std::max<int>(fampk, (int)(S.na(k) * (S.na(k) + 1) / 2));
@@ -840,7 +914,7 @@ void classify_levels(const Symbolic& S, Keep keep, std::vector<LevelClass>& lvl,
       }
       if (cand.empty() || fam_bytes_for(famna, famcna, fampan, fampk) > LDS_LIMIT) continue;
       LevelClass& L = lvl[l];
-      L.famna = famna; L.fampan = fampan; L.fampk = fampk; L.famcna = famcna;
+      L.famna = famna; L.fampan = fampan; L.fampk = fampk; L.famcna = famcna; L.famnn = famnn; L.famcnn = famcnn;
       for (int64_t k : cand) {
         special[k] = 1;
         for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) special[S.chidx[q2]] = 1;
@@ -902,7 +976,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
     hipSetDevice(D.device);
     void* ptrs[] = {D.p_yaa, D.p_fac, D.p_faci, D.p_lfd, D.p_info, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
-                    D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv};
+                    D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int set = 1; set <= 2; ++set) if (c->sets[set].lev2) hipFree(c->sets[set].lev2);
     if (D.info_host) hipHostFree(D.info_host);

@@ -92,6 +92,10 @@ struct DeviceCtx {
   int32_t* kc_ptr = nullptr; // nsn * (m + 1) : clique k, constraint j -> first entry
   int32_t* kc_off = nullptr; // cnnz : position inside the clique's panel
   double* kc_val = nullptr;  // cnnz
+  int32_t* kc_ij = nullptr;  // cnnz : the same position as (row | column << 16) of the clique's panel (k_fam_sparse)
+  double* famc = nullptr;    // children's constants of the family parents of one sweep call, in LDS layout (k_fam2_prep)
+  int64_t famc_len = 0;
+  int64_t kc_maxlist = 0;    // longest entry list of a (clique, constraint) pair among possible family members
   double* vbuf = nullptr;    // n x vcols : S^-1[:, K_s] of the chunk in flight
   int64_t vcols = 0;
   double* hd = nullptr;      // md x md Gram block of the dense constraints (when ns > 0)
@@ -162,6 +166,7 @@ struct LevelClass {
   // k_hess_up_fam; every other operation treats the LDS class as one list.
   int64_t nS = 0;
   int famna = 0, fampan = 0, fampk = 0, famcna = 0;   // sizing over the family parents / their children
+  int famnn = 0, famcnn = 0;                          // widest supernode among the parents / among the children
 };
 }  // namespace smcp
 

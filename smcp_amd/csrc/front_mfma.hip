@@ -96,7 +96,7 @@ struct MfmaArgs {
   const int32_t* kc_ptr; const int32_t* kc_off; const double* kc_val; const int32_t* kc_ids;
   int kc_stride, kc_j0;
   // host-side only (level loop of hess_up_fast): level index and the family tail of the LDS class (LevelClass::nS ...)
-  int level, nS, famna, fampan, fampk, famcna;
+  int level, nS, famna, fampan, fampk, famcna, famnn, famcnn;
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }

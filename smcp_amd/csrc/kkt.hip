@@ -301,13 +301,13 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   const Symbolic& S = c->S;
   HIPCHK(hipSetDevice(D.device));
   void* old[] = {D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack,
-                 D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val};
+                 D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.kc_ij};
   for (void* p : old) if (p) hipFree(p);
   D.cptr = nullptr; D.cidx = nullptr; D.cval = nullptr; D.cwval = nullptr; D.rpos = nullptr;
   D.rptr = nullptr; D.rcon = nullptr; D.rval = nullptr; D.ustack = nullptr;
   D.a_r = D.a_c = D.s_rloc = D.s_cloc = D.dlist = D.slist = D.kidx = nullptr;
   D.vbuf = D.hd = nullptr;
-  D.kc_ptr = D.kc_off = nullptr; D.kc_val = nullptr;
+  D.kc_ptr = D.kc_off = nullptr; D.kc_val = nullptr; D.kc_ij = nullptr;
   D.md = D.ns = D.vcols = 0;
   if (D.qr_ws) { hipFree(D.qr_ws); D.bytes -= D.qr_len * 8; D.qr_ws = nullptr; D.qr_len = 0; }
   D.qr_valid = false;
@@ -429,6 +429,13 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
         }
       }
     }
+    D.kc_maxlist = 0;             // over the cliques that can be members of a family (nn <= 16, na <= 64)
+    for (int64_t k = 0; k < S.nsn; ++k)
+      if (S.nn(k) <= 16 && S.na(k) <= 64)
+        for (int64_t j = 0; j < m; ++j) {
+          const size_t q = (size_t)k * (m + 1) + j;
+          D.kc_maxlist = std::max<int64_t>(D.kc_maxlist, kptr[q + 1] - kptr[q]);
+        }
     std::vector<int32_t> fill(kptr.begin(), kptr.end() - 1);
     for (int64_t j = 0; j < m; ++j)
       for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
@@ -437,6 +444,18 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
         kval[q] = cval[e];
       }
     kptr.pop_back();
+    // the same positions as (row | column << 16) of the clique's panel, for k_fam_sparse (its members have < 2^16 rows)
+    std::vector<int32_t> kij(nnz);
+    {
+      std::vector<int32_t> fill2(kptr.begin(), kptr.end());
+      for (int64_t j = 0; j < m; ++j)
+        for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+          const int64_t nf = S.nf(ek[e]);
+          const int32_t q = fill2[(size_t)ek[e] * (m + 1) + j]++;
+          kij[q] = (int32_t)((eoff[e] % nf) & 0xffff) | (int32_t)((eoff[e] / nf) << 16);
+        }
+    }
+    if ((rc = dev_upload(&D.kc_ij, kij, D.bytes))) return rc;
     if ((rc = dev_upload(&D.kc_ptr, kptr, D.bytes))) return rc;
     if ((rc = dev_upload(&D.kc_off, koff, D.bytes))) return rc;
     if ((rc = dev_upload(&D.kc_val, kval, D.bytes))) return rc;
