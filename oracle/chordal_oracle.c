@@ -52,8 +52,39 @@ typedef struct {
 
 /* ------------------------------------------------------------------ dense helpers */
 
+/* Optional host BLAS / LAPACK for the per-clique dense operations (what CHOMPACK calls through CVXOPT [EXT]):
+ * oracle.use_blas() hands over the Fortran-interface entry points of the OpenBLAS that scipy bundles
+ * (scipy.linalg.cython_blas / cython_lapack).  Used for blocks with a dimension >= blas_min only; the plain loops
+ * below remain the default and the parity checker (tests/test_oracle_identities.py runs both). */
+typedef void (*dgemm_f)(char *, char *, int *, int *, int *, double *, double *, int *, double *, int *, double *, double *, int *);
+typedef void (*dtrsm_f)(char *, char *, char *, char *, int *, int *, double *, double *, int *, double *, int *);
+typedef void (*dtrmm_f)(char *, char *, char *, char *, int *, int *, double *, double *, int *, double *, int *);
+typedef void (*dsyrk_f)(char *, char *, int *, int *, double *, double *, int *, double *, double *, int *);
+typedef void (*dpotrf_f)(char *, int *, double *, int *, int *);
+static struct { dgemm_f gemm; dtrsm_f trsm; dtrmm_f trmm; dsyrk_f syrk; dpotrf_f potrf; int min; } blas = {0, 0, 0, 0, 0, 32};
+void orc_set_blas(void *gemm_, void *trsm_, void *trmm_, void *syrk_, void *potrf_, int min_dim) {
+  blas.gemm = (dgemm_f)gemm_; blas.trsm = (dtrsm_f)trsm_; blas.trmm = (dtrmm_f)trmm_;
+  blas.syrk = (dsyrk_f)syrk_; blas.potrf = (dpotrf_f)potrf_; blas.min = min_dim > 0 ? min_dim : 32;
+}
+int orc_blas_enabled(void) { return blas.gemm != 0; }
+static int use_blas(int64_t a, int64_t b) { return blas.gemm && (a >= blas.min || b >= blas.min) && a > 0 && b > 0; }
+static void blas_tr(int mm, dtrsm_f f, char side, char trans, int64_t m, int64_t n, const double *L, int64_t ldl,
+                    double *B, int64_t ldb) {
+  char uplo = 'L', diag = 'N';
+  int m_ = (int)m, n_ = (int)n, ldl_ = (int)ldl, ldb_ = (int)ldb;
+  double one = 1.0;
+  (void)mm;
+  f(&side, &uplo, &trans, &diag, &m_, &n_, &one, (double *)L, &ldl_, B, &ldb_);
+}
+
 /* in-place lower Cholesky; returns 0 or j+1 of the failing pivot */
 static int potrf_l(int64_t n, double *A, int64_t lda) {
+  if (blas.potrf && n >= blas.min) {
+    char uplo = 'L';
+    int n_ = (int)n, lda_ = (int)lda, info = 0;
+    blas.potrf(&uplo, &n_, A, &lda_, &info);
+    return info > 0 ? info : 0;
+  }
   for (int64_t j = 0; j < n; ++j) {
     double d = A[j + j * lda];
     if (!(d > 0.0)) return (int)(j + 1);
@@ -70,6 +101,7 @@ static int potrf_l(int64_t n, double *A, int64_t lda) {
 }
 /* B (m x n) <- L^-1 B, L m x m lower */
 static void trsm_llN(int64_t m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+  if (use_blas(m, n)) { blas_tr(0, blas.trsm, 'L', 'N', m, n, L, ldl, B, ldb); return; }
   for (int64_t c = 0; c < n; ++c) {
     double *b = B + c * ldb;
     for (int64_t j = 0; j < m; ++j) {
@@ -81,6 +113,7 @@ static void trsm_llN(int64_t m, int64_t n, const double *L, int64_t ldl, double 
 }
 /* B (m x n) <- L^-T B */
 static void trsm_llT(int64_t m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+  if (use_blas(m, n)) { blas_tr(0, blas.trsm, 'L', 'T', m, n, L, ldl, B, ldb); return; }
   for (int64_t c = 0; c < n; ++c) {
     double *b = B + c * ldb;
     for (int64_t j = m - 1; j >= 0; --j) {
@@ -92,6 +125,7 @@ static void trsm_llT(int64_t m, int64_t n, const double *L, int64_t ldl, double 
 }
 /* B (m x n) <- B L^-T, L n x n lower:  X L^T = B  => column j of X depends on columns < j */
 static void trsm_rlT(int64_t m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+  if (use_blas(m, n)) { blas_tr(0, blas.trsm, 'R', 'T', m, n, L, ldl, B, ldb); return; }
   for (int64_t j = 0; j < n; ++j) {
     double *bj = B + j * ldb;
     for (int64_t k = 0; k < j; ++k) {
@@ -105,6 +139,7 @@ static void trsm_rlT(int64_t m, int64_t n, const double *L, int64_t ldl, double 
 }
 /* B (m x n) <- B L^-1:  X L = B => column j of X depends on columns > j */
 static void trsm_rlN(int64_t m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+  if (use_blas(m, n)) { blas_tr(0, blas.trsm, 'R', 'N', m, n, L, ldl, B, ldb); return; }
   for (int64_t j = n - 1; j >= 0; --j) {
     double *bj = B + j * ldb;
     for (int64_t k = j + 1; k < n; ++k) {
@@ -118,6 +153,7 @@ static void trsm_rlN(int64_t m, int64_t n, const double *L, int64_t ldl, double 
 }
 /* B (m x n) <- B L^T : new col j = sum_{k<=j} B[:,k] L[j,k]; go j descending to stay in place */
 static void trmm_rlT(int64_t m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+  if (use_blas(m, n)) { blas_tr(0, (dtrsm_f)blas.trmm, 'R', 'T', m, n, L, ldl, B, ldb); return; }
   for (int64_t j = n - 1; j >= 0; --j) {
     double *bj = B + j * ldb;
     double d = L[j + j * ldl];
@@ -131,6 +167,7 @@ static void trmm_rlT(int64_t m, int64_t n, const double *L, int64_t ldl, double 
 }
 /* B (m x n) <- B L : new col j = sum_{k>=j} B[:,k] L[k,j]; go j ascending */
 static void trmm_rlN(int64_t m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+  if (use_blas(m, n)) { blas_tr(0, (dtrsm_f)blas.trmm, 'R', 'N', m, n, L, ldl, B, ldb); return; }
   for (int64_t j = 0; j < n; ++j) {
     double *bj = B + j * ldb;
     double d = L[j + j * ldl];
@@ -144,6 +181,7 @@ static void trmm_rlN(int64_t m, int64_t n, const double *L, int64_t ldl, double 
 }
 /* B (m x n) <- L B, L m x m lower (left, notrans): rows descending in place */
 static void trmm_llN(int64_t m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+  if (use_blas(m, n)) { blas_tr(0, (dtrsm_f)blas.trmm, 'L', 'N', m, n, L, ldl, B, ldb); return; }
   for (int64_t c = 0; c < n; ++c) {
     double *b = B + c * ldb;
     for (int64_t i = m - 1; i >= 0; --i) {
@@ -155,6 +193,7 @@ static void trmm_llN(int64_t m, int64_t n, const double *L, int64_t ldl, double 
 }
 /* B (m x n) <- L^T B */
 static void trmm_llT(int64_t m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+  if (use_blas(m, n)) { blas_tr(0, (dtrsm_f)blas.trmm, 'L', 'T', m, n, L, ldl, B, ldb); return; }
   for (int64_t c = 0; c < n; ++c) {
     double *b = B + c * ldb;
     for (int64_t i = 0; i < m; ++i) {
@@ -167,6 +206,12 @@ static void trmm_llT(int64_t m, int64_t n, const double *L, int64_t ldl, double 
 /* C (m x n) = beta C + alpha op(A) op(B); ta/tb: 0 = as is, 1 = transposed. k = inner dim */
 static void gemm(int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                  int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc) {
+  if (blas.gemm && m > 0 && n > 0 && k > 0 && (m >= blas.min || n >= blas.min || k >= blas.min)) {
+    char ta_ = ta ? 'T' : 'N', tb_ = tb ? 'T' : 'N';
+    int m_ = (int)m, n_ = (int)n, k_ = (int)k, lda_ = (int)lda, ldb_ = (int)ldb, ldc_ = (int)ldc;
+    blas.gemm(&ta_, &tb_, &m_, &n_, &k_, &alpha, (double *)A, &lda_, (double *)B, &ldb_, &beta, C, &ldc_);
+    return;
+  }
   for (int64_t j = 0; j < n; ++j) {
     double *c = C + j * ldc;
     if (beta == 0.0) for (int64_t i = 0; i < m; ++i) c[i] = 0.0;
@@ -253,6 +298,12 @@ int orc_cholesky(const orc_sym *s, double *x, double *upd) {
     if (potrf_l(nn, P, nf)) return (int)(k + 1);
     if (na) {
       trsm_rlT(na, nn, P, nf, P + nn, nf);
+      if (blas.syrk && (na >= blas.min || nn >= blas.min)) {
+        char uplo = 'L', tr = 'N';
+        int na_ = (int)na, nn_ = (int)nn, nf_ = (int)nf;
+        double mone = -1.0, one = 1.0;
+        blas.syrk(&uplo, &tr, &na_, &nn_, &mone, P + nn, &nf_, &one, Uk, &na_);
+      } else
       for (int64_t j = 0; j < na; ++j)
         for (int64_t p = 0; p < nn; ++p) {
           double b = P[nn + j + p * nf];

@@ -60,6 +60,9 @@ def lib():
         L.orc_hess_g_masked.argtypes = [S, P, P, P, P, P]
         L.orc_schur_columns.restype = ctypes.c_int
         L.orc_schur_columns.argtypes = [S, P, P, ctypes.c_int64, P, P, P, P, ctypes.c_int64, ctypes.c_int64, P, ctypes.c_int, P]
+        L.orc_set_blas.restype = None
+        L.orc_set_blas.argtypes = [P, P, P, P, P, ctypes.c_int]
+        L.orc_blas_enabled.restype = ctypes.c_int
         L.orc_scmcolumn2.restype = None
         L.orc_scmcolumn2.argtypes = [ctypes.c_int64, ctypes.c_int64, P, P, P, P, P, P, P, ctypes.c_int64]
         _lib = L
@@ -68,6 +71,42 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def use_blas(on=True, min_dim=32):
+    """Route the per-clique dense operations with a dimension >= min_dim through the host BLAS / LAPACK that scipy
+    bundles (OpenBLAS; Fortran-interface entry points from scipy.linalg.cython_blas / cython_lapack), one BLAS thread
+    (the independent Schur columns are what is spread over OpenMP threads).  Returns a description of the library, or
+    None when switched off / unavailable.  The plain loops stay the default: they are the parity checker."""
+    L = lib()
+    if not on:
+        L.orc_set_blas(None, None, None, None, None, int(min_dim))
+        return None
+    try:
+        from scipy.linalg import cython_blas, cython_lapack
+    except Exception:
+        return None
+    ctypes.pythonapi.PyCapsule_GetName.restype = ctypes.c_char_p
+    ctypes.pythonapi.PyCapsule_GetName.argtypes = [ctypes.py_object]
+    ctypes.pythonapi.PyCapsule_GetPointer.restype = ctypes.c_void_p
+    ctypes.pythonapi.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+
+    def fptr(mod, name):
+        cap = mod.__pyx_capi__[name]
+        return ctypes.pythonapi.PyCapsule_GetPointer(cap, ctypes.pythonapi.PyCapsule_GetName(cap))
+
+    L.orc_set_blas(fptr(cython_blas, "dgemm"), fptr(cython_blas, "dtrsm"), fptr(cython_blas, "dtrmm"),
+                   fptr(cython_blas, "dsyrk"), fptr(cython_lapack, "dpotrf"), int(min_dim))
+    desc = "scipy-bundled BLAS"
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        threadpool_limits(1, user_api="blas")
+        for info in threadpool_info():
+            if info.get("user_api") == "blas":
+                desc = "%s %s (1 BLAS thread)" % (info.get("internal_api", "blas"), info.get("version", ""))
+    except Exception:
+        pass
+    return desc
 
 
 class Sym:

@@ -151,6 +151,35 @@ def test_maxcut_config4_shape():
     assert abs(np.sum(Cd * X) - sol["y"].sum()) < 1e-5 * (1 + abs(sol["y"].sum()))
 
 
+def test_maxcut_config4_full_size_through_sdpa_file(tmp_path):
+    """BASELINE config 4 at full size: max-cut relaxation on a random 1000-node / 5909-edge graph (the size of SDPLIB's
+    maxG51; the file itself cannot be obtained offline), m = 1000 column-sparse constraints, non-chordal pattern embedded
+    by the library's own minimum-degree ordering.  The problem takes the route a real SDPLIB file would: written in SDPA
+    sparse format, read back through SDP(filename) (N1), solved by the feasible-start driver with dual scaling.  Dense
+    dual certificate: S = C - Diag(y) is positive semidefinite and b'y equals the primal objective; diag(X) = 1."""
+    from smcp_amd import base, solvers
+    solvers.options.update(show_progress=False, maxiters=80)
+    n = 1000
+    P0 = base.maxcut_SDP(n, 5909, seed=0)
+    P0.write_sdpa(str(tmp_path / "maxcut_g51like"))
+    P = base.SDP(str(tmp_path / "maxcut_g51like.dat-s"))
+    assert (P.n, P.m) == (n, n) and not P.ischordal
+    assert abs(sp.csc_matrix(P.A) - sp.csc_matrix(P0.A)).max() == 0 and np.array_equal(P.b, P0.b)
+    C = P.get_A(0)
+    y0 = -np.ones(n) * (abs(C).sum(axis=1).max() + 1.0)
+    sol = P.solve_feas(scaling="dual", dualstart={"y": y0})
+    assert sol["status"] == "optimal"
+    Cd = np.asarray(C.todense())
+    y = np.asarray(sol["y"]).reshape(-1)
+    Sd = Cd - np.diag(y)
+    assert np.linalg.eigvalsh(Sd).min() > -1e-6 * (1 + np.abs(Cd).max())          # dual feasible
+    X = sol["x"]
+    assert np.allclose(X.diagonal(), 1.0, atol=1e-6)                              # primal feasible on the constraints
+    pobj = float(C.multiply(X).sum())
+    assert abs(pobj - y.sum()) < 1e-5 * (1 + abs(pobj))                            # zero duality gap
+    assert max(abs(sol["dimacs"][0]), abs(sol["dimacs"][2])) < 1e-5
+
+
 def test_phase1_finds_strictly_feasible_point():
     """Row N3: SDP.solve_phase1 (base.py:370-470, misc.phase1_sdp): when the least-norm solution of the
     equality constraints is not positive definite, the Phase-I SDP solved by the feasible-start driver must

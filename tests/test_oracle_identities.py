@@ -16,6 +16,18 @@ TOL = 1e-10
 NAMES = sorted(PATTERNS)
 
 
+@pytest.fixture(autouse=True, params=["loops", "blas"])
+def _dense_backend(request):
+    """Every identity runs twice: on the plain loops (the parity checker) and with the per-clique dense operations
+    routed through the host BLAS / LAPACK (the cpu_baseline path of bench.py), here from dimension 2 on so that the
+    small test patterns exercise every BLAS call."""
+    if request.param == "blas":
+        if orc.use_blas(True, min_dim=2) is None:
+            pytest.skip("no host BLAS available through scipy")
+    yield
+    orc.use_blas(False)
+
+
 def rel(a, b):
     return np.linalg.norm(a - b) / max(1.0, np.linalg.norm(b))
 
