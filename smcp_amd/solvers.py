@@ -439,6 +439,8 @@ def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", 
         relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
         pinfres = math.sqrt(max(dot(hrx, hrx), 0.0)) / resx0 / by if by > 0.0 else None
         dinfres = _nrm2(hry) / resy0 / (-cx) if cx < 0.0 else None
+        if isinstance(options.get("trace"), list):       # per-iteration record for tests (not in the reference)
+            options["trace"].append((it, pcost, dcost, gap, pres, dres))
         if show_progress:
             print("%3d % .4e % .4e %.1e %.1e %.1e %.1e %s" % (it, pcost, dcost, gap, pres, dres, kappa / tau,
                                                                "" if step is None else "%.1e" % step))

@@ -321,3 +321,13 @@ def test_socp_and_sdp_front_ends_on_device():
     th.check_socp_solution(solvers.socp(*case), *case)
     case = th._sdp_case()
     th.check_sdp_solution(solvers.sdp(*case), *case)
+
+
+def test_phase1_golden_cases_on_device():
+    """Row N3: the Phase-I fixtures generated over the CPU oracle (tests/golden/phase1_cases.json: least-norm branch
+    and augmented-SDP branch) are reproduced on the HIP path: same branch, Phase-I iteration count +- 1, X0 feasible
+    to 1e-9 and strictly inside the cone, the main problem started from X0 reaches the stored optimum."""
+    import ipm_golden
+    from smcp_amd import solvers
+    solvers.options.update(show_progress=False, maxiters=100)
+    ipm_golden.check_phase1(iter_slack=1, obj_tol=2e-6)

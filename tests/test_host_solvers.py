@@ -327,3 +327,42 @@ def test_sdp_front_end_returns_reference_keys():
         with pytest.raises(ValueError, match="'Gs' and 'hs' cannot be zero"):
             solvers.sdp(case[0], case[1], case[2])
     check_sdp_solution(sol, *case)
+
+
+def test_esd_reference_refinement_scheme_history():
+    """chordalsolver_esd with the reference's exact refinement scheme (esd_kkt_refinement = 0, esd_ds_from_hessian = True;
+    solvers.py:2017-2056) against this package's default, on the stored histories of tests/golden/esd_reference_scheme.json
+    (generator beside it): the two schemes walk through THE SAME iterates for the first ~19 iterations (one algorithm,
+    restated once), then the reference scheme's feasibility residuals stall at 1e-6..1e-7 -- the cancellation in
+    x = t H(A'y - bx) that DESIGN.md section 5 describes -- and it ends 'unknown' at feastol = 1e-8 although its
+    objective is already that of the default scheme."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_esd_scheme_golden", os.path.join(here, "golden", "make_esd_scheme_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = json.load(open(os.path.join(here, "golden", "esd_reference_scheme.json")))
+    with oracle_backend():
+        got = {name: gen.run(name, base, solvers) for name in gen.SCHEMES}
+    for name in gen.SCHEMES:                                   # the stored runs are reproduced
+        assert got[name]["status"] == gold[name]["status"] and got[name]["iterations"] == gold[name]["iterations"]
+        for a, b_ in zip(got[name]["trace"][:15], gold[name]["trace"][:15]):
+            assert np.allclose(a[1:4], b_[1:4], rtol=1e-6, atol=1e-9)
+    ref, dfl = got["reference"], got["default"]
+    for a, b_ in zip(ref["trace"][:16], dfl["trace"][:16]):    # same iterates while mu is above ~1e-5
+        assert np.allclose(a[1:4], b_[1:4], rtol=1e-4, atol=1e-8), (a, b_)
+    assert dfl["status"] == "optimal" and dfl["iterations"] <= 25
+    assert ref["status"] == "unknown"                          # never meets feastol = 1e-8 ...
+    tail = ref["trace"][-20:]
+    assert min(r[4] for r in tail) > 1e-8 and max(r[4] for r in tail) < 1e-5      # ... stalled at 1e-6..1e-7
+    assert abs(ref["pobj"] - dfl["pobj"]) < 1e-4 * (1 + abs(dfl["pobj"]))          # at the same optimum
+
+
+def test_phase1_golden_cases_over_the_oracle():
+    """Row N3: both branches of SDP.solve_phase1 (least-norm point already feasible / augmented Phase-I SDP,
+    base.py:370-470, misc.c:1004-1054) reproduce the stored runs of tests/golden/phase1_cases.json."""
+    import ipm_golden
+    with oracle_backend():
+        ipm_golden.check_phase1(iter_slack=0, obj_tol=1e-9)
