@@ -560,6 +560,50 @@ bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
              (const double*)D.famc, cnn, csa, (const int32_t*)D.kc_ij, tabpasses, ecap);
   return true;
 }
+// pipelined twelve-wave variant for parents with four row tiles (49..64 separator rows)
+template <int KSN>
+bool launch_fam12(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  const int cnn = std::max(1, a.famcnn), csa = 16 * std::max(1, (a.famcna + 15) / 16);
+  const int64_t lim = (160 * 1024 - 1024) / 8;
+  const int64_t fixed = fam12_layout(cnn, csa).oTab;
+  if (fixed + fam2_tail_doubles(4, 9) + 64 > lim) return false;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k_fam_sparse12<KSN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)k_fam2_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    attr = true;
+  }
+  const int64_t need = (int64_t)cnt * fam2_const_doubles(cnn, csa);
+  if (D.famc_len < need) {
+    if (D.famc) { if (hipFree(D.famc) != hipSuccess) return false; D.bytes -= D.famc_len * 8; }
+    D.famc = nullptr; D.famc_len = 0;
+    if (dev_alloc(&D.famc, need, D.bytes)) return false;
+    D.famc_len = need;
+  }
+  static int ncu = 0;
+  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  int g = 1;
+  int64_t best = -1;
+  for (int gc = 1; gc <= std::min(nrhs, 32); ++gc) {
+    const int64_t rounds = ((int64_t)cnt * gc + ncu - 1) / ncu;
+    const int64_t passes = (nrhs + gc - 1) / gc;
+    const int64_t cost = rounds * (passes + 12);                        // set-up ~ 12 passes
+    if (best < 0 || cost < best) { best = cost; g = gc; }
+  }
+  const int passes = (nrhs + g - 1) / g;
+  const double avg = 9.0 * (double)D.cnnz / ((double)c->S.nsn * (double)std::max<int64_t>(1, D.m));
+  int tabpasses = std::min(passes, 113);
+  while (tabpasses > 4 && fixed + fam2_tail_doubles(tabpasses, 9) + (int64_t)(1.5 * avg * tabpasses) + 8 > lim) tabpasses = (tabpasses + 1) / 2;
+  const int64_t left = lim - fixed - fam2_tail_doubles(tabpasses, 9) - 4;
+  const int ecap = (int)std::max<int64_t>(0, (left * 2) / 3 - 2);
+  if (9 * D.kc_maxlist > ecap) return false;
+  launch_lds(c, KID_fam2_prep, k_fam2_prep, dim3(cnt), dim3(512), (size_t)8 * fam2_child_layout(cnn, csa).cstride * sizeof(double), st,
+             a, D.famc, cnn, csa);
+  launch_lds(c, KID_hess_up_fam, k_fam_sparse12<KSN>, dim3(cnt, g), dim3(768), (size_t)lim * 8, st, a, U, ldu,
+             (const double*)D.famc, cnn, csa, (const int32_t*)D.kc_ij, tabpasses, ecap);
+  return true;
+}
 bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   static int off = -1;
   if (off < 0) { const char* e = getenv("SMCP_FAM2"); off = (e && e[0] == '0') ? 1 : 0; }
@@ -568,6 +612,9 @@ bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64
   if (c->D.cnnz > (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m)) return false;
   const int nat = std::max(1, (a.famna + 15) / 16);
   const bool k2 = a.famnn <= 8;
+  static int f12 = -1;
+  if (f12 < 0) { const char* e = getenv("SMCP_FAM12"); f12 = (e && e[0] == '1') ? 1 : 0; }   // pipelined variant: measured slower
+  if (nat == 4 && f12 && (k2 ? launch_fam12<2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam12<4>(c, a, cnt, nrhs, U, ldu, st))) return true;
   switch (nat) {
     case 1: return k2 ? launch_fam2<1, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<1, 4>(c, a, cnt, nrhs, U, ldu, st);
     case 2: return k2 ? launch_fam2<2, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<2, 4>(c, a, cnt, nrhs, U, ldu, st);
