@@ -177,12 +177,18 @@ def main():
             raise RuntimeError("%s failed rc=%d" % (what, rc))
 
     def step():
+        bx.blkval.copy_(bx0)
+        by.copy_(by0)
+        if part is not None and args.kktsolver != "qr":
+            # N > 1: every sweep of the step sharded by subtree (cholesky, projected_inverse, Schur sweeps, the two
+            # Hessians of solve_); boundary update blocks + H + Amap + the completed x travel over RCCL
+            Ls, Ys = kkt.factor_scaling(S, dist.group.WORLD)
+            kkt.factor(Ls, Ys, dist.group.WORLD)(bx, by, 1.0)
+            return
         L.blkval.copy_(S.blkval)
         chk(lib.csp_cholesky(h, L.blkval.data_ptr(), st()), "cholesky")
         Y.blkval.copy_(L.blkval)
         chk(lib.csp_projected_inverse(h, Y.blkval.data_ptr(), st()), "projected_inverse")
-        bx.blkval.copy_(bx0)
-        by.copy_(by0)
         if args.kktsolver == "qr":
             kkt.factor_qr(L, Y, dist.group.WORLD if world > 1 else None)(bx, by, 1.0)
             return

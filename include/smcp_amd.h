@@ -27,6 +27,7 @@ typedef struct csp_ctx csp_ctx;
 #define SMCP_ENODEV (-2)
 #define SMCP_EHIP (-3)
 #define SMCP_ENOMEM (-4)
+#define SMCP_ESTALE (-5)  /* the prepared sharded factor was overwritten by another call: kkt_prepare_part again */
 
 /* ---- symbolic layer (host only, no GPU needed) ------------------------------------- */
 
@@ -162,6 +163,25 @@ int kkt_gram_accumulate(csp_ctx* ctx, int64_t nranges, const int64_t* ranges, do
                         void* stream);
 int csp_exchange_copy(csp_ctx* ctx, int64_t nk, const int64_t* cliques, int64_t nrhs, double* buf,
                       int unpack, void* stream);
+
+/* ---- subtree-sharded factorisation and solve (every leaves->root / root->leaves sweep of the path
+ * shards; reference call sites of the sweeps: solvers.py:881-891 cholesky + projected_inverse, 521-532 the two
+ * Hessians of solve_).  set: 1 = the cliques this rank owns, 2 = the replicated top.
+ *   leaves->root (cholesky, hessian dir 0): part(set 1) -> csp_exchange_copy of the subtree roots' packed updates
+ *     (nrhs = 1) around one collective -> part(set 2);
+ *   root->leaves (projected_inverse, kkt_prepare_part, hessian dir 1): part(set 2) -> part(set 1), no communication.
+ * After them a matrix is valid on the owned cliques and the top; the other blkval ranges keep what they held.
+ * kkt_prepare_part: Y_AA blocks and their Cholesky factors (and, with_lk != 0, the inverse-form factor of L) of one set;
+ * kkt_gram_prepare_part: what is left of kkt_gram_prepare once both sets are prepared;
+ * csp_hessian_sweep_part: one half of hessian(L, Y, U, adj=None, inv=False) over one set (dir 0 up, 1 down).
+ * The prepared state lives in the context's shared lk / yaa / fac buffers: any call that rewrites them for other
+ * matrices (csp_projected_inverse, csp_hessian, kkt_* on another pair) makes the sweeps return SMCP_ESTALE until
+ * kkt_prepare_part (with_lk = 1) has been called again for set 2, then set 1. */
+int csp_cholesky_part(csp_ctx* ctx, double* blkval, int set, void* stream);
+int csp_projected_inverse_part(csp_ctx* ctx, double* blkval, int set, void* stream);
+int kkt_prepare_part(csp_ctx* ctx, const double* L, const double* Y, int set, int with_lk, void* stream);
+int kkt_gram_prepare_part(csp_ctx* ctx, void* stream);
+int csp_hessian_sweep_part(csp_ctx* ctx, double* U, int64_t nrhs, int64_t ldu, int set, int dir, void* stream);
 
 /* ---- derived-quantity cache ------------------------------------------------------------
  * csp_hessian, csp_completion and the kkt_* entry points keep quantities derived from their (L, Y)

@@ -289,8 +289,9 @@ static void add_children(const orc_sym *s, int64_t k, const double *upd, double 
 /* ------------------------------------------------------------------ public kernels */
 
 /* X -> L, L L^T = X.  upd: workspace of updptr[nsn] doubles.  Returns 0 or k+1 (clique). */
-int orc_cholesky(const orc_sym *s, double *x, double *upd) {
+static int cholesky_m(const orc_sym *s, double *x, double *upd, const unsigned char *mask) {
   for (int64_t k = 0; k < s->nsn; ++k) {
+    if (mask && !mask[k]) continue;
     int64_t nn = NN(s, k), nf = NF(s, k), na = nf - nn;
     double *P = x + s->blkptr[k], *Uk = upd + s->updptr[k];
     memset(Uk, 0, sizeof(double) * na * na);
@@ -313,6 +314,7 @@ int orc_cholesky(const orc_sym *s, double *x, double *upd) {
   }
   return 0;
 }
+int orc_cholesky(const orc_sym *s, double *x, double *upd) { return cholesky_m(s, x, upd, 0); }
 
 /* L -> X = L L^T restricted to V */
 int orc_llt(const orc_sym *s, double *x, double *upd) {
@@ -342,8 +344,9 @@ int orc_llt(const orc_sym *s, double *x, double *upd) {
 }
 
 /* L -> Y = P_V((L L^T)^-1) */
-int orc_projected_inverse(const orc_sym *s, double *x, double *upd) {
+static int projected_inverse_m(const orc_sym *s, double *x, double *upd, const unsigned char *mask) {
   for (int64_t k = s->nsn - 1; k >= 0; --k) {
+    if (mask && !mask[k]) continue;
     int64_t nn = NN(s, k), nf = NF(s, k), na = nf - nn, p = s->snpar[k];
     double *P = x + s->blkptr[k], *Uk = upd + s->updptr[k];
     if (p >= 0) gather_sep(s, k, x + s->blkptr[p], upd + s->updptr[p], Uk);
@@ -371,6 +374,7 @@ int orc_projected_inverse(const orc_sym *s, double *x, double *upd) {
   }
   return 0;
 }
+int orc_projected_inverse(const orc_sym *s, double *x, double *upd) { return projected_inverse_m(s, x, upd, 0); }
 
 /* "UL" factorisation S = U U^T (U upper) of a full symmetric nn x nn matrix, then
  * return L = U^-T (lower) in Lout (full storage, zeros above).  0 ok / j+1 on failure */
@@ -423,17 +427,23 @@ int orc_completion(const orc_sym *s, double *x, double *upd) {
 }
 
 /* yaa[k] <- Y[A_k,A_k] (lower); if fac != NULL also fac[k] <- chol(Y_AA) (lower). */
-static int prepare_yaa(const orc_sym *s, const double *Y, double *yaa, double *fac) {
-  gather_all(s, Y, yaa);
+static int prepare_yaa_m(const orc_sym *s, const double *Y, double *yaa, double *fac, const unsigned char *mask) {
+  for (int64_t k = s->nsn - 1; k >= 0; --k) {
+    int64_t p = s->snpar[k];
+    if (p < 0 || (mask && !mask[k])) continue;
+    gather_sep(s, k, Y + s->blkptr[p], yaa + s->updptr[p], yaa + s->updptr[k]);
+  }
   if (fac) {
-    memcpy(fac, yaa, sizeof(double) * s->updptr[s->nsn]);
     for (int64_t k = 0; k < s->nsn; ++k) {
       int64_t na = NF(s, k) - NN(s, k);
+      if (mask && !mask[k]) continue;
+      memcpy(fac + s->updptr[k], yaa + s->updptr[k], sizeof(double) * na * na);
       if (na && potrf_l(na, fac + s->updptr[k], na)) return (int)(k + 1);
     }
   }
   return 0;
 }
+static int prepare_yaa(const orc_sym *s, const double *Y, double *yaa, double *fac) { return prepare_yaa_m(s, Y, yaa, fac, 0); }
 
 /* leaves->root half of the Hessian: panel <- (G_NN, G_AN) */
 static void hess_up_m(const orc_sym *s, const double *L, double *u, double *upd, const unsigned char *mask) {
@@ -474,8 +484,9 @@ static void hess_up_m(const orc_sym *s, const double *L, double *u, double *upd,
 static void hess_up(const orc_sym *s, const double *L, double *u, double *upd) { hess_up_m(s, L, u, upd, 0); }
 
 /* root->leaves half: panel holds (G_NN, Q); result Z = 𝐋^-T [G_NN Q^T; Q Z_AA] 𝐋^-1 on V */
-static void hess_down(const orc_sym *s, const double *L, double *u, double *upd) {
+static void hess_down_m(const orc_sym *s, const double *L, double *u, double *upd, const unsigned char *mask) {
   for (int64_t k = s->nsn - 1; k >= 0; --k) {
+    if (mask && !mask[k]) continue;
     int64_t nn = NN(s, k), nf = NF(s, k), na = nf - nn, p = s->snpar[k];
     const double *Lk = L + s->blkptr[k];
     double *P = u + s->blkptr[k], *Uk = upd + s->updptr[k];
@@ -503,6 +514,7 @@ static void hess_down(const orc_sym *s, const double *L, double *u, double *upd)
     free(M);
   }
 }
+static void hess_down(const orc_sym *s, const double *L, double *u, double *upd) { hess_down_m(s, L, u, upd, 0); }
 
 /* inverse of hess_down: Z (on V) -> (G_NN, Q).  Clique-local once Z_AA has been gathered. */
 static void hess_down_inv(const orc_sym *s, const double *L, double *u, double *upd) {
@@ -648,6 +660,24 @@ void orc_hess_g_masked(const orc_sym *s, const double *L, const double *fac, dou
                        const unsigned char *mask) {
   hess_up_m(s, L, u, upd, mask);
   scale_an_m(s, u, 0, fac, 0, mask);
+}
+
+/* Masked pieces for the sharded factorisation / solve (tests/test_distributed.py): each acts on the cliques with
+ * mask[k] != 0 only and takes the update / separator blocks of the others as they stand in upd (yaa). */
+int orc_cholesky_masked(const orc_sym *s, double *x, double *upd, const unsigned char *mask) { return cholesky_m(s, x, upd, mask); }
+int orc_projected_inverse_masked(const orc_sym *s, double *x, double *upd, const unsigned char *mask) {
+  return projected_inverse_m(s, x, upd, mask);
+}
+int orc_prepare_fac_masked(const orc_sym *s, const double *Y, double *yaa, double *fac, const unsigned char *mask) {
+  return prepare_yaa_m(s, Y, yaa, fac, mask);
+}
+/* the two halves of hessian(adj=None, inv=False): up (with the Y_AA scaling of the AN blocks) and down */
+void orc_hess_up_masked(const orc_sym *s, const double *L, const double *yaa, double *u, double *upd, const unsigned char *mask) {
+  hess_up_m(s, L, u, upd, mask);
+  scale_an_m(s, u, yaa, 0, 4, mask);
+}
+void orc_hess_down_masked(const orc_sym *s, const double *L, double *u, double *upd, const unsigned char *mask) {
+  hess_down_m(s, L, u, upd, mask);
 }
 
 /* supernodal triangular solve with a dense n x nrhs right-hand side in permuted row order.

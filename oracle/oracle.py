@@ -58,6 +58,15 @@ def lib():
         L.orc_prepare_fac.argtypes = [S, P, P, P]
         L.orc_hess_g_masked.restype = None
         L.orc_hess_g_masked.argtypes = [S, P, P, P, P, P]
+        for name in ("orc_cholesky_masked", "orc_projected_inverse_masked"):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = [S, P, P, P]
+        L.orc_prepare_fac_masked.restype = ctypes.c_int
+        L.orc_prepare_fac_masked.argtypes = [S, P, P, P, P]
+        L.orc_hess_up_masked.restype = None
+        L.orc_hess_up_masked.argtypes = [S, P, P, P, P, P]
+        L.orc_hess_down_masked.restype = None
+        L.orc_hess_down_masked.argtypes = [S, P, P, P, P]
         L.orc_schur_columns.restype = ctypes.c_int
         L.orc_schur_columns.argtypes = [S, P, P, ctypes.c_int64, P, P, P, P, ctypes.c_int64, ctypes.c_int64, P, ctypes.c_int, P]
         L.orc_set_blas.restype = None
@@ -222,6 +231,36 @@ def hess_g_masked(S, L, fac, u, upd, mask):
     """G sweep (adj=False) over the cliques with mask != 0; upd: this right-hand side's update workspace."""
     mask = np.ascontiguousarray(mask, dtype=np.uint8)
     lib().orc_hess_g_masked(S.ref(), _p(L), _p(fac), _p(u), _p(upd), _p(mask))
+
+
+# ---- masked pieces of the sharded factorisation / solve (tests/test_distributed.py, tests/oracle_backend.py) ----
+def _mask(mask):
+    return np.ascontiguousarray(mask, dtype=np.uint8)
+
+
+def cholesky_masked(S, x, upd, mask):
+    mask = _mask(mask)
+    _chk(lib().orc_cholesky_masked(S.ref(), _p(x), _p(upd), _p(mask)), "cholesky")
+
+
+def projected_inverse_masked(S, x, upd, mask):
+    mask = _mask(mask)
+    _chk(lib().orc_projected_inverse_masked(S.ref(), _p(x), _p(upd), _p(mask)), "projected_inverse")
+
+
+def prepare_fac_masked(S, Y, yaa, fac, mask):
+    mask = _mask(mask)
+    _chk(lib().orc_prepare_fac_masked(S.ref(), _p(Y), _p(yaa), _p(fac), _p(mask)), "prepare_fac")
+
+
+def hess_up_masked(S, L, yaa, u, upd, mask):
+    mask = _mask(mask)
+    lib().orc_hess_up_masked(S.ref(), _p(L), _p(yaa), _p(u), _p(upd), _p(mask))
+
+
+def hess_down_masked(S, L, u, upd, mask):
+    mask = _mask(mask)
+    lib().orc_hess_down_masked(S.ref(), _p(L), _p(u), _p(upd), _p(mask))
 
 
 def trsm(S, L, B, trans="N"):

@@ -53,6 +53,11 @@ SIGNATURES = {
     "kkt_gram_sweep": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_i64, c_vp]),
     "kkt_gram_accumulate": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "csp_exchange_copy": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, ctypes.c_int, c_vp]),
+    "csp_cholesky_part": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp]),
+    "csp_projected_inverse_part": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp]),
+    "kkt_prepare_part": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp]),
+    "kkt_gram_prepare_part": (ctypes.c_int, [c_vp, c_vp]),
+    "csp_hessian_sweep_part": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_int, ctypes.c_int, c_vp]),
     "kkt_set_tnzcols": (ctypes.c_int, [c_vp, ctypes.c_double]),
     "dense_potrf": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "dense_potrs": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),

@@ -18,7 +18,7 @@ def _chk(rc, what):
     if rc < 0:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, {
             -1: "invalid argument", -2: "no MI355X device initialised (no CPU fallback)",
-            -3: "HIP error", -4: "out of memory"}.get(rc, "?")))
+            -3: "HIP error", -4: "out of memory", -5: "prepared sharded factor overwritten"}.get(rc, "?")))
 
 
 def _ensure(symb, nrhs=1):

@@ -398,6 +398,17 @@ void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
   }
   c->D.lk_tag_L = L;
   c->D.lk_tag_Y = nullptr;
+  c->D.part_valid = false;
+}
+// the same for the cliques of one set of the partition (clique-local: no order among the levels needed)
+void prep_lk_set(csp_ctx* c, int set, const double* L, hipStream_t st) {
+  TreeArgs t = tree_args(c);
+  MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+  for (int64_t l = 0; l < c->S.nlev; ++l)
+    for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
+      if (lds) { t.lev = am.t.lev; launch(c, KID_prep_lk, k_prep_lk, dim3(cnt), dim3(NT), st, t, L, c->D.lk); }
+      else lf_prep(c, am, cnt, L, st);
+    }, set);
 }
 // The KKT entry points are called with (L, Y) where either LK was just prepared from this very L,
 // or Y = projected_inverse(L) was produced by csp_projected_inverse (which prepares LK from L
@@ -685,7 +696,19 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
       else { dense_input(a, cnt); launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu); }
     }, set);
 }
-void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st) {
+// the same for the cliques of a set of the partition (1 = owned, 2 = replicated top), root -> leaves
+void gather_set(csp_ctx* c, int set, const double* x, int64_t ldx, int nrhs, double* updbase, hipStream_t st) {
+  TreeArgs a = tree_args(c);
+  const LevelSet& LS = c->sets[set];
+  for (int64_t l = c->S.nlev - 1; l >= 0; --l) {
+    const LevelClass& L = LS.lvl[l];
+    const int cnt = (int)(L.nI + L.nII);
+    if (!cnt) continue;
+    a.lev = LS.lev2 + LS.off[l];
+    launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(std::max(L.namaxI, L.namaxII))), dim3(NT), st, a, x, ldx, updbase);
+  }
+}
+void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0) {
   MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
   for (int64_t l = c->S.nlev - 1; l >= 0; --l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
@@ -702,7 +725,7 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
         lf_down(c, a2, cnt, nrhs, U, ldu, st);
       }
       else launch_lds(c, KID_hess_down_mfma_hbm, k_hess_down_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu);
-    });
+    }, set);
 }
 
 // inverse of the triangular factors in fac (large fronts: blocked over the chip; the rest: one workgroup each)
@@ -735,6 +758,7 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
     gather_all(c, Y, 0, 1, c->D.yaa, st);
     c->D.yaa_tag = Y;
     c->D.fac_tag = c->D.faci_tag = nullptr;
+    c->D.part_valid = false;
   }
   const bool fast = !use_generic() && use_large();
   if (need_fac && c->D.fac_tag != Y) {
@@ -1267,7 +1291,13 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
 
 int64_t csp_device_bytes(const csp_ctx* c) { return c ? c->D.bytes : 0; }
 
-int csp_cholesky(csp_ctx* c, double* x, void* stream) {
+static int cholesky_impl(csp_ctx* c, double* x, void* stream, int set);
+int csp_cholesky(csp_ctx* c, double* x, void* stream) { return cholesky_impl(c, x, stream, 0); }
+int csp_cholesky_part(csp_ctx* c, double* x, int set, void* stream) {
+  if (set < 1 || set > 2 || !c || !c->sets[set].lev2 || use_generic()) return SMCP_EINVAL;
+  return cholesky_impl(c, x, stream, set);
+}
+static int cholesky_impl(csp_ctx* c, double* x, void* stream, int set) {
   if (int rc = ready(c)) return rc;
   invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
@@ -1281,7 +1311,7 @@ int csp_cholesky(csp_ctx* c, double* x, void* stream) {
         if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
         else if (use_large() && c->D.gp_tptr) lf_chol(c, am, cnt, x, st);
         else launch_lds(c, KID_chol_mfma_hbm, k_chol_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
-      });
+      }, set);
   } else
   for_levels_up(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
@@ -1321,22 +1351,31 @@ int csp_llt(csp_ctx* c, double* x, void* stream) {
   return 0;
 }
 
-int csp_projected_inverse(csp_ctx* c, double* x, void* stream) {
+static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set);
+int csp_projected_inverse(csp_ctx* c, double* x, void* stream) { return projected_inverse_impl(c, x, stream, 0); }
+int csp_projected_inverse_part(csp_ctx* c, double* x, int set, void* stream) {
+  if (set < 1 || set > 2 || !c || !c->sets[set].lev2 || use_generic()) return SMCP_EINVAL;
+  return projected_inverse_impl(c, x, stream, set);
+}
+static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set) {
   if (int rc = ready(c)) return rc;
   invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
   if (!use_generic()) {
+    if (set) { prep_lk_set(c, set, x, st); c->D.lk_tag_L = nullptr; c->D.lk_tag_Y = nullptr; }   // partial: no cache claim
+    else {
     prep_lk(c, x, st);
     c->D.lk_tag_L = nullptr;   // x is about to be overwritten by Y: LK stays valid for the pair (L, Y = x)
     c->D.lk_tag_Y = x;
+    }
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
     for (int64_t l = c->S.nlev - 1; l >= 0; --l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
         if (lds) launch_lds(c, KID_pinv_mfma, k_pinv_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
         else if (use_large()) lf_pinv(c, am, cnt, x, st);
         else launch_lds(c, KID_pinv_mfma_hbm, k_pinv_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
-      });
+      }, set);
   } else
   for_levels_down(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;

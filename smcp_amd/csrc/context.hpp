@@ -110,6 +110,7 @@ struct DeviceCtx {
   // the orthonormal factor Q itself overwrites ustack
   double* qr_ws = nullptr;
   int64_t qr_len = 0;
+  bool part_valid = false;     // lk / yaa / fac hold the sharded factor prepared by kkt_prepare_part (sets 2 then 1)
   bool qr_valid = false;       // ustack holds Q and qr_ws the factor for the matrices (qr_L, qr_Y)
   const void* qr_L = nullptr; const void* qr_Y = nullptr;
   // probe slots (csp_probe_*): K private copies of the workspaces a trial factorisation writes besides the

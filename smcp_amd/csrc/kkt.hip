@@ -845,6 +845,25 @@ int kkt_gram_prepare(csp_ctx* c, const double* L, const double* Y, void* stream)
   if (!c->D.m || use_generic()) return SMCP_EINVAL;
   return gram_prepare(c, L, Y, (hipStream_t)stream);
 }
+// the same when the factor (L, Y) is valid on the owned cliques and the top only: kkt_prepare_part has been called
+// for both sets; this clears the failure flag and rewrites the input stack if the sweeps read their input from it
+int kkt_gram_prepare_part(csp_ctx* c, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  if (!D.m || use_generic()) return SMCP_EINVAL;
+  if (!D.part_valid) return SMCP_ESTALE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t m = D.m, bl = c->S.blklen();
+  D.qr_valid = false;
+  if (!D.kc_ptr) {
+    HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * m * bl, st));
+    for (int64_t jb = 0; jb < m; jb += 65535)
+      launch(c, KID_scatter_constraints, k_scatter_constraints, dim3(8, (unsigned)std::min<int64_t>(65535, m - jb)),
+             dim3(256), st, jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
+  }
+  HIPCHK(end_call(c));
+  return 0;
+}
 int kkt_gram_sweep(csp_ctx* c, int set, int64_t j0, int64_t j1, void* stream) {
   if (int rc = ready(c)) return rc;
   DeviceCtx& D = c->D;
@@ -860,6 +879,49 @@ int kkt_gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, doub
   if (!c->D.m || ldh < c->D.m || nranges < 0) return SMCP_EINVAL;
   if (int rc = gram_accumulate(c, nranges, ranges, H, ldh, (hipStream_t)stream)) return rc;
   return fetch_info(c, (hipStream_t)stream);
+}
+// ---- sharded factorisation and solve (every leaves->root / root->leaves sweep shards by subtree) ----
+// Y_AA blocks and their Cholesky factors of the cliques of one set (1 = owned, 2 = replicated top; call 2 before 1:
+// a subtree root gathers from its parent's panel, which lies in the top); with_lk: also the inverse-form factor of L.
+int kkt_prepare_part(csp_ctx* c, const double* L, const double* Y, int set, int with_lk, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (set < 1 || set > 2 || !c->sets[set].lev2 || use_generic() || !use_large()) return SMCP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  DeviceCtx& D = c->D;
+  D.yaa_tag = D.fac_tag = D.faci_tag = nullptr;        // partial content: nothing to claim for the caches
+  D.lk_tag_L = D.lk_tag_Y = nullptr;
+  D.part_valid = false;
+  if (set == 2) HIPCHK(zero_flag(c, st));
+  if (with_lk) prep_lk_set(c, set, L, st);
+  gather_set(c, set, Y, 0, 1, D.yaa, st);
+  HIPCHK(hipMemcpyAsync(D.fac, D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st));
+  MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+  for (int64_t l = 0; l < c->S.nlev; ++l)
+    for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
+      if (!am.namax) return;
+      if (lds) {
+        size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
+        launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(256), bytes, st, am, (const double*)D.yaa, D.fac);
+      } else lf_factor_yaa(c, am, cnt, D.fac, st);
+    }, set);
+  HIPCHK(end_call(c));
+  if (set == 2) return 0;
+  if (int rc = fetch_info(c, st)) return rc;
+  D.part_valid = true;
+  return 0;
+}
+// one half of the Hessian hessian(L, Y, U, adj=None) over the cliques of a set: dir 0 = leaves->root (with the Y_AA
+// scaling of the separator rows), dir 1 = root->leaves.  The caller exchanges the packed updates of the subtree roots
+// between the owned and the top pass of dir 0 (csp_exchange_copy); dir 1 needs no exchange.
+int csp_hessian_sweep_part(csp_ctx* c, double* U, int64_t nrhs, int64_t ldu, int set, int dir, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (set < 1 || set > 2 || !c->sets[set].lev2 || use_generic() || nrhs < 1 || nrhs > c->D.max_rhs) return SMCP_EINVAL;
+  if (!c->D.part_valid) return SMCP_ESTALE;
+  hipStream_t st = (hipStream_t)stream;
+  if (dir == 0) hess_up_fast(c, U, (int)nrhs, ldu, c->D.yaa, 1, st, set);
+  else hess_down_fast(c, U, (int)nrhs, ldu, nullptr, 0, st, set);
+  HIPCHK(end_call(c));
+  return 0;
 }
 // boundary exchange: copy the packed update blocks of the listed cliques (host list) of nrhs right-hand
 // sides to (unpack = 0) or from (unpack = 1) the contiguous device buffer buf

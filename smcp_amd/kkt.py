@@ -47,6 +47,17 @@ def _all_gather(out_list, t, group):
         dist.all_gather(out_list, t, group=group)
 
 
+def _all_gather_into(recv, send, group):
+    """One fused all-gather: recv (world * len(send)) <- every rank's send, both preallocated 1-D tensors."""
+    import torch.distributed as dist
+    if send.is_cuda and _backend_is_gloo(group):
+        h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(h, send.cpu(), group=group)
+        recv.copy_(h)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+
+
 class ShardedSchur:
     """Multi-GPU assembly of the Schur complement.
 
@@ -70,17 +81,50 @@ class ShardedSchur:
         import torch.distributed as dist
         from .shard import subtree_partition
         world = dist.get_world_size(group)
-        self.partition = subtree_partition(self.symb, world)
-        self._apply_partition(self.partition, dist.get_rank(group))
-        return self.partition
+        rank = dist.get_rank(group)
+        P = self.partition = subtree_partition(self.symb, world)
+        self._apply_partition(P, rank)
+        # blkval positions this rank accounts for in sums over the whole matrix (the top counts once, on rank 0)
+        mask = np.zeros(self.symb.blklen)
+        for a, b in list(P.ranges_by_rank[rank]) + (list(P.top_ranges) if rank == 0 else []):
+            mask[a:b] = 1.0
+        self._own_mask = torch.from_numpy(mask).to(self.dev)
+        self.__dict__.pop("_spair", None)
+        return P
+
+    def _world(self, group):
+        import torch.distributed as dist
+        if group is None or not dist.is_initialized():
+            return 1, 0
+        return dist.get_world_size(group), dist.get_rank(group)
+
+    def _exchange(self, group, nrhs):
+        """Boundary exchange of a leaves->root sweep: the packed update blocks of the subtree roots of every rank
+        (nrhs right-hand sides) travel in ONE all-gather on buffers that are allocated once per width."""
+        world, rank = self._world(group)
+        P = self.partition
+        sizes = [self._exchange_size(P.roots_by_rank[r], nrhs) for r in range(world)]
+        width = max(max(sizes), 1)
+        bufs = self.__dict__.setdefault("_xchg", {})
+        if width not in bufs:
+            bufs[width] = (torch.zeros(width, dtype=torch.float64, device=self.dev),
+                           torch.empty(width * world, dtype=torch.float64, device=self.dev))
+        send, recv = bufs[width]
+        if sizes[rank]:
+            self._exchange_pack(P.roots_by_rank[rank], nrhs, send[:sizes[rank]])
+        _all_gather_into(recv, send, group)
+        self.collectives += 1
+        for r in range(world):
+            if r != rank and sizes[r]:
+                self._exchange_unpack(P.roots_by_rank[r], nrhs, recv[r * width:r * width + sizes[r]])
+
+    collectives = 0          # collectives issued so far (tests and DESIGN.md section 6 count them per KKT solve)
 
     def build_schur(self, L, Y, group=None):
-        import torch.distributed as dist
-        world = dist.get_world_size(group) if (group is not None and dist.is_initialized()) else 1
+        world, rank = self._world(group)
         if world == 1:
             self._columns(L, Y, 0, self.m)
             return
-        rank = dist.get_rank(group)
         P = self.partition
         if P is None:
             j0, j1 = column_range(self.m, rank, world)
@@ -88,27 +132,100 @@ class ShardedSchur:
             if j1 > j0:
                 self._columns(L, Y, j0, j1)
             _all_reduce(self.H, group)
+            self.collectives += 1
             return
         # ---- subtree-sharded Gram path
-        self._gram_prepare(L, Y)
+        if self._sharded_pair(L, Y):
+            self._gram_prepare_part()                                    # (L, Y) came from factor_scaling
+        else:
+            self._gram_prepare(L, Y)
         step = self._gram_chunk()
         for j0 in range(0, self.m, step):
             j1 = min(self.m, j0 + step)
             self._gram_sweep(1, j0, j1)                                  # owned subtrees
-            mine = self._exchange_pack(P.roots_by_rank[rank], j1 - j0)   # 1-D tensor (may be empty)
-            sizes = [self._exchange_size(P.roots_by_rank[r], j1 - j0) for r in range(world)]
-            width = max(max(sizes), 1)
-            send = torch.zeros(width, dtype=torch.float64, device=self.dev)
-            send[:mine.numel()] = mine
-            recv = [torch.empty(width, dtype=torch.float64, device=self.dev) for _ in range(world)]
-            _all_gather(recv, send, group)
-            for r in range(world):
-                if r != rank and sizes[r]:
-                    self._exchange_unpack(P.roots_by_rank[r], j1 - j0, recv[r][:sizes[r]])
+            self._exchange(group, j1 - j0)
             self._gram_sweep(2, j0, j1)                                  # replicated top
         ranges = list(P.ranges_by_rank[rank]) + (list(P.top_ranges) if rank == 0 else [])
         self._gram_accumulate(ranges)
         _all_reduce(self.H, group)
+        self.collectives += 1
+
+    # ---- sharded factorisation at a scaling point and the sharded solve_ (include/smcp_amd.h: *_part)
+    def _sharded_pair(self, L, Y):
+        sp = self.__dict__.get("_spair")
+        return sp is not None and sp[0] is L and sp[1] is Y and sp[2] == (L.state(), Y.state())
+
+    def factor_scaling(self, S, group=None):
+        """L = cholesky(S), Y = projected_inverse(L) (solvers.py:881-891) with every sweep sharded by subtree: the
+        leaves->root factorisation runs on the owned cliques, ONE exchange hands the subtree roots' update blocks to
+        every rank, the top is factored redundantly; the root->leaves inverse needs no communication.  Returns
+        (L, Y), each valid on this rank's cliques and the top (other ranges keep S's values); `factor(L, Y, group)`
+        recognises the pair and shards the Schur sweeps and solve_ the same way."""
+        from . import chordal
+        world, rank = self._world(group)
+        L = S.copy()
+        if world == 1 or self.partition is None:
+            chordal.cholesky(L)
+            Y = L.copy()
+            chordal.projected_inverse(Y)
+            return L, Y
+        err = None
+        try:
+            self._chol_part(L, 1)
+        except ArithmeticError as e:     # keep the collectives matched: the failure is agreed on below
+            err = e
+        self._exchange(group, 1)
+        try:
+            self._chol_part(L, 2)
+        except ArithmeticError as e:
+            err = err or e
+        Y = L.copy()
+        if err is None:
+            try:
+                self._pinv_part(Y, 2)
+                self._pinv_part(Y, 1)
+                self._prepare_part(L, Y, 2)
+                self._prepare_part(L, Y, 1)
+            except ArithmeticError as e:
+                err = e
+        bad = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=self.dev)
+        _all_reduce(bad, group)
+        self.collectives += 1
+        if float(bad[0]) > 0:
+            raise err or ArithmeticError("cholesky: not positive definite on another rank")
+        self.__dict__["_spair"] = (L, Y, (L.state(), Y.state()))
+        return L, Y
+
+    def _solve_sharded(self, L, Y, bx, by, kk, group, complete):
+        """solve_ of kkt_chol (solvers.py:521-541) on a sharded factor: both Hessians run as owned sweep -> exchange ->
+        top (up), top -> owned (down); Amap sums over the blkval ranges this rank accounts for and ONE all-reduce
+        completes it; the m x m solve is replicated.  With complete=True one more all-reduce fills x in on every
+        rank, otherwise x is valid on the owned cliques and the top (what the next sharded sweep needs)."""
+        def W(U):
+            self._hess_part(U, 1, 0)
+            self._exchange(group, 1)
+            self._hess_part(U, 2, 0)
+            self._hess_part(U, 2, 1)
+            self._hess_part(U, 1, 1)
+        r1 = bx.copy()
+        W(r1)
+        r1.blkval.mul_(self._own_mask)
+        yp = self.amap(r1)
+        _all_reduce(yp, group)
+        self.collectives += 1
+        by.mul_(kk).add_(yp)
+        self._potrs(by)
+        x = self.aadj(by)
+        bx.blkval.neg_().add_(x.blkval)
+        bx.touched()
+        W(bx)
+        bx.blkval.mul_(1.0 / kk)
+        if complete:
+            bx.blkval.mul_(self._own_mask)
+            _all_reduce(bx.blkval, group)
+            self.collectives += 1
+        bx.touched()
+        return bx, by
 
     def _exchange_size(self, cliques, nrhs):
         na = np.diff(self.symb.rowptr) - np.diff(self.symb.snptr)
@@ -198,19 +315,60 @@ class KKTSystem(ShardedSchur):
     def _gram_sweep(self, which, j0, j1):
         _chk(_lib.lib().kkt_gram_sweep(self.symb.handle, int(which), int(j0), int(j1), _stream()), "kkt_gram_sweep")
 
-    def _exchange_pack(self, cliques, nrhs):
-        buf = torch.empty(self._exchange_size(cliques, nrhs), dtype=torch.float64, device=self.dev)
-        if len(cliques):
-            lst = np.ascontiguousarray(cliques, dtype=np.int64)
-            _chk(_lib.lib().csp_exchange_copy(self.symb.handle, len(lst), lst.ctypes.data, int(nrhs), buf.data_ptr(), 0,
-                                              _stream()), "csp_exchange_copy")
-        return buf
+    def _reprepare(self):
+        """Another call on this Symbolic has rewritten the context's lk / yaa / fac buffers (SMCP_ESTALE): rebuild
+        them from the sharded pair, top first."""
+        L, Y = self._spair[0], self._spair[1]
+        for which in (2, 1):
+            _chk(_lib.lib().kkt_prepare_part(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), which, 1,
+                                             _stream()), "kkt_prepare_part")
+
+    def _gram_prepare_part(self):
+        self._own()
+        rc = _lib.lib().kkt_gram_prepare_part(self.symb.handle, _stream())
+        if rc == -5:
+            self._reprepare()
+            rc = _lib.lib().kkt_gram_prepare_part(self.symb.handle, _stream())
+        _chk(rc, "kkt_gram_prepare_part")
+
+    def _exchange_pack(self, cliques, nrhs, out):
+        lst = np.ascontiguousarray(cliques, dtype=np.int64)
+        _chk(_lib.lib().csp_exchange_copy(self.symb.handle, len(lst), lst.ctypes.data, int(nrhs), out.data_ptr(), 0,
+                                          _stream()), "csp_exchange_copy")
 
     def _exchange_unpack(self, cliques, nrhs, buf):
         lst = np.ascontiguousarray(cliques, dtype=np.int64)
-        buf = buf.contiguous()
+        assert buf.is_contiguous()
         _chk(_lib.lib().csp_exchange_copy(self.symb.handle, len(lst), lst.ctypes.data, int(nrhs), buf.data_ptr(), 1,
                                           _stream()), "csp_exchange_copy")
+
+    # ---- sharded factorisation / solve sweeps (C-ABI: csp_cholesky_part, csp_projected_inverse_part,
+    #      kkt_prepare_part, csp_hessian_sweep_part)
+    def _chol_part(self, L, which):
+        L.touched()
+        _chk(_lib.lib().csp_cholesky_part(self.symb.handle, L.blkval.data_ptr(), int(which), _stream()), "cholesky")
+
+    def _pinv_part(self, Y, which):
+        Y.touched()
+        _chk(_lib.lib().csp_projected_inverse_part(self.symb.handle, Y.blkval.data_ptr(), int(which), _stream()),
+             "projected_inverse")
+
+    def _prepare_part(self, L, Y, which):
+        _chk(_lib.lib().kkt_prepare_part(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), int(which), 0,
+                                         _stream()), "kkt_prepare_part")
+
+    def _hess_part(self, U, which, direction):
+        U.touched()
+        args = (self.symb.handle, U.blkval.data_ptr(), 1, self.symb.blklen, int(which), int(direction), _stream())
+        rc = _lib.lib().csp_hessian_sweep_part(*args)
+        if rc == -5 and which == 1 and direction == 0:      # only before the first sweep of a Hessian
+            self._reprepare()
+            rc = _lib.lib().csp_hessian_sweep_part(*args)
+        _chk(rc, "csp_hessian_sweep_part")
+
+    def _potrs(self, y):
+        _chk(_lib.lib().dense_potrs(self.symb.handle, self.H.data_ptr(), self.m, self.m, y.data_ptr(), 1, self.m,
+                                    _stream()), "dense_potrs")
 
     def _gram_accumulate(self, ranges):
         r = np.ascontiguousarray(np.asarray(ranges, dtype=np.int64).reshape(-1))
@@ -222,6 +380,14 @@ class KKTSystem(ShardedSchur):
         returns solve_(bx, by, kk)."""
         self.build_schur(L, Y, group)
         self._potrf()
+        if self._sharded_pair(L, Y):
+            def solve_sharded(bx, by, kk, complete=True):
+                """Overwrites bx (cspmatrix) with x and by (device vector) with y; sharded sweeps."""
+                self._own()
+                if not self._sharded_pair(L, Y):
+                    raise RuntimeError("the sharded factor (L, Y) has been modified or replaced: factor again")
+                return self._solve_sharded(L, Y, bx, by, kk, group, complete)
+            return solve_sharded
 
         def solve_(bx, by, kk):
             """Overwrites bx (cspmatrix) with x and by (device vector) with y."""

@@ -59,25 +59,66 @@ class OracleKKT(kkt.ShardedSchur):
     def _gram_sweep(self, which, j0, j1):
         for j in range(j0, j1):
             orc.hess_g_masked(self.K.S, self._L, self._fac, self._G[j], self._upd[j], self._mask[which])
-        self._chunk = (j0, j1)
+        self._xbufs = self._upd[j0:j1]          # what the next boundary exchange carries
 
-    def _exchange_pack(self, cliques, nrhs):
-        S, (j0, j1) = self.K.S, self._chunk
-        parts = [self._upd[j][S.updptr[k]:S.updptr[k + 1]] for k in cliques for j in range(j0, j1)]
-        return torch.from_numpy(np.concatenate(parts)) if parts else torch.empty(0, dtype=torch.float64)
+    def _exchange_pack(self, cliques, nrhs, out):
+        S = self.K.S
+        assert nrhs == len(self._xbufs)
+        parts = [u[S.updptr[k]:S.updptr[k + 1]] for k in cliques for u in self._xbufs]
+        out.copy_(torch.from_numpy(np.concatenate(parts)))
 
     def _exchange_size(self, cliques, nrhs):        # the oracle exchanges full squares
         S = self.K.S
         return int(sum(int(S.updptr[k + 1] - S.updptr[k]) for k in cliques) * nrhs)
 
     def _exchange_unpack(self, cliques, nrhs, buf):
-        S, (j0, j1) = self.K.S, self._chunk
+        S = self.K.S
         b, o = buf.numpy(), 0
         for k in cliques:
             n = int(S.updptr[k + 1] - S.updptr[k])
-            for j in range(j0, j1):
-                self._upd[j][S.updptr[k]:S.updptr[k + 1]] = b[o:o + n]
+            for u in self._xbufs:
+                u[S.updptr[k]:S.updptr[k + 1]] = b[o:o + n]
                 o += n
+
+    # ---- sharded factorisation / solve, emulated with the oracle's masked sweeps
+    def _upd1(self):
+        if "_u1" not in self.__dict__:
+            self._u1 = np.zeros(max(1, self.K.S.updlen))
+        self._xbufs = [self._u1]
+        return self._u1
+
+    def _chol_part(self, L, which):
+        orc.cholesky_masked(self.K.S, _np(L), self._upd1(), self._mask[which])
+
+    def _pinv_part(self, Y, which):
+        orc.projected_inverse_masked(self.K.S, _np(Y), self._upd1(), self._mask[which])
+
+    def _prepare_part(self, L, Y, which):
+        S = self.K.S
+        if which == 2:
+            self._L = _np(L)
+            self._yaa, self._fac = np.zeros(max(1, S.updlen)), np.zeros(max(1, S.updlen))
+        orc.prepare_fac_masked(S, _np(Y), self._yaa, self._fac, self._mask[which])
+
+    def _gram_prepare_part(self):
+        S = self.K.S
+        self._G = [self.K.constraint(j) for j in range(self.m)]
+        self._upd = [np.zeros(max(1, S.updlen)) for _ in range(self.m)]
+
+    def _hess_part(self, U, which, direction):
+        if direction == 0:
+            orc.hess_up_masked(self.K.S, self._L, self._yaa, _np(U), self._upd1(), self._mask[which])
+        else:
+            orc.hess_down_masked(self.K.S, self._L, _np(U), self._upd1(), self._mask[which])
+
+    def _potrs(self, y):
+        H = np.asfortranarray(self.H.numpy().T)
+        b = np.asfortranarray(y.numpy().copy())
+        orc.dense_potrs(H, b)
+        y.copy_(torch.from_numpy(b))
+
+    def _own(self):
+        pass
 
     def _gram_accumulate(self, ranges):
         S = self.K.S
@@ -102,6 +143,8 @@ class OracleKKT(kkt.ShardedSchur):
     def factor(self, L, Y, group=None):
         self.build_schur(L, Y, group)
         self._potrf()
+        if self._sharded_pair(L, Y):
+            return lambda bx, by, kk, complete=True: self._solve_sharded(L, Y, bx, by, kk, group, complete)
         H = np.asfortranarray(self.H.numpy().T)
 
         def solve_(bx, by, kk):

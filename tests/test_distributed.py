@@ -44,6 +44,9 @@ def _worker(rank, world, port, out, mode):
         cptr, cidx, cval = problems.random_constraints(symb, m, density=0.1, seed=3)
         L, Y = cspmatrix(symb, torch.from_numpy(Lh)), cspmatrix(symb, torch.from_numpy(Yh))
         sharded = OracleKKT(symb, cptr, cidx, cval)
+        if mode == "factor":
+            _factor_mode(rank, world, out, symb, sharded, OracleKKT(symb, cptr, cidx, cval), A, Lh, Yh, m)
+            return
         if mode == "subtree":
             part = sharded.set_partition(dist.group.WORLD)            # subtree sharding + boundary exchange
             assert (part.owner >= 0).sum() > 0 and len(part.top) >= 1
@@ -67,6 +70,58 @@ def _worker(rank, world, port, out, mode):
         dist.destroy_process_group()
 
 
+def _factor_mode(rank, world, out, symb, sharded, single, A, Lh, Yh, m):
+    """Sharded cholesky + projected_inverse + Schur build + solve_ against the single-rank results."""
+    from smcp_amd.cspmatrix import cspmatrix
+    P = sharded.set_partition(dist.group.WORLD)
+    S0 = cspmatrix(symb, torch.from_numpy(A.copy()))
+    L, Y = sharded.factor_scaling(S0, dist.group.WORLD)
+    n_fact = sharded.collectives
+    own = sharded._own_mask.numpy().astype(bool)
+    for a, b in P.top_ranges:
+        own[a:b] = True                                         # every rank holds the top
+    eL = float(np.abs(L.blkval.numpy() - Lh)[own].max() / np.abs(Lh).max())
+    eY = float(np.abs(Y.blkval.numpy() - Yh)[own].max() / np.abs(Yh).max())
+    untouched = bool(np.array_equal(L.blkval.numpy()[~own], A[~own]))     # foreign ranges keep S's values
+    solve = sharded.factor(L, Y, group=dist.group.WORLD)
+    n_build = sharded.collectives - n_fact
+    Ls, Ys = cspmatrix(symb, torch.from_numpy(Lh.copy())), cspmatrix(symb, torch.from_numpy(Yh.copy()))
+    solve1 = single.factor(Ls, Ys)
+    eH = float((sharded.H - single.H).abs().max() / single.H.abs().max())
+    rng = np.random.default_rng(5)
+    msk = np.zeros(symb.blklen, dtype=bool)
+    msk[symb.ccs_to_blk()] = True
+    b0 = rng.standard_normal(symb.blklen) * msk
+    y0 = rng.standard_normal(m)
+    bx, by = cspmatrix(symb, torch.from_numpy(b0.copy())), torch.from_numpy(y0.copy())
+    cx, cy = cspmatrix(symb, torch.from_numpy(b0.copy())), torch.from_numpy(y0.copy())
+    before = sharded.collectives
+    solve(bx, by, 0.5)
+    n_solve = sharded.collectives - before
+    solve1(cx, cy, 0.5)
+    ex = float((bx.blkval - cx.blkval).abs()[torch.from_numpy(msk)].max() / cx.blkval.abs().max())
+    ey = float((by - cy).abs().max() / cy.abs().max())
+    # without the completing all-reduce x is valid where the next sharded sweep reads it
+    px, py = cspmatrix(symb, torch.from_numpy(b0.copy())), torch.from_numpy(y0.copy())
+    solve(px, py, 0.5, complete=False)
+    ep = float((px.blkval - cx.blkval).abs()[torch.from_numpy(own & msk)].max() / cx.blkval.abs().max())
+    if rank == 0:
+        out.put(dict(eL=eL, eY=eY, eH=eH, ex=ex, ey=ey, ep=ep, untouched=untouched, n_fact=n_fact, n_build=n_build,
+                     n_solve=n_solve, chunks=-(-m // sharded._gram_chunk())))
+
+
+def test_sharded_factorisation_and_solve_two_ranks_gloo():
+    """cholesky, projected_inverse, the Schur sweeps and both Hessians of solve_ sharded by
+    subtree reproduce the single-rank L, Y, H, x, y; collectives are counted."""
+    r = _run_two("factor")
+    for k in ("eL", "eY", "eH", "ex", "ey", "ep"):
+        assert r[k] < 1e-11, (k, r)
+    assert r["untouched"]
+    assert r["n_fact"] == 2                      # subtree-root updates of the factorisation + the agreed status flag
+    assert r["n_build"] == r["chunks"] + 1       # one exchange per chunk of right-hand sides + the all-reduce of H
+    assert r["n_solve"] == 4                     # two Hessian exchanges + Amap all-reduce + completion of x
+
+
 def test_partition_covers_tree():
     from smcp_amd import problems
     from smcp_amd.shard import subtree_partition
@@ -85,8 +140,7 @@ def test_partition_covers_tree():
             assert all(P.owner[k] == r and P.owner[par[k]] == -1 for k in P.roots_by_rank[r])
 
 
-@pytest.mark.parametrize("mode", ["columns", "subtree"])
-def test_sharded_schur_two_ranks_gloo(mode):
+def _run_two(mode):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -99,5 +153,10 @@ def test_sharded_schur_two_ranks_gloo(mode):
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
-    err, spread = out.get()
+    return out.get()
+
+
+@pytest.mark.parametrize("mode", ["columns", "subtree"])
+def test_sharded_schur_two_ranks_gloo(mode):
+    err, spread = _run_two(mode)
     assert err < 1e-12 and spread == 0.0

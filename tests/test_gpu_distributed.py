@@ -37,6 +37,9 @@ def _worker(rank, world, port, out, mode):
         single.factor(L, Y)
         Href = single.H.clone()
         sharded = KKTSystem(symb, cptr, cidx, cval, max_rhs=4)
+        if mode == "factor":
+            _factor_mode(rank, out, symb, S, L, Y, single, sharded, m)
+            return
         if mode == "subtree":
             sharded.set_partition(dist.group.WORLD)
         solve = sharded.factor(L, Y, group=dist.group.WORLD)
@@ -56,8 +59,65 @@ def _worker(rank, world, port, out, mode):
         dist.destroy_process_group()
 
 
+def _factor_mode(rank, out, symb, S, L1, Y1, single, sharded, m):
+    """csp_cholesky_part / csp_projected_inverse_part / kkt_prepare_part / csp_hessian_sweep_part against the
+    single-rank csp_cholesky / csp_projected_inverse / kkt_schur / kkt_solve on the same device."""
+    from smcp_amd import chordal
+    from smcp_amd.cspmatrix import cspmatrix
+    P = sharded.set_partition(dist.group.WORLD)
+    L, Y = sharded.factor_scaling(S, dist.group.WORLD)
+    n_fact = sharded.collectives
+    own = sharded._own_mask.bool().clone()
+    for a, b in P.top_ranges:
+        own[a:b] = True
+    rel = lambda a, b, w: float((a - b).abs()[w].max() / b.abs().max())
+    eL, eY = rel(L.blkval, L1.blkval, own), rel(Y.blkval, Y1.blkval, own)
+    untouched = bool(torch.equal(L.blkval[~own], S.blkval[~own]))
+    solve = sharded.factor(L, Y, group=dist.group.WORLD)
+    n_build = sharded.collectives - n_fact
+    solve1 = single.factor(L1, Y1)
+    eH = float((sharded.H - single.H).abs().max() / single.H.abs().max())
+    rng = np.random.default_rng(5)
+    msk = np.zeros(symb.blklen, dtype=bool)
+    msk[symb.ccs_to_blk()] = True
+    b0 = torch.from_numpy(rng.standard_normal(symb.blklen) * msk).cuda()
+    y0 = torch.from_numpy(rng.standard_normal(m)).cuda()
+    mskd = torch.from_numpy(msk).cuda()
+    res = {}
+    for trial in range(2):
+        bx, by = cspmatrix(symb, b0.clone()), y0.clone()
+        cx, cy = cspmatrix(symb, b0.clone()), y0.clone()
+        before = sharded.collectives
+        solve(bx, by, 0.5)
+        res["n_solve"] = sharded.collectives - before
+        solve1(cx, cy, 0.5)               # rewrites the context's lk / yaa / fac: the next sharded solve re-prepares
+        res["ex%d" % trial] = rel(bx.blkval, cx.blkval, mskd)
+        res["ey%d" % trial] = float((by - cy).abs().max() / cy.abs().max())
+    # a different pair through the shared caches, then the sharded Hessian again (SMCP_ESTALE path)
+    U = cspmatrix(symb, b0.clone())
+    chordal.hessian(L1, Y1, U, adj=None)
+    px, py = cspmatrix(symb, b0.clone()), y0.clone()
+    solve(px, py, 0.5, complete=False)
+    res["ep"] = rel(px.blkval, cx.blkval, own & mskd)
+    if rank == 0:
+        out.put(dict(res, eL=eL, eY=eY, eH=eH, untouched=untouched, n_fact=n_fact, n_build=n_build,
+                     chunks=-(-m // sharded._gram_chunk())))
+
+
+def test_sharded_factorisation_and_solve_two_ranks_one_gpu():
+    r = _run_two("factor")
+    for k in ("eL", "eY", "eH", "ex0", "ey0", "ex1", "ey1", "ep"):
+        assert r[k] < 1e-11, (k, r)
+    assert r["untouched"] and r["n_fact"] == 2 and r["n_build"] == r["chunks"] + 1 and r["n_solve"] == 4
+
+
 @pytest.mark.parametrize("mode", ["columns", "subtree"])
 def test_two_ranks_one_gpu(mode):
+    err, spread = _run_two(mode)
+    assert err < 1e-11 and spread < 1e-12
+
+
+def _run_two(mode):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -70,5 +130,4 @@ def test_two_ranks_one_gpu(mode):
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
-    err, spread = out.get()
-    assert err < 1e-11 and spread < 1e-12
+    return out.get()
