@@ -1210,10 +1210,17 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
 // processed in PAIRS with independent accumulator chains so that an MFMA never waits for the operands or the result
 // of the one before it -- with one dependent chain per tile the MFMA pipe was busy 45 % of the time, PMC
 // SQ_VALU_MFMA_BUSY_CYCLES).  Slots past the last tile of a wave recompute tile 0 and are not stored.
+// up to GRAM_MAXR blkval ranges per launch (the subtrees a rank owns): workgroups first[q] .. first[q + 1] - 1 take range q
+constexpr int GRAM_MAXR = 8;
+struct GramRanges { int64_t lo[GRAM_MAXR], hi[GRAM_MAXR]; int first[GRAM_MAXR + 1]; int n; };
 template <int NT, int NW>
-__global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
+__global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(const double* G, int64_t ldg, int m, GramRanges rg,
                                                       const double* sw, int64_t chunk, double* partial, int coff,
                                                       int nchunk_total, int skip) {
+  int rq = 0;
+  while (rq + 1 < rg.n && (int)blockIdx.x >= rg.first[rq + 1]) ++rq;
+  const int64_t e_lo = rg.lo[rq], e_hi = rg.hi[rq];
+  const int wg_in_range = (int)blockIdx.x - rg.first[rq];
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // LDS image [column][k = 64], ld GRAM_LDK = 66 doubles: the staging store is contiguous along k (no transpose)
   // and the operand reads (row = column l15, k = kq + 4 s) hit 32 distinct 8-byte bank pairs per half wave
@@ -1240,7 +1247,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(co
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
   for (int e = threadIdx.x; e < GRAM_BLK * GRAM_LDK; e += 64 * NW) sA[e] = 0.0;   // columns >= m stay zero
-  const int64_t e_begin = e_lo + (int64_t)blockIdx.x * chunk, e_end = min(e_hi, e_begin + chunk);
+  const int64_t e_begin = e_lo + (int64_t)wg_in_range * chunk, e_end = min(e_hi, e_begin + chunk);
   double pre[NC], pre_sw = 0.0;
   auto fetch = [&](int64_t e0) {
     const int64_t e = e0 + lane;

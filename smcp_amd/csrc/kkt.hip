@@ -632,8 +632,21 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
                            int64_t mcols = -1) {
   DeviceCtx& D = c->D;
   const int64_t m = mcols < 0 ? D.m : mcols, bl = c->S.blklen();
+  // sorted, with touching ranges merged (the subtrees of one rank are often neighbours in the postorder)
+  std::vector<std::pair<int64_t, int64_t>> rs;
+  for (int64_t q = 0; q < nranges; ++q)
+    if (ranges[2 * q + 1] > ranges[2 * q]) rs.push_back({ranges[2 * q], ranges[2 * q + 1]});
+  std::sort(rs.begin(), rs.end());
+  {
+    size_t w = 0;
+    for (size_t q = 0; q < rs.size(); ++q) {
+      if (w && rs[q].first <= rs[w - 1].second) rs[w - 1].second = std::max(rs[w - 1].second, rs[q].second);
+      else rs[w++] = rs[q];
+    }
+    rs.resize(w);
+  }
   int64_t total = 0;
-  for (int64_t q = 0; q < nranges; ++q) total += std::max<int64_t>(0, ranges[2 * q + 1] - ranges[2 * q]);
+  for (auto& r : rs) total += r.second - r.first;
   if (total <= 0) {
     HIPCHK(hipMemset2DAsync(H, ldh * sizeof(double), 0, m * sizeof(double), m, st));
     return 0;
@@ -641,10 +654,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
   // ~one resident wave of workgroups (2 per CU) over all ranges
   int64_t chunk = std::max<int64_t>(2048, ((total / 512 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS);
   int nchunk = 0;
-  for (int64_t q = 0; q < nranges; ++q) {
-    int64_t len = ranges[2 * q + 1] - ranges[2 * q];
-    if (len > 0) nchunk += (int)((len + chunk - 1) / chunk);
-  }
+  for (auto& r : rs) nchunk += (int)((r.second - r.first + chunk - 1) / chunk);
   int nb = (int)((m + GRAM_BLK - 1) / GRAM_BLK);
   int nblk = nb * (nb + 1) / 2;
   int64_t need = (int64_t)nblk * nchunk * 64 * 256;
@@ -655,42 +665,53 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     D.gpart_len = need;
   }
   int coff = 0;
-  for (int64_t q = 0; q < nranges; ++q) {
-    int64_t lo = ranges[2 * q], hi = ranges[2 * q + 1];
-    if (hi <= lo) continue;
-    int nc = (int)((hi - lo + chunk - 1) / chunk);
-    if (nblk == 1)
-    {
-      // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
-      // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
-      static int nw = -1;
-      if (nw < 0) { const char* e = getenv("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
-      const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + nw - 1) / nw;   // lower tiles per wave
-      static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
-      if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
-      const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
+  if (nblk == 1) {
+    // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
+    // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
+    static int nw = -1;
+    if (nw < 0) { const char* e = getenv("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
+    const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + nw - 1) / nw;   // lower tiles per wave
+    static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
+    if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
+    const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
+    for (size_t q0 = 0; q0 < rs.size(); q0 += GRAM_MAXR) {      // all ranges of a rank in one launch (up to GRAM_MAXR)
+      GramRanges rg;
+      rg.n = (int)std::min<size_t>(GRAM_MAXR, rs.size() - q0);
+      int nc = 0;
+      for (int q = 0; q < GRAM_MAXR; ++q) {
+        const bool on = q < rg.n;
+        rg.lo[q] = on ? rs[q0 + q].first : 0;
+        rg.hi[q] = on ? rs[q0 + q].second : 0;
+        rg.first[q] = nc;
+        if (on) nc += (int)((rg.hi[q] - rg.lo[q] + chunk - 1) / chunk);
+      }
+      rg.first[GRAM_MAXR] = nc;
 #define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nc, 1), dim3(1024), lds, st, \
-                 (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
+                 (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
                else if (nw == 8) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nc, 1), dim3(512), lds, st, \
-                 (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
+                 (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
                else launch_lds(c, KID_gram_partial, k_gram_diag128<N, 4>, dim3(nc, 1), dim3(256), lds, st, \
-                 (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); break;
+                 (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); break;
       switch (npw) {
         SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)
         SMCP_GRAM_CASE(6) SMCP_GRAM_CASE(7) SMCP_GRAM_CASE(8) SMCP_GRAM_CASE(9)
       }
 #undef SMCP_GRAM_CASE
+      coff += nc;
     }
-    else
-      for (int bi = 0; bi < nb; ++bi)
-        for (int bj = 0; bj <= bi; ++bj) {
-          if (bi == bj)
-            launch_lds(c, KID_gram_partial, k_gram_partial<true>, dim3(nc), dim3(256), (size_t)GRAM_KS * GRAM_LD * sizeof(double), st,
-                       (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, bi, bj);
-          else
-            launch_lds(c, KID_gram_partial, k_gram_partial<false>, dim3(nc), dim3(256), (size_t)2 * GRAM_KS * GRAM_LD * sizeof(double), st,
-                       (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, bi, bj);
-        }
+  } else
+  for (auto& r : rs) {
+    const int64_t lo = r.first, hi = r.second;
+    const int nc = (int)((hi - lo + chunk - 1) / chunk);
+    for (int bi = 0; bi < nb; ++bi)
+      for (int bj = 0; bj <= bi; ++bj) {
+        if (bi == bj)
+          launch_lds(c, KID_gram_partial, k_gram_partial<true>, dim3(nc), dim3(256), (size_t)GRAM_KS * GRAM_LD * sizeof(double), st,
+                     (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, bi, bj);
+        else
+          launch_lds(c, KID_gram_partial, k_gram_partial<false>, dim3(nc), dim3(256), (size_t)2 * GRAM_KS * GRAM_LD * sizeof(double), st,
+                     (const double*)D.ustack, bl, (int)m, lo, hi, (const double*)D.sw, chunk, D.gpart, coff, nchunk, bi, bj);
+      }
     coff += nc;
   }
   launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
