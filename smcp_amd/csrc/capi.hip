@@ -47,7 +47,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -65,7 +65,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -345,11 +345,25 @@ void lf_pinv(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
 constexpr size_t LF_DIAG_LDS = (size_t)(2 * LB * LBD + 256 + 16 * LB) * sizeof(double);
 
 // blocked Cholesky of the large fronts of one level (children already factored): clear + assemble + steps
+// fronts of at most MID_MAXROWS rows: the blocked Cholesky of a front in one workgroup (k_mid_chol); SMCP_MID=0: per-step kernels
+bool use_mid(int rowsmax) {
+  static int g = -1;
+  if (g < 0) {
+    const char* e = getenv("SMCP_MID");
+    g = (e && e[0] == '0') ? 0 : 1;
+    if (g && hipFuncSetAttribute((const void*)k_mid_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_chol_lds(MID_MAXROWS)) != hipSuccess) g = 0;
+  }
+  return g == 1 && rowsmax <= MID_MAXROWS;
+}
 void lf_chol(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) {
   dim3 blk(256);
   const int nfmax = a.nnmax + a.namax;
   launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, 1), blk, st, a);
   lf_assemble(c, a, cnt, 1, x, 0, 0, st);
+  if (use_mid(nfmax)) {
+    launch_lds(c, KID_mid_chol, k_mid_chol, dim3(cnt), dim3(1024), mid_chol_lds(nfmax), st, a, x, (double*)nullptr, 0);
+    return;
+  }
   const int mtA = tiles64(a.namax);
   for (int jb = 0; jb < a.nnmax; jb += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, x, (double*)nullptr, 0, jb, 1);
@@ -364,6 +378,10 @@ void lf_chol(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
 // chol(Y_AA) of the large fronts of one level, in place in fac (already a copy of yaa)
 void lf_factor_yaa(csp_ctx* c, const MfmaArgs& a, int cnt, double* fac, hipStream_t st) {
   dim3 blk(256);
+  if (use_mid(a.namax)) {
+    launch_lds(c, KID_mid_chol, k_mid_chol, dim3(cnt), dim3(1024), mid_chol_lds(a.namax), st, a, (double*)nullptr, fac, 2);
+    return;
+  }
   for (int jb = 0; jb < a.namax; jb += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, (double*)nullptr, fac, 2, jb, 1);
     const int mrem = a.namax - jb - 1;
@@ -377,10 +395,20 @@ void lf_factor_yaa(csp_ctx* c, const MfmaArgs& a, int cnt, double* fac, hipStrea
 // inverse-form factor of the large fronts of one level
 void lf_prep(csp_ctx* c, const MfmaArgs& a, int cnt, const double* L, hipStream_t st) {
   dim3 blk(256);
+  static int hoist = -1;
+  if (hoist < 0) { const char* e = getenv("SMCP_MID"); hoist = (e && e[0] == '0') ? 0 : 1; }
+  if (hoist) {
+    // the diagonal blocks' inverses do not depend on each other: one launch for all of them, then the block rows
+    launch_lds(c, KID_lf_diag_inv, k_lf_diag_inv, dim3(cnt, tiles64(a.nnmax)), blk, LF_DIAG_LDS, st, a, L, c->D.lk);
+    for (int ib = LB; ib < a.nnmax; ib += LB) {
+      launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, L, c->D.lk, ib, 0);
+      launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib)), cnt), blk, st, a, L, c->D.lk, ib, 0, 1);
+    }
+  } else
   for (int ib = 0; ib < a.nnmax; ib += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, const_cast<double*>(L), (double*)nullptr, 1, ib, 0);
     if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, L, c->D.lk, ib, 0);
-    launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, L, c->D.lk, ib, 0);
+    launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, L, c->D.lk, ib, 0, 0);
   }
   if (a.namax) launch(c, KID_lf_prep_k, k_lf_prep_k, dim3(umax1(tiles64(a.namax) * tiles64(a.nnmax)), cnt), blk, st, a, L, c->D.lk);
 }
@@ -734,7 +762,7 @@ void lf_factor_inverse(csp_ctx* c, const MfmaArgs& a, int cnt, hipStream_t st) {
   for (int ib = 0; ib < a.namax; ib += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, (double*)nullptr, c->D.fac, 4, ib, 0);
     if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, (const double*)c->D.fac, c->D.faci, ib, 4);
-    launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, (const double*)c->D.fac, c->D.faci, ib, 4);
+    launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, (const double*)c->D.fac, c->D.faci, ib, 4, 0);
   }
 }
 
@@ -1424,7 +1452,7 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
         for (int ib = 0; ib < am.nnmax; ib += LB) {
           launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, ib, 0);
           if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3);
-          launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3);
+          launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3, 0);
         }
         launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(ntN * ntN + mtA * ntN), cnt), blk, st, am, x, 3);
       });

@@ -757,6 +757,90 @@ __global__ void k_lf_pack_upd(MfmaArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fronts of at most MID_MAXROWS rows: the whole blocked Cholesky of one front in ONE workgroup (sixteen waves), one
+// 64-wide block column at a time in LDS.  The per-step kernels above spend ~37 us per diagonal block and ~7-10 us per
+// panel / trailing launch on fronts this small (the (64,128) mid fronts and the (208,0) root of synth50k: 12 + 4
+// launches for the two levels); here a block column is loaded once, factored in place by 16-column steps
+// (potrf_inv16 on the diagonal 16 x 16, the rows below scaled by its inverse, the rest of the block column updated --
+// all operands in LDS), written back, and the columns to its right and the update block are updated from the LDS copy.
+// mode 0: front of x with its update block (assembled beforehand; published as packed lower triangle after the last
+// block column); mode 2: the Y_AA block in aux (fac), in place.
+// ---------------------------------------------------------------------------------------------
+constexpr int MID_MAXROWS = 272;
+__host__ __device__ inline int mid_ld(int rows) { return ((rows + 15) / 32) * 32 + 16; }   // >= rows, = 16 mod 32 (bank spread)
+__host__ __device__ inline size_t mid_chol_lds(int rowsmax) { return ((size_t)mid_ld(rowsmax) * LB + 256 + 8) * sizeof(double); }
+
+__global__ void __launch_bounds__(1024) k_mid_chol(MfmaArgs a, double* x, double* aux, int mode) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (*a.t.info) return;
+  const int k = a.t.lev[blockIdx.x];
+  const LfMat M = lf_mat(a, k, mode, x, aux);
+  const CliqueDesc d = a.t.cl[k];
+  const int tid = threadIdx.x;
+  const int ldp = mid_ld(M.nrow);
+  double* const Pb = smem;
+  double* const d16 = Pb + (size_t)ldp * LB;
+  const int64_t ld = M.ld;
+  for (int jb = 0; jb < M.ncol; jb += LB) {
+    const int w = min(LB, M.ncol - jb), rows = M.nrow - jb;
+    const double* Ab = M.A + jb + (int64_t)jb * ld;
+    for (int e = tid; e < rows * w; e += 1024) {
+      const int i = e % rows, j = e / rows;
+      Pb[i + j * ldp] = (i >= j) ? Ab[i + (int64_t)j * ld] : 0.0;
+    }
+    __syncthreads();
+    for (int jj = 0; jj < w; jj += 16) {
+      const int bw = min(16, w - jj);
+      const int f = potrf_inv16(Pb + jj + jj * ldp, ldp, bw, d16);
+      if (f) { if (tid == 0) atomicCAS(a.t.info, 0, k + 1); return; }
+      const int rbelow = rows - jj - bw, crem = w - jj - bw;
+      if (rbelow > 0) {
+        double* Sb = Pb + (jj + bw) + jj * ldp;          // rows below the diagonal block, this step's columns
+        // one column tile (bw <= 16): a wave reads the whole 16 x bw input of its tile before it stores it
+        wg_mma(rbelow, bw, bw, [=](int m, int kk) { return Sb[m + kk * ldp]; },
+               [=](int kk, int n) { return d16[n + kk * 16]; },
+               [=](int m, int n, double acc) { Sb[m + n * ldp] = acc; });
+        __syncthreads();
+        if (crem > 0) {
+          double* Tb = Pb + (jj + bw) + (jj + bw) * ldp;
+          wg_mma(rbelow, crem, bw, [=](int m, int kk) { return Sb[m + kk * ldp]; },
+                 [=](int kk, int n) { return Sb[n + kk * ldp]; },
+                 [=](int m, int n, double acc) { if (m >= n) Tb[m + n * ldp] -= acc; }, true);
+          __syncthreads();
+        }
+      }
+    }
+    // the factored block column goes back; the columns to its right and the update block take -P P^T from the LDS copy
+    double* Aw = M.A + jb + (int64_t)jb * ld;
+    for (int e = tid; e < rows * w; e += 1024) {
+      const int i = e % rows, j = e / rows;
+      if (i >= j) Aw[i + (int64_t)j * ld] = Pb[i + j * ldp];
+    }
+    const int ncr = M.ncol - jb - w, mrem = rows - w;
+    if (ncr > 0) {
+      double* Tr = M.A + (jb + w) + (int64_t)(jb + w) * ld;
+      const double* Pr = Pb + w;
+      wg_mma(mrem, ncr, w, [=](int m, int kk) { return Pr[m + kk * ldp]; }, [=](int kk, int n) { return Pr[n + kk * ldp]; },
+             [=](int m, int n, double acc) { if (m >= n) Tr[m + (int64_t)n * ld] -= acc; }, true);
+    }
+    if (M.upd) {
+      const int na = M.na;
+      const double* Pa = Pb + (M.ncol - jb);            // separator rows of this block column
+      double* U = M.upd;
+      if (jb + w >= M.ncol) {
+        double* UP = a.t.updp + d.updp;
+        wg_mma(na, na, w, [=](int m, int kk) { return Pa[m + kk * ldp]; }, [=](int kk, int n) { return Pa[n + kk * ldp]; },
+               [=](int m, int n, double acc) { if (m >= n) UP[pk_idx(m, n, na)] = U[m + (int64_t)n * na] - acc; }, true);
+      } else {
+        wg_mma(na, na, w, [=](int m, int kk) { return Pa[m + kk * ldp]; }, [=](int kk, int n) { return Pa[n + kk * ldp]; },
+               [=](int m, int n, double acc) { if (m >= n) U[m + (int64_t)n * na] -= acc; }, true);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- inverse-form factor of large fronts: Li = L_NN^-1 by block rows, K = L_AN Li
 // step ib: (after k_lf_diag wrote Dinv of block ib) S = L[ib, 0:ib] Li[0:ib, 0:ib] ; Li[ib, 0:ib] = -Dinv S
 // view of one triangular inversion: src (lower, ld) -> dst (ld), order n, row-block scratch S
@@ -796,7 +880,8 @@ __global__ void __launch_bounds__(256) k_lf_prep_s(MfmaArgs a, const double* L, 
               [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB, n0);
   tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { S[s0 + m * sm + n * sn] = v; });
 }
-__global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L, double* LK, int ib, int mode) {
+// hoisted != 0: the inverses of ALL diagonal blocks are already in place in dst (k_lf_diag_inv)
+__global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L, double* LK, int ib, int mode, int hoisted) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
@@ -805,11 +890,13 @@ __global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L
   const int64_t nf = V.ld;
   if (ib >= nn) return;
   const int w = min(LB, nn - ib);
-  const double* Di = a.lfd + (int64_t)d.pad * (LB * LB);       // w x w (ld w)
+  const double* Di = hoisted ? V.dst + ib + (int64_t)ib * nf : a.lfd + (int64_t)d.pad * (LB * LB);       // w x w
+  const int64_t ldd = hoisted ? nf : w;
   double* Li = V.dst;
   const int t = blockIdx.x;
   const int ntS = tiles64(ib);
   if (t == ntS) {   // diagonal block of Li (and zeros above it)
+    if (hoisted) return;
     for (int e = threadIdx.x; e < w * w; e += blockDim.x) {
       int i = e % w, j = e / w;
       Li[(ib + i) + (int64_t)(ib + j) * nf] = (i >= j) ? Di[i + j * w] : 0.0;
@@ -827,9 +914,40 @@ __global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L
   const int64_t sm = mode == 4 ? nf : 1, sn = mode == 4 ? 1 : w, s0 = mode == 4 ? (int64_t)ib * nf : 0;
   d4 acc[2][2];
   tile64_zero(acc);
-  gemm_tile64(acc, w, ib, w, 0, n0, [=](int m, int kk) { return Di[m + kk * w]; },
+  gemm_tile64(acc, w, ib, w, 0, n0, [=](int m, int kk) { return Di[m + kk * ldd]; },
               [=](int kk, int n) { return S[s0 + kk * sm + n * sn]; }, sA, sB);
   tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { Li[(ib + m) + (int64_t)n * nf] = -v; });
+}
+// inverses of ALL 64 x 64 diagonal blocks of L_NN at once (they do not depend on each other), straight into the
+// diagonal blocks of Li, with the zeros above the diagonal and in the rows above each block (mode 0 of inv_view only)
+__global__ void __launch_bounds__(256) k_lf_diag_inv(MfmaArgs a, const double* L, double* LK) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const D = smem;
+  double* const Di = D + LB * LBD;
+  double* const d16 = Di + LB * LBD;
+  double* const s16 = d16 + 256;
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, ib = blockIdx.y * LB;
+  const int64_t nf = d.nn + d.na;
+  if (ib >= nn) return;
+  const int w = min(LB, nn - ib);
+  const double* Ab = L + d.blk + ib + (int64_t)ib * nf;
+  for (int e = threadIdx.x; e < w * w; e += blockDim.x) {
+    int i = e % w, j = e / w;
+    D[i + j * LBD] = (i >= j) ? Ab[i + (int64_t)j * nf] : 0.0;
+  }
+  __syncthreads();
+  potrf_inv64(D, w, Di, d16, s16, false);
+  double* Li = LK + d.blk;
+  for (int e = threadIdx.x; e < w * w; e += blockDim.x) {
+    int i = e % w, j = e / w;
+    Li[(ib + i) + (int64_t)(ib + j) * nf] = (i >= j) ? Di[i + j * LBD] : 0.0;
+  }
+  for (int e = threadIdx.x; e < ib * w; e += blockDim.x) {   // rows above the block in these columns
+    int i = e % ib, j = e / ib;
+    Li[i + (int64_t)(ib + j) * nf] = 0.0;
+  }
 }
 __global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, double* LK) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
