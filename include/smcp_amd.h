@@ -38,6 +38,14 @@ typedef struct csp_ctx csp_ctx;
 csp_ctx* csp_symbolic_create(int64_t n, const int64_t* colptr, const int64_t* rowind,
                              const int64_t* perm, int64_t* info);
 void csp_symbolic_destroy(csp_ctx* ctx);
+/* K (<= 16) independent copies of the pattern of `base` as one symbolic object: copy t owns cliques t*nsn .., columns
+ * t*n .. and the blkval range [t*blklen, (t+1)*blklen).  csp_cholesky / csp_completion on it factor K trial matrices
+ * (stored one after the other) with the kernel launches of ONE factorisation, each copy with its own failure flag:
+ * the trial factorisations of the reference's step-length searches (solvers.py:615-689, 928-939, 2172-2209), which
+ * the reference runs one after the other.  The factorisation returns the first failing copy's code;
+ * csp_trial_flags then gives every copy's flag (0 = inside the cone, else 1 + failing clique within the copy). */
+csp_ctx* csp_symbolic_replicate(const csp_ctx* base, int64_t K, int64_t* info);
+int csp_trial_flags(csp_ctx* ctx, int64_t K, int* out);
 
 /* symb.p / snode / snptr / relptr / blkptr ... (cspmatrix internals [EXT], SURVEY App. A.1;
  * supernodes()/separators()/cliques() at analysis.py:173-175).  Returns the number of
@@ -192,20 +200,6 @@ int csp_hessian_sweep_part(csp_ctx* ctx, double* U, int64_t nrhs, int64_t ldu, i
  * to a buffer drops the cache entries derived from it.  A caller that changes the contents of L or
  * Y by any other means (its own kernels, memcpy) must call csp_cache_reset() before the next call. */
 int csp_cache_reset(csp_ctx* ctx);
-
-/* Device-resident line search: the reference's line searches factor X + alpha*dX for a ladder of alpha one
- * after the other, each behind a read-back of the failure flag (src/python/solvers.py:615-689 bisection / backtracking of
- * the feasible-start solver, 928-939, 2172-2209 embedding solver).  Here K trial matrices are factored CONCURRENTLY:
- * reserve K private workspace slots (K <= max_rhs of csp_device_init), launch probe `slot` on its own stream (kind 0:
- * cholesky, 1: completion; in place on x; returns without waiting), synchronise the streams, then read the K failure
- * flags (0 = inside the cone, k+1 = failed at clique k) with one copy. */
-int csp_probe_reserve(csp_ctx* ctx, int64_t K);
-int csp_probe_launch(csp_ctx* ctx, int kind, double* x, int64_t slot, void* stream);
-int csp_probe_results(csp_ctx* ctx, int64_t K, int* out);
-/* The three calls above in one: trial matrices T + k*ldT (k < K <= 16, written on producer_stream) are factored in place
- * on K library-owned streams (SMCP_PROBE_GRAPH=1: after the first run per cone the launch sequence of every slot is
- * replayed from a captured hipGraph).  Returns when all probes are done; out[k] as csp_probe_results. */
-int csp_probe_run(csp_ctx* ctx, int kind, int64_t K, double* T, int64_t ldT, void* producer_stream, int* out);
 
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on its own stream. */

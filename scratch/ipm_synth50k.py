@@ -39,8 +39,25 @@ rows.insert(0, I + n * J); cols.insert(0, np.zeros(nv, dtype=np.int64)); vals.in
 A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows).astype(np.int64), np.concatenate(cols).astype(np.int64))), shape=(n * n, m + 1))
 print("problem built in %.1f s: n=%d |V|=%d m=%d nnz(A_i)=%d" % (time.time() - t0, n, nv, m, per), flush=True)
 solvers.options.update(show_progress=True, maxiters=100)
+if os.environ.get("VERIFY_PROBES"):           # every probe against the same trials factored one after the other
+    orig = chordal.probe_factors
+    stats = {"calls": 0, "bad": 0}
+    def checked(b, d, als, kind):
+        ok, fac = orig(b, d, als, kind)
+        want = []
+        for al in als:
+            T = b + d * al
+            try: (chordal.completion if kind == "p" else chordal.cholesky)(T); want.append(True)
+            except ArithmeticError: want.append(False)
+        stats["calls"] += 1
+        if ok != want:
+            stats["bad"] += 1
+            print("MISMATCH call", stats["calls"], kind, ["%.4g" % a for a in als], ok, want, flush=True)
+        return ok, fac
+    chordal.probe_factors = checked
 t0 = time.time()
 sol = solvers.chordalsolver_feas(A, b, primalstart={"x": X0}, dualstart={"y": y0, "s": S0}, scaling="dual", kktsolver=kktsolver)
 dt = time.time() - t0
+if os.environ.get("VERIFY_PROBES"): print("probe check", stats)
 print("kktsolver", kktsolver, "status", sol["status"], "iterations", sol["iterations"], "pobj %.8g dobj %.8g gap %.2e" % (sol["primal objective"], sol["dual objective"], sol["gap"]),
       "total %.2f s, %.3f s/iteration (incl. symbolic setup)" % (dt, dt / max(1, sol["iterations"])), "dimacs", ["%.1e" % v for v in sol["dimacs"]])

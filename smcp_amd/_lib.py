@@ -18,6 +18,8 @@ c_vp = ctypes.c_void_p
 SIGNATURES = {
     "csp_symbolic_create": (c_vp, [c_i64, c_vp, c_vp, c_vp, c_i64p]),
     "csp_symbolic_destroy": (None, [c_vp]),
+    "csp_symbolic_replicate": (c_vp, [c_vp, c_i64, c_i64p]),
+    "csp_trial_flags": (ctypes.c_int, [c_vp, c_i64, c_vp]),
     "csp_symbolic_query": (c_i64, [c_vp, ctypes.c_int, c_vp]),
     "csp_maxcardsearch": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp]),
     "csp_mindegree": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp]),
@@ -39,10 +41,6 @@ SIGNATURES = {
     "kkt_schur_factor": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kkt_schur_columns": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "csp_cache_reset": (ctypes.c_int, [c_vp]),
-    "csp_probe_reserve": (ctypes.c_int, [c_vp, c_i64]),
-    "csp_probe_launch": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_i64, c_vp]),
-    "csp_probe_results": (ctypes.c_int, [c_vp, c_i64, c_vp]),
-    "csp_probe_run": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "csp_profile_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "csp_profile_kinds": (c_i64, []),
     "csp_profile_filter": (ctypes.c_int, [c_vp, ctypes.c_int]),

@@ -105,34 +105,60 @@ def logdiagsum(X):
     return out.value
 
 
-_probe_streams = []
+PROBE_WIDTH = 8       # trial factorisations per probe round (copies of the pattern in the replicated context)
 
 
-def probe_cone(base, d, alphas, kind):
-    """Concurrent trial factorisations (device-resident line search, include/smcp_amd.h csp_probe_*): for every
-    alpha in `alphas`, is base + alpha * d inside the cone?  kind 'd': positive definite on V (cholesky, the dual cone
-    K_V); kind 'p': positive definite completable (completion, the primal cone C_V).  The K trial matrices are formed
-    with one broadcast, each is factored on its own stream with its own workspace slot, and the K failure flags come
-    back with one copy -- the reference probes them one after the other (solvers.py:615-689)."""
+def _forest(symb, K):
+    """The K-fold replicated Symbolic of `symb` on the same device, with its persistent trial buffer."""
+    import torch
+    fs = symb.__dict__.setdefault("_forests", {})
+    if K not in fs:
+        _ensure(symb)
+        F = symb.replicate(K)
+        F.device_init(symb._device, 1)
+        F.__dict__["_trial_T"] = torch.empty((K, symb.blklen), dtype=torch.float64, device="cuda:%d" % symb._device)
+        fs[K] = F
+    return fs[K]
+
+
+def probe_factors(base, d, alphas, kind):
+    """Trial factorisations of base + alpha * d for every alpha in `alphas` in ONE factorisation of the K-fold
+    replicated pattern (include/smcp_amd.h csp_symbolic_replicate): the launches of a single cholesky (kind 'd': the
+    dual cone K_V) or completion (kind 'p': the primal cone C_V), K times as wide, one failure flag per trial.  The
+    reference factors its trial points one after the other (solvers.py:615-689, 928-939, 2172-2209).
+    Returns (ok, factors): ok[k] = trial k is inside the cone; factors[k] = its factor as a cspmatrix VIEW of the
+    trial buffer (valid until the next probe on this pattern), or None where the trial failed."""
     import torch
     symb = base.symb
     K = len(alphas)
-    _ensure(symb, K)
-    if symb._max_rhs < K:                       # slot s uses right-hand-side copy s of the update workspaces
-        symb.device_init(symb._device, K)
+    # one replicated pattern per base pattern (building it costs about as much as the base context): rounds of fewer
+    # than PROBE_WIDTH trials repeat their last trial, longer lists are split
+    if K > PROBE_WIDTH:
+        ok, fac = [], []
+        for k0 in range(0, K, PROBE_WIDTH):
+            o, f = probe_factors(base, d, alphas[k0:k0 + PROBE_WIDTH], kind)
+            if k0 + PROBE_WIDTH < K:
+                f = [None if x is None else x.copy() for x in f]     # the next round overwrites the trial buffer
+            ok += o
+            fac += f
+        return ok, fac
+    alphas = list(alphas) + [alphas[-1]] * (PROBE_WIDTH - K)
+    F = _forest(symb, PROBE_WIDTH)
+    T = F.__dict__["_trial_T"]
+    al = torch.as_tensor(alphas, dtype=torch.float64, device=T.device)
+    torch.mul(al.unsqueeze(1), d.blkval.unsqueeze(0), out=T)
+    T.add_(base.blkval.unsqueeze(0))
     L = _lib.lib()
-    _chk(L.csp_probe_reserve(symb.handle, K), "csp_probe_reserve")
-    al = torch.as_tensor(list(alphas), dtype=torch.float64, device=base.blkval.device)
-    # persistent trial buffer per pattern: its address is part of the key of the captured launch sequences
-    T = symb.__dict__.get("_probe_T")
-    if T is None or T.shape[0] < K or T.device != base.blkval.device:
-        T = torch.empty((max(K, 8), symb.blklen), dtype=torch.float64, device=base.blkval.device)
-        symb.__dict__["_probe_T"] = T
-    Tk = T[:K]
-    torch.mul(al.unsqueeze(1), d.blkval.unsqueeze(0), out=Tk)
-    Tk.add_(base.blkval.unsqueeze(0))
-    out = (ctypes.c_int * K)()
-    rc = L.csp_probe_run(symb.handle, 1 if kind == "p" else 0, K, Tk.data_ptr(), T.stride(0), _stream(), out)
+    rc = (L.csp_completion if kind == "p" else L.csp_cholesky)(F.handle, T.data_ptr(), _stream())
     if rc < 0:
-        raise RuntimeError("csp_probe_run failed (%d)" % rc)
-    return [out[k] == 0 for k in range(K)]
+        _chk(rc, "probe")
+    flags = (ctypes.c_int * PROBE_WIDTH)()
+    if rc > 0:
+        _chk(L.csp_trial_flags(F.handle, PROBE_WIDTH, flags), "csp_trial_flags")
+    ok = [flags[k] == 0 for k in range(K)]
+    return ok, [cspmatrix(symb, T[k]) if ok[k] else None for k in range(K)]
+
+
+def probe_cone(base, d, alphas, kind):
+    """ok[k]: is base + alphas[k] * d inside the cone?  (probe_factors without the factors.)"""
+    return probe_factors(base, d, alphas, kind)[0]

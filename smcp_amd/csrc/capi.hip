@@ -139,6 +139,7 @@ TreeArgs tree_args(csp_ctx* c) {
   a.updplen = c->S.updplen();
   a.tmp = c->D.tmp;
   a.info = c->D.info;
+  a.nsn1 = (int)(c->S.nsn / c->ntrial);
   a.gp_tptr = c->D.gp_tptr;
   a.gp_tgt = c->D.gp_tgt;
   a.gp_cptr = c->D.gp_cptr;
@@ -155,10 +156,16 @@ int ready(csp_ctx* c) {
 // read back the device failure flag (synchronises the stream)
 int fetch_info(csp_ctx* c, hipStream_t st) {
   if (c->launch_err) { c->launch_err = 0; return SMCP_EHIP; }
-  if (c->nowait) return 0;      // probe launch: the caller collects the flags of all slots later (csp_probe_results)
-  HIPCHK(hipMemcpyAsync(c->D.info_host, c->D.info, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->D.info_host, c->D.info, sizeof(int) * c->ntrial, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  return *c->D.info_host;
+  for (int64_t t = 0; t < c->ntrial; ++t)      // a replicated context: the first copy that failed (csp_trial_flags has them all)
+    if (c->D.info_host[t]) {
+      // the flag must not outlive the call that reports it: kernels of later calls that do not clear it themselves
+      // (the factor of Y_AA inside kkt_qr_solve, say) return early on a set flag and would leave their output stale
+      HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int) * c->ntrial, st));
+      return c->D.info_host[t];
+    }
+  return 0;
 }
 
 constexpr int NT = 256;
@@ -766,16 +773,7 @@ void lf_factor_inverse(csp_ctx* c, const MfmaArgs& a, int cnt, hipStream_t st) {
   }
 }
 
-// In probe mode (c->nowait: the launch sequence may be under stream capture) the failure flag is cleared and the
-// separator blocks are copied by kernels rather than by memset / memcpy nodes
-__global__ void k_zero_flag(int* p) { *p = 0; }
-__global__ void k_copy_doubles(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) dst[e] = src[e];
-}
-inline hipError_t zero_flag(csp_ctx* c, hipStream_t st) {
-  if (c->nowait) { hipLaunchKernelGGL(k_zero_flag, dim3(1), dim3(1), 0, st, c->D.info); return hipGetLastError(); }
-  return hipMemsetAsync(c->D.info, 0, sizeof(int), st);
-}
+inline hipError_t zero_flag(csp_ctx* c, hipStream_t st) { return hipMemsetAsync(c->D.info, 0, sizeof(int) * c->ntrial, st); }
 // yaa <- separator blocks of Y; fac <- their Cholesky factors (need_fac); faci <- inverses of those (need_inv).
 // Each stage is skipped when the cache already holds it for the matrix at this address (see invalidate_tags).
 int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool need_inv) {
@@ -791,11 +789,7 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
   const bool fast = !use_generic() && use_large();
   if (need_fac && c->D.fac_tag != Y) {
     if (fast) {
-      if (c->nowait)
-        hipLaunchKernelGGL(k_copy_doubles, dim3((unsigned)std::min<int64_t>(1024, (c->S.updlen() + 255) / 256 + 1)), dim3(256), 0, st,
-                           (const double*)c->D.yaa, c->D.fac, c->S.updlen());
-      else
-        (void)hipMemcpyAsync(c->D.fac, c->D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(c->D.fac, c->D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st);
       MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
       for (int64_t l = 0; l < c->S.nlev; ++l)
         for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
@@ -1068,23 +1062,80 @@ csp_ctx* csp_symbolic_create(int64_t n, const int64_t* colptr, const int64_t* ro
   return c;
 }
 
+// K independent copies of the pattern as ONE symbolic object: the clique forest in which copy t owns the cliques
+// t * nsn .. (t + 1) * nsn - 1, the columns t * n .., the blkval range [t * blklen, (t + 1) * blklen) and so on.
+// Every tree operation on it runs the launches of one factorisation, K times as wide (the concurrent trial
+// factorisations of the line searches, smcp_amd/chordal.py probe_cone).
+csp_ctx* csp_symbolic_replicate(const csp_ctx* base, int64_t K, int64_t* info) {
+  if (!base || K < 1 || K > 16 || base->ntrial != 1 || base->S.n * K > (int64_t)0x7fffffff) { if (info) *info = SMCP_EINVAL; return nullptr; }
+  csp_ctx* c = new (std::nothrow) csp_ctx();
+  if (!c) { if (info) *info = SMCP_ENOMEM; return nullptr; }
+  const Symbolic& B = base->S;
+  Symbolic& S = c->S;
+  S.n = B.n * K; S.nnz = B.nnz * K; S.nsn = B.nsn * K; S.fill = B.fill * K;
+  S.nlev = B.nlev; S.max_nn = B.max_nn; S.max_na = B.max_na; S.max_front = B.max_front;
+  auto rep_ptr = [&](const std::vector<int64_t>& src, std::vector<int64_t>& dst) {     // pointer array: shift by the copy's total
+    const int64_t cnt = (int64_t)src.size() - 1, tot = src.back();
+    dst.resize(cnt * K + 1);
+    for (int64_t t = 0; t < K; ++t)
+      for (int64_t i = 0; i < cnt; ++i) dst[t * cnt + i] = src[i] + t * tot;
+    dst[cnt * K] = tot * K;
+  };
+  auto rep_val = [&](const auto& src, auto& dst, int64_t shift, bool keep_negative) {  // values: shift by `shift` per copy
+    const int64_t cnt = (int64_t)src.size();
+    dst.resize(cnt * K);
+    for (int64_t t = 0; t < K; ++t)
+      for (int64_t i = 0; i < cnt; ++i)
+        dst[t * cnt + i] = (keep_negative && src[i] < 0) ? src[i] : (decltype(dst[0] + 0))(src[i] + t * shift);
+  };
+  rep_val(B.p, S.p, B.n, false);
+  rep_val(B.ip, S.ip, B.n, false);
+  rep_ptr(B.snptr, S.snptr);
+  rep_val(B.snode, S.snode, B.nsn, false);
+  rep_val(B.snpar, S.snpar, B.nsn, true);
+  rep_ptr(B.rowptr, S.rowptr);
+  rep_val(B.rowidx, S.rowidx, B.n, false);
+  rep_ptr(B.sepptr, S.sepptr);
+  rep_val(B.relidx, S.relidx, 0, false);
+  rep_ptr(B.blkptr, S.blkptr);
+  rep_ptr(B.updptr, S.updptr);
+  rep_ptr(B.updpptr, S.updpptr);
+  rep_ptr(B.chptr, S.chptr);
+  rep_val(B.chidx, S.chidx, B.nsn, false);
+  rep_val(B.level, S.level, 0, false);
+  rep_ptr(B.ccsptr, S.ccsptr);
+  S.levptr.assign(B.nlev + 1, 0);
+  S.levidx.resize(S.nsn);
+  int64_t q = 0;
+  for (int64_t l = 0; l < B.nlev; ++l) {                 // a level of the forest = that level of every copy
+    S.levptr[l] = q;
+    for (int64_t t = 0; t < K; ++t)
+      for (int64_t e = B.levptr[l]; e < B.levptr[l + 1]; ++e) S.levidx[q++] = B.levidx[e] + t * B.nsn;
+  }
+  S.levptr[B.nlev] = q;
+  c->ntrial = K;
+  if (info) *info = 0;
+  return c;
+}
+// failure flags of the copies after csp_cholesky / csp_completion on a replicated context (0 = inside the cone,
+// otherwise 1 + the failing clique within the copy); the factorisation call has already synchronised and read them
+int csp_trial_flags(csp_ctx* c, int64_t K, int* out) {
+  if (!c || !out || K != c->ntrial || c->D.device < 0) return SMCP_EINVAL;
+  for (int64_t t = 0; t < K; ++t) out[t] = c->D.info_host[t];
+  return 0;
+}
+
 void csp_symbolic_destroy(csp_ctx* c) {
   if (!c) return;
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.p_yaa, D.p_fac, D.p_faci, D.p_lfd, D.p_info, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int set = 1; set <= 2; ++set) if (c->sets[set].lev2) hipFree(c->sets[set].lev2);
     if (D.info_host) hipHostFree(D.info_host);
-    for (int q = 0; q < 2; ++q)
-      for (int k = 0; k < DeviceCtx::PROBE_MAX; ++k)
-        if (D.p_graph[q][k]) (void)hipGraphExecDestroy(D.p_graph[q][k]);
-    for (int k = 0; k < DeviceCtx::PROBE_MAX; ++k)
-      if (D.p_stream[k]) (void)hipStreamDestroy(D.p_stream[k]);
-    if (D.p_ev) (void)hipEventDestroy(D.p_ev);
   }
   delete c;
 }
@@ -1217,7 +1268,8 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       std::vector<int32_t> tgt, src;
       cptr.push_back(0);
       std::vector<std::pair<int32_t, int32_t>> pr;  // (target code, src offset)
-      for (int64_t k = 0; k < S.nsn; ++k) {
+      const int64_t nsn1 = S.nsn / c->ntrial;       // a replicated pattern: plan of the first copy, shifted for the others
+      for (int64_t k = 0; k < nsn1; ++k) {
         pr.clear();
         const int64_t nnp = S.nn(k);
         for (int64_t q = S.chptr[k]; q < S.chptr[k + 1]; ++q) {
@@ -1240,6 +1292,17 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
         }
         if (!pr.empty()) cptr.push_back((int64_t)src.size());
         tptr[k + 1] = (int64_t)tgt.size();
+      }
+      if (c->ntrial > 1) {
+        const int64_t nt1 = (int64_t)tgt.size(), ns1 = (int64_t)src.size(), up1 = S.updplen() / c->ntrial;
+        tgt.resize(nt1 * c->ntrial);
+        src.resize(ns1 * c->ntrial);
+        cptr.resize(nt1 * c->ntrial + 1);
+        for (int64_t t = 1; t < c->ntrial; ++t) {
+          for (int64_t k = 0; k < nsn1; ++k) tptr[t * nsn1 + k + 1] = tptr[k + 1] + t * nt1;
+          for (int64_t e = 0; e < nt1; ++e) { tgt[t * nt1 + e] = tgt[e]; cptr[t * nt1 + e + 1] = cptr[e + 1] + t * ns1; }
+          for (int64_t e = 0; e < ns1; ++e) src[t * ns1 + e] = (int32_t)(src[e] + t * up1);
+        }
       }
       // cptr has one entry per target plus the leading 0: make it ntargets+1 long
       if ((rc = dev_upload(&D.gp_tptr, tptr, D.bytes))) return rc;
@@ -1299,8 +1362,8 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     }
     if ((rc = dev_alloc(&D.faci, S.updlen(), D.bytes))) return rc;
     if ((rc = dev_alloc(&D.red, 1024, D.bytes))) return rc;
-    if ((rc = dev_alloc(&D.info, 4, D.bytes))) return rc;
-    HIPCHK(hipMemset(D.info, 0, sizeof(int) * 4));
+    if ((rc = dev_alloc(&D.info, 16, D.bytes))) return rc;
+    HIPCHK(hipMemset(D.info, 0, sizeof(int) * 16));
     HIPCHK(hipHostMalloc((void**)&D.info_host, 64));
     D.device = device;
   } else {
@@ -1313,7 +1376,6 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
   if ((rc = dev_alloc(&D.updp, max_rhs * S.updplen(), D.bytes))) return rc;
   if ((rc = dev_alloc(&D.tmp, max_rhs * D.tmplen, D.bytes))) return rc;
   D.max_rhs = max_rhs;
-  D.ws_gen++;
   return 0;
 }
 
@@ -1544,125 +1606,6 @@ int csp_axpby(int64_t len, double a, const double* x, double b, double* y, void*
   return 0;
 }
 
-
-// ---- device-resident line search: concurrent trial factorisations ---------------------------------
-// The drivers' line searches factor X + alpha dX for a ladder of alpha (solvers.py:615-689, 928-939, 2172-2209), one
-// after the other, each followed by a read-back of the failure flag.  A trial factorisation is a chain of small
-// launches (latency bound), so K of them overlap almost perfectly on K streams -- provided they do not share scratch.
-// Slot s uses right-hand-side copy s of upd / updp / tmp and its own yaa / fac / faci / lfd / failure flag.
-int csp_probe_reserve(csp_ctx* c, int64_t K) {
-  if (int rc = ready(c)) return rc;
-  DeviceCtx& D = c->D;
-  if (K < 1 || K > D.max_rhs) return SMCP_EINVAL;          // upd / updp / tmp hold max_rhs copies
-  if (D.probe_K >= K) return 0;
-  HIPCHK(hipSetDevice(D.device));
-  void* old[] = {D.p_yaa, D.p_fac, D.p_faci, D.p_lfd, D.p_info};
-  for (void* p : old) if (p) (void)hipFree(p);
-  D.p_yaa = D.p_fac = D.p_faci = D.p_lfd = nullptr; D.p_info = nullptr; D.probe_K = 0;
-  const int64_t ul = std::max<int64_t>(c->S.updlen(), 1);
-  int rc;
-  if ((rc = dev_alloc(&D.p_yaa, K * ul, D.bytes))) return rc;
-  if ((rc = dev_alloc(&D.p_fac, K * ul, D.bytes))) return rc;
-  if ((rc = dev_alloc(&D.p_faci, K * ul, D.bytes))) return rc;
-  if ((rc = dev_alloc(&D.p_lfd, K * std::max<int64_t>(D.lfd_len, 1), D.bytes))) return rc;
-  if ((rc = dev_alloc(&D.p_info, K, D.bytes))) return rc;
-  D.probe_K = (int)K;
-  return 0;
-}
-// kind 0: cholesky(x), 1: completion(x), in place, on `stream`, WITHOUT waiting; slot < reserved K.
-int csp_probe_launch(csp_ctx* c, int kind, double* x, int64_t slot, void* stream) {
-  if (int rc = ready(c)) return rc;
-  DeviceCtx& D = c->D;
-  if (slot < 0 || slot >= D.probe_K || (kind != 0 && kind != 1) || use_generic()) return SMCP_EINVAL;
-  const int64_t ul = std::max<int64_t>(c->S.updlen(), 1);
-  // the launches capture their pointer arguments when they are enqueued: shift the workspaces to the slot's copies for
-  // the duration of the (host-side) call and put everything back afterwards
-  struct Saved { double *upd, *updp, *tmp, *yaa, *fac, *faci, *lfd, *lfd_dense; int* info;
-                 const void *lkL, *lkY, *ty, *tf, *tfi; } sv =
-      {D.upd, D.updp, D.tmp, D.yaa, D.fac, D.faci, D.lfd, D.lfd_dense, D.info, D.lk_tag_L, D.lk_tag_Y, D.yaa_tag, D.fac_tag, D.faci_tag};
-  D.upd += slot * c->S.updlen();
-  D.updp += slot * c->S.updplen();
-  D.tmp += slot * D.tmplen;
-  D.yaa = D.p_yaa + slot * ul;
-  D.fac = D.p_fac + slot * ul;
-  D.faci = D.p_faci + slot * ul;
-  D.lfd = D.p_lfd + slot * std::max<int64_t>(D.lfd_len, 1);
-  D.lfd_dense = D.lfd + (D.lfd_len - 64 * 64);
-  D.info = D.p_info + slot;
-  D.yaa_tag = D.fac_tag = D.faci_tag = nullptr;
-  const bool prof = c->prof.on;
-  c->prof.on = false;
-  c->nowait = true;
-  const int rc = kind ? csp_completion(c, x, stream) : csp_cholesky(c, x, stream);
-  c->nowait = false;
-  c->prof.on = prof;
-  D.upd = sv.upd; D.updp = sv.updp; D.tmp = sv.tmp; D.yaa = sv.yaa; D.fac = sv.fac; D.faci = sv.faci;
-  D.lfd = sv.lfd; D.lfd_dense = sv.lfd_dense; D.info = sv.info;
-  D.lk_tag_L = sv.lkL; D.lk_tag_Y = sv.lkY; D.yaa_tag = sv.ty; D.fac_tag = sv.tf; D.faci_tag = sv.tfi;
-  return rc;
-}
-// failure flags of slots 0..K-1 (0 = the trial matrix is in the cone); the caller has synchronised the probes' streams
-int csp_probe_results(csp_ctx* c, int64_t K, int* out) {
-  if (int rc = ready(c)) return rc;
-  if (K < 1 || K > c->D.probe_K || !out) return SMCP_EINVAL;
-  HIPCHK(hipMemcpy(out, c->D.p_info, sizeof(int) * K, hipMemcpyDeviceToHost));
-  return 0;
-}
-
-// K trial matrices T + k*ldT (k < K <= 16) factored concurrently, in place; out[k] = failure flag (0 = in the cone).
-// The trial matrices must have been written on `producer_stream` (the caller's stream); the call returns when all K
-// probes have finished.  A completion is ~40 launches and it is the host's launch rate, not the device, that limits
-// concurrent probes; an opt-in path captures the launch sequence of each (cone, slot) into a hipGraph after one plain
-// run per cone and replays it (see below why it is not the default).
-int csp_probe_run(csp_ctx* c, int kind, int64_t K, double* T, int64_t ldT, void* producer_stream, int* out) {
-  if (int rc = ready(c)) return rc;
-  DeviceCtx& D = c->D;
-  if (K < 1 || K > DeviceCtx::PROBE_MAX || (kind != 0 && kind != 1) || !T || !out || ldT < c->S.blklen()) return SMCP_EINVAL;
-  if (int rc = csp_probe_reserve(c, K)) return rc;
-  HIPCHK(hipSetDevice(D.device));
-  if (!D.p_ev) HIPCHK(hipEventCreateWithFlags(&D.p_ev, hipEventDisableTiming));
-  for (int k = 0; k < K; ++k)
-    if (!D.p_stream[k]) HIPCHK(hipStreamCreateWithFlags(&D.p_stream[k], hipStreamNonBlocking));
-  HIPCHK(hipEventRecord(D.p_ev, (hipStream_t)producer_stream));
-  // Graph replay is opt-in (SMCP_PROBE_GRAPH=1).  It is correct only because the probe path clears its failure flag and
-  // copies the separator blocks with KERNELS (zero_flag, k_copy_doubles): with hipMemsetAsync / hipMemcpyAsync captured as
-  // memset / memcpy nodes, graphs of different slots replayed concurrently came back with spurious failure flags (74 of
-  // 92 rounds of scratch/probe_ipm_verify.py; 0 of 92 with kernel nodes only).  The gain is within noise on the cases
-  // measured (band n = 200: 0.31 vs 0.33 s per solve, synth50k 2.2 s either way), hence not the default.
-  static int nograph = -1;
-  if (nograph < 0) { const char* e = getenv("SMCP_PROBE_GRAPH"); nograph = (e && e[0] == '1') ? 0 : 1; }
-  const bool use_graph = !nograph && D.p_warm[kind];
-  for (int k = 0; k < K; ++k) {
-    hipStream_t st = D.p_stream[k];
-    double* x = T + k * ldT;
-    HIPCHK(hipStreamWaitEvent(st, D.p_ev, 0));
-    bool launched = false;
-    if (use_graph) {
-      if (!D.p_graph[kind][k] || D.p_graph_x[kind][k] != x || D.p_graph_gen[kind][k] != D.ws_gen) {
-        if (D.p_graph[kind][k]) { (void)hipGraphExecDestroy(D.p_graph[kind][k]); D.p_graph[kind][k] = nullptr; }
-        hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
-          const int rc = csp_probe_launch(c, kind, x, k, st);
-          const hipError_t e = hipStreamEndCapture(st, &g);
-          if (rc == 0 && e == hipSuccess && g && hipGraphInstantiate(&D.p_graph[kind][k], g, nullptr, nullptr, 0) == hipSuccess) {
-            D.p_graph_x[kind][k] = x;
-            D.p_graph_gen[kind][k] = D.ws_gen;
-          } else {
-            D.p_graph[kind][k] = nullptr;
-          }
-          if (g) (void)hipGraphDestroy(g);
-        }
-        (void)hipGetLastError();
-      }
-      if (D.p_graph[kind][k]) launched = hipGraphLaunch(D.p_graph[kind][k], st) == hipSuccess;
-    }
-    if (!launched)
-      if (int rc = csp_probe_launch(c, kind, x, k, st)) return rc;
-  }
-  D.p_warm[kind] = true;
-  for (int k = 0; k < K; ++k) HIPCHK(hipStreamSynchronize(D.p_stream[k]));
-  return csp_probe_results(c, K, out);
-}
 
 int csp_cache_reset(csp_ctx* c) {
   if (!c) return SMCP_EINVAL;

@@ -113,22 +113,7 @@ struct DeviceCtx {
   bool part_valid = false;     // lk / yaa / fac hold the sharded factor prepared by kkt_prepare_part (sets 2 then 1)
   bool qr_valid = false;       // ustack holds Q and qr_ws the factor for the matrices (qr_L, qr_Y)
   const void* qr_L = nullptr; const void* qr_Y = nullptr;
-  // probe slots (csp_probe_*): K private copies of the workspaces a trial factorisation writes besides the
-  // per-right-hand-side ones (upd / updp / tmp are indexed by the slot as if it were a right-hand side)
-  int probe_K = 0;
-  int64_t lfd_len = 0;         // doubles of one lfd copy (large-front slots + the dense slot)
-  double* p_yaa = nullptr; double* p_fac = nullptr; double* p_faci = nullptr; double* p_lfd = nullptr;
-  int* p_info = nullptr;       // K device failure flags
-  // csp_probe_run: one stream and one captured launch sequence (hipGraph) per (cone, slot); a graph is replayed as
-  // long as the trial buffer and the workspaces it was captured with are unchanged (ws_gen)
-  static constexpr int PROBE_MAX = 16;
-  hipStream_t p_stream[PROBE_MAX] = {};
-  hipGraphExec_t p_graph[2][PROBE_MAX] = {};
-  const void* p_graph_x[2][PROBE_MAX] = {};
-  int64_t p_graph_gen[2][PROBE_MAX] = {};
-  bool p_warm[2] = {false, false};
-  hipEvent_t p_ev = nullptr;
-  int64_t ws_gen = 0;          // bumped whenever csp_device_init (re)allocates workspaces
+  int64_t lfd_len = 0;         // doubles of lfd (large-front slots + the dense slot)
   int64_t bytes = 0;
 };
 
@@ -191,8 +176,8 @@ struct csp_ctx {
   std::vector<int> lev_namax;   // per level: largest separator (sizes the gather launches)
   std::vector<int64_t> fam;     // per clique: family role (CSP_Q_FAMILY)
   std::vector<uint8_t> is_diag_cache;
+  int64_t ntrial = 1;                   // copies of the pattern in S (csp_symbolic_replicate): one failure flag per copy
   int launch_err = 0;                   // first failed kernel launch of the running call (launch helpers); read by end_call
-  bool nowait = false;                  // csp_probe_launch: factorisations return without reading the failure flag back
   double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)
   std::vector<int64_t> h_kptr;          // ns + 1 : offsets into kidx, host copy for chunk planning
   std::vector<int32_t> h_slist;

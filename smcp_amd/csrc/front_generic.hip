@@ -26,13 +26,18 @@ struct TreeArgs {
   double* updp;        // packed child->parent exchange buffer (fast kernels)
   int64_t updplen;
   double* tmp;
-  int* info;
+  int* info;           // failure flags: one per copy of the pattern (a replicated context factors ntrial matrices at once)
+  int nsn1;            // cliques per copy (= nsn of an ordinary context): clique k belongs to copy k / nsn1
   // extend-add gather plan (null = not available)
   const int64_t* gp_tptr;
   const int32_t* gp_tgt;
   const int64_t* gp_cptr;
   const int32_t* gp_src;
 };
+
+// failure flag of the copy clique k belongs to, and the value a failure in clique k leaves there
+__device__ inline int* info_of(const TreeArgs& t, int k) { return t.info + k / t.nsn1; }
+__device__ inline int info_val(const TreeArgs& t, int k) { return k % t.nsn1 + 1; }
 
 // ---- extend-add / gather -------------------------------------------------------------
 __device__ inline void add_children(const TreeArgs& a, const CliqueDesc& d, const double* updbase,
@@ -81,8 +86,8 @@ __global__ void k_gather_level(TreeArgs a, const double* x, int64_t ldx, double*
 
 // ---- cholesky ------------------------------------------------------------------------
 __global__ void k_chol_level(TreeArgs a, double* x) {
-  if (*a.info) return;
   const int k = a.lev[blockIdx.x];
+  if (*info_of(a, k)) return;
   const CliqueDesc d = a.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
   double* P = x + d.blk;
@@ -91,7 +96,7 @@ __global__ void k_chol_level(TreeArgs a, double* x) {
   add_children(a, d, a.upd, P, Uk, 1.0, 1.0);
   int f = potrf(nn, P, nf);
   if (f) {
-    if (SMCP_TID == 0) atomicCAS(a.info, 0, k + 1);
+    if (SMCP_TID == 0) atomicCAS(info_of(a, k), 0, info_val(a, k));
     return;
   }
   if (na) {
@@ -161,7 +166,7 @@ __global__ void k_completion_all(TreeArgs a, double* x) {
   double* T = Mi + (int64_t)nn * nn;       // na x nn
   if (na) {
     int f = potrf(na, R, na);
-    if (f) { if (SMCP_TID == 0) atomicCAS(a.info, 0, k + 1); return; }
+    if (f) { if (SMCP_TID == 0) atomicCAS(info_of(a, k), 0, info_val(a, k)); return; }
     trsm_llN(na, nn, R, na, P + nn, nf);  // Z = R^-1 X_AN
   }
   // Sigma = X_NN - Z^T Z, stored reversed: Sg[i,j] = Sigma[nn-1-i, nn-1-j]
@@ -174,7 +179,7 @@ __global__ void k_completion_all(TreeArgs a, double* x) {
   }
   __syncthreads();
   int f = potrf(nn, Sg, nn);
-  if (f) { if (SMCP_TID == 0) atomicCAS(a.info, 0, k + 1); return; }
+  if (f) { if (SMCP_TID == 0) atomicCAS(info_of(a, k), 0, info_val(a, k)); return; }
   set_identity(nn, Mi, nn);
   trsm_llN(nn, nn, Sg, nn, Mi, nn);  // Mi = M^-1 (lower)
   // L_NN[i,j] = Mi[nn-1-j, nn-1-i]
@@ -417,7 +422,7 @@ __global__ void k_factor_yaa(TreeArgs a, const double* yaa, double* fac) {
   double* R = fac + d.upd;
   copy_lower(na, yaa + d.upd, na, R, na);
   int f = potrf(na, R, na);
-  if (f && SMCP_TID == 0) atomicCAS(a.info, 0, k + 1);
+  if (f && SMCP_TID == 0) atomicCAS(info_of(a, k), 0, info_val(a, k));
 }
 
 // ---- supernodal triangular solves with a dense right-hand side ------------------------

@@ -261,7 +261,7 @@ __global__ void k_completion_mfma(MfmaArgs a, double* x) {
          });
   __syncthreads();
   int f = wg_potrf_blocked(nn, v.T, v.ldt, D16);
-  if (f) { if (threadIdx.x == 0) atomicCAS(a.t.info, 0, k + 1); return; }
+  if (f) { if (threadIdx.x == 0) atomicCAS(info_of(a.t, k), 0, info_val(a.t, k)); return; }
   wg_tri_inverse(nn, v.T, v.ldt, v.Fnn, v.ldn, D16, S);       // Mi = M^-1 (lower)
   // L_NN[i][j] = Mi[nn-1-j][nn-1-i] (i >= j), zeros above
   for (int e = threadIdx.x; e < nn * nn; e += blockDim.x) {

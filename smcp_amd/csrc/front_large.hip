@@ -661,8 +661,8 @@ __global__ void __launch_bounds__(256) k_lf_diag(MfmaArgs a, double* x, double* 
   double* const Di = D + LB * LBD;
   double* const d16 = Di + LB * LBD;
   double* const s16 = d16 + 256;
-  if (*a.t.info) return;
   const int k = a.t.lev[blockIdx.x];
+  if (*info_of(a.t, k)) return;
   const LfMat M = lf_mat(a, k, mode, x, aux);
   if (jb >= M.ncol) return;
   const int w = min(LB, M.ncol - jb);
@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(256) k_lf_diag(MfmaArgs a, double* x, double* 
   }
   __syncthreads();
   int f = potrf_inv64(D, w, Di, d16, s16, do_potrf != 0);
-  if (f) { if (threadIdx.x == 0) atomicCAS(a.t.info, 0, k + 1); return; }
+  if (f) { if (threadIdx.x == 0) atomicCAS(info_of(a.t, k), 0, info_val(a.t, k)); return; }
   for (int e = threadIdx.x; e < w * w; e += blockDim.x) {
     int i = e % w, j = e / w;
     if (do_potrf && i >= j) Ab[i + (int64_t)j * M.ld] = D[i + j * LBD];
@@ -683,8 +683,8 @@ __global__ void __launch_bounds__(256) k_lf_diag(MfmaArgs a, double* x, double* 
 // panel step: rows below the diagonal block <- rows * Dinv^T   (one 64x64 tile per workgroup, in place)
 __global__ void __launch_bounds__(256) k_lf_chol_panel(MfmaArgs a, double* x, double* aux, int mode, int jb) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
-  if (*a.t.info) return;
   const int k = a.t.lev[blockIdx.y];
+  if (*info_of(a.t, k)) return;
   const LfMat M = lf_mat(a, k, mode, x, aux);
   if (jb >= M.ncol) return;
   const int w = min(LB, M.ncol - jb);
@@ -704,8 +704,8 @@ __global__ void __launch_bounds__(256) k_lf_chol_panel(MfmaArgs a, double* x, do
 // trailing step: remaining columns of the panel and the update block -= P P^T (lower tiles)
 __global__ void __launch_bounds__(256) k_lf_chol_trail(MfmaArgs a, double* x, double* aux, int mode, int jb) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
-  if (*a.t.info) return;
   const int k = a.t.lev[blockIdx.y];
+  if (*info_of(a.t, k)) return;
   const LfMat M = lf_mat(a, k, mode, x, aux);
   if (jb >= M.ncol) return;
   const int w = min(LB, M.ncol - jb);
@@ -773,8 +773,8 @@ __host__ __device__ inline size_t mid_chol_lds(int rowsmax) { return ((size_t)mi
 
 __global__ void __launch_bounds__(1024) k_mid_chol(MfmaArgs a, double* x, double* aux, int mode) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (*a.t.info) return;
   const int k = a.t.lev[blockIdx.x];
+  if (*info_of(a.t, k)) return;
   const LfMat M = lf_mat(a, k, mode, x, aux);
   const CliqueDesc d = a.t.cl[k];
   const int tid = threadIdx.x;
@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(1024) k_mid_chol(MfmaArgs a, double* x, double
     for (int jj = 0; jj < w; jj += 16) {
       const int bw = min(16, w - jj);
       const int f = potrf_inv16(Pb + jj + jj * ldp, ldp, bw, d16);
-      if (f) { if (tid == 0) atomicCAS(a.t.info, 0, k + 1); return; }
+      if (f) { if (tid == 0) atomicCAS(info_of(a.t, k), 0, info_val(a.t, k)); return; }
       const int rbelow = rows - jj - bw, crem = w - jj - bw;
       if (rbelow > 0) {
         double* Sb = Pb + (jj + bw) + jj * ldp;          // rows below the diagonal block, this step's columns
@@ -1158,8 +1158,8 @@ __global__ void __launch_bounds__(256) k_lf_uinv2(MfmaArgs a, double* u, int64_t
 // step 0: E = Ri X_AN ; step 1: G = Ri^T E ; step 2: T = reversed(X_NN - X_AN^T G) ; step 3: L_NN = reversed(T^-1)^T, L_AN = -G L_NN
 __global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, int step) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
-  if (*a.t.info) return;
   const LfCtx c = lf_ctx(a, x, 0);
+  if (*info_of(a.t, c.k)) return;
   const int nn = c.nn, na = c.na, nf = c.nf;
   const int mtA = tiles64(na), ntN = tiles64(nn);
   const int t = blockIdx.x;

@@ -559,8 +559,8 @@ __global__ void k_hess_down_mfma(MfmaArgs a, double* u, int64_t ldu) {
 template <bool LDS>
 __global__ void k_chol_mfma(MfmaArgs a, double* x) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (*a.t.info) return;
   const int k = a.t.lev[blockIdx.x];
+  if (*info_of(a.t, k)) return;
   const CliqueDesc d = a.t.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
   Work w = make_work<LDS>(a, d, smem, k, 0);
@@ -585,7 +585,7 @@ __global__ void k_chol_mfma(MfmaArgs a, double* x) {
   for (int jb = 0; jb < nn; jb += 16) {
     const int bw = min(16, nn - jb);
     int f = potrf_inv16(v.F + jb + jb * v.ldf, v.ldf, bw, v.D16);
-    if (f) { if (threadIdx.x == 0) atomicCAS(a.t.info, 0, k + 1); return; }
+    if (f) { if (threadIdx.x == 0) atomicCAS(info_of(a.t, k), 0, info_val(a.t, k)); return; }
     const int mrem = nf - jb - bw, ncr = nn - jb - bw;
     const double* Pj = v.F + (jb + bw) + jb * v.ldf;  // rows below the diagonal block, block column jb
     double* Pw = v.F + (jb + bw) + jb * v.ldf;
@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(256) k_factor_yaa_lds(MfmaArgs a, const double
   for (int jb = 0; jb < na; jb += 16) {
     const int bw = min(16, na - jb);
     int f = potrf_inv16(M + jb + jb * ld, ld, bw, D16);
-    if (f) { if (threadIdx.x == 0) atomicCAS(a.t.info, 0, k + 1); return; }
+    if (f) { if (threadIdx.x == 0) atomicCAS(info_of(a.t, k), 0, info_val(a.t, k)); return; }
     const int mrem = na - jb - bw;
     if (mrem > 0) {
       double* Pj = M + (jb + bw) + jb * ld;

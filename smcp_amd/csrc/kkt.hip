@@ -829,6 +829,7 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
     if (D.max_rhs < 2) return SMCP_ENOMEM;
     ytmp = D.ustack + bl;
   }
+  HIPCHK(zero_flag(c, st));
   // the Y_AA cache must correspond to (L, Y): recompute (cheap, one gather sweep)
   if (!(c->D.yaa_tag == Y && c->D.yaa_tag)) prepare_yaa(c, Y, false, st);
   if (!use_generic()) prep_lk_cached(c, L, Y, st);

@@ -479,6 +479,7 @@ int kkt_qr_solve(csp_ctx* c, const double* L, const double* Y, double kk, double
   double* r2 = xm + m;
   // the half-Hessians below need chol(Y_AA), not only Y_AA (kkt_solve's full Hessian does with the latter): another
   // factorisation between kkt_qr_factor and this call (a line-search completion, say) leaves the cache with its own
+  HIPCHK(zero_flag(c, st));
   prepare_yaa(c, Y, true, st);
   prep_lk_cached(c, L, Y, st);
   HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));

@@ -189,6 +189,44 @@ def _nrm2(a):
     return float(torch.linalg.vector_norm(a).item())
 
 
+def _batched():
+    return bool(options.get("batched_linesearch", True)) and (torch.cuda.is_available()
+                                                               or getattr(chordal, "_probe_emulated", False))
+
+
+def _backtrack(base, d, which, s, beta, smin, accept=None, batch=8, strict=False):
+    """The reference's backtracking loops (solvers.py:928-939, 2172-2209): the first step of s, s*beta, s*beta^2, ...
+    (while >= smin) for which base + step * d is inside the cone `which` ('p': completion, 'd': cholesky) and
+    accept(factor, step) holds (if given).  Returns the step, or None when the steps run out.
+    The trial points are the reference's and are examined in the reference's order, so the result is the same;
+    with options['batched_linesearch'] everything after a first failure is factored `batch` steps at a time in one
+    factorisation of the replicated pattern (chordal.probe_factors) instead of one after the other."""
+    op = chordal.completion if which == "p" else chordal.cholesky
+    first = True
+    more = (lambda v: v > smin) if strict else (lambda v: v >= smin)
+    while more(s):
+        if first or not _batched():
+            first = False
+            T = base + d * s
+            try:
+                op(T)
+                if accept is None or accept(T, s):
+                    return s
+            except ArithmeticError:
+                pass
+            s *= beta
+            continue
+        steps = []
+        while len(steps) < batch and more(s):
+            steps.append(s)
+            s *= beta
+        ok, fac = chordal.probe_factors(base, d, steps, which)
+        for k, st_ in enumerate(steps):
+            if ok[k] and (accept is None or accept(fac[k], st_)):
+                return st_
+    return None
+
+
 def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", kktsolver="chol", p=None):
     """Extended self-dual embedding solver for
 
@@ -396,25 +434,10 @@ def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", 
             s *= BETA
             if s < MINSTEP:
                 return None
-        while True:
-            Lt = X + dX * s
-            try:
-                chordal.completion(Lt)
-                break
-            except ArithmeticError:
-                s *= BETA
-                if s < MINSTEP:
-                    return None
-        while True:
-            Lt = S + dS * s
-            try:
-                chordal.cholesky(Lt)
-                break
-            except ArithmeticError:
-                s *= BETA
-                if s < MINSTEP:
-                    return None
-        return s
+        s = _backtrack(X, dX, "p", s, BETA, MINSTEP)
+        if s is None:
+            return None
+        return _backtrack(S, dS, "d", s, BETA, MINSTEP)
 
     if show_progress:
         print("smcp_amd: extended self-dual embedding, %s scaling (Cholesky), n=%d m=%d cliques=%d%s"
@@ -633,6 +656,11 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
         lo, hi, g_ = MINSTEP, 1.0, MINSTEP
         if BATCHED:
             KP = 8
+            try:                               # the full step first, on its own: one factorisation instead of a round
+                in_cone(base_ + d, which)
+                return a
+            except ArithmeticError:
+                pass
             for _ in range(3):
                 pts = [lo + (hi - lo) * (k + 1) / KP for k in range(KP)]
                 ok = chordal.probe_cone(base_, d, pts, which)
@@ -677,37 +705,43 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
                 g_ = None
         return g_ if g_ else lo
 
+    def _last_step(smin, strict):
+        g = last = 1.0
+        while (g > smin) if strict else (g >= smin):
+            last = g
+            g *= BETA
+        return last, g
+
     def backtrack_primal(X, dx, tt, ntd):
         """Damped centering step on X (solvers.py:928-939)."""
-        gam, logdetL, tdcdx = 1.0, chordal.logdiagsum(st["L"]), tt * dot(C, dx)
-        Xt = X
-        while gam > MINSTEP:
-            Xt = X + dx * gam
-            val = tdcdx + gam * ALPHA * ntd ** 2
-            try:
-                Lt = in_cone(Xt, "p")
-                if gam * val < 2 * (logdetL - chordal.logdiagsum(Lt)):
-                    break
-            except ArithmeticError:
-                pass
-            gam *= BETA
-        return Xt, gam
+        logdetL, tdcdx = chordal.logdiagsum(st["L"]), tt * dot(C, dx)
+
+        def accept(Lt, gam):
+            return gam * (tdcdx + gam * ALPHA * ntd ** 2) < 2 * (logdetL - chordal.logdiagsum(Lt))
+
+        gam = _backtrack(X, dx, "p", 1.0, BETA, MINSTEP, accept, strict=True)
+        if gam is None:                      # steps exhausted: the reference leaves the loop with its last trial
+            last, gam = _last_step(MINSTEP, True)
+            return X + dx * last, gam
+        return X + dx * gam, gam
 
     def backtrack_dual(y, dy, tt, ntd):
-        gam, logdetL, ddyb = 1.0, chordal.logdiagsum(st["L"]), -tt * _dot(dy, bv)
-        yt, St = y, None
-        while gam > MINSTEP:
-            yt = y + gam * dy
-            St = S_of(yt)
-            val = ddyb + gam * ALPHA * ntd ** 2
-            try:
-                Lt = in_cone(St, "d")
-                if gam * val < 2 * (chordal.logdiagsum(Lt) - logdetL):
-                    break
-            except ArithmeticError:
-                pass
-            gam *= BETA
-        return yt, St, gam
+        logdetL, ddyb = chordal.logdiagsum(st["L"]), -tt * _dot(dy, bv)
+
+        def accept(Lt, gam):
+            return gam * (ddyb + gam * ALPHA * ntd ** 2) < 2 * (chordal.logdiagsum(Lt) - logdetL)
+
+        gam = _backtrack(S_of(y), Aadj(-dy), "d", 1.0, BETA, MINSTEP, accept, strict=True)
+        last = gam
+        if gam is None:
+            last, gam = _last_step(MINSTEP, True)
+        yt = y + last * dy
+        return yt, S_of(yt), gam
+
+    def step_into_cone(base_, d, which):
+        """gam = 1, BETA, BETA^2, ... until base_ + gam d is inside the cone (or gam < 1e-14: the last trial is kept)."""
+        gam = _backtrack(base_, d, which, 1.0, BETA, 1e-14)
+        return gam if gam is not None else _last_step(1e-14, False)[0]
 
     # ---- starting points (solvers.py:691-814) ---------------------------------------------
     X = y = S = None
@@ -904,18 +938,9 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
                         X, _g = backtrack_primal(X, dx, t, ntd)
                     else:
                         X += dx
-                    gam = 1.0
-                    while True:
-                        yt = y + gam * dy
-                        St = S_of(yt)
-                        try:
-                            in_cone(St, "d")
-                            break
-                        except ArithmeticError:
-                            gam *= BETA
-                            if gam < 1e-14:
-                                break
-                    y, S = yt, St
+                    gam = step_into_cone(S_of(y), Aadj(-dy), "d")
+                    y = y + gam * dy
+                    S = S_of(y)
                 else:
                     ntd = ntdecr_dual(dy)
                     if ntd >= 1.0:
@@ -923,17 +948,7 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
                     else:
                         y = y + dy
                         S = S_of(y)
-                    gam = 1.0
-                    while True:
-                        Xt = X + dx * gam
-                        try:
-                            in_cone(Xt, "p")
-                            break
-                        except ArithmeticError:
-                            gam *= BETA
-                            if gam < 1e-14:
-                                break
-                    X = Xt
+                    X = X + dx * step_into_cone(X, dx, "p")
             try:
                 in_cone(X, "p")
                 in_cone(S, "d")

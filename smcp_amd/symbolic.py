@@ -71,6 +71,9 @@ class Symbolic:
         self._h = L.csp_symbolic_create(n, _ptr(cp), _ptr(ri), _ptr(perm), ctypes.byref(info))
         if not self._h:
             raise ValueError("csp_symbolic_create failed (%d)" % info.value)
+        self._finish()
+
+    def _finish(self):
         sc = self._query("scalars")
         (self.n, self.nnz, self.Nsn, self.fill, self.blklen, self.updlen, self.nlev, self.max_nn,
          self.max_na, self.max_front) = [int(v) for v in sc]
@@ -86,6 +89,20 @@ class Symbolic:
             except Exception:
                 pass
             self._h = None
+
+    def replicate(self, K):
+        """K independent copies of this pattern as one Symbolic (csp_symbolic_replicate): copy t owns the blkval range
+        [t * blklen, (t + 1) * blklen).  One cholesky / completion on it factors K trial matrices at once."""
+        info = ctypes.c_int64(0)
+        h = _lib.lib().csp_symbolic_replicate(self._h, int(K), ctypes.byref(info))
+        if not h:
+            raise ValueError("csp_symbolic_replicate failed (%d)" % info.value)
+        F = Symbolic.__new__(Symbolic)
+        F._cp = F._ri = None
+        F._h = h
+        F.copies = int(K)
+        F._finish()
+        return F
 
     def _query(self, what):
         L = _lib.lib()

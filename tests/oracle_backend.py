@@ -185,17 +185,24 @@ def oracle_backend():
     chordal.hessian = hessian
     chordal.trsm = lambda L, B, trans="N": orc.trsm(_S(L.symb), _np(L), B.numpy(), trans)
 
-    def probe_cone(base, d, alphas, kind):          # the concurrent probes, emulated one after the other
-        out = []
+    def probe_factors(base, d, alphas, kind):       # the trial factorisations of one probe, emulated one after the other
+        ok, fac = [], []
         for al in alphas:
             t = _np(base) + al * _np(d)
             try:
                 (orc.completion if kind == "p" else orc.cholesky)(_S(base.symb), t)
-                out.append(True)
+                ok.append(True)
+                fac.append(cspmatrix(base.symb, torch.from_numpy(t)))
             except ArithmeticError:
-                out.append(False)
-        return out
+                ok.append(False)
+                fac.append(None)
+        return ok, fac
 
+    def probe_cone(base, d, alphas, kind):
+        return probe_factors(base, d, alphas, kind)[0]
+
+    saved["probe_factors"] = getattr(chordal, "probe_factors", None)
+    chordal.probe_factors = probe_factors
     saved["probe_cone"] = getattr(chordal, "probe_cone", None)
     saved["_probe_emulated"] = getattr(chordal, "_probe_emulated", False)
     chordal.probe_cone = probe_cone

@@ -454,6 +454,66 @@ def test_concurrent_cone_probes_match_sequential_factorisations(name):
     assert rel(host(Ub)[msk], host(Ua)[msk]) < 1e-13
 
 
+@pytest.mark.parametrize("name", ["nested_mid", "arrow_big", "band", "fam_odd", "rand2", "diag"])
+def test_trial_factorisations_against_the_oracle(name):
+    """Step-length probes on the replicated pattern (csp_symbolic_replicate + one csp_cholesky / csp_completion for all
+    trials): the in-cone verdict of every trial equals the ORACLE's cholesky / completion of the same trial matrix,
+    and the factors of the trials inside the cone match the oracle's factors."""
+    symb, S, A, msk = setup(name, 71)
+    D = problems.random_factor_blkval(symb, 72)
+    orc.llt(S, D)
+    D *= -1.0
+    X, Dm = dev(symb, A), dev(symb, D)
+    for K, als in ((8, [0.02 * 2 ** k for k in range(8)]), (5, [0.0, 0.3, 0.01, 5.0, 0.05])):
+        for kind, op in (("d", orc.cholesky), ("p", orc.completion)):
+            ok, fac = chordal.probe_factors(X, Dm, als, kind)
+            want = []
+            for k, al in enumerate(als):
+                T = A + al * D
+                try:
+                    op(S, T)
+                    want.append(True)
+                    assert ok[k] and rel(host(fac[k])[msk], T[msk]) < TOL
+                except ArithmeticError:
+                    want.append(False)
+            assert ok == want and any(want) and not all(want)
+    # the base context is untouched: an ordinary factorisation still works and gives the oracle's factor
+    Lc = X.copy()
+    chordal.cholesky(Lc)
+    Lo = A.copy()
+    orc.cholesky(S, Lo)
+    assert rel(host(Lc)[msk], Lo[msk]) < TOL
+
+
+@pytest.mark.parametrize("name", ["arrow_big", "nested_mid"])
+def test_failed_factorisation_does_not_poison_later_calls(name):
+    """A trial matrix outside the cone (ArithmeticError from completion / cholesky, the everyday event of a line search)
+    must not leave the device failure flag behind: kernels of later calls return early on a set flag, and kkt_qr's
+    solve_ -- which refactors Y_AA without a failure check of its own -- then worked with a stale factor (found as a
+    36 -> 42 iteration drift of the arrow_feas_qr golden case once a line search probed on the main context)."""
+    symb, S, msk, L, Yh, cptr, cidx, cval = _kkt_qr_case(name, 8, 81)
+    sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=8, tnzcols=0.0)
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    rng = np.random.default_rng(82)
+    b0 = rng.standard_normal(symb.blklen) * msk
+    y0 = rng.standard_normal(8)
+    bad = S.project(np.eye(symb.n)) * -1.0                     # negative definite: every factorisation of it fails
+    for factor in (sys_.factor_qr, sys_.factor):
+        solve = factor(Ld, Yd)
+
+        def run():
+            bx, by = dev(symb, b0), torch.from_numpy(y0.copy()).cuda()
+            solve(bx, by, 0.7)
+            return host(bx), by.cpu().numpy()
+
+        x1, y1 = run()
+        for op in (chordal.completion, chordal.cholesky):
+            with pytest.raises(ArithmeticError):
+                op(dev(symb, bad))
+            x2, y2 = run()
+            assert rel(x2[msk], x1[msk]) < 1e-12 and rel(y2, y1) < 1e-12
+
+
 def _kkt_qr_case(name, m, seed, density=0.05):
     symb, S, A, msk = setup(name, seed)
     L = A.copy()

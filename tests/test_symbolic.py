@@ -127,3 +127,29 @@ def test_index_map_roundtrip():
     assert (pos >= 0).all() and len(np.unique(pos)) == len(pos)
     assert (np.sort(pos) == np.sort(s.ccs_to_blk())).all()
     assert (s.index_map(cols, ri) == pos).all()          # symmetric lookup
+
+
+@pytest.mark.parametrize("name", sorted(PATTERNS))
+def test_replicated_symbolic_is_k_independent_copies(name):
+    """csp_symbolic_replicate (the trial forest of the step-length searches): copy t of every index array is the
+    base array shifted by t times the base totals; levels are the union of the copies' levels."""
+    s = Symbolic(PATTERNS[name]())
+    K = 3
+    F = s.replicate(K)
+    assert (F.n, F.nnz, F.Nsn, F.blklen, F.updlen, F.nlev) == (K * s.n, K * s.nnz, K * s.Nsn, K * s.blklen, K * s.updlen, s.nlev)
+    assert (F.max_nn, F.max_na, F.max_front) == (s.max_nn, s.max_na, s.max_front)
+    for name_, tot in (("snptr", s.n), ("blkptr", s.blklen), ("updptr", s.updlen), ("rowptr", len(s.rowidx)),
+                       ("sepptr", len(s.relidx)), ("chptr", len(s.chidx)), ("ccsptr", s.nnz)):
+        a, f = getattr(s, name_), getattr(F, name_)
+        assert np.array_equal(f, np.concatenate([a[:-1] + t * tot for t in range(K)] + [[K * tot]])), name_
+    assert np.array_equal(F.rowidx, np.concatenate([s.rowidx + t * s.n for t in range(K)]))
+    assert np.array_equal(F.relidx, np.tile(s.relidx, K))
+    assert np.array_equal(F.chidx, np.concatenate([s.chidx + t * s.Nsn for t in range(K)]))
+    assert np.array_equal(F.snpar, np.concatenate([np.where(s.snpar >= 0, s.snpar + t * s.Nsn, -1) for t in range(K)]))
+    assert np.array_equal(F.p, np.concatenate([np.asarray(s.p) + t * s.n for t in range(K)]))
+    for l in range(s.nlev):
+        base = s.levidx[s.levptr[l]:s.levptr[l + 1]]
+        got = F.levidx[F.levptr[l]:F.levptr[l + 1]]
+        assert sorted(got.tolist()) == sorted(np.concatenate([base + t * s.Nsn for t in range(K)]).tolist())
+    with pytest.raises(ValueError):
+        F.replicate(2)                                  # a forest is not replicated again
