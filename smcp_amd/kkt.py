@@ -199,7 +199,7 @@ class ShardedSchur:
     def _solve_sharded(self, L, Y, bx, by, kk, group, complete):
         """solve_ of kkt_chol (solvers.py:521-541) on a sharded factor: both Hessians run as owned sweep -> exchange ->
         top (up), top -> owned (down); Amap sums over the blkval ranges this rank accounts for and ONE all-reduce
-        completes it; the m x m solve is replicated.  With complete=True one more all-reduce fills x in on every
+        completes it; the m x m solve is replicated.  With complete=True one all-gather of the owned ranges fills x in on every
         rank, otherwise x is valid on the owned cliques and the top (what the next sharded sweep needs)."""
         def W(U):
             self._hess_part(U, 1, 0)
@@ -221,11 +221,35 @@ class ShardedSchur:
         W(bx)
         bx.blkval.mul_(1.0 / kk)
         if complete:
-            bx.blkval.mul_(self._own_mask)
-            _all_reduce(bx.blkval, group)
-            self.collectives += 1
+            self._complete_owned(bx, group)
         bx.touched()
         return bx, by
+
+    def _complete_owned(self, X, group):
+        """Fill X in on every rank: each rank contributes the blkval ranges of its subtrees (the top is already valid
+        everywhere) through ONE all-gather -- |V| / world doubles sent per rank instead of an all-reduce of all of V."""
+        world, rank = self._world(group)
+        P = self.partition
+        lens = [sum(b - a for a, b in P.ranges_by_rank[r]) for r in range(world)]
+        width = max(max(lens), 1)
+        bufs = self.__dict__.setdefault("_xchg", {})
+        if ("own", width) not in bufs:
+            bufs[("own", width)] = (torch.zeros(width, dtype=torch.float64, device=self.dev),
+                                    torch.empty(width * world, dtype=torch.float64, device=self.dev))
+        send, recv = bufs[("own", width)]
+        o = 0
+        for a, b in P.ranges_by_rank[rank]:
+            send[o:o + b - a].copy_(X.blkval[a:b])
+            o += b - a
+        _all_gather_into(recv, send, group)
+        self.collectives += 1
+        for r in range(world):
+            if r == rank:
+                continue
+            o = r * width
+            for a, b in P.ranges_by_rank[r]:
+                X.blkval[a:b].copy_(recv[o:o + b - a])
+                o += b - a
 
     def _exchange_size(self, cliques, nrhs):
         na = np.diff(self.symb.rowptr) - np.diff(self.symb.snptr)
