@@ -186,9 +186,9 @@ def main():
             kkt.factor(Ls, Ys, dist.group.WORLD)(bx, by, 1.0)
             return
         L.blkval.copy_(S.blkval)
-        chk(lib.csp_cholesky(h, L.blkval.data_ptr(), st()), "cholesky")
+        chordal.cholesky(L)                  # csp_cholesky
         Y.blkval.copy_(L.blkval)
-        chk(lib.csp_projected_inverse(h, Y.blkval.data_ptr(), st()), "projected_inverse")
+        chordal.projected_inverse(Y)         # csp_projected_inverse (leaves the inverse-form factor of L for the sweeps)
         if args.kktsolver == "qr":
             kkt.factor_qr(L, Y, dist.group.WORLD if world > 1 else None)(bx, by, 1.0)
             return

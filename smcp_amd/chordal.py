@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .cspmatrix import cspmatrix, _stream, sync_cache
+from .cspmatrix import cspmatrix, _stream, note_cache, sync_cache
 
 
 def _chk(rc, what):
@@ -31,25 +31,37 @@ def _ensure(symb, nrhs=1):
 def cholesky(X):
     _ensure(X.symb)
     X.touched()
-    _chk(_lib.lib().csp_cholesky(X.symb.handle, X.blkval.data_ptr(), _stream()), "cholesky")
+    try:
+        _chk(_lib.lib().csp_cholesky(X.symb.handle, X.blkval.data_ptr(), _stream()), "cholesky")
+    finally:
+        note_cache(X.symb, X)
 
 
 def llt(L):
     _ensure(L.symb)
     L.touched()
-    _chk(_lib.lib().csp_llt(L.symb.handle, L.blkval.data_ptr(), _stream()), "llt")
+    try:
+        _chk(_lib.lib().csp_llt(L.symb.handle, L.blkval.data_ptr(), _stream()), "llt")
+    finally:
+        note_cache(L.symb, L)
 
 
 def projected_inverse(L):
     _ensure(L.symb)
     L.touched()
-    _chk(_lib.lib().csp_projected_inverse(L.symb.handle, L.blkval.data_ptr(), _stream()), "projected_inverse")
+    try:
+        _chk(_lib.lib().csp_projected_inverse(L.symb.handle, L.blkval.data_ptr(), _stream()), "projected_inverse")
+    finally:
+        note_cache(L.symb, L)
 
 
 def completion(X):
     _ensure(X.symb)
     X.touched()
-    _chk(_lib.lib().csp_completion(X.symb.handle, X.blkval.data_ptr(), _stream()), "completion")
+    try:
+        _chk(_lib.lib().csp_completion(X.symb.handle, X.blkval.data_ptr(), _stream()), "completion")
+    finally:
+        note_cache(X.symb, X)
 
 
 _ADJ = {False: 0, True: 1, None: 2}

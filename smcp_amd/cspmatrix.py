@@ -17,15 +17,41 @@ def _stream():
 _uid = [0]
 
 
-def sync_cache(symb, *mats):
-    """Drop the device-side caches derived from (L, Y) unless `mats` are the very matrices, unchanged,
-    that the caches were built from (include/smcp_amd.h, csp_cache_reset).  Contents are tracked by
-    object identity + torch's in-place version counter + the count of in-place library calls."""
-    key = tuple(m.state() for m in mats)
-    if getattr(symb, "_cache_key", None) != key:
+def _cache_reg(symb):
+    return symb.__dict__.setdefault("_cache_reg", {})
+
+
+def note_cache(symb, X):
+    """Record the state of X after an in-place library call on it (the library has dropped what it had derived from
+    the old contents at this address and may have derived new quantities: csp_projected_inverse leaves the
+    inverse-form factor of its input behind for the pair (L, Y = X))."""
+    reg = _cache_reg(symb)
+    if len(reg) > 256:                     # addresses of long-dead matrices: start over
         if symb._device is not None:
             _lib.lib().csp_cache_reset(symb.handle)
-        symb._cache_key = key
+        reg.clear()
+    reg[X.blkval.data_ptr()] = X.state()
+
+
+def sync_cache(symb, *mats):
+    """Keep the device-side caches derived from (L, Y) (include/smcp_amd.h, csp_cache_reset) only while they are valid.
+    The library keys them by ADDRESS and drops them itself when one of its in-place operations writes to that address;
+    what it cannot see is a change made by torch (copy_, +=, ...) or a new matrix in the memory of a dead one.  Every
+    matrix that reaches a caching entry point is therefore registered with its state (object identity + torch's
+    in-place version counter + the count of in-place library calls); a matrix whose address is registered with a
+    different state means the caches may be stale and all of them are dropped."""
+    reg = _cache_reg(symb)
+    stale = False
+    for m in mats:
+        st = reg.get(m.blkval.data_ptr())
+        if st is not None and st != m.state():
+            stale = True
+    if stale:
+        if symb._device is not None:
+            _lib.lib().csp_cache_reset(symb.handle)
+        reg.clear()
+    for m in mats:
+        reg[m.blkval.data_ptr()] = m.state()
 
 
 class cspmatrix:
