@@ -26,8 +26,8 @@ pytestmark = pytest.mark.gpu
 CONFIGS = {
     # name: (pattern factory, m constraints, right-hand sides held on the device at once)
     "config1_band200": (lambda: problems.band_pattern(200, 3), 100, 100),
-    "config2_dense4096": (lambda: problems.band_pattern(4096, 4095), 4, 4),
-    "config3_arrow2000x64+128": (lambda: problems.block_arrow_pattern(2000, 64, 128), 12, 12),
+    "config2_dense4096": (lambda: problems.band_pattern(4096, 4095), 16, 16),                  # m as bench.py --workload dense4096
+    "config3_arrow2000x64+128": (lambda: problems.block_arrow_pattern(2000, 64, 128), 100, 60),  # m as bench.py --workload arrow
     "config5_synth50k": (lambda: problems.nested_block_arrow_pattern(), 100, 100),
 }
 
