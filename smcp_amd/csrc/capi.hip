@@ -407,6 +407,16 @@ void lf_prep(csp_ctx* c, const MfmaArgs& a, int cnt, const double* L, hipStream_
   if (hoist) {
     // the diagonal blocks' inverses do not depend on each other: one launch for all of them, then the block rows
     launch_lds(c, KID_lf_diag_inv, k_lf_diag_inv, dim3(cnt, tiles64(a.nnmax)), blk, LF_DIAG_LDS, st, a, L, c->D.lk);
+    static int rec = -1;
+    if (rec < 0) { const char* e = getenv("SMCP_TRTRI"); rec = (e && e[0] == '0') ? 0 : 1; }
+    if (rec) {
+      // recursive doubling: log2(nn / 64) levels of two tile-product launches each (k_lf_trtri)
+      for (int b = LB; b < a.nnmax; b *= 2) {
+        const int pairs = (a.nnmax + 2 * b - 1) / (2 * b), tpb = b / LB;
+        for (int step = 0; step < 2; ++step)
+          launch(c, KID_lf_prep_s, k_lf_trtri, dim3(umax1(pairs * tpb * tpb), cnt), blk, st, a, L, c->D.lk, b, step);
+      }
+    } else
     for (int ib = LB; ib < a.nnmax; ib += LB) {
       launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, L, c->D.lk, ib, 0);
       launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib)), cnt), blk, st, a, L, c->D.lk, ib, 0, 1);

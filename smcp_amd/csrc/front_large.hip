@@ -949,6 +949,45 @@ __global__ void __launch_bounds__(256) k_lf_diag_inv(MfmaArgs a, const double* L
     Li[i + (int64_t)(ib + j) * nf] = 0.0;
   }
 }
+// Recursive blocked inversion of L_NN, one doubling level per pair of launches (after k_lf_diag_inv has inverted the
+// 64 x 64 diagonal blocks): at block size b (64, 128, 256, ...) the pair p covers rows / columns [2pb, 2pb + 2b) with
+// A = the first b of them, C = the rest (b2 <= b), B = L[C, A], and inv([A 0; B C]) = [Ai 0; -Ci B Ai, Ci].
+// step 0: W = B * Ai into the clique's scratch;  step 1: X[C, A] = -Ci * W.  Every level is two launches of
+// (pairs x (b/64)^2) tiles -- log2(nn/64) levels with growing parallelism -- where the row-by-row scheme (k_lf_prep_s /
+// k_lf_prep_row per 64-row block) runs nn/64 dependent steps of at most nn/64 workgroups: 4096 front, 18.4 ms -> see DESIGN.
+__global__ void __launch_bounds__(256) k_lf_trtri(MfmaArgs a, const double* L, double* LK, int b, int step) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  const InvView V = inv_view(a, k, d, 0, L, LK);
+  const int nn = V.n;
+  const int64_t nf = V.ld;
+  const int tpb = b / LT, tpp = tpb * tpb;
+  const int p = blockIdx.x / tpp, t = blockIdx.x % tpp;
+  const int r0 = 2 * p * b;
+  if (r0 + b >= nn) return;                       // no C block: nothing to do for this pair at this level
+  const int b2 = min(b, nn - r0 - b);
+  const int m0 = (t % tpb) * LT, n0 = (t / tpb) * LT;
+  if (m0 >= b2) return;
+  double* W = V.S + (int64_t)p * b * b;           // b2 x b, ld b
+  const double* Lk = V.src;
+  double* Li = V.dst;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  if (step == 0) {
+    const double* Bm = Lk + (r0 + b) + (int64_t)r0 * nf;
+    const double* Ai = Li + r0 + (int64_t)r0 * nf;
+    gemm_tile64(acc, b2, b, b, m0, n0, [=](int m, int kk) { return Bm[m + (int64_t)kk * nf]; },
+                [=](int kk, int n) { return kk >= n ? Ai[kk + (int64_t)n * nf] : 0.0; }, sA, sB, n0);       // Ai(k, n) = 0 for k < n
+    tile64_foreach(acc, m0, n0, b2, b, [=](int m, int n, double v) { W[m + (int64_t)n * b] = v; });
+  } else {
+    const double* Ci = Li + (r0 + b) + (int64_t)(r0 + b) * nf;
+    gemm_tile64(acc, b2, b, min(b2, m0 + LT), m0, n0, [=](int m, int kk) { return m >= kk ? Ci[m + (int64_t)kk * nf] : 0.0; },
+                [=](int kk, int n) { return W[kk + (int64_t)n * b]; }, sA, sB);                               // Ci(m, k) = 0 for k > m
+    double* X = Li + (r0 + b) + (int64_t)r0 * nf;
+    tile64_foreach(acc, m0, n0, b2, b, [=](int m, int n, double v) { X[m + (int64_t)n * nf] = -v; });
+  }
+}
 __global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, double* LK) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const int k = a.t.lev[blockIdx.y];
