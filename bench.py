@@ -307,7 +307,19 @@ def main():
                 tot += 8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask].sum() + Upch[fam_mask].sum()) + Bk[fam_mask].sum())
             return tot
 
-        alg = {"k_hess_up_fam": fam_bytes(), "k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
+        # sparse-input sweep of childless large fronts (front_lfsp.hip; three launches -- Q, update, G_NN -- per chunk):
+        # writes the output panel and the packed update of every (front, constraint), reads the constants of a front
+        # (Li, K, R^T K: 2 panels; R^T: na^2) once per launch
+        nch = np.diff(symb.chptr)
+        sp_mask = (~lds_ok) & (nch == 0) & (nn_ <= 64) & (na_ <= 128) & (na_ > 0)
+
+        def lfsp_bytes():
+            tot = 0.0
+            for r in up_chunks[:-2]:
+                tot += 8.0 * (r * (Bk[sp_mask].sum() + Upk[sp_mask].sum()) + 3 * (2 * Bk[sp_mask].sum() + Uk[sp_mask].sum()))
+            return tot
+
+        alg = {"k_hess_up_fam": fam_bytes(), "k_lfsp_up": lfsp_bytes(), "k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
                "k_hess_up_pad": up_bytes(lds_ok),
                "k_hess_up_n16": up_bytes(lds_ok & (nn_ <= 16) & (na_ <= 64)),
                "k_hess_up_mfma<true>": cls_bytes(lds_ok), "k_hess_down_mfma<true>": cls_bytes(lds_ok),
@@ -349,6 +361,10 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "bytes_per_launch": per_launch, "avg_launch_us": round(1e6 * avg_s, 2),
                         "launches_per_step": dom_launches}
+            if dom == "k_lfsp_up":
+                roofline["note"] = ("three launches per chunk of right-hand sides (Q, update, G_NN) are timed under this "
+                                    "name; bytes = output panels + packed updates of every (front, constraint) + the "
+                                    "fronts' constants once per launch, averaged over the launches")
             if dom == "k_hess_up_fam":
                 # The fused kernel keeps the children's update matrices in LDS, so the bytes it HAS to move are the
                 # output panels + the parents' packed updates + the constants (not SURVEY 8d's per-level figure, which

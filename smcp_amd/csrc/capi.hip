@@ -18,6 +18,7 @@
 #include "front_n16.hip"
 #include "front_fam.hip"
 #include "front_fam2.hip"
+#include "front_lfsp.hip"
 
 using namespace smcp;
 
@@ -47,7 +48,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -65,7 +66,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -236,6 +237,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.lfd = c->D.lfd;
   a.dn = 0; a.dld = 0;
   a.kc_ptr = nullptr; a.kc_off = nullptr; a.kc_val = nullptr; a.kc_ids = nullptr;
+  a.sp_rt = c->D.sp_rt; a.sp_mk = c->D.sp_mk;
   a.kc_stride = 0; a.kc_j0 = 0;
   a.level = 0; a.nS = 0; a.famna = a.fampan = a.fampk = a.famcna = a.famnn = a.famcnn = 0;
   return a;
@@ -444,6 +446,7 @@ void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
   c->D.lk_tag_L = L;
   c->D.lk_tag_Y = nullptr;
   c->D.part_valid = false;
+  c->D.lk_gen++;
 }
 // the same for the cliques of one set of the partition (clique-local: no order among the levels needed)
 void prep_lk_set(csp_ctx* c, int set, const double* L, hipStream_t st) {
@@ -454,6 +457,7 @@ void prep_lk_set(csp_ctx* c, int set, const double* L, hipStream_t st) {
       if (lds) { t.lev = am.t.lev; launch(c, KID_prep_lk, k_prep_lk, dim3(cnt), dim3(NT), st, t, L, c->D.lk); }
       else lf_prep(c, am, cnt, L, st);
     }, set);
+  c->D.lk_gen++;
 }
 // The KKT entry points are called with (L, Y) where either LK was just prepared from this very L,
 // or Y = projected_inverse(L) was produced by csp_projected_inverse (which prepares LK from L
@@ -684,6 +688,44 @@ bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_
   return a.kc_ptr ? try_fam_sp<true>(c, a, cnt, nrhs, U, ldu, st) : try_fam_sp<false>(c, a, cnt, nrhs, U, ldu, st);
 }
 
+// childless fronts beyond the LDS class with nn <= 64, na <= 128, sparse input, R^T scaling: swept from their entry lists
+// (front_lfsp.hip).  R^T and R^T K are formed when fac or lk have changed since they were formed last.  SMCP_LFSP=0 disables.
+bool try_lfsp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMCP_LFSP"); on = (e && e[0] == '0') ? 0 : 1; }
+  DeviceCtx& D = c->D;
+  if (!on || !a.kc_ptr || a.nchmax != 0 || a.ymode != 2 || !a.ysc || a.nnmax > 64 || a.namax > 128) return false;
+  if (D.kc_maxlist_large <= 0 || D.kc_maxlist_large > LFSP_ECAP || !D.lfsp_cnt) return false;
+  const bool exact = D.lfsp_exact;      // every such front is exactly (64, 128): no bounds checks in the kernel
+  if (!D.sp_rt) {
+    if (dev_alloc(&D.sp_rt, std::max<int64_t>(c->S.updlen(), 1), D.bytes)) return false;
+    if (dev_alloc(&D.sp_mk, std::max<int64_t>(c->S.blklen(), 1), D.bytes)) return false;
+  }
+  MfmaArgs b = a;
+  b.sp_rt = D.sp_rt; b.sp_mk = D.sp_mk;
+  if (D.sp_fac_gen != D.fac_gen || D.sp_lk_gen != D.lk_gen) {      // for ALL such fronts of the tree at once
+    MfmaArgs p = b;
+    p.t.lev = D.lfsp_list;
+    launch(c, KID_lfsp_prep, k_lfsp_prep, dim3((unsigned)D.lfsp_cnt), dim3(256), st, p, a.ysc, D.sp_rt, D.sp_mk);
+    D.sp_fac_gen = D.fac_gen; D.sp_lk_gen = D.lk_gen;
+  }
+  static int gdiv = -1;
+  if (gdiv < 0) { const char* e = getenv("SMCP_LFSP_G"); gdiv = e ? std::max(1, atoi(e)) : 1; }
+  const int g = std::max(1, (nrhs + gdiv - 1) / gdiv);            // right-hand sides per workgroup: gdiv
+  // one launch per phase (Q, Upd, G_NN): fewer live accumulators per wave, three to four waves per SIMD
+  const dim3 grid(g, cnt), blk(256);
+  if (exact) {
+    launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 1, 3, 1, false, true>, grid, blk, st, b, U, ldu);
+    launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 2, 1, false, true>, grid, blk, st, b, U, ldu);
+    launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 4, 4, 1, false, true>, grid, blk, st, b, U, ldu);
+  } else {
+    launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 1, 3, 1, false, false>, grid, blk, st, b, U, ldu);
+    launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 2, 1, false, false>, grid, blk, st, b, U, ldu);
+    launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 4, 4, 1, false, false>, grid, blk, st, b, U, ldu);
+  }
+  return true;
+}
+
 // sparse_j0 >= 0: the right-hand sides are the constraints sparse_j0 .. (through `ids` if given) and are taken from
 // their per-clique entry lists (MfmaArgs::kc_*) -- U is output only and need not be cleared or scattered into
 void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0,
@@ -737,7 +779,11 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
           dense_input(a, cnt);
           launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
         }
-      } else if (use_large() && c->D.gp_tptr) { dense_input(a, cnt); lf_up(c, a, cnt, nrhs, U, ldu, st); }
+      } else if (use_large() && c->D.gp_tptr) {
+        if (sparse && try_lfsp(c, a, cnt, nrhs, U, ldu, st)) return;
+        dense_input(a, cnt);
+        lf_up(c, a, cnt, nrhs, U, ldu, st);
+      }
       else { dense_input(a, cnt); launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu); }
     }, set);
 }
@@ -813,6 +859,7 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
     }
     c->D.fac_tag = Y;
     c->D.faci_tag = nullptr;
+    c->D.fac_gen++;
   }
   if (need_inv && c->D.faci_tag != Y) {
     if (fast) {
@@ -1140,7 +1187,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1260,6 +1307,15 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       }
       D.nI_total = (int64_t)lev3.size();
       D.nII_total = (int64_t)large.size();
+      {
+        std::vector<int32_t> sp;       // childless large fronts the sparse-input sweep can take (front_lfsp.hip)
+        for (int32_t k : large)
+          if (S.chptr[k + 1] == S.chptr[k] && S.nn(k) <= 64 && S.na(k) <= 128 && S.na(k) > 0) sp.push_back(k);
+        D.lfsp_cnt = (int64_t)sp.size();
+        D.lfsp_exact = !sp.empty();
+        for (int32_t k : sp) if (S.nn(k) != 64 || S.na(k) != 128) D.lfsp_exact = false;
+        if (!sp.empty() && (rc = dev_upload(&D.lfsp_list, sp, D.bytes))) return rc;
+      }
       lev3.insert(lev3.end(), large.begin(), large.end());
       if ((rc = dev_upload(&D.lev3idx, lev3, D.bytes))) return rc;
       D.lfd_len = (int64_t)(slot + 1) * 64 * 64;

@@ -110,6 +110,12 @@ struct DeviceCtx {
   // the orthonormal factor Q itself overwrites ustack
   double* qr_ws = nullptr;
   int64_t qr_len = 0;
+  // sparse-input sweep of childless large fronts (front_lfsp.hip): R^T and R^T K of the current factors, the longest
+  // entry list of such a front, and the generations of fac / lk they were formed from
+  double* sp_rt = nullptr; double* sp_mk = nullptr;
+  int32_t* lfsp_list = nullptr; int64_t lfsp_cnt = 0; bool lfsp_exact = false;
+  int64_t kc_maxlist_large = 0;
+  int64_t fac_gen = 0, lk_gen = 0, sp_fac_gen = -1, sp_lk_gen = -1;
   bool part_valid = false;     // lk / yaa / fac hold the sharded factor prepared by kkt_prepare_part (sets 2 then 1)
   bool qr_valid = false;       // ustack holds Q and qr_ws the factor for the matrices (qr_L, qr_Y)
   const void* qr_L = nullptr; const void* qr_Y = nullptr;

@@ -95,6 +95,8 @@ struct MfmaArgs {
   // only), so the m x blklen stack needs neither clearing nor scattering.  null = dense input in u.
   const int32_t* kc_ptr; const int32_t* kc_off; const double* kc_val; const int32_t* kc_ids;
   int kc_stride, kc_j0;
+  // sparse-input sweep of childless large fronts (front_lfsp.hip): R^T (update layout) and R^T K (blkval layout, K rows)
+  const double* sp_rt; const double* sp_mk;
   // host-side only (level loop of hess_up_fast): level index and the family tail of the LDS class (LevelClass::nS ...)
   int level, nS, famna, fampan, fampk, famcna, famnn, famcnn;
 };

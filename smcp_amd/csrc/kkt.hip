@@ -436,6 +436,13 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
           const size_t q = (size_t)k * (m + 1) + j;
           D.kc_maxlist = std::max<int64_t>(D.kc_maxlist, kptr[q + 1] - kptr[q]);
         }
+    D.kc_maxlist_large = 0;       // over the childless fronts beyond the small classes (sparse-input sweep of large fronts)
+    for (int64_t k = 0; k < S.nsn; ++k)
+      if ((S.nn(k) > 16 || S.na(k) > 64) && S.nn(k) <= 64 && S.na(k) <= 128 && S.chptr[k + 1] == S.chptr[k])
+        for (int64_t j = 0; j < m; ++j) {
+          const size_t q = (size_t)k * (m + 1) + j;
+          D.kc_maxlist_large = std::max<int64_t>(D.kc_maxlist_large, kptr[q + 1] - kptr[q]);
+        }
     std::vector<int32_t> fill(kptr.begin(), kptr.end() - 1);
     for (int64_t j = 0; j < m; ++j)
       for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
@@ -913,6 +920,7 @@ int kkt_prepare_part(csp_ctx* c, const double* L, const double* Y, int set, int 
   D.yaa_tag = D.fac_tag = D.faci_tag = nullptr;        // partial content: nothing to claim for the caches
   D.lk_tag_L = D.lk_tag_Y = nullptr;
   D.part_valid = false;
+  D.fac_gen++;
   if (set == 2) HIPCHK(zero_flag(c, st));
   if (with_lk) prep_lk_set(c, set, L, st);
   gather_set(c, set, Y, 0, 1, D.yaa, st);
