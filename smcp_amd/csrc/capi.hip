@@ -84,13 +84,26 @@ inline hipError_t end_call(csp_ctx* c) {
   return e;
 }
 
+// SMCP_TRACE=1: name every launch on stderr and wait for it (a device fault aborts the process: the last name printed
+// is the kernel that faulted)
+inline bool trace_on() {
+  static int t = -1;
+  if (t < 0) { const char* e = getenv("SMCP_TRACE"); t = (e && e[0] == '1') ? 1 : 0; }
+  return t == 1;
+}
+inline void trace_launch(int kid, dim3 grid, dim3 block, size_t lds, hipStream_t st, bool before) {
+  if (before) fprintf(stderr, "launch %s grid (%u,%u,%u) block %u lds %zu\n", KID_NAMES[kid], grid.x, grid.y, grid.z, block.x, lds);
+  else (void)hipStreamSynchronize(st);
+}
 template <class K, class... A>
 inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+  if (trace_on()) trace_launch(kid, grid, block, lds, st, true);
   Profiler& P = c->prof;
   const bool timed = P.want(kid);
   if (timed) (void)hipEventRecord(P.next(), st);
   hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
   note_launch(c, kid);
+  if (trace_on()) trace_launch(kid, grid, block, lds, st, false);
   if (timed) {
     (void)hipEventRecord(P.next(), st);
     P.kids.push_back(kid);
@@ -98,11 +111,13 @@ inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_
 }
 template <class K, class... A>
 inline void launch(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, hipStream_t st, A... args) {
+  if (trace_on()) trace_launch(kid, grid, block, 0, st, true);
   Profiler& P = c->prof;
   const bool timed = P.want(kid);
   if (timed) (void)hipEventRecord(P.next(), st);
   hipLaunchKernelGGL(kern, grid, block, 0, st, args...);
   note_launch(c, kid);
+  if (trace_on()) trace_launch(kid, grid, block, 0, st, false);
   if (timed) {
     (void)hipEventRecord(P.next(), st);
     P.kids.push_back(kid);

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256, OCC) k_lfsp_up(MfmaArgs a, double* u, int
           for (int s2 = 0; s2 < 2; ++s2) {
             const bool in = 4 * s2 < n4;
             const int t = in ? b0 + 4 * s2 + kq : 0;
-            kc[s2][i] = Kk[mc + s_aj[t]];
+            kc[s2][i] = Kk[mc + (in ? s_aj[t] : 0)];            // (a pair without AN entries leaves the tables unwritten)
             bc[s2][i] = (in && l15 == (s_ar[t] & 15)) ? -s_av[t] : 0.0;
           }
         }

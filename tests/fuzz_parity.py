@@ -2,6 +2,7 @@
 band, block-arrow, fat cliques beyond LDS), with and without amalgamation; every tree operation, every Hessian mode
 and the KKT solvers (kkt_chol with three constraint classifications, kkt_qr) against the oracle.
 Used by tests/test_gpu_fuzz.py (a few cases) and scratch/fuzz_parity.py (long sweeps)."""
+import os
 import time
 
 import numpy as np
@@ -59,6 +60,8 @@ def run(ncases, seed0=0, verbose=False):
             if emb is not None:
                 symb = Symbolic(emb[0], emb[1])
         tag = "case %d kind %d n=%d nsn=%d maxnn=%d maxna=%d" % (seed0 + case, case % 6, symb.n, symb.Nsn, symb.max_nn, symb.max_na)
+        if os.environ.get("SMCP_FUZZ_TRACE"):        # the case about to run (a device fault leaves no other trace)
+            print(tag, flush=True)
         m = int(rng.integers(1, 20))
         nrhs = int(rng.integers(1, 6))
         symb.device_init(0, max(nrhs, min(m, int(rng.integers(1, 8)))))

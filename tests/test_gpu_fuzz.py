@@ -10,3 +10,12 @@ def test_random_patterns_against_oracle():
     assert len(worst) >= 12                      # every check ran on at least one case
     for k, (v, tag) in worst.items():
         assert v <= 1e-9, (k, v, tag)
+
+
+def test_random_patterns_round2_seeds():
+    """Seeds 60000-60011: case 60004 (fat childless fronts of odd sizes, constraints without entries in the AN block of
+    some of them) made the sparse-input sweep of large fronts read an unwritten term table -- a device memory fault."""
+    import fuzz_parity
+    worst = fuzz_parity.run(12, seed0=60000)
+    for k, (v, tag) in worst.items():
+        assert v <= 1e-9, (k, v, tag)
