@@ -122,6 +122,14 @@ def test_sharded_factorisation_and_solve_two_ranks_gloo():
     assert r["n_solve"] == 4                     # two Hessian exchanges + Amap all-reduce + completion of x
 
 
+def test_sharded_factorisation_and_solve_three_ranks_gloo():
+    """Three ranks on a tree with two top-level subtrees: uneven shares (the cut goes one level deeper)."""
+    r = _run_two("factor", world=3)
+    for k in ("eL", "eY", "eH", "ex", "ey", "ep"):
+        assert r[k] < 1e-11, (k, r)
+    assert r["untouched"] and r["n_solve"] == 4
+
+
 def test_partition_covers_tree():
     from smcp_amd import problems
     from smcp_amd.shard import subtree_partition
@@ -140,14 +148,14 @@ def test_partition_covers_tree():
             assert all(P.owner[k] == r and P.owner[par[k]] == -1 for k in P.roots_by_rank[r])
 
 
-def _run_two(mode):
+def _run_two(mode, world=2):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, mode)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, mode)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
