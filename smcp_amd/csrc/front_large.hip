@@ -339,7 +339,11 @@ __global__ void k_lf_clear_upd(MfmaArgs a) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += (int64_t)gridDim.x * blockDim.x) U[e] = 0.0;
 }
 
-// ---- up-sweep phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place) ; T = Li F_NN
+// G_NN = Li F_NN Li^T through Z = Li Fl (F_NN = Fl + Fl^T) for wide fronts, through T = Li F_NN otherwise: in tile products
+// of 64 the two routes cost sum_t (t+1) nt + sum (nt-t)(t+1) against 3 sum (nt-t)(t+1) -- equal at four column tiles, 12 % less
+// at eight, 25 % less in the limit
+__host__ __device__ inline bool lf_sym_split(int nn) { return nn > 6 * LT; }
+// ---- up-sweep phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place) ; Z = Li Fl (into T)
 __global__ void __launch_bounds__(256) k_lf_up1(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
@@ -363,14 +367,24 @@ __global__ void __launch_bounds__(256) k_lf_up1(MfmaArgs a, double* u, int64_t l
       Pw[nn + m + (int64_t)n * nf] = f - v;
     });
   } else {
+    // Z = Li Fl with Fl = the lower triangle of F_NN, its diagonal halved (F_NN = Fl + Fl^T): a product of two lower
+    // triangular matrices -- only the lower tiles, k from the tile's first column to its last row (nn^3 / 3 flops where
+    // T = Li F_NN took nn^3); phase 2 forms G_NN = Z Li^T + Li Z^T.  Tiles above the diagonal are never read.
     const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
     const double* Li = c.Li;
-    gemm_tile64(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; }, fsym, sA, sB);   // Li(m, k) = 0 for k > m
+    if (lf_sym_split(nn)) {
+      if (n0 > m0) return;
+      gemm_tile64(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
+                  [=](int kk, int n) { return kk > n ? P[kk + (int64_t)n * nf] : (kk == n ? 0.5 * P[kk + (int64_t)n * nf] : 0.0); },
+                  sA, sB, n0);
+    } else {
+      gemm_tile64(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; }, fsym, sA, sB);   // Li(m, k) = 0 for k > m
+    }
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
   }
 }
-// ---- up-sweep phase 2: U -= K E^T + E K^T (lower tiles) ; G = X Li^T ; G_NN = T Li^T (lower, in place)
+// ---- up-sweep phase 2: U -= K E^T + E K^T (lower tiles) ; G = X Li^T ; G_NN = Z Li^T + Li Z^T (lower, in place)
 __global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
@@ -414,7 +428,10 @@ __global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t l
     lower_pair(t - nU - nG, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
     gemm_tile64(acc, nn, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return T[m + (int64_t)kk * nn]; },
-                [=](int kk, int n) { return Li[n + (int64_t)kk * nf]; }, sA, sB);
+                [=](int kk, int n) { return Li[n + (int64_t)kk * nf]; }, sA, sB);                 // Z Li^T  (T holds Z, phase 1)
+    if (lf_sym_split(nn))
+      gemm_tile64(acc, nn, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
+                  [=](int kk, int n) { return T[n + (int64_t)kk * nn]; }, sA, sB);               // + Li Z^T
     double* Pw = c.P;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
   }
