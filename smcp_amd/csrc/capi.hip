@@ -757,7 +757,11 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
     for (int r0 = 0; r0 < nrhs; r0 += 65535) {
       MfmaArgs af = a;
       af.kc_j0 = a.kc_j0 + r0;
-      launch(c, KID_scatter_constraints, k_panel_fill, dim3(cnt, std::min(65535, nrhs - r0)), dim3(256), st, af, U + (int64_t)r0 * ldu, ldu);
+      // big panels are shared by several workgroups (column ranges): a single 4096 front would otherwise be filled by
+      // one workgroup per right-hand side
+      const int64_t pan = (int64_t)(a.nnmax + a.namax) * a.nnmax;
+      const int nz = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(a.nnmax, 64), pan / 16384));
+      launch(c, KID_scatter_constraints, k_panel_fill, dim3(cnt, std::min(65535, nrhs - r0), nz), dim3(256), st, af, U + (int64_t)r0 * ldu, ldu);
     }
     a.kc_ptr = nullptr;
   };

@@ -481,8 +481,16 @@ __global__ void __launch_bounds__(256) k_lf_down1(MfmaArgs a, double* u, int64_t
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = v; });
   } else {
     const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
-    gemm_tile64(acc, nn, nn, nn, m0, n0,
-                [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : P[kk + (int64_t)m * nf]; }, li, sA, sB, n0);
+    if (lf_sym_split(nn)) {
+      // wide fronts: Z' = Gl Li with Gl = the lower triangle of G_NN, diagonal halved (lower tiles only, k from the tile's
+      // first column to its last row); phase 3 forms Li^T G_NN Li = Li^T Z' + Z'^T Li  (see k_lf_up1)
+      if (n0 > m0) return;
+      gemm_tile64(acc, nn, nn, min(nn, m0 + LT), m0, n0,
+                  [=](int m, int kk) { return m > kk ? P[m + (int64_t)kk * nf] : (m == kk ? 0.5 * P[m + (int64_t)kk * nf] : 0.0); }, li, sA, sB, n0);
+    } else {
+      gemm_tile64(acc, nn, nn, nn, m0, n0,
+                  [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : P[kk + (int64_t)m * nf]; }, li, sA, sB, n0);
+    }
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
   }
@@ -526,6 +534,9 @@ __global__ void __launch_bounds__(256) k_lf_down3(MfmaArgs a, double* u, int64_t
   tile64_zero(acc);
   gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
               [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB, m0);                 // Li(k, m) = 0 for k < m
+  if (lf_sym_split(nn))
+    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return T[kk + (int64_t)m * nn]; },
+                [=](int kk, int n) { return Li[kk + (int64_t)n * nf]; }, sA, sB, m0);             // + Z'^T Li (T holds Z')
   gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -K[kk + (int64_t)m * nf]; },
               [=](int kk, int n) { return D[kk + (int64_t)n * na]; }, sA, sB);
   gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -D[kk + (int64_t)m * na]; },

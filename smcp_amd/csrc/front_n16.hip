@@ -403,12 +403,19 @@ __global__ void k_panel_fill(MfmaArgs a, double* u, int64_t ldu) {
   const CliqueDesc d = a.t.cl[k];
   const int r = blockIdx.y;
   double* P = u + (int64_t)r * ldu + d.blk;
-  const int npan = (d.nn + d.na) * d.nn;
-  for (int e = threadIdx.x; e < npan; e += blockDim.x) P[e] = 0.0;
+  const int nf = d.nn + d.na;
+  // gridDim.z workgroups share a panel by column ranges; the sweeps read the NN block through its lower triangle only,
+  // so a column is cleared from its diagonal down (half of the panel of a front without separator: config 2)
+  const int c0 = (int)(((int64_t)d.nn * blockIdx.z) / gridDim.z), c1 = (int)(((int64_t)d.nn * (blockIdx.z + 1)) / gridDim.z);
+  for (int j = c0; j < c1; ++j)
+    for (int i = j + threadIdx.x; i < nf; i += blockDim.x) P[i + (int64_t)j * nf] = 0.0;
   __syncthreads();
   const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
   const int32_t* kp = a.kc_ptr + (int64_t)k * a.kc_stride;
-  for (int p = kp[j] + threadIdx.x; p < kp[j + 1]; p += blockDim.x) P[a.kc_off[p]] = a.kc_val[p];
+  for (int p = kp[j] + threadIdx.x; p < kp[j + 1]; p += blockDim.x) {
+    const int off = a.kc_off[p], col = off / nf;
+    if (col >= c0 && col < c1) P[off] = a.kc_val[p];
+  }
 }
 
 }  // namespace smcp
