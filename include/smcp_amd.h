@@ -162,20 +162,24 @@ int kkt_qr_inspect(csp_ctx* ctx, double* Rt_host, double* G_dev, void* stream);
  * The elimination tree is cut into subtrees owned by single ranks plus a replicated top
  * (owner[k] = rank, or -1 for the top).  Per solve: kkt_gram_prepare; for every chunk of right-hand
  * sides: kkt_gram_sweep(set 1 = owned) -> exchange of the subtree roots' packed update blocks
- * (csp_exchange_copy + one collective) -> kkt_gram_sweep(set 2 = top); then kkt_gram_accumulate over
+ * (csp_exchange_pack -> one all-gather -> csp_exchange_unpack) -> kkt_gram_sweep(set 2 = top); then kkt_gram_accumulate over
  * the blkval ranges this rank owns and one all-reduce of H. */
 int csp_set_partition(csp_ctx* ctx, const int32_t* owner, int rank);
 int kkt_gram_prepare(csp_ctx* ctx, const double* L, const double* Y, void* stream);
 int kkt_gram_sweep(csp_ctx* ctx, int set, int64_t j0, int64_t j1, void* stream);
 int kkt_gram_accumulate(csp_ctx* ctx, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh,
                         void* stream);
-int csp_exchange_copy(csp_ctx* ctx, int64_t nk, const int64_t* cliques, int64_t nrhs, double* buf,
-                      int unpack, void* stream);
+/* boundary exchange (after csp_set_partition): doubles per right-hand side every rank contributes; pack of THIS rank's
+ * subtree roots into buf ([root][rhs][packed block]); unpack of all OTHER ranks' roots from the all-gathered buffers
+ * (`width` doubles per rank).  One launch each, no host synchronisation. */
+int csp_exchange_sizes(csp_ctx* ctx, int64_t world, int64_t* sizes_per_rhs);
+int csp_exchange_pack(csp_ctx* ctx, int64_t nrhs, double* buf, void* stream);
+int csp_exchange_unpack(csp_ctx* ctx, int64_t nrhs, const double* buf, int64_t width, void* stream);
 
 /* ---- subtree-sharded factorisation and solve (every leaves->root / root->leaves sweep of the path
  * shards; reference call sites of the sweeps: solvers.py:881-891 cholesky + projected_inverse, 521-532 the two
  * Hessians of solve_).  set: 1 = the cliques this rank owns, 2 = the replicated top.
- *   leaves->root (cholesky, hessian dir 0): part(set 1) -> csp_exchange_copy of the subtree roots' packed updates
+ *   leaves->root (cholesky, hessian dir 0): part(set 1) -> csp_exchange_pack / all-gather / csp_exchange_unpack of the subtree roots' packed updates
  *     (nrhs = 1) around one collective -> part(set 2);
  *   root->leaves (projected_inverse, kkt_prepare_part, hessian dir 1): part(set 2) -> part(set 1), no communication.
  * After them a matrix is valid on the owned cliques and the top; the other blkval ranges keep what they held.

@@ -1211,6 +1211,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int set = 1; set <= 2; ++set) if (c->sets[set].lev2) hipFree(c->sets[set].lev2);
+    for (void* p : {(void*)c->xr_roots, (void*)c->xr_owner, (void*)c->xr_bptr}) if (p) hipFree(p);
     if (D.info_host) hipHostFree(D.info_host);
   }
   delete c;

@@ -182,6 +182,11 @@ struct csp_ctx {
   std::vector<int> lev_namax;   // per level: largest separator (sizes the gather launches)
   std::vector<int64_t> fam;     // per clique: family role (CSP_Q_FAMILY)
   std::vector<uint8_t> is_diag_cache;
+  // boundary exchange of the subtree partition: the subtree roots of all ranks (device: clique, owning rank, offset in
+  // doubles per right-hand side inside the owner's region), what every rank contributes per right-hand side, the widest block
+  int32_t* xr_roots = nullptr; int32_t* xr_owner = nullptr; int64_t* xr_bptr = nullptr;
+  int64_t xr_n = 0; int xr_me = -1; int64_t xr_npmax = 1;
+  std::vector<int64_t> xr_size;
   int64_t ntrial = 1;                   // copies of the pattern in S (csp_symbolic_replicate): one failure flag per copy
   int launch_err = 0;                   // first failed kernel launch of the running call (launch helpers); read by end_call
   double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)

@@ -1338,4 +1338,21 @@ __global__ void k_exchange_copy(const CliqueDesc* cl, const int64_t* list, const
   }
 }
 
+// the same for the subtree roots of a partition (csp_set_partition): root q belongs to rank owner[q] and starts bptr[q]
+// doubles (per right-hand side) into its rank's region.  pack: this rank's roots -> buf; unpack: every OTHER rank's roots
+// <- buf + owner * width (the all-gathered regions one after the other).  One launch each, nothing on the host.
+__global__ void k_exchange_roots(const CliqueDesc* cl, const int32_t* roots, const int32_t* owner, const int64_t* bptr, int me,
+                                 int nrhs, double* updp, int64_t updplen, double* buf, int64_t width, int unpack) {
+  const int q = blockIdx.y;
+  if (unpack ? owner[q] == me : owner[q] != me) return;
+  const CliqueDesc d = cl[roots[q]];
+  const int np = d.na * (d.na + 1) / 2;
+  const int r = blockIdx.z;
+  double* slab = buf + (unpack ? owner[q] * width : 0) + bptr[q] * nrhs + (int64_t)r * np;
+  double* src = updp + (int64_t)r * updplen + d.updp;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < np; e += gridDim.x * blockDim.x) {
+    if (unpack) src[e] = slab[e]; else slab[e] = src[e];
+  }
+}
+
 }  // namespace smcp

@@ -867,6 +867,27 @@ int csp_set_partition(csp_ctx* c, const int32_t* owner, int rank) {
     classify_levels(S, [&](int64_t k) { return owner[k] == want; }, LS.lvl, lev2, LS.off);
     if (int rc = dev_upload(&LS.lev2, lev2, c->D.bytes)) return rc;
   }
+  // subtree roots (owned clique whose parent lies in the replicated top), rank by rank in ascending clique order
+  int world = 0;
+  for (int64_t k = 0; k < S.nsn; ++k) world = std::max(world, owner[k] + 1);
+  std::vector<int32_t> roots, own;
+  std::vector<int64_t> bptr;
+  c->xr_size.assign(std::max(world, rank + 1), 0);
+  c->xr_npmax = 1;
+  for (int r = 0; r < world; ++r)
+    for (int64_t k = 0; k < S.nsn; ++k)
+      if (owner[k] == r && S.snpar[k] >= 0 && owner[S.snpar[k]] == -1) {
+        const int64_t np = S.na(k) * (S.na(k) + 1) / 2;
+        roots.push_back((int32_t)k); own.push_back(r); bptr.push_back(c->xr_size[r]);
+        c->xr_size[r] += np;
+        c->xr_npmax = std::max(c->xr_npmax, np);
+      }
+  for (void* p : {(void*)c->xr_roots, (void*)c->xr_owner, (void*)c->xr_bptr}) if (p) HIPCHK(hipFree(p));
+  c->xr_roots = nullptr; c->xr_owner = nullptr; c->xr_bptr = nullptr;
+  c->xr_n = (int64_t)roots.size(); c->xr_me = rank;
+  if (int rc = dev_upload(&c->xr_roots, roots, c->D.bytes)) return rc;
+  if (int rc = dev_upload(&c->xr_owner, own, c->D.bytes)) return rc;
+  if (int rc = dev_upload(&c->xr_bptr, bptr, c->D.bytes)) return rc;
   return 0;
 }
 int kkt_gram_prepare(csp_ctx* c, const double* L, const double* Y, void* stream) {
@@ -942,7 +963,7 @@ int kkt_prepare_part(csp_ctx* c, const double* L, const double* Y, int set, int 
 }
 // one half of the Hessian hessian(L, Y, U, adj=None) over the cliques of a set: dir 0 = leaves->root (with the Y_AA
 // scaling of the separator rows), dir 1 = root->leaves.  The caller exchanges the packed updates of the subtree roots
-// between the owned and the top pass of dir 0 (csp_exchange_copy); dir 1 needs no exchange.
+// between the owned and the top pass of dir 0 (csp_exchange_pack / unpack); dir 1 needs no exchange.
 int csp_hessian_sweep_part(csp_ctx* c, double* U, int64_t nrhs, int64_t ldu, int set, int dir, void* stream) {
   if (int rc = ready(c)) return rc;
   if (set < 1 || set > 2 || !c->sets[set].lev2 || use_generic() || nrhs < 1 || nrhs > c->D.max_rhs) return SMCP_EINVAL;
@@ -953,32 +974,27 @@ int csp_hessian_sweep_part(csp_ctx* c, double* U, int64_t nrhs, int64_t ldu, int
   HIPCHK(end_call(c));
   return 0;
 }
-// boundary exchange: copy the packed update blocks of the listed cliques (host list) of nrhs right-hand
-// sides to (unpack = 0) or from (unpack = 1) the contiguous device buffer buf
-int csp_exchange_copy(csp_ctx* c, int64_t nk, const int64_t* cliques, int64_t nrhs, double* buf, int unpack, void* stream) {
-  if (int rc = ready(c)) return rc;
-  if (nk <= 0) return 0;
-  if (nrhs < 1 || nrhs > c->D.max_rhs) return SMCP_EINVAL;
-  const Symbolic& S = c->S;
-  std::vector<int64_t> host(2 * nk + 1);
-  int64_t off = 0, npmax = 1;
-  for (int64_t q = 0; q < nk; ++q) {
-    if (cliques[q] < 0 || cliques[q] >= S.nsn) return SMCP_EINVAL;
-    host[q] = cliques[q];
-    host[nk + q] = off;
-    int64_t np = S.na(cliques[q]) * (S.na(cliques[q]) + 1) / 2;
-    off += np;
-    npmax = std::max(npmax, np);
-  }
-  int64_t* dlist = nullptr;
-  HIPCHK(hipMalloc((void**)&dlist, sizeof(int64_t) * 2 * nk));
-  HIPCHK(hipMemcpyAsync(dlist, host.data(), sizeof(int64_t) * 2 * nk, hipMemcpyHostToDevice, (hipStream_t)stream));
-  launch(c, KID_axpby, k_exchange_copy, dim3((unsigned)std::min<int64_t>(32, (npmax + 255) / 256), (unsigned)nk, (unsigned)nrhs),
-         dim3(256), (hipStream_t)stream, (const CliqueDesc*)c->D.cl, (const int64_t*)dlist, (const int64_t*)(dlist + nk), (int)nrhs,
-         c->D.updp, c->S.updplen(), buf, unpack);
-  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  HIPCHK(hipFree(dlist));
+// boundary exchange of the subtree partition: doubles per right-hand side that every rank contributes (host array of
+// `world` entries), pack of this rank's subtree roots into buf ([root][rhs][packed block]) and unpack of all OTHER ranks'
+// roots from the all-gathered buffers (`width` doubles per rank).  One launch each; nothing is allocated or waited for.
+int csp_exchange_sizes(csp_ctx* c, int64_t world, int64_t* sizes) {
+  if (!c || !sizes || world < 1) return SMCP_EINVAL;
+  for (int64_t r = 0; r < world; ++r) sizes[r] = r < (int64_t)c->xr_size.size() ? c->xr_size[r] : 0;
   return 0;
+}
+static int exchange_roots(csp_ctx* c, int64_t nrhs, double* buf, int64_t width, int unpack, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (c->xr_me < 0 || nrhs < 1 || nrhs > c->D.max_rhs || !buf) return SMCP_EINVAL;
+  if (!c->xr_n) return 0;
+  launch(c, KID_axpby, k_exchange_roots, dim3((unsigned)std::min<int64_t>(32, (c->xr_npmax + 255) / 256), (unsigned)c->xr_n, (unsigned)nrhs),
+         dim3(256), (hipStream_t)stream, (const CliqueDesc*)c->D.cl, (const int32_t*)c->xr_roots, (const int32_t*)c->xr_owner,
+         (const int64_t*)c->xr_bptr, c->xr_me, (int)nrhs, c->D.updp, c->S.updplen(), buf, width, unpack);
+  HIPCHK(end_call(c));
+  return 0;
+}
+int csp_exchange_pack(csp_ctx* c, int64_t nrhs, double* buf, void* stream) { return exchange_roots(c, nrhs, buf, 0, 0, stream); }
+int csp_exchange_unpack(csp_ctx* c, int64_t nrhs, const double* buf, int64_t width, void* stream) {
+  return exchange_roots(c, nrhs, const_cast<double*>(buf), width, 1, stream);
 }
 
 }  // extern "C"

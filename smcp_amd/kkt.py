@@ -90,6 +90,7 @@ class ShardedSchur:
             mask[a:b] = 1.0
         self._own_mask = torch.from_numpy(mask).to(self.dev)
         self.__dict__.pop("_spair", None)
+        self.__dict__.pop("_xchg", None)
         return P
 
     def _world(self, group):
@@ -103,9 +104,11 @@ class ShardedSchur:
         (nrhs right-hand sides) travel in ONE all-gather on buffers that are allocated once per width."""
         world, rank = self._world(group)
         P = self.partition
-        sizes = [self._exchange_size(P.roots_by_rank[r], nrhs) for r in range(world)]
-        width = max(max(sizes), 1)
         bufs = self.__dict__.setdefault("_xchg", {})
+        if ("sizes", nrhs) not in bufs:
+            bufs[("sizes", nrhs)] = [self._exchange_size(P.roots_by_rank[r], nrhs) for r in range(world)]
+        sizes = bufs[("sizes", nrhs)]
+        width = max(max(sizes), 1)
         if width not in bufs:
             bufs[width] = (torch.zeros(width, dtype=torch.float64, device=self.dev),
                            torch.empty(width * world, dtype=torch.float64, device=self.dev))
@@ -114,7 +117,10 @@ class ShardedSchur:
             self._exchange_pack(P.roots_by_rank[rank], nrhs, send[:sizes[rank]])
         _all_gather_into(recv, send, group)
         self.collectives += 1
-        for r in range(world):
+        self._exchange_unpack_all(P, rank, nrhs, recv, width, sizes)
+
+    def _exchange_unpack_all(self, P, rank, nrhs, recv, width, sizes):
+        for r in range(len(sizes)):
             if r != rank and sizes[r]:
                 self._exchange_unpack(P.roots_by_rank[r], nrhs, recv[r * width:r * width + sizes[r]])
 
@@ -321,7 +327,7 @@ class KKTSystem(ShardedSchur):
     def _potrf(self):
         _chk(_lib.lib().dense_potrf(self.symb.handle, self.H.data_ptr(), self.m, self.m, _stream()), "dense_potrf")
 
-    # ---- subtree-sharded Gram path (C-ABI: csp_set_partition, kkt_gram_*, csp_exchange_copy)
+    # ---- subtree-sharded Gram path (C-ABI: csp_set_partition, kkt_gram_*, csp_exchange_pack / unpack)
     def _apply_partition(self, P, rank):
         self._part_rank = int(rank)
         owner = np.ascontiguousarray(P.owner, dtype=np.int32)
@@ -356,15 +362,12 @@ class KKTSystem(ShardedSchur):
         _chk(rc, "kkt_gram_prepare_part")
 
     def _exchange_pack(self, cliques, nrhs, out):
-        lst = np.ascontiguousarray(cliques, dtype=np.int64)
-        _chk(_lib.lib().csp_exchange_copy(self.symb.handle, len(lst), lst.ctypes.data, int(nrhs), out.data_ptr(), 0,
-                                          _stream()), "csp_exchange_copy")
+        # this rank's subtree roots (the list csp_set_partition derived from the owner array: the same cliques)
+        _chk(_lib.lib().csp_exchange_pack(self.symb.handle, int(nrhs), out.data_ptr(), _stream()), "csp_exchange_pack")
 
-    def _exchange_unpack(self, cliques, nrhs, buf):
-        lst = np.ascontiguousarray(cliques, dtype=np.int64)
-        assert buf.is_contiguous()
-        _chk(_lib.lib().csp_exchange_copy(self.symb.handle, len(lst), lst.ctypes.data, int(nrhs), buf.data_ptr(), 1,
-                                          _stream()), "csp_exchange_copy")
+    def _exchange_unpack_all(self, P, rank, nrhs, recv, width, sizes):
+        _chk(_lib.lib().csp_exchange_unpack(self.symb.handle, int(nrhs), recv.data_ptr(), int(width), _stream()),
+             "csp_exchange_unpack")
 
     # ---- sharded factorisation / solve sweeps (C-ABI: csp_cholesky_part, csp_projected_inverse_part,
     #      kkt_prepare_part, csp_hessian_sweep_part)

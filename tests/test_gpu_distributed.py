@@ -1,6 +1,6 @@
 """Subtree-sharded Schur complement on the HIP path with two ranks sharing ONE GPU (gloo backend; the
 collectives are staged through the host): checks the device-side pieces the CPU gloo test cannot --
-csp_set_partition, kkt_gram_sweep by clique set, csp_exchange_copy, kkt_gram_accumulate by range."""
+csp_set_partition, kkt_gram_sweep by clique set, csp_exchange_pack / unpack, kkt_gram_accumulate by range."""
 import os
 import socket
 
