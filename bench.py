@@ -330,8 +330,11 @@ def main():
         # up3 = scaling product (na^2 nn, triangular operand)
         big = ~lds_ok
         nnf, naf = nn_[big].astype(np.float64), na_[big].astype(np.float64)
-        lf_flops = {"k_lf_up1": (2 * naf * nnf ** 2 + nnf ** 3).sum(),
-                    "k_lf_up2": (2 * naf ** 2 * nnf + naf * nnf ** 2 + nnf ** 3 / 3).sum(),
+        # fronts of more than six 64-column tiles form G_NN = Li F_NN Li^T as Z = Li Fl (nn^3 / 3, phase 1) and
+        # Z Li^T + Li Z^T (2 nn^3 / 3, phase 2) instead of T = Li F_NN (nn^3) and T Li^T (nn^3 / 3): front_large.hip lf_sym_split
+        split = nnf > 6 * 64
+        lf_flops = {"k_lf_up1": (2 * naf * nnf ** 2 + np.where(split, nnf ** 3 / 3, nnf ** 3)).sum(),
+                    "k_lf_up2": (2 * naf ** 2 * nnf + naf * nnf ** 2 + np.where(split, 2 * nnf ** 3 / 3, nnf ** 3 / 3)).sum(),
                     "k_lf_up3": (naf ** 2 * nnf).sum()}
         if dom in lf_flops and alg is None:
             nr = sum(chunks)
