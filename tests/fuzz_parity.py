@@ -42,8 +42,9 @@ def nested(rng, ln, la, mn, ma):
                                                nleaf_per_mid=int(rng.integers(1, 11)), leaf=(ln_, la_), mid=(mn_, ma_),
                                                top=(tn, ta), root=root, seed=int(rng.integers(1 << 30)))
 
-def run(ncases, seed0=0, verbose=False):
-    """Returns {check: (worst relative error, case description)} over ncases random problems."""
+def run(ncases, seed0=0, verbose=False, patterns=None):
+    """Returns {check: (worst relative error, case description)} over ncases random problems (or over the given
+    patterns, one case each)."""
     worst = {}
 
     def note(k, v, tag):
@@ -53,9 +54,9 @@ def run(ncases, seed0=0, verbose=False):
     t0 = time.time()
     for case in range(ncases):
         rng = np.random.default_rng(seed0 + case)
-        pat = pattern(rng, case)
+        pat = patterns[case] if patterns is not None else pattern(rng, case)
         symb = Symbolic(pat)
-        if rng.random() < 0.4:
+        if patterns is None and rng.random() < 0.4:
             emb = amalgamate(symb)
             if emb is not None:
                 symb = Symbolic(emb[0], emb[1])

@@ -19,3 +19,18 @@ def test_random_patterns_round2_seeds():
     worst = fuzz_parity.run(12, seed0=60000)
     for k, (v, tag) in worst.items():
         assert v <= 1e-9, (k, v, tag)
+
+
+def test_wide_fronts_against_oracle():
+    """Fronts of more than six 64-column tiles take their own routes (recursive-doubling inverse of L_NN, symmetric split
+    of Li F_NN Li^T in both sweeps, panel fill by column ranges): a single dense front of 450 columns, a (400, 60) front
+    over a tail, and fronts just below / above the one-workgroup Cholesky limit of 272 rows -- every check of the sweep
+    against the oracle."""
+    import fuzz_parity
+    from smcp_amd import problems
+    pats = [problems.band_pattern(450, 449), problems.block_arrow_pattern(1, 400, 60),
+            problems.block_arrow_pattern(2, 200, 70), problems.block_arrow_pattern(2, 210, 70)]
+    worst = fuzz_parity.run(len(pats), seed0=81000, patterns=pats)
+    assert len(worst) >= 12
+    for k, (v, tag) in worst.items():
+        assert v <= 1e-9, (k, v, tag)
