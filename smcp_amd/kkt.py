@@ -332,6 +332,14 @@ class KKTSystem(ShardedSchur):
         self._part_rank = int(rank)
         owner = np.ascontiguousarray(P.owner, dtype=np.int32)
         _chk(_lib.lib().csp_set_partition(self.symb.handle, owner.ctypes.data, int(rank)), "csp_set_partition")
+        # the library derives the subtree roots from the owner array; the host logic sizes the collective from
+        # P.roots_by_rank: the two must agree rank by rank
+        world = len(P.roots_by_rank)
+        sizes = np.zeros(world, dtype=np.int64)
+        _chk(_lib.lib().csp_exchange_sizes(self.symb.handle, world, sizes.ctypes.data), "csp_exchange_sizes")
+        want = [self._exchange_size(P.roots_by_rank[r], 1) for r in range(world)]
+        if sizes.tolist() != want:
+            raise RuntimeError("subtree roots of the partition disagree between host and library: %s vs %s" % (sizes.tolist(), want))
 
     def _gram_chunk(self):
         return int(self.symb._max_rhs)
