@@ -1355,4 +1355,12 @@ __global__ void k_exchange_roots(const CliqueDesc* cl, const int32_t* roots, con
   }
 }
 
+// dst <- src on the update-layout blocks (na x na at d.upd) of the cliques of a launch list
+__global__ void k_copy_upd_blocks(TreeArgs a, const double* src, double* dst) {
+  const CliqueDesc d = a.cl[a.lev[blockIdx.x]];
+  const int64_t len = (int64_t)d.na * d.na;
+  for (int64_t e = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; e < len; e += (int64_t)gridDim.y * blockDim.x)
+    dst[d.upd + e] = src[d.upd + e];
+}
+
 }  // namespace smcp

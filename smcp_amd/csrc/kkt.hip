@@ -945,7 +945,22 @@ int kkt_prepare_part(csp_ctx* c, const double* L, const double* Y, int set, int 
   if (set == 2) HIPCHK(zero_flag(c, st));
   if (with_lk) prep_lk_set(c, set, L, st);
   gather_set(c, set, Y, 0, 1, D.yaa, st);
-  HIPCHK(hipMemcpyAsync(D.fac, D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st));
+  {
+    // fac <- yaa on the blocks of THIS set only: the other set's blocks may already hold their factors (a copy of the
+    // whole array for set 1 used to put the unfactored Y_AA back over the factors of the top, set 2 -- unnoticed as long
+    // as the top was a root without separator)
+    TreeArgs t = tree_args(c);
+    const LevelSet& LS = c->sets[set];
+    for (int64_t l = 0; l < c->S.nlev; ++l) {
+      const int cnt = (int)(LS.lvl[l].nI + LS.lvl[l].nII);
+      if (!cnt) continue;
+      t.lev = LS.lev2 + LS.off[l];
+      const int namax = std::max(LS.lvl[l].namaxI, LS.lvl[l].namaxII);
+      if (!namax) continue;
+      launch(c, KID_axpby, k_copy_upd_blocks, dim3(cnt, umax1(std::min(64, (namax * namax + 1023) / 1024))), dim3(256), st, t,
+             (const double*)D.yaa, D.fac);
+    }
+  }
   MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
   for (int64_t l = 0; l < c->S.nlev; ++l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
