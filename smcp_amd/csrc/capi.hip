@@ -1398,7 +1398,9 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     }
     if ((rc = dev_alloc(&D.lk, S.blklen(), D.bytes))) return rc;
     HIPCHK(hipMemset(D.lk, 0, sizeof(double) * std::max<int64_t>(S.blklen(), 1)));
-    {
+    static bool attrs_done = false;     // function attributes are per process (one device per process): set them once
+    if (!attrs_done) {
+      attrs_done = true;
       const int mx = 160 * 1024 - 1024;
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_pad, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
