@@ -75,6 +75,7 @@ class ShardedSchur:
     _exchange_pack, _exchange_unpack, _gram_accumulate, _apply_partition."""
 
     partition = None
+    force_sharded = False    # tests: take the sharded routes (and their collectives) with a group of ONE rank as well
 
     def set_partition(self, group):
         """Cut the tree for the ranks of `group` (deterministic: every rank computes the same cut)."""
@@ -128,7 +129,7 @@ class ShardedSchur:
 
     def build_schur(self, L, Y, group=None):
         world, rank = self._world(group)
-        if world == 1:
+        if world == 1 and not (self.force_sharded and self.partition is not None and group is not None):
             self._columns(L, Y, 0, self.m)
             return
         P = self.partition
@@ -170,7 +171,7 @@ class ShardedSchur:
         from . import chordal
         world, rank = self._world(group)
         L = S.copy()
-        if world == 1 or self.partition is None:
+        if (world == 1 and not (self.force_sharded and group is not None)) or self.partition is None:
             chordal.cholesky(L)
             Y = L.copy()
             chordal.projected_inverse(Y)

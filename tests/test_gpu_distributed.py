@@ -141,3 +141,58 @@ def test_sharded_step_on_random_trees(world, seed0, ncases):
     separator: H off by 4e-2)."""
     import fuzz_sharded
     assert fuzz_sharded.main(ncases, seed0, world) == 0
+
+
+def _rccl_worker(port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from smcp_amd import chordal, problems
+        from smcp_amd.cspmatrix import cspmatrix
+        from smcp_amd.kkt import KKTSystem
+        from smcp_amd.symbolic import Symbolic
+        symb = Symbolic(problems.nested_block_arrow_pattern(nsub=2, nmid=4, nleaf_per_mid=6, seed=4))
+        symb.device_init(0, 4)
+        S = cspmatrix(symb, torch.from_numpy(problems.random_factor_blkval(symb, 0)).cuda())
+        chordal.llt(S)
+        m = 9
+        cptr, cidx, cval = problems.random_constraints(symb, m, density=0.03, seed=2)
+        L1 = S.copy(); chordal.cholesky(L1); Y1 = L1.copy(); chordal.projected_inverse(Y1)
+        single = KKTSystem(symb, cptr, cidx, cval, max_rhs=4, tnzcols=0.0)
+        solve1 = single.factor(L1, Y1)
+        H1 = single.H.clone()
+        rng = np.random.default_rng(3)
+        msk = np.zeros(symb.blklen, dtype=bool); msk[symb.ccs_to_blk()] = True
+        b0 = torch.from_numpy(rng.standard_normal(symb.blklen) * msk).cuda(); y0 = torch.from_numpy(rng.standard_normal(m)).cuda()
+        cx, cy = cspmatrix(symb, b0.clone()), y0.clone()
+        solve1(cx, cy, 0.8)
+        sh = KKTSystem(symb, cptr, cidx, cval, max_rhs=4, tnzcols=0.0)
+        sh.force_sharded = True
+        sh.set_partition(dist.group.WORLD)
+        L, Y = sh.factor_scaling(S, dist.group.WORLD)          # all-gather + all-reduce over RCCL (one rank)
+        solve = sh.factor(L, Y, group=dist.group.WORLD)
+        bx, by = cspmatrix(symb, b0.clone()), y0.clone()
+        solve(bx, by, 0.8)
+        mskd = torch.from_numpy(msk).cuda()
+        out.put(dict(eH=float((sh.H - H1).abs().max() / H1.abs().max()),
+                     ex=float((bx.blkval - cx.blkval).abs()[mskd].max() / cx.blkval.abs().max()),
+                     ey=float((by - cy).abs().max() / cy.abs().max()), ncoll=sh.collectives,
+                     backend=dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_routes_over_rccl_with_one_rank():
+    """The collectives of the sharded step (all_gather_into_tensor on the exchange buffers, all-reduce of H / Amap / the
+    status flag, all-gather of x) on the REAL backend of the N-GPU runs -- RCCL -- with a group of one rank: the boxes
+    here have one GPU, and two RCCL ranks cannot share a device."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_worker, args=(port, out))
+    p.start(); p.join(timeout=600)
+    assert p.exitcode == 0
+    r = out.get()
+    assert r["backend"] == "nccl" and r["ncoll"] >= 7
+    assert r["eH"] < 1e-11 and r["ex"] < 1e-11 and r["ey"] < 1e-11, r
