@@ -135,6 +135,14 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
+    # SMCP_BENCH_FORCE_SHARDED=1 (N = 1 only): the subtree-sharded route and its collectives over RCCL with a group of ONE
+    # rank -- what the host logic and the collective launches of the N-GPU step cost beside the plain single-GPU step
+    force_sharded = world == 1 and os.environ.get("SMCP_BENCH_FORCE_SHARDED") == "1"
+    if force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = _lib.lib()
 
@@ -152,7 +160,8 @@ def main():
     cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=1)
     kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs, tnzcols=0.0 if args.kktsolver == "qr" else None)
     part = None
-    if world > 1 and args.shard == "subtree":
+    if (world > 1 or force_sharded) and args.shard == "subtree":
+        kkt.force_sharded = force_sharded
         part = kkt.set_partition(dist.group.WORLD)   # subtrees -> ranks, replicated top, boundary exchange lists
     Lh = problems.random_factor_blkval(symb, seed=0)
     S = cspmatrix(symb, torch.from_numpy(Lh).to(dev))
@@ -182,7 +191,7 @@ def main():
         if part is not None and args.kktsolver != "qr":
             # N > 1: every sweep of the step sharded by subtree (cholesky, projected_inverse, Schur sweeps, the two
             # Hessians of solve_); boundary update blocks + H + Amap + the completed x travel over RCCL
-            Ls, Ys = kkt.factor_scaling(S, dist.group.WORLD)
+            Ls, Ys = kkt.factor_scaling(S, dist.group.WORLD, defer_status=True)   # status agreed with H's all-reduce
             kkt.factor(Ls, Ys, dist.group.WORLD)(bx, by, 1.0)
             return
         L.blkval.copy_(S.blkval)

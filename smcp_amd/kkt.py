@@ -81,8 +81,10 @@ class ShardedSchur:
         """Cut the tree for the ranks of `group` (deterministic: every rank computes the same cut)."""
         import torch.distributed as dist
         from .shard import subtree_partition
-        world = dist.get_world_size(group)
-        rank = dist.get_rank(group)
+        return self._install_partition(dist.get_world_size(group), dist.get_rank(group))
+
+    def _install_partition(self, world, rank):
+        from .shard import subtree_partition
         P = self.partition = subtree_partition(self.symb, world)
         self._apply_partition(P, rank)
         # blkval positions this rank accounts for in sums over the whole matrix (the top counts once, on rank 0)
@@ -100,7 +102,7 @@ class ShardedSchur:
             return 1, 0
         return dist.get_world_size(group), dist.get_rank(group)
 
-    def _exchange(self, group, nrhs):
+    def _exchange(self, group, nrhs, live=True):
         """Boundary exchange of a leaves->root sweep: the packed update blocks of the subtree roots of every rank
         (nrhs right-hand sides) travel in ONE all-gather on buffers that are allocated once per width."""
         world, rank = self._world(group)
@@ -114,11 +116,12 @@ class ShardedSchur:
             bufs[width] = (torch.zeros(width, dtype=torch.float64, device=self.dev),
                            torch.empty(width * world, dtype=torch.float64, device=self.dev))
         send, recv = bufs[width]
-        if sizes[rank]:
+        if sizes[rank] and live:
             self._exchange_pack(P.roots_by_rank[rank], nrhs, send[:sizes[rank]])
         _all_gather_into(recv, send, group)
         self.collectives += 1
-        self._exchange_unpack_all(P, rank, nrhs, recv, width, sizes)
+        if live:       # a rank whose sweep has failed only keeps the collective matched
+            self._exchange_unpack_all(P, rank, nrhs, recv, width, sizes)
 
     def _exchange_unpack_all(self, P, rank, nrhs, recv, width, sizes):
         for r in range(len(sizes)):
@@ -141,33 +144,54 @@ class ShardedSchur:
             _all_reduce(self.H, group)
             self.collectives += 1
             return
-        # ---- subtree-sharded Gram path
+        # ---- subtree-sharded Gram path.  A rank that fails (its part of a deferred factorisation, or chol(Y_AA) in its
+        # sweeps) keeps taking part in the collectives; a status word rides on H's all-reduce and every rank raises.
+        pend = self.__dict__.pop("_pending_status", None)
+        if pend is not None and pend[0] is not L:
+            raise RuntimeError("factor_scaling(defer_status=True) must be followed by factor() on the pair it returned")
+        err = [pend[1] if pend is not None else None]
+
+        def guarded(f, *args):
+            if err[0] is None:
+                try:
+                    f(*args)
+                except ArithmeticError as e:
+                    err[0] = e
+
         if self._sharded_pair(L, Y):
-            self._gram_prepare_part()                                    # (L, Y) came from factor_scaling
+            guarded(self._gram_prepare_part)                             # (L, Y) came from factor_scaling
         else:
-            self._gram_prepare(L, Y)
+            guarded(self._gram_prepare, L, Y)
         step = self._gram_chunk()
         for j0 in range(0, self.m, step):
             j1 = min(self.m, j0 + step)
-            self._gram_sweep(1, j0, j1)                                  # owned subtrees
-            self._exchange(group, j1 - j0)
-            self._gram_sweep(2, j0, j1)                                  # replicated top
+            guarded(self._gram_sweep, 1, j0, j1)                         # owned subtrees
+            self._exchange(group, j1 - j0, live=err[0] is None)
+            guarded(self._gram_sweep, 2, j0, j1)                         # replicated top
         ranges = list(P.ranges_by_rank[rank]) + (list(P.top_ranges) if rank == 0 else [])
-        self._gram_accumulate(ranges)
-        _all_reduce(self.H, group)
+        guarded(self._gram_accumulate, ranges)
+        self._Hbuf[-1] = 0.0 if err[0] is None else 1.0
+        _all_reduce(self._Hbuf, group)
         self.collectives += 1
+        if float(self._Hbuf[-1]) > 0:
+            self.__dict__.pop("_spair", None)
+            raise err[0] or ArithmeticError("not positive definite on another rank")
 
     # ---- sharded factorisation at a scaling point and the sharded solve_ (include/smcp_amd.h: *_part)
     def _sharded_pair(self, L, Y):
         sp = self.__dict__.get("_spair")
         return sp is not None and sp[0] is L and sp[1] is Y and sp[2] == (L.state(), Y.state())
 
-    def factor_scaling(self, S, group=None):
+    def factor_scaling(self, S, group=None, defer_status=False):
         """L = cholesky(S), Y = projected_inverse(L) (solvers.py:881-891) with every sweep sharded by subtree: the
         leaves->root factorisation runs on the owned cliques, ONE exchange hands the subtree roots' update blocks to
         every rank, the top is factored redundantly; the root->leaves inverse needs no communication.  Returns
         (L, Y), each valid on this rank's cliques and the top (other ranges keep S's values); `factor(L, Y, group)`
-        recognises the pair and shards the Schur sweeps and solve_ the same way."""
+        recognises the pair and shards the Schur sweeps and solve_ the same way.
+        A rank whose subtree is not positive definite must not leave the others in a collective: the failure is agreed
+        on by an all-reduce of a status word before this returns -- or, with defer_status=True, together with H's
+        all-reduce in the `factor(L, Y, group)` that must follow (one collective and one host read-back fewer per
+        step; the ArithmeticError is then raised there, on every rank)."""
         from . import chordal
         world, rank = self._world(group)
         L = S.copy()
@@ -181,7 +205,7 @@ class ShardedSchur:
             self._chol_part(L, 1)
         except ArithmeticError as e:     # keep the collectives matched: the failure is agreed on below
             err = e
-        self._exchange(group, 1)
+        self._exchange(group, 1, live=err is None)
         try:
             self._chol_part(L, 2)
         except ArithmeticError as e:
@@ -195,6 +219,10 @@ class ShardedSchur:
                 self._prepare_part(L, Y, 1)
             except ArithmeticError as e:
                 err = e
+        if defer_status:
+            self.__dict__["_pending_status"] = (L, err)
+            self.__dict__["_spair"] = (L, Y, (L.state(), Y.state()))
+            return L, Y
         bad = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=self.dev)
         _all_reduce(bad, group)
         self.collectives += 1
@@ -281,7 +309,10 @@ class KKTSystem(ShardedSchur):
                      np.ascontiguousarray(cval, dtype=np.float64))
         self._tnzcols = 0.1 if tnzcols is None else float(tnzcols)      # the reference's default (solvers.py:31)
         self.dev = torch.device("cuda", symb._device)
-        self.H = torch.zeros((self.m, self.m), dtype=torch.float64, device=self.dev)
+        # H is a view of a buffer with one slot more: the agreed status of a deferred sharded factorisation rides on
+        # H's all-reduce (factor_scaling(defer_status=True))
+        self._Hbuf = torch.zeros(self.m * self.m + 1, dtype=torch.float64, device=self.dev)
+        self.H = self._Hbuf[:self.m * self.m].view(self.m, self.m)
         self._install()
 
     # The constraint set (entry lists, classification, the swept stack / Q of kkt_qr) lives in the Symbolic's native

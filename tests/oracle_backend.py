@@ -28,7 +28,8 @@ class OracleKKT(kkt.ShardedSchur):
         self.m = len(cptr) - 1
         self.K = orc.KKT(_S(symb), np.asarray(cptr), np.asarray(cidx), np.asarray(cval))
         self.dev = torch.device("cpu")
-        self.H = torch.zeros((self.m, self.m), dtype=torch.float64)   # H.T is the column-major matrix
+        self._Hbuf = torch.zeros(self.m * self.m + 1, dtype=torch.float64)     # + the status word of the all-reduce
+        self.H = self._Hbuf[:self.m * self.m].view(self.m, self.m)             # H.T is the column-major matrix
 
     def amap(self, X):
         return torch.from_numpy(self.K.amap(_np(X)))

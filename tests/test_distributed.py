@@ -105,9 +105,41 @@ def _factor_mode(rank, world, out, symb, sharded, single, A, Lh, Yh, m):
     px, py = cspmatrix(symb, torch.from_numpy(b0.copy())), torch.from_numpy(y0.copy())
     solve(px, py, 0.5, complete=False)
     ep = float((px.blkval - cx.blkval).abs()[torch.from_numpy(own & msk)].max() / cx.blkval.abs().max())
+    # status agreed together with H (defer_status): one collective fewer, the same numbers
+    c0 = sharded.collectives
+    L2, Y2 = sharded.factor_scaling(cspmatrix(symb, torch.from_numpy(A.copy())), dist.group.WORLD, defer_status=True)
+    n_fact_def = sharded.collectives - c0
+    solve2 = sharded.factor(L2, Y2, group=dist.group.WORLD)
+    n_step_def = sharded.collectives - c0
+    eHd = float((sharded.H - single.H).abs().max() / single.H.abs().max())
+    dx, dy = cspmatrix(symb, torch.from_numpy(b0.copy())), torch.from_numpy(y0.copy())
+    solve2(dx, dy, 0.5)
+    exd = float((dx.blkval - cx.blkval).abs()[torch.from_numpy(msk)].max() / cx.blkval.abs().max())
+    # a subtree of the LAST rank is not positive definite: every rank raises, at the agreed point, in both modes
+    k = int(np.nonzero(np.asarray(P.owner) == world - 1)[0][0])
+    bad = A.copy()
+    bad[symb.blkptr[k]] = -1.0                                    # first diagonal entry of clique k
+    raised = []
+    for defer in (False, True):
+        where = "scaling"
+        try:
+            Lb, Yb = sharded.factor_scaling(cspmatrix(symb, torch.from_numpy(bad.copy())), dist.group.WORLD, defer_status=defer)
+            where = "factor"
+            sharded.factor(Lb, Yb, group=dist.group.WORLD)
+            where = "none"
+        except ArithmeticError:
+            pass
+        raised.append(where)
+    flags = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(flags, torch.tensor([raised[0] == "scaling", raised[1] == "factor"], dtype=torch.int64))
+    agreed = bool(all(int(f.min()) == 1 for f in flags))
+    # ... and the next factorisation on good data works again
+    L3, Y3 = sharded.factor_scaling(cspmatrix(symb, torch.from_numpy(A.copy())), dist.group.WORLD)
+    eL3 = float(np.abs(L3.blkval.numpy() - Lh)[own].max() / np.abs(Lh).max())
     if rank == 0:
         out.put(dict(eL=eL, eY=eY, eH=eH, ex=ex, ey=ey, ep=ep, untouched=untouched, n_fact=n_fact, n_build=n_build,
-                     n_solve=n_solve, chunks=-(-m // sharded._gram_chunk())))
+                     n_solve=n_solve, chunks=-(-m // sharded._gram_chunk()), n_fact_def=n_fact_def, n_step_def=n_step_def,
+                     eHd=eHd, exd=exd, agreed=agreed, eL3=eL3))
 
 
 def test_sharded_factorisation_and_solve_two_ranks_gloo():
@@ -120,6 +152,9 @@ def test_sharded_factorisation_and_solve_two_ranks_gloo():
     assert r["n_fact"] == 2                      # subtree-root updates of the factorisation + the agreed status flag
     assert r["n_build"] == r["chunks"] + 1       # one exchange per chunk of right-hand sides + the all-reduce of H
     assert r["n_solve"] == 4                     # two Hessian exchanges + Amap all-reduce + completion of x
+    assert r["n_fact_def"] == 1 and r["n_step_def"] == 1 + r["chunks"] + 1     # the status rides on H's all-reduce
+    assert r["eHd"] < 1e-11 and r["exd"] < 1e-11 and r["eL3"] < 1e-11
+    assert r["agreed"]                           # a failure on one rank is raised by every rank at the same point
 
 
 def test_sharded_factorisation_and_solve_three_ranks_gloo():

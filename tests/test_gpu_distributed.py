@@ -99,6 +99,37 @@ def _factor_mode(rank, out, symb, S, L1, Y1, single, sharded, m):
     px, py = cspmatrix(symb, b0.clone()), y0.clone()
     solve(px, py, 0.5, complete=False)
     res["ep"] = rel(px.blkval, cx.blkval, own & mskd)
+    # the status agreed together with H (defer_status): one collective and one read-back fewer, the same numbers
+    c0 = sharded.collectives
+    L2, Y2 = sharded.factor_scaling(S, dist.group.WORLD, defer_status=True)
+    res["n_fact_def"] = sharded.collectives - c0
+    solve2 = sharded.factor(L2, Y2, group=dist.group.WORLD)
+    res["eHd"] = float((sharded.H - single.H).abs().max() / single.H.abs().max())
+    dx, dy = cspmatrix(symb, b0.clone()), y0.clone()
+    solve2(dx, dy, 0.5)
+    res["exd"] = rel(dx.blkval, cx.blkval, mskd)
+    # a subtree of the last rank is not positive definite: both ranks raise at the agreed point, in both modes, and
+    # the device context recovers for the next factorisation
+    world = dist.get_world_size()
+    k = int(np.nonzero(np.asarray(P.owner) == world - 1)[0][0])
+    bad = S.copy()
+    bad.blkval[int(symb.blkptr[k])] = -1.0
+    raised = []
+    for defer in (False, True):
+        where = "scaling"
+        try:
+            Lb, Yb = sharded.factor_scaling(bad, dist.group.WORLD, defer_status=defer)
+            where = "factor"
+            sharded.factor(Lb, Yb, group=dist.group.WORLD)
+            where = "none"
+        except ArithmeticError:
+            pass
+        raised.append(where)
+    flags = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(flags, torch.tensor([raised[0] == "scaling", raised[1] == "factor"], dtype=torch.int64))
+    res["agreed"] = bool(all(int(f.min()) == 1 for f in flags))
+    L3, Y3 = sharded.factor_scaling(S, dist.group.WORLD)
+    res["eL3"] = rel(L3.blkval, L1.blkval, own)
     if rank == 0:
         out.put(dict(res, eL=eL, eY=eY, eH=eH, untouched=untouched, n_fact=n_fact, n_build=n_build,
                      chunks=-(-m // sharded._gram_chunk())))
@@ -109,6 +140,8 @@ def test_sharded_factorisation_and_solve_two_ranks_one_gpu():
     for k in ("eL", "eY", "eH", "ex0", "ey0", "ex1", "ey1", "ep"):
         assert r[k] < 1e-11, (k, r)
     assert r["untouched"] and r["n_fact"] == 2 and r["n_build"] == r["chunks"] + 1 and r["n_solve"] == 4
+    assert r["n_fact_def"] == 1 and r["eHd"] < 1e-11 and r["exd"] < 1e-11 and r["eL3"] < 1e-11
+    assert r["agreed"]
 
 
 @pytest.mark.parametrize("mode", ["columns", "subtree"])
