@@ -113,6 +113,12 @@ def main():
               file=sys.stderr)
         raise SystemExit(2)
 
+    # RCCL prints a version banner on stdout when its first communicator comes up: everything but the result line goes
+    # to stderr (file descriptor 1 points at stderr from here on; rank 0 writes the JSON line to the saved stdout)
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from smcp_amd import _lib, chordal, problems
@@ -475,8 +481,8 @@ def main():
             # calibration pass that precedes them (events around every launch)
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
         }
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), file=real_stdout, flush=True)
+    if world > 1 or force_sharded:
         dist.destroy_process_group()
 
 

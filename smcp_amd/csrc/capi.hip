@@ -367,6 +367,12 @@ void lf_pinv(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
 }
 
 constexpr size_t LF_DIAG_LDS = (size_t)(2 * LB * LBD + 256 + 16 * LB) * sizeof(double);
+// threads of the one-workgroup diagonal-block step (SMCP_DIAG_THREADS, timing studies; multiple of 64, at most 1024)
+static dim3 diag_blk() {
+  static int t = 0;
+  if (!t) { const char* e = getenv("SMCP_DIAG_THREADS"); t = e ? atoi(e) : 512; if (t < 64 || t > 1024 || (t & 63)) t = 512; }
+  return dim3(t);
+}
 
 // blocked Cholesky of the large fronts of one level (children already factored): clear + assemble + steps
 // fronts of at most MID_MAXROWS rows: the blocked Cholesky of a front in one workgroup (k_mid_chol); SMCP_MID=0: per-step kernels
@@ -390,7 +396,7 @@ void lf_chol(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
   }
   const int mtA = tiles64(a.namax);
   for (int jb = 0; jb < a.nnmax; jb += LB) {
-    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, x, (double*)nullptr, 0, jb, 1);
+    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, a, x, (double*)nullptr, 0, jb, 1);
     const int mrem = nfmax - jb - 1, ncr = std::max(0, a.nnmax - jb - 1);
     if (mrem > 0) launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(umax1(tiles64(mrem)), cnt), blk, st, a, x, (double*)nullptr, 0, jb);
     const int mt = tiles64(mrem), nt = tiles64(ncr);
@@ -407,7 +413,7 @@ void lf_factor_yaa(csp_ctx* c, const MfmaArgs& a, int cnt, double* fac, hipStrea
     return;
   }
   for (int jb = 0; jb < a.namax; jb += LB) {
-    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, (double*)nullptr, fac, 2, jb, 1);
+    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, a, (double*)nullptr, fac, 2, jb, 1);
     const int mrem = a.namax - jb - 1;
     if (mrem > 0) {
       launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(umax1(tiles64(mrem)), cnt), blk, st, a, (double*)nullptr, fac, 2, jb);
@@ -440,7 +446,7 @@ void lf_prep(csp_ctx* c, const MfmaArgs& a, int cnt, const double* L, hipStream_
     }
   } else
   for (int ib = 0; ib < a.nnmax; ib += LB) {
-    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, const_cast<double*>(L), (double*)nullptr, 1, ib, 0);
+    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, a, const_cast<double*>(L), (double*)nullptr, 1, ib, 0);
     if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, L, c->D.lk, ib, 0);
     launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, L, c->D.lk, ib, 0, 0);
   }
@@ -842,7 +848,7 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
 void lf_factor_inverse(csp_ctx* c, const MfmaArgs& a, int cnt, hipStream_t st) {
   dim3 blk(256);
   for (int ib = 0; ib < a.namax; ib += LB) {
-    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, a, (double*)nullptr, c->D.fac, 4, ib, 0);
+    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, a, (double*)nullptr, c->D.fac, 4, ib, 0);
     if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, a, (const double*)c->D.fac, c->D.faci, ib, 4);
     launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, a, (const double*)c->D.fac, c->D.faci, ib, 4, 0);
   }
@@ -1591,7 +1597,7 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
         }
         launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(ntN * ntN), cnt), blk, st, am, x, 2);
         for (int jb = 0; jb < am.nnmax; jb += LB) {
-          launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, jb, 1);
+          launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, jb, 1);
           const int mrem = am.nnmax - jb - 1;
           if (mrem > 0) {
             launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(umax1(tiles64(mrem)), cnt), blk, st, am, (double*)nullptr, (double*)nullptr, 3, jb);
@@ -1600,7 +1606,7 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
           }
         }
         for (int ib = 0; ib < am.nnmax; ib += LB) {
-          launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), blk, LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, ib, 0);
+          launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, ib, 0);
           if (ib > 0) launch(c, KID_lf_prep_s, k_lf_prep_s, dim3(umax1(tiles64(ib)), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3);
           launch(c, KID_lf_prep_row, k_lf_prep_row, dim3(umax1(tiles64(ib) + 1), cnt), blk, st, am, (const double*)nullptr, (double*)nullptr, ib, 3, 0);
         }

@@ -683,7 +683,7 @@ __device__ inline LfMat lf_mat(const MfmaArgs& a, int k, int mode, double* x, do
 }
 
 // diag step: factor (or only invert) the diagonal block at column jb; L block written back, inverse to scratch
-__global__ void __launch_bounds__(256) k_lf_diag(MfmaArgs a, double* x, double* aux, int mode, int jb, int do_potrf) {
+__global__ void __launch_bounds__(1024) k_lf_diag(MfmaArgs a, double* x, double* aux, int mode, int jb, int do_potrf) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const D = smem;
   double* const Di = D + LB * LBD;

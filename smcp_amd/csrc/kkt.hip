@@ -118,10 +118,16 @@ __global__ void k_dense_potrs(const double* A, int n, int64_t lda, double* B, in
   wg::trsm_llN(n, nrhs, A, lda, B, ldb);
   wg::trsm_llT(n, nrhs, A, lda, B, ldb);
 }
+// threads of the one-workgroup factorisation of H (SMCP_POTRF_THREADS, timing studies)
+static dim3 potrf_blk() {
+  static int t = 0;
+  if (!t) { const char* e = getenv("SMCP_POTRF_THREADS"); t = e ? atoi(e) : 1024; if (t < 64 || t > 1024 || (t & 63)) t = 1024; }
+  return dim3(t);
+}
 // m <= 128: the whole factorisation in the LDS of one workgroup -- 16-wide block columns, diagonal blocks factored
 // and inverted by one wavefront (potrf_inv16), panel and trailing updates on MFMA (the scheme of k_factor_yaa_lds).
 // The inverses of the diagonal blocks are kept (dinv: 256 doubles per block) for k_dense_potrs_small.
-__global__ void __launch_bounds__(256) k_dense_potrf_small(double* A, int n, int64_t lda, int* info, double* dinv) {
+__global__ void __launch_bounds__(1024) k_dense_potrf_small(double* A, int n, int64_t lda, int* info, double* dinv) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int ld = n | 1;
   double* const M = smem;
@@ -530,7 +536,7 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
       HIPCHK(hipFuncSetAttribute((const void*)k_dense_potrf_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
       attr_set = true;
     }
-    launch_lds(c, KID_dense_potrf, k_dense_potrf_small, dim3(1), dim3(256), lds, st, A, (int)n, lda, c->D.info, c->D.hinv);
+    launch_lds(c, KID_dense_potrf, k_dense_potrf_small, dim3(1), potrf_blk(), lds, st, A, (int)n, lda, c->D.info, c->D.hinv);
   } else if (use_generic()) {
     launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
   } else {
@@ -549,7 +555,7 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
       c->D.hinv_cap = need;
     }
     for (int jb = 0; jb < (int)n; jb += LB) {
-      launch_lds(c, KID_lf_diag, k_lf_diag, dim3(1), blk, LF_DIAG_LDS, st, a, A, (double*)nullptr, 5, jb, 1);
+      launch_lds(c, KID_lf_diag, k_lf_diag, dim3(1), dim3(512), LF_DIAG_LDS, st, a, A, (double*)nullptr, 5, jb, 1);
       HIPCHK(hipMemcpyAsync(c->D.hinv + (int64_t)(jb / LB) * LB * LB, c->D.lfd_dense, sizeof(double) * LB * LB, hipMemcpyDeviceToDevice, st));
       const int mrem = (int)n - jb - LB;
       if (mrem > 0) {
