@@ -191,7 +191,18 @@ def main():
         if rc != 0:
             raise RuntimeError("%s failed rc=%d" % (what, rc))
 
+    # failure reports deferred: the factorisations latch "not positive definite" on the device and the step reads the
+    # latch once, at its end (chordal.lazy_status; SMCP_BENCH_EAGER=1: a read-back after every factorisation)
+    lazy = os.environ.get("SMCP_BENCH_EAGER") != "1"
+    if lazy:
+        chordal.lazy_status(symb, True)
+
     def step():
+        _step()
+        if lazy:
+            chordal.check_status(symb)
+
+    def _step():
         bx.blkval.copy_(bx0)
         by.copy_(by0)
         if part is not None and args.kktsolver != "qr":
@@ -257,6 +268,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
+    if lazy:
+        chordal.lazy_status(symb, False)
 
     # ---------------- roofline of the dominant kernel (HIP events on its launches inside the timed region) ------
     roofline = None

@@ -47,6 +47,17 @@ void csp_symbolic_destroy(csp_ctx* ctx);
 csp_ctx* csp_symbolic_replicate(const csp_ctx* base, int64_t K, int64_t* info);
 int csp_trial_flags(csp_ctx* ctx, int64_t K, int* out);
 
+/* Deferred status.  The factorisations (csp_cholesky, csp_completion, the chol(Y_AA) inside the Hessians and the Schur
+ * sweeps, dense_potrf) report "not positive definite" by reading a device flag back, which synchronises the stream:
+ * the reference's calls raise at once (CHOMPACK cholesky -> ArithmeticError, solvers.py:881-891).  With
+ * csp_lazy_status(ctx, 1) they return 0 without waiting and the first failure is latched on the device;
+ * csp_status(ctx, stream) synchronises, returns the latched code (0 = none; otherwise what the failing call would
+ * have returned) and clears it.  After a failure the calls that follow run on meaningless data until the status is
+ * read -- safe (no index depends on values), but their results are void.  One KKT solve then costs one host
+ * synchronisation instead of four. */
+int csp_lazy_status(csp_ctx* ctx, int on);
+int csp_status(csp_ctx* ctx, void* stream);
+
 /* symb.p / snode / snptr / relptr / blkptr ... (cspmatrix internals [EXT], SURVEY App. A.1;
  * supernodes()/separators()/cliques() at analysis.py:173-175).  Returns the number of
  * elements of array `what`; when out != NULL copies them as int64 (host). */

@@ -20,6 +20,8 @@ SIGNATURES = {
     "csp_symbolic_destroy": (None, [c_vp]),
     "csp_symbolic_replicate": (c_vp, [c_vp, c_i64, c_i64p]),
     "csp_trial_flags": (ctypes.c_int, [c_vp, c_i64, c_vp]),
+    "csp_lazy_status": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "csp_status": (ctypes.c_int, [c_vp, c_vp]),
     "csp_symbolic_query": (c_i64, [c_vp, ctypes.c_int, c_vp]),
     "csp_maxcardsearch": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp]),
     "csp_mindegree": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp]),

@@ -28,6 +28,22 @@ def _ensure(symb, nrhs=1):
         symb.device_init(torch.cuda.current_device(), max(1, nrhs))
 
 
+def lazy_status(symb, on=True):
+    """Deferred failure reports (include/smcp_amd.h: csp_lazy_status): with on=True the factorisations on `symb` no
+    longer wait for the device to tell whether the matrix was positive definite -- they return at once and the first
+    failure is latched on the device until ``check_status`` reads it.  The reference's calls raise immediately
+    (solvers.py:881-891); a driver that knows its scaling point is inside the cone (the line search has just factored
+    it) can run a whole KKT solve with ONE host synchronisation this way."""
+    _ensure(symb)
+    _chk(_lib.lib().csp_lazy_status(symb.handle, 1 if on else 0), "csp_lazy_status")
+    symb.__dict__["_lazy_status"] = bool(on)
+
+
+def check_status(symb, what="factorisation (deferred status)"):
+    """Synchronises and raises the ArithmeticError a factorisation since the last check would have raised."""
+    _chk(_lib.lib().csp_status(symb.handle, _stream()), what)
+
+
 def cholesky(X):
     _ensure(X.symb)
     X.touched()

@@ -170,12 +170,16 @@ class ShardedSchur:
             guarded(self._gram_sweep, 2, j0, j1)                         # replicated top
         ranges = list(P.ranges_by_rank[rank]) + (list(P.top_ranges) if rank == 0 else [])
         guarded(self._gram_accumulate, ranges)
+        guarded(self._deferred_status)               # chordal.lazy_status: the one read-back of the step happens here
         self._Hbuf[-1] = 0.0 if err[0] is None else 1.0
         _all_reduce(self._Hbuf, group)
         self.collectives += 1
         if float(self._Hbuf[-1]) > 0:
             self.__dict__.pop("_spair", None)
             raise err[0] or ArithmeticError("not positive definite on another rank")
+
+    def _deferred_status(self):
+        pass
 
     # ---- sharded factorisation at a scaling point and the sharded solve_ (include/smcp_amd.h: *_part)
     def _sharded_pair(self, L, Y):
@@ -375,6 +379,11 @@ class KKTSystem(ShardedSchur):
 
     def _gram_chunk(self):
         return int(self.symb._max_rhs)
+
+    def _deferred_status(self):
+        if self.symb.__dict__.get("_lazy_status"):
+            from . import chordal
+            chordal.check_status(self.symb)
 
     def _gram_prepare(self, L, Y):
         self._own()

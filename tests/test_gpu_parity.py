@@ -151,6 +151,53 @@ def test_trsm(name):
         assert rel(Bd.cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize("name", ["arrow", "nested_mid", "fam_odd"])
+def test_deferred_status(name):
+    """chordal.lazy_status: the factorisations return without reading the device flag back; check_status raises what they
+    would have raised, once, and a whole KKT solve under the deferred regime equals the eager one (H, x and y
+    to rounding: the extend-adds and Amap sum with atomics)."""
+    symb, S, A, msk = setup(name, 2)
+    rng = np.random.default_rng(4)
+    m = 6
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.05, seed=9)
+    kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=4)
+    b0 = rng.standard_normal(symb.blklen) * msk
+    y0 = rng.standard_normal(m)
+
+    def solve(mat):
+        L = dev(symb, mat)
+        chordal.cholesky(L)
+        Y = L.copy()
+        chordal.projected_inverse(Y)
+        f = kkt.factor(L, Y)
+        bx, by = dev(symb, b0), torch.from_numpy(y0.copy()).cuda()
+        f(bx, by, 0.7)
+        return host(bx), by.cpu().numpy(), kkt.H.cpu().numpy().copy()
+
+    x1, y1, H1 = solve(A)
+    bad = A.copy()
+    bad[symb.blkptr[symb.Nsn // 2]] = -1.0
+    chordal.lazy_status(symb, True)
+    try:
+        x2, y2, H2 = solve(A)
+        chordal.check_status(symb)                       # nothing failed
+        assert rel(H2, H1) < 1e-13 and rel(y2, y1) < 1e-12 and rel(x2[msk], x1[msk]) < 1e-12
+        chordal.cholesky(dev(symb, bad))                 # returns at once ...
+        with pytest.raises(ArithmeticError):
+            chordal.check_status(symb)                   # ... the failure is reported here
+        chordal.check_status(symb)                       # and only once
+        solve(bad)                                       # a whole solve on a matrix outside the cone: no hang, no fault
+        with pytest.raises(ArithmeticError):
+            chordal.check_status(symb)
+        x3, y3, H3 = solve(A)                            # the context recovers
+        chordal.check_status(symb)
+        assert rel(H3, H1) < 1e-13 and rel(y3, y1) < 1e-12
+    finally:
+        chordal.lazy_status(symb, False)
+    with pytest.raises(ArithmeticError):
+        chordal.cholesky(dev(symb, bad))                 # eager again
+
+
 @pytest.mark.parametrize("name", ["arrow", "rand2", "nested_mid", "diag", "fam_max", "fam_odd", "fam_nine", "nested", "rand1"])
 def test_kkt_factor_and_solve(name):
     symb, S, A, msk = setup(name, 7)
