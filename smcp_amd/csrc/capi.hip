@@ -324,6 +324,18 @@ bool use_large() {
   return g == 1;
 }
 inline unsigned umax1(int x) { return (unsigned)std::max(1, x); }
+// threads of the clique-local factorisation kernels on a class of small fronts (nn <= 16, na <= 32: the leaves of
+// synth50k).  Measured (bench.py kernel times, SMCP_FTHR_* sweeps): k_factor_yaa_lds 0.149 -> 0.110 ms per step with 64 threads (a chain of
+// one-wave 16 x 16 factorisations: more, smaller workgroups in flight), k_chol_mfma 0.179 -> 0.171 with 128,
+// k_pinv_mfma is fastest with 256; the larger classes do not care.  SMCP_FTHR_CHOL / _PINV / _YAA override.
+static int fact_threads(const MfmaArgs& am, int thr, int kind) {
+  static int t[3] = {0, 0, 0};
+  if (!t[0]) {
+    auto rd = [](const char* n, int d) { const char* e = getenv(n); int v = e ? atoi(e) : d; return (v >= 64 && v <= 1024 && !(v & 63)) ? v : d; };
+    t[0] = rd("SMCP_FTHR_CHOL", 128); t[1] = rd("SMCP_FTHR_PINV", 256); t[2] = rd("SMCP_FTHR_YAA", 64);
+  }
+  return (am.nnmax <= 16 && am.namax <= 32) ? t[kind] : thr;
+}
 
 // children -> front extend-add of the large fronts of one level: gather plan (one owner thread per front position;
 // measured 1.27 ms on the synth50k top level) or, without a plan / with SMCP_ASM=tiled, the child-major tiled kernel
@@ -894,7 +906,7 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
         for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
           if (!lds) return;
           size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
-          if (am.namax) launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(256), bytes, st, am, (const double*)c->D.yaa, c->D.fac);
+          if (am.namax) launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(fact_threads(am, 256, 2)), bytes, st, am, (const double*)c->D.yaa, c->D.fac);
         });
       for_all_large(c, a0, [&](MfmaArgs am, int cnt) { if (am.namax) lf_factor_yaa(c, am, cnt, c->D.fac, st); });
     } else {
@@ -1527,7 +1539,7 @@ static int cholesky_impl(csp_ctx* c, double* x, void* stream, int set) {
     a0.LK = nullptr;
     for (int64_t l = 0; l < c->S.nlev; ++l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
-        if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
+        if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(fact_threads(am, thr, 0)), bytes, st, am, x);
         else if (use_large() && c->D.gp_tptr) lf_chol(c, am, cnt, x, st);
         else launch_lds(c, KID_chol_mfma_hbm, k_chol_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
       }, set);
@@ -1591,7 +1603,7 @@ static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set) 
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
     for (int64_t l = c->S.nlev - 1; l >= 0; --l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
-        if (lds) launch_lds(c, KID_pinv_mfma, k_pinv_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
+        if (lds) launch_lds(c, KID_pinv_mfma, k_pinv_mfma<true>, dim3(cnt), dim3(fact_threads(am, thr, 1)), bytes, st, am, x);
         else if (use_large()) lf_pinv(c, am, cnt, x, st);
         else launch_lds(c, KID_pinv_mfma_hbm, k_pinv_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
       }, set);

@@ -973,7 +973,7 @@ int kkt_prepare_part(csp_ctx* c, const double* L, const double* Y, int set, int 
       if (!am.namax) return;
       if (lds) {
         size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
-        launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(256), bytes, st, am, (const double*)D.yaa, D.fac);
+        launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(fact_threads(am, 256, 2)), bytes, st, am, (const double*)D.yaa, D.fac);
       } else lf_factor_yaa(c, am, cnt, D.fac, st);
     }, set);
   HIPCHK(end_call(c));
