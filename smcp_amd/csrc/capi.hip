@@ -1607,6 +1607,15 @@ static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set) 
         else if (use_large()) lf_pinv(c, am, cnt, x, st);
         else launch_lds(c, KID_pinv_mfma_hbm, k_pinv_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
       }, set);
+    // The root->leaves pass has just gathered the separator block Y_AA of every clique into the update workspace
+    // (each clique's children read it from there): keep a copy as yaa for the pair (L, Y = x), so that the sweeps that
+    // follow do not gather all of it again (four launches, 72 us on synth50k, against 30 us for the copy).
+    if (!set && !cache_off() && c->D.yaa && c->D.upd && c->S.updlen() > 0) {
+      HIPCHK(hipMemcpyAsync(c->D.yaa, c->D.upd, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st));
+      c->D.yaa_tag = x;
+      c->D.fac_tag = c->D.faci_tag = nullptr;
+      c->D.part_valid = false;
+    }
   } else
   for_levels_down(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
