@@ -340,7 +340,10 @@ static int fact_threads(const MfmaArgs& am, int thr, int kind) {
 // children -> front extend-add of the large fronts of one level: gather plan (one owner thread per front position;
 // measured 1.27 ms on the synth50k top level) or, without a plan / with SMCP_ASM=tiled, the child-major tiled kernel
 // (coalesced reads but a latency-bound scan of every child by every tile: 2.40 ms on the same level)
-void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, int sgn, hipStream_t st) {
+// clear_first (sgn 0 callers): the update blocks must read as zero where no child contributes -- the gather plan and the
+// tiled kernel store only what they receive, so the blocks are cleared before them; k_lf_assemble_lds assigns the whole
+// lower triangle (zeros included) and needs no clear pass (26 us per Schur sweep on synth50k: 105 MB of stores)
+void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, int sgn, hipStream_t st, bool clear_first = false) {
   static int plan = -1;
   if (plan < 0) { const char* e = getenv("SMCP_ASM"); plan = (e && e[0] == 't') ? 0 : 1; }
   {
@@ -358,6 +361,8 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
       }
     }
   }
+  if (clear_first)
+    launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), dim3(256), st, a);
   if (plan && a.t.gp_tptr) {
     launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
     return;
@@ -371,8 +376,7 @@ void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t 
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
   if (a.nchmax > 0) {     // a level of childless large fronts has nothing to assemble (k_lf_up2 does not read their update blocks)
-    launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), blk, st, a);
-    lf_assemble(c, a, cnt, nrhs, U, ldu, 0, st);
+    lf_assemble(c, a, cnt, nrhs, U, ldu, 0, st, true);
   }
   launch(c, KID_lf_up1, k_lf_up1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
   launch(c, KID_lf_up2, k_lf_up2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);

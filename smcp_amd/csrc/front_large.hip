@@ -215,7 +215,13 @@ __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u,
   extern __shared__ __attribute__((aligned(16))) double T[];
   const int k = a.t.lev[blockIdx.x];
   const CliqueDesc d = a.t.cl[k];
-  if (d.chend == d.chbeg) return;
+  if (d.chend == d.chbeg) {
+    if (!sgn) {      // a childless front among fronts with children: its update block is assigned too (zero)
+      double* U0 = a.t.upd + (int64_t)blockIdx.y * a.t.updlen + d.upd;
+      for (int e = threadIdx.x; e < d.na * d.na; e += blockDim.x) U0[e] = 0.0;
+    }
+    return;
+  }
   const int r = blockIdx.y;
   const int nn = d.nn, na = d.na, nf = nn + na;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
