@@ -31,7 +31,7 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-result", "-Wno-unused-value", "-pthread", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if os.environ.get("SMCP_STAMPS") == "1":      # diagnostic build with in-kernel cycle stamps
         cmd.insert(1, "-DSMCP_STAMPS")
     if verbose:

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/smcp_amd.h"
@@ -1410,22 +1411,48 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       std::vector<int64_t> tptr(S.nsn + 1, 0), cptr;
       std::vector<int32_t> tgt, src;
       cptr.push_back(0);
-      std::vector<std::pair<int32_t, int32_t>> pr;  // (target code, src offset)
       const int64_t nsn1 = S.nsn / c->ntrial;       // a replicated pattern: plan of the first copy, shifted for the others
-      for (int64_t k = 0; k < nsn1; ++k) {
-        pr.clear();
-        const int64_t nnp = S.nn(k);
-        for (int64_t q = S.chptr[k]; q < S.chptr[k + 1]; ++q) {
-          const int64_t cc = S.chidx[q], nac = S.na(cc);
-          const int32_t* rel = &S.relidx[S.sepptr[cc]];
-          for (int64_t j = 0; j < nac; ++j)
-            for (int64_t i = j; i < nac; ++i) {
-              int32_t ri = rel[i], rj = rel[j];
-              int32_t code = rj < nnp ? (ri | (rj << 15)) : ((1 << 30) | (ri - (int32_t)nnp) | ((rj - (int32_t)nnp) << 15));
-              pr.emplace_back(code, (int32_t)(S.updpptr[cc] + j * nac - j * (j - 1) / 2 + (i - j)));
+      // (target code, src offset) pairs of every clique with children, sorted per clique: the cliques are independent,
+      // so host threads take them round-robin (5.5 M pairs on synth50k: 0.2 s of the set-up on one thread)
+      std::vector<int64_t> par;
+      for (int64_t k = 0; k < nsn1; ++k) if (S.chptr[k + 1] > S.chptr[k]) par.push_back(k);
+      std::vector<std::vector<std::pair<int32_t, int32_t>>> prs(par.size());
+      {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nth = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hw ? hw : 1), (int64_t)16, (int64_t)par.size() / 64 + 1}));
+        auto work = [&](int tix) {
+          for (size_t x = (size_t)tix; x < par.size(); x += (size_t)nth) {
+            const int64_t k = par[x];
+            auto& pr = prs[x];
+            const int64_t nnp = S.nn(k);
+            size_t tot = 0;
+            for (int64_t q = S.chptr[k]; q < S.chptr[k + 1]; ++q) { const int64_t nac = S.na(S.chidx[q]); tot += (size_t)(nac * (nac + 1) / 2); }
+            pr.reserve(tot);
+            for (int64_t q = S.chptr[k]; q < S.chptr[k + 1]; ++q) {
+              const int64_t cc = S.chidx[q], nac = S.na(cc);
+              const int32_t* rel = &S.relidx[S.sepptr[cc]];
+              for (int64_t j = 0; j < nac; ++j)
+                for (int64_t i = j; i < nac; ++i) {
+                  int32_t ri = rel[i], rj = rel[j];
+                  int32_t code = rj < nnp ? (ri | (rj << 15)) : ((1 << 30) | (ri - (int32_t)nnp) | ((rj - (int32_t)nnp) << 15));
+                  pr.emplace_back(code, (int32_t)(S.updpptr[cc] + j * nac - j * (j - 1) / 2 + (i - j)));
+                }
             }
+            std::sort(pr.begin(), pr.end());
+          }
+        };
+        if (nth == 1) work(0);
+        else {
+          std::vector<std::thread> pool;
+          for (int tix = 0; tix < nth; ++tix) pool.emplace_back(work, tix);
+          for (auto& th : pool) th.join();
         }
-        std::sort(pr.begin(), pr.end());
+      }
+      size_t nextpar = 0;
+      static const std::vector<std::pair<int32_t, int32_t>> none;
+      for (int64_t k = 0; k < nsn1; ++k) {
+        const bool has = nextpar < par.size() && par[nextpar] == k;
+        const auto& pr = has ? prs[nextpar] : none;
         for (size_t e = 0; e < pr.size(); ++e) {
           if (e == 0 || pr[e].first != pr[e - 1].first) {
             if (e) cptr.push_back((int64_t)src.size());
@@ -1435,6 +1462,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
         }
         if (!pr.empty()) cptr.push_back((int64_t)src.size());
         tptr[k + 1] = (int64_t)tgt.size();
+        if (has) { std::vector<std::pair<int32_t, int32_t>>().swap(prs[nextpar]); ++nextpar; }
       }
       if (c->ntrial > 1) {
         const int64_t nt1 = (int64_t)tgt.size(), ns1 = (int64_t)src.size(), up1 = S.updplen() / c->ntrial;
