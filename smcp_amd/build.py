@@ -34,6 +34,8 @@ def build(force=False, verbose=True):
            "-Wno-unused-result", "-Wno-unused-value", "-pthread", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if os.environ.get("SMCP_STAMPS") == "1":      # diagnostic build with in-kernel cycle stamps
         cmd.insert(1, "-DSMCP_STAMPS")
+    for flag in os.environ.get("SMCP_CXXFLAGS", "").split():      # experiment builds (-DSMCP_FAM2_NT ...)
+        cmd.insert(1, flag)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -35,6 +35,13 @@
 
 namespace smcp {
 
+// result stores of the family kernels: streamed once, read again only by the Gram kernel a millisecond later
+#ifdef SMCP_FAM2_NT
+#define FAM2_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define FAM2_ST(p, v) (*(p) = (v))
+#endif
+
 typedef const int32_t __attribute__((address_space(4))) cs_i32;
 typedef const double __attribute__((address_space(4))) cs_f64;
 __device__ inline cs_i32* as_scalar(const int32_t* p) { return (cs_i32*)(unsigned long long)p; }
@@ -449,7 +456,7 @@ __global__ void __launch_bounds__(512) k_fam_sparse(MfmaArgs a, double* u, int64
             }
           }
 #pragma unroll
-          for (int x = 0; x < 6; ++x) { const int e = e0 + hl + 32 * x; if (e < npan && !(a.skip & 1)) Pc[e] = acc[x]; }
+          for (int x = 0; x < 6; ++x) { const int e = e0 + hl + 32 * x; if (e < npan && !(a.skip & 1)) FAM2_ST(&Pc[e], acc[x]); }
         }
       }
       STAMP(7);
@@ -532,7 +539,7 @@ __global__ void __launch_bounds__(512) k_fam_sparse(MfmaArgs a, double* u, int64
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int jn = kq + 4 * s;
-            if (l15 < nn && jn <= l15 && !(a.skip & 2)) P[l15 + (int64_t)jn * nf] = gn[s];
+            if (l15 < nn && jn <= l15 && !(a.skip & 2)) FAM2_ST(&P[l15 + (int64_t)jn * nf], gn[s]);
           }
         }
       }
@@ -572,7 +579,7 @@ __global__ void __launch_bounds__(512) k_fam_sparse(MfmaArgs a, double* u, int64
           for (int s = 0; s < 4; ++s)
             if (po[s] >= 0) {
               sU[po[s]] = 0.0;
-              if (!(a.skip & 2)) UkP[po[s]] = uv[s] - acc[s];
+              if (!(a.skip & 2)) FAM2_ST(&UkP[po[s]], uv[s] - acc[s]);
             }
         }
         // Q = R^T G: row tile RT; R^T is zero left of its diagonal block
@@ -588,7 +595,7 @@ __global__ void __launch_bounds__(512) k_fam_sparse(MfmaArgs a, double* u, int64
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int n = kq + 4 * s;
-          if (m < na && n < nn && !(a.skip & 2)) P[(nn + m) + (int64_t)n * nf] = acc[s];
+          if (m < na && n < nn && !(a.skip & 2)) FAM2_ST(&P[(nn + m) + (int64_t)n * nf], acc[s]);
         }
       };
       if (active) {
@@ -896,7 +903,7 @@ __global__ void __launch_bounds__(768) k_fam_sparse12(MfmaArgs a, double* u, int
               }
             }
 #pragma unroll
-            for (int x = 0; x < 6; ++x) { const int e = e0 + hl + 32 * x; if (e < npan && !(a.skip & 1)) Pc[e] = acc[x]; }
+            for (int x = 0; x < 6; ++x) { const int e = e0 + hl + 32 * x; if (e < npan && !(a.skip & 1)) FAM2_ST(&Pc[e], acc[x]); }
           }
           // supernode-block entries of the children, shared by the four child waves (a quarter of the positions each)
           {
@@ -996,7 +1003,7 @@ __global__ void __launch_bounds__(768) k_fam_sparse12(MfmaArgs a, double* u, int
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int jn = kq + 4 * s;
-            if (l15 < nn && jn <= l15 && !(a.skip & 2)) P[l15 + (int64_t)jn * nf] = gn[s];
+            if (l15 < nn && jn <= l15 && !(a.skip & 2)) FAM2_ST(&P[l15 + (int64_t)jn * nf], gn[s]);
           }
         }
         STAMP(1);
@@ -1059,7 +1066,7 @@ __global__ void __launch_bounds__(768) k_fam_sparse12(MfmaArgs a, double* u, int
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int n = kq + 4 * s, m = 16 * tq + l15, m3 = 48 + l15;
-            if (m < na && n < nn && !(a.skip & 2)) P[(nn + m) + (int64_t)n * nf] = acc[s];
+            if (m < na && n < nn && !(a.skip & 2)) FAM2_ST(&P[(nn + m) + (int64_t)n * nf], acc[s]);
             if (wave == 6 && m3 < na && n < nn && !(a.skip & 2)) P[(nn + m3) + (int64_t)n * nf] = acc3[s];
           }
         }
