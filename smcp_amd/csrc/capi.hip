@@ -918,8 +918,14 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
   const bool fast = !use_generic() && use_large();
   if (need_fac && c->D.fac_tag != Y) {
     if (fast) {
-      (void)hipMemcpyAsync(c->D.fac, c->D.yaa, sizeof(double) * c->S.updlen(), hipMemcpyDeviceToDevice, st);
+      // k_factor_yaa_lds reads yaa and writes the lower triangle of fac (what every reader of fac uses; the strict upper
+      // triangles of fac stay zero from csp_device_init); only the large fronts factor in place and need their blocks
+      // copied first -- not all 85 MB of synth50k (37 us per step)
       MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+      for_all_large(c, a0, [&](MfmaArgs am, int cnt) {
+        if (am.namax) launch(c, KID_axpby, k_copy_upd_blocks, dim3(cnt, umax1(std::min(64, (am.namax * am.namax + 1023) / 1024))), dim3(256), st,
+                             am.t, (const double*)c->D.yaa, c->D.fac);
+      });
       for (int64_t l = 0; l < c->S.nlev; ++l)
         for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
           if (!lds) return;
@@ -1592,6 +1598,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     if ((rc = dev_upload(&D.tmpptr, c->h_tmpptr, D.bytes))) return rc;
     if ((rc = dev_alloc(&D.yaa, S.updlen(), D.bytes))) return rc;
     if ((rc = dev_alloc(&D.fac, S.updlen(), D.bytes))) return rc;
+    HIPCHK(hipMemset(D.fac, 0, sizeof(double) * std::max<int64_t>(S.updlen(), 1)));     // strict upper triangles stay zero (prepare_yaa)
     if (!D.sw) {
       if ((rc = dev_alloc(&D.sw, S.blklen(), D.bytes))) return rc;
       hipLaunchKernelGGL(k_fill_sqrt_weights, dim3((unsigned)std::min<int64_t>(S.nsn, 4096)), dim3(256), 0, 0, D.cl, (int)S.nsn, D.sw);
