@@ -86,6 +86,38 @@ inline hipError_t end_call(csp_ctx* c) {
   return e;
 }
 
+// Independent clique-local stages (the inverse-form factor of the small cliques beside that of the large fronts; the
+// Cholesky factors of the separator blocks of the leaves, of the mid fronts and of the large fronts) are launches of a
+// few hundred workgroups or of eight: one after the other they leave most of the chip idle.  Fork puts a branch on a
+// side stream that starts after everything already queued on the caller's stream and is joined back before anything
+// that follows (events only, no host synchronisation).  SMCP_FORK=0: everything on the caller's stream.
+struct Fork {
+  csp_ctx* c; hipStream_t main; hipStream_t s; int which; bool on;
+  static bool enabled() {
+    static int e = -1;
+    if (e < 0) { const char* v = getenv("SMCP_FORK"); e = (v && v[0] == '0') ? 0 : 1; }
+    return e == 1 && !trace_on_early();
+  }
+  static bool trace_on_early() { const char* e = getenv("SMCP_TRACE"); return e && e[0] == '1'; }
+  Fork(csp_ctx* c_, hipStream_t st, int which_) : c(c_), main(st), s(st), which(which_), on(false) {
+    if (!enabled()) return;
+    if (!c->aux_fork && hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming) != hipSuccess) { c->aux_fork = nullptr; return; }
+    if (!c->aux_stream[which] && hipStreamCreateWithFlags(&c->aux_stream[which], hipStreamNonBlocking) != hipSuccess) { c->aux_stream[which] = nullptr; return; }
+    if (!c->aux_join[which] && hipEventCreateWithFlags(&c->aux_join[which], hipEventDisableTiming) != hipSuccess) { c->aux_join[which] = nullptr; return; }
+    if (hipEventRecord(c->aux_fork, main) != hipSuccess) return;
+    if (hipStreamWaitEvent(c->aux_stream[which], c->aux_fork, 0) != hipSuccess) return;
+    s = c->aux_stream[which];
+    on = true;
+  }
+  void join() {
+    if (!on) return;
+    on = false;
+    if (hipEventRecord(c->aux_join[which], s) != hipSuccess || hipStreamWaitEvent(main, c->aux_join[which], 0) != hipSuccess)
+      (void)hipStreamSynchronize(s);      // fall back to a host wait: the branch must be complete before the caller goes on
+  }
+  ~Fork() { join(); }
+};
+
 // SMCP_TRACE=1: name every launch on stderr and wait for it (a device fault aborts the process: the last name printed
 // is the kernel that faulted)
 inline bool trace_on() {
@@ -505,9 +537,12 @@ void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
   TreeArgs t = tree_args(c);
   if (use_large()) {
     t.lev = c->D.lev3idx;
-    if (c->D.nI_total) launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->D.nI_total), dim3(NT), st, t, L, c->D.lk);
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
-    for_all_large(c, a0, [&](MfmaArgs am, int cnt) { lf_prep(c, am, cnt, L, st); });
+    {
+      Fork f(c, st, 0);          // the blocked inversions of the large fronts run beside the small cliques' launch
+      for_all_large(c, a0, [&](MfmaArgs am, int cnt) { lf_prep(c, am, cnt, L, f.s); });
+      if (c->D.nI_total) launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->D.nI_total), dim3(NT), st, t, L, c->D.lk);
+    }
   } else {
     t.lev = nullptr;
     launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->S.nsn), dim3(NT), st, t, L, c->D.lk);
@@ -926,13 +961,20 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
         if (am.namax) launch(c, KID_axpby, k_copy_upd_blocks, dim3(cnt, umax1(std::min(64, (am.namax * am.namax + 1023) / 1024))), dim3(256), st,
                              am.t, (const double*)c->D.yaa, c->D.fac);
       });
-      for (int64_t l = 0; l < c->S.nlev; ++l)
-        for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
-          if (!lds) return;
-          size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
-          if (am.namax) launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(fact_threads(am, 256, 2)), bytes, st, am, (const double*)c->D.yaa, c->D.fac);
-        });
-      for_all_large(c, a0, [&](MfmaArgs am, int cnt) { if (am.namax) lf_factor_yaa(c, am, cnt, c->D.fac, st); });
+      {
+        // clique-local: the large fronts' factorisations on one side stream, the LDS classes alternating between the
+        // caller's stream and a second one (leaves and mid fronts of synth50k run side by side)
+        Fork fl(c, st, 0);
+        for_all_large(c, a0, [&](MfmaArgs am, int cnt) { if (am.namax) lf_factor_yaa(c, am, cnt, c->D.fac, fl.s); });
+        Fork fs(c, st, 1);
+        int turn = 0;
+        for (int64_t l = 0; l < c->S.nlev; ++l)
+          for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
+            if (!lds) return;
+            size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
+            if (am.namax) launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(fact_threads(am, 256, 2)), bytes, (turn++ & 1) ? fs.s : st, am, (const double*)c->D.yaa, c->D.fac);
+          });
+      }
     } else {
       launch(c, KID_factor_yaa, k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), st, a, c->D.yaa, c->D.fac);
     }
@@ -1287,6 +1329,11 @@ void csp_symbolic_destroy(csp_ctx* c) {
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (int q = 0; q < 2; ++q) {
+      if (c->aux_stream[q]) { (void)hipStreamSynchronize(c->aux_stream[q]); (void)hipStreamDestroy(c->aux_stream[q]); }
+      if (c->aux_join[q]) (void)hipEventDestroy(c->aux_join[q]);
+    }
+    if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
     for (int set = 1; set <= 2; ++set) if (c->sets[set].lev2) hipFree(c->sets[set].lev2);
     for (void* p : {(void*)c->xr_roots, (void*)c->xr_owner, (void*)c->xr_bptr}) if (p) hipFree(p);
     if (D.info_host) hipHostFree(D.info_host);

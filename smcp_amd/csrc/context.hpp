@@ -188,6 +188,9 @@ struct csp_ctx {
   int64_t xr_n = 0; int xr_me = -1; int64_t xr_npmax = 1;
   std::vector<int64_t> xr_size;
   int64_t ntrial = 1;                   // copies of the pattern in S (csp_symbolic_replicate): one failure flag per copy
+  // side streams for clique-local launches that do not depend on each other (Fork in capi.hip): created on first use
+  hipStream_t aux_stream[2] = {nullptr, nullptr};
+  hipEvent_t aux_fork = nullptr, aux_join[2] = {nullptr, nullptr};
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status
   int launch_err = 0;                   // first failed kernel launch of the running call (launch helpers); read by end_call
   double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)
