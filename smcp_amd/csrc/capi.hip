@@ -841,19 +841,20 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
     a0.kc_stride = (int)(c->D.m + 1); a0.kc_j0 = (int)sparse_j0;
   }
   // kernels that read their input from U get dense panels built first (zeros + the constraint's entries)
-  auto dense_input = [&](MfmaArgs& a, int cnt) {
+  auto dense_input_on = [&](MfmaArgs& a, int cnt, double* Ub, int nr, hipStream_t s) {
     if (!sparse) return;
-    for (int r0 = 0; r0 < nrhs; r0 += 65535) {
+    for (int r0 = 0; r0 < nr; r0 += 65535) {
       MfmaArgs af = a;
       af.kc_j0 = a.kc_j0 + r0;
       // big panels are shared by several workgroups (column ranges): a single 4096 front would otherwise be filled by
       // one workgroup per right-hand side
       const int64_t pan = (int64_t)(a.nnmax + a.namax) * a.nnmax;
       const int nz = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(a.nnmax, 64), pan / 16384));
-      launch(c, KID_scatter_constraints, k_panel_fill, dim3(cnt, std::min(65535, nrhs - r0), nz), dim3(256), st, af, U + (int64_t)r0 * ldu, ldu);
+      launch(c, KID_scatter_constraints, k_panel_fill, dim3(cnt, std::min(65535, nr - r0), nz), dim3(256), s, af, Ub + (int64_t)r0 * ldu, ldu);
     }
     a.kc_ptr = nullptr;
   };
+  auto dense_input = [&](MfmaArgs& a, int cnt) { dense_input_on(a, cnt, U, nrhs, st); };
   for (int64_t l = 0; l < c->S.nlev; ++l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       if (lds && a.nS > 0 && (sparse || nrhs >= 4)) {
@@ -889,6 +890,28 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         }
       } else if (use_large() && c->D.gp_tptr) {
         if (sparse && try_lfsp(c, a, cnt, nrhs, U, ldu, st)) return;
+        // Many right-hand sides on a few large fronts with children (the Schur sweeps over the top of synth50k: 8 fronts
+        // x 100): the extend-add runs one workgroup per CU (LDS front) and leaves a partial last round, the three phase
+        // kernels after it are short.  The right-hand sides are independent: two halves on two streams fill each
+        // other's tails (every per-right-hand-side buffer is addressed through bases shifted to the half's first one).
+        static int split_min = -1;
+        if (split_min < 0) { const char* e = getenv("SMCP_RHS_SPLIT"); split_min = e ? atoi(e) : 16; }
+        if (split_min > 0 && a.nchmax > 0 && nrhs >= split_min && Fork::enabled()) {
+          const int h = nrhs / 2;
+          MfmaArgs a1 = a, a2 = a;
+          a1.nrhs = h;
+          a2.nrhs = nrhs - h;
+          a2.t.upd += (int64_t)h * a.t.updlen;
+          a2.t.updp += (int64_t)h * a.t.updplen;
+          a2.t.tmp += (int64_t)h * a.t.tmplen;
+          a2.kc_j0 = a.kc_j0 + h;
+          Fork f(c, st, 0);
+          dense_input_on(a2, cnt, U + (int64_t)h * ldu, nrhs - h, f.s);
+          lf_up(c, a2, cnt, nrhs - h, U + (int64_t)h * ldu, ldu, f.s);
+          dense_input_on(a1, cnt, U, h, st);
+          lf_up(c, a1, cnt, h, U, ldu, st);
+          return;
+        }
         dense_input(a, cnt);
         lf_up(c, a, cnt, nrhs, U, ldu, st);
       }
