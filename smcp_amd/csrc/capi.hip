@@ -833,7 +833,7 @@ bool try_lfsp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64
 // sparse_j0 >= 0: the right-hand sides are the constraints sparse_j0 .. (through `ids` if given) and are taken from
 // their per-clique entry lists (MfmaArgs::kc_*) -- U is output only and need not be cleared or scattered into
 void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0,
-                  int64_t sparse_j0 = -1, const int32_t* ids = nullptr) {
+                  int64_t sparse_j0 = -1, const int32_t* ids = nullptr, int64_t lev_lo = 0, int64_t lev_hi = -1) {
   MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
   const bool sparse = sparse_j0 >= 0 && c->D.kc_ptr;
   if (sparse) {
@@ -855,7 +855,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
     a.kc_ptr = nullptr;
   };
   auto dense_input = [&](MfmaArgs& a, int cnt) { dense_input_on(a, cnt, U, nrhs, st); };
-  for (int64_t l = 0; l < c->S.nlev; ++l)
+  for (int64_t l = lev_lo; l < (lev_hi < 0 ? c->S.nlev : lev_hi); ++l)     // [lev_lo, lev_hi): the caller may sweep in two parts
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       if (lds && a.nS > 0 && (sparse || nrhs >= 4)) {
         // families: the childless members (level 0) are swept inside their parents' workgroups (k_hess_up_fam);

@@ -674,79 +674,98 @@ static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_
   HIPCHK(end_call(c));
   return 0;
 }
-// H = sum over the given blkval ranges of G^T W G (ranges: host array of nranges (begin, end) pairs)
-static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, hipStream_t st,
-                           int64_t mcols = -1) {
-  DeviceCtx& D = c->D;
-  const int64_t m = mcols < 0 ? D.m : mcols, bl = c->S.blklen();
-  // sorted, with touching ranges merged (the subtrees of one rank are often neighbours in the postorder)
+// sorted blkval ranges with touching ones merged
+static std::vector<std::pair<int64_t, int64_t>> gram_merge_ranges(int64_t nranges, const int64_t* ranges) {
   std::vector<std::pair<int64_t, int64_t>> rs;
   for (int64_t q = 0; q < nranges; ++q)
     if (ranges[2 * q + 1] > ranges[2 * q]) rs.push_back({ranges[2 * q], ranges[2 * q + 1]});
   std::sort(rs.begin(), rs.end());
-  {
-    size_t w = 0;
-    for (size_t q = 0; q < rs.size(); ++q) {
-      if (w && rs[q].first <= rs[w - 1].second) rs[w - 1].second = std::max(rs[w - 1].second, rs[q].second);
-      else rs[w++] = rs[q];
-    }
-    rs.resize(w);
+  size_t w = 0;
+  for (size_t q = 0; q < rs.size(); ++q) {
+    if (w && rs[q].first <= rs[w - 1].second) rs[w - 1].second = std::max(rs[w - 1].second, rs[q].second);
+    else rs[w++] = rs[q];
   }
-  int64_t total = 0;
-  for (auto& r : rs) total += r.second - r.first;
-  if (total <= 0) {
-    HIPCHK(hipMemset2DAsync(H, ldh * sizeof(double), 0, m * sizeof(double), m, st));
-    return 0;
-  }
-  // ~one resident wave of workgroups (2 per CU) over all ranges
-  int64_t chunk = std::max<int64_t>(2048, ((total / 512 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS);
-  int nchunk = 0;
-  for (auto& r : rs) nchunk += (int)((r.second - r.first + chunk - 1) / chunk);
-  int nb = (int)((m + GRAM_BLK - 1) / GRAM_BLK);
-  int nblk = nb * (nb + 1) / 2;
-  int64_t need = (int64_t)nblk * nchunk * 64 * 256;
+  rs.resize(w);
+  return rs;
+}
+// chunking of a Gram accumulation over `total` rows: ~one resident wave of workgroups (2 per CU) over all ranges
+static int64_t gram_chunk_rows(int64_t total) { return std::max<int64_t>(2048, ((total / 512 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS); }
+static int gram_count_chunks(const std::vector<std::pair<int64_t, int64_t>>& rs, int64_t chunk) {
+  int n = 0;
+  for (auto& r : rs) n += (int)((r.second - r.first + chunk - 1) / chunk);
+  return n;
+}
+static int gram_reserve(csp_ctx* c, int64_t m, int nchunk) {
+  DeviceCtx& D = c->D;
+  const int nb = (int)((m + GRAM_BLK - 1) / GRAM_BLK), nblk = nb * (nb + 1) / 2;
+  const int64_t need = (int64_t)nblk * nchunk * 64 * 256;
   if (D.gpart_len < need) {
     if (D.gpart) { HIPCHK(hipFree(D.gpart)); D.bytes -= D.gpart_len * 8; }
     D.gpart = nullptr;
     if (int rc = dev_alloc(&D.gpart, need, D.bytes)) return rc;
     D.gpart_len = need;
   }
-  int coff = 0;
-  if (nblk == 1) {
-    // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
-    // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
-    static int nw = -1;
-    if (nw < 0) { const char* e = getenv("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
-    const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + nw - 1) / nw;   // lower tiles per wave
-    static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
-    if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
-    const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
-    for (size_t q0 = 0; q0 < rs.size(); q0 += GRAM_MAXR) {      // all ranges of a rank in one launch (up to GRAM_MAXR)
-      GramRanges rg;
-      rg.n = (int)std::min<size_t>(GRAM_MAXR, rs.size() - q0);
-      int nc = 0;
-      for (int q = 0; q < GRAM_MAXR; ++q) {
-        const bool on = q < rg.n;
-        rg.lo[q] = on ? rs[q0 + q].first : 0;
-        rg.hi[q] = on ? rs[q0 + q].second : 0;
-        rg.first[q] = nc;
-        if (on) nc += (int)((rg.hi[q] - rg.lo[q] + chunk - 1) / chunk);
-      }
-      rg.first[GRAM_MAXR] = nc;
-#define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nc, 1), dim3(1024), lds, st, \
-                 (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
-               else if (nw == 8) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nc, 1), dim3(512), lds, st, \
-                 (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
-               else launch_lds(c, KID_gram_partial, k_gram_diag128<N, 4>, dim3(nc, 1), dim3(256), lds, st, \
-                 (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); break;
-      switch (npw) {
-        SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)
-        SMCP_GRAM_CASE(6) SMCP_GRAM_CASE(7) SMCP_GRAM_CASE(8) SMCP_GRAM_CASE(9)
-      }
-#undef SMCP_GRAM_CASE
-      coff += nc;
+  return 0;
+}
+// partial Gram tiles of the ranges rs (m <= GRAM_BLK: one block) into the chunk slots coff .. of D.gpart (nchunk slots in all)
+static void gram_partials_one_block(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& rs, int64_t m, int64_t chunk, int coff,
+                                    int nchunk, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  const int64_t bl = c->S.blklen();
+  // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
+  // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
+  static int nw = -1;
+  if (nw < 0) { const char* e = getenv("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
+  const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + nw - 1) / nw;   // lower tiles per wave
+  static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
+  if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
+  const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
+  for (size_t q0 = 0; q0 < rs.size(); q0 += GRAM_MAXR) {      // all ranges of a rank in one launch (up to GRAM_MAXR)
+    GramRanges rg;
+    rg.n = (int)std::min<size_t>(GRAM_MAXR, rs.size() - q0);
+    int nc = 0;
+    for (int q = 0; q < GRAM_MAXR; ++q) {
+      const bool on = q < rg.n;
+      rg.lo[q] = on ? rs[q0 + q].first : 0;
+      rg.hi[q] = on ? rs[q0 + q].second : 0;
+      rg.first[q] = nc;
+      if (on) nc += (int)((rg.hi[q] - rg.lo[q] + chunk - 1) / chunk);
     }
-  } else
+    rg.first[GRAM_MAXR] = nc;
+#define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nc, 1), dim3(1024), lds, st, \
+               (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
+             else if (nw == 8) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nc, 1), dim3(512), lds, st, \
+               (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
+             else launch_lds(c, KID_gram_partial, k_gram_diag128<N, 4>, dim3(nc, 1), dim3(256), lds, st, \
+               (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); break;
+    switch (npw) {
+      SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)
+      SMCP_GRAM_CASE(6) SMCP_GRAM_CASE(7) SMCP_GRAM_CASE(8) SMCP_GRAM_CASE(9)
+    }
+#undef SMCP_GRAM_CASE
+    coff += nc;
+  }
+}
+// H = sum over the given blkval ranges of G^T W G (ranges: host array of nranges (begin, end) pairs)
+static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, hipStream_t st,
+                           int64_t mcols = -1) {
+  DeviceCtx& D = c->D;
+  const int64_t m = mcols < 0 ? D.m : mcols, bl = c->S.blklen();
+  const std::vector<std::pair<int64_t, int64_t>> rs = gram_merge_ranges(nranges, ranges);
+  int64_t total = 0;
+  for (auto& r : rs) total += r.second - r.first;
+  if (total <= 0) {
+    HIPCHK(hipMemset2DAsync(H, ldh * sizeof(double), 0, m * sizeof(double), m, st));
+    return 0;
+  }
+  const int64_t chunk = gram_chunk_rows(total);
+  const int nchunk = gram_count_chunks(rs, chunk);
+  const int nb = (int)((m + GRAM_BLK - 1) / GRAM_BLK);
+  const int nblk = nb * (nb + 1) / 2;
+  if (int rc = gram_reserve(c, m, nchunk)) return rc;
+  int coff = 0;
+  if (nblk == 1) gram_partials_one_block(c, rs, m, chunk, 0, nchunk, st);
+  else
   for (auto& r : rs) {
     const int64_t lo = r.first, hi = r.second;
     const int nc = (int)((hi - lo + chunk - 1) / chunk);
@@ -773,6 +792,43 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
   const int64_t m = D.m, bl = c->S.blklen();
   if (!D.ns) {
     if (int rc = gram_prepare(c, L, Y, st)) return rc;
+    // The rows of the swept stack that belong to the levels below the first large front are final as soon as those
+    // levels are swept: their Gram tiles (90 % of the rows on synth50k) are accumulated on a side stream while the
+    // large fronts at the top of the tree -- extend-adds that run one workgroup per CU, short phase kernels -- are
+    // still being swept; the rows of the top follow, and one reduction adds all partial tiles.  MEASURED AND LEFT OFF
+    // (SMCP_GRAM_OVERLAP=1 enables it): 5.92 ms per step against 5.61 with the accumulation after the sweep -- the Gram
+    // workgroups (two per CU, 70 KB of LDS each) and the extend-add's (one per CU, 148 KB) cannot share a CU, so the
+    // two stages only take CUs from each other, and each runs slower on a part of the chip than alone on all of it
+    // (the same outcome as the two-stream attempt of round 1).
+    static int ovl = -1;
+    if (ovl < 0) { const char* e = getenv("SMCP_GRAM_OVERLAP"); ovl = (e && e[0] == '1') ? 1 : 0; }
+    int64_t lc = c->S.nlev;
+    for (int64_t l = 0; l < c->S.nlev; ++l) if (c->lvl[l].nII > 0) { lc = l; break; }
+    // (lc >= 2: the childless members of a family sit at level 0 and are swept by their parents' launch at level 1)
+    if (ovl && Fork::enabled() && D.max_rhs >= m && m <= GRAM_BLK && lc >= 2 && lc < c->S.nlev) {
+      std::vector<int64_t> ra, rb;
+      for (int64_t l = 0; l < c->S.nlev; ++l)
+        for (int64_t q = c->S.levptr[l]; q < c->S.levptr[l + 1]; ++q) {
+          const int64_t k = c->S.levidx[q];
+          std::vector<int64_t>& r = l < lc ? ra : rb;
+          r.push_back(c->S.blkptr[k]); r.push_back(c->S.blkptr[k + 1]);
+        }
+      const auto rsA = gram_merge_ranges((int64_t)ra.size() / 2, ra.data()), rsB = gram_merge_ranges((int64_t)rb.size() / 2, rb.data());
+      const int64_t chunk = gram_chunk_rows(bl);
+      const int nA = gram_count_chunks(rsA, chunk), nB = gram_count_chunks(rsB, chunk);
+      if (int rc = gram_reserve(c, m, nA + nB)) return rc;
+      hess_up_fast(c, D.ustack, (int)m, bl, D.fac, 2, st, 0, D.kc_ptr ? 0 : -1, nullptr, 0, lc);
+      {
+        Fork f(c, st, 1);
+        gram_partials_one_block(c, rsA, m, chunk, 0, nA + nB, f.s);
+        hess_up_fast(c, D.ustack, (int)m, bl, D.fac, 2, st, 0, D.kc_ptr ? 0 : -1, nullptr, lc, -1);
+      }
+      gram_partials_one_block(c, rsB, m, chunk, nA, nA + nB, st);
+      launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(256), st, (const double*)D.gpart, nA + nB, (int)m, H, ldh);
+      HIPCHK(end_call(c));
+      if (int f = fetch_info(c, st)) return f;   // chol(Y_AA) failure
+      return 0;
+    }
     for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
       int nr = (int)std::min(D.max_rhs, m - jb);
       hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st, 0, D.kc_ptr ? jb : -1);     // G(A_j) = (G_NN, R^T G_AN)
