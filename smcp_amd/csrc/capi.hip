@@ -896,20 +896,32 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         // other's tails (every per-right-hand-side buffer is addressed through bases shifted to the half's first one).
         static int split_min = -1;
         if (split_min < 0) { const char* e = getenv("SMCP_RHS_SPLIT"); split_min = e ? atoi(e) : 16; }
+        static int parts = -1;
+        if (parts < 0) { const char* e = getenv("SMCP_RHS_PARTS"); parts = (e && e[0] == '3') ? 3 : 2; }
         if (split_min > 0 && a.nchmax > 0 && nrhs >= split_min && Fork::enabled()) {
+          auto part = [&](int r0, int nr, hipStream_t s) {       // right-hand sides r0 .. r0 + nr - 1 on stream s
+            MfmaArgs ap = a;
+            ap.nrhs = nr;
+            ap.t.upd += (int64_t)r0 * a.t.updlen;
+            ap.t.updp += (int64_t)r0 * a.t.updplen;
+            ap.t.tmp += (int64_t)r0 * a.t.tmplen;
+            ap.kc_j0 = a.kc_j0 + r0;
+            dense_input_on(ap, cnt, U + (int64_t)r0 * ldu, nr, s);
+            lf_up(c, ap, cnt, nr, U + (int64_t)r0 * ldu, ldu, s);
+          };
+          if (parts == 3 && nrhs >= 3) {
+            const int h1 = nrhs / 3, h2 = (2 * nrhs) / 3;
+            Fork f0(c, st, 0);
+            part(h2, nrhs - h2, f0.s);
+            Fork f1(c, st, 1);
+            part(h1, h2 - h1, f1.s);
+            part(0, h1, st);
+            return;
+          }
           const int h = nrhs / 2;
-          MfmaArgs a1 = a, a2 = a;
-          a1.nrhs = h;
-          a2.nrhs = nrhs - h;
-          a2.t.upd += (int64_t)h * a.t.updlen;
-          a2.t.updp += (int64_t)h * a.t.updplen;
-          a2.t.tmp += (int64_t)h * a.t.tmplen;
-          a2.kc_j0 = a.kc_j0 + h;
           Fork f(c, st, 0);
-          dense_input_on(a2, cnt, U + (int64_t)h * ldu, nrhs - h, f.s);
-          lf_up(c, a2, cnt, nrhs - h, U + (int64_t)h * ldu, ldu, f.s);
-          dense_input_on(a1, cnt, U, h, st);
-          lf_up(c, a1, cnt, h, U, ldu, st);
+          part(h, nrhs - h, f.s);
+          part(0, h, st);
           return;
         }
         dense_input(a, cnt);
