@@ -898,7 +898,12 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         if (split_min < 0) { const char* e = getenv("SMCP_RHS_SPLIT"); split_min = e ? atoi(e) : 16; }
         static int parts = -1;
         if (parts < 0) { const char* e = getenv("SMCP_RHS_PARTS"); parts = (e && e[0] == '3') ? 3 : 2; }
-        if (split_min > 0 && a.nchmax > 0 && nrhs >= split_min && Fork::enabled()) {
+        static int ncu_split = 0;
+        if (!ncu_split) { hipDeviceProp_t p; ncu_split = (hipGetDeviceProperties(&p, c->D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+        // only when the extend-add needs more than one round of the chip: with fewer (front, right-hand side) pairs than
+        // CUs (one rank's share of an 8-rank job: 100 pairs) there is no tail to fill and the halves only add launches
+        // (measured on the partition of rank 0 of 8: 2.83 ms per step with the split, 2.67 without)
+        if (split_min > 0 && a.nchmax > 0 && nrhs >= split_min && (int64_t)cnt * nrhs > ncu_split && Fork::enabled()) {
           auto part = [&](int r0, int nr, hipStream_t s) {       // right-hand sides r0 .. r0 + nr - 1 on stream s
             MfmaArgs ap = a;
             ap.nrhs = nr;
