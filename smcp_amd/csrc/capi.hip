@@ -584,7 +584,15 @@ template <int NAT, bool CH>
 bool launch_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   const size_t bytes = n16_lds_bytes<NAT, CH>(a.nchmax, a.panmax, a.pkmax, a.plansum);
   if (bytes > LDS_LIMIT) return false;
-  const int thr = bytes > 48 * 1024 ? 512 : 256;
+  int thr = bytes > 48 * 1024 ? 512 : 256;
+  if (!CH && NAT <= 2 && nrhs <= 2) {
+    // one or two right-hand sides on childless small fronts (the Hessians of solve_): the launch is rounds x per-workgroup
+    // set-up latency, and two waves carry the three tile tasks of a phase as well as four: 128 threads put twice as many
+    // fronts on a CU (k_hess_up_n16 0.297 -> 0.274 ms per step; 64 threads: 0.286; SMCP_N16_THR_LEAF overrides)
+    static int tl = 0;
+    if (!tl) { const char* e = getenv("SMCP_N16_THR_LEAF"); tl = e ? atoi(e) : 128; if (tl < 64 || tl > 512 || (tl & 63)) tl = 128; }
+    thr = tl;
+  }
   // Split the right-hand sides over g workgroups per clique so that the grid fills a whole number of rounds of
   // the resident-workgroup slots: cost(g) = rounds x (passes per workgroup + set-up, counted as 4 passes).
   static size_t nb_bytes = 0;    // occupancy of this instantiation, cached per LDS size
@@ -952,7 +960,10 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
   for (int64_t l = c->S.nlev - 1; l >= 0; --l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
-      if (lds) launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+      if (lds) {
+        // (fewer threads per workgroup do NOT help this kernel on the leaves: 0.302 ms per step with 256, 0.330 with 128)
+        launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+      }
       else if (use_large() && (ymode == 0 || ymode == 3 || ymode == 2)) {
         if (ymode && a.namax) {   // Q = R Ghat_AN (ymode 3) / R^T Ghat_AN (ymode 2) first, then the unscaled sweep
           const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
