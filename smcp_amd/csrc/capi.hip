@@ -533,6 +533,9 @@ void lf_prep(csp_ctx* c, const MfmaArgs& a, int cnt, const double* L, hipStream_
   if (a.namax) launch(c, KID_lf_prep_k, k_lf_prep_k, dim3(umax1(tiles64(a.namax) * tiles64(a.nnmax)), cnt), blk, st, a, L, c->D.lk);
 }
 
+// dynamic LDS of k_prep_lk: the row-block scratch of supernodes wider than 16 columns (none otherwise)
+static size_t prep_lk_lds_bytes(int nnmax) { return nnmax > 16 ? (size_t)16 * 16 * 16 * sizeof(double) : 0; }
+static int prep_lk_threads(int nnmax) { return nnmax > 16 ? NT : 128; }
 void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
   TreeArgs t = tree_args(c);
   if (use_large()) {
@@ -541,11 +544,15 @@ void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
     {
       Fork f(c, st, 0);          // the blocked inversions of the large fronts run beside the small cliques' launch
       for_all_large(c, a0, [&](MfmaArgs am, int cnt) { lf_prep(c, am, cnt, L, f.s); });
-      if (c->D.nI_total) launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->D.nI_total), dim3(NT), st, t, L, c->D.lk);
+      if (c->D.nI_total) {
+        int nnI = 0;
+        for (const LevelClass& Lc : c->lvl) if (Lc.nI) nnI = std::max(nnI, (int)Lc.nnmaxI);
+        launch_lds(c, KID_prep_lk, k_prep_lk, dim3((int)c->D.nI_total), dim3(prep_lk_threads(nnI)), prep_lk_lds_bytes(nnI), st, t, L, c->D.lk);
+      }
     }
   } else {
     t.lev = nullptr;
-    launch(c, KID_prep_lk, k_prep_lk, dim3((int)c->S.nsn), dim3(NT), st, t, L, c->D.lk);
+    launch_lds(c, KID_prep_lk, k_prep_lk, dim3((int)c->S.nsn), dim3(NT), prep_lk_lds_bytes(1 << 20), st, t, L, c->D.lk);
   }
   c->D.lk_tag_L = L;
   c->D.lk_tag_Y = nullptr;
@@ -558,7 +565,7 @@ void prep_lk_set(csp_ctx* c, int set, const double* L, hipStream_t st) {
   MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
   for (int64_t l = 0; l < c->S.nlev; ++l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
-      if (lds) { t.lev = am.t.lev; launch(c, KID_prep_lk, k_prep_lk, dim3(cnt), dim3(NT), st, t, L, c->D.lk); }
+      if (lds) { t.lev = am.t.lev; launch_lds(c, KID_prep_lk, k_prep_lk, dim3(cnt), dim3(prep_lk_threads(am.nnmax)), prep_lk_lds_bytes(am.nnmax), st, t, L, c->D.lk); }
       else lf_prep(c, am, cnt, L, st);
     }, set);
   c->D.lk_gen++;

@@ -734,7 +734,10 @@ __global__ void k_prep_lk(TreeArgs t, const double* L, double* LK) {
   double* Li = LK + d.blk;
   double* Kk = Li + nn;
   __shared__ double Dinv[256];
-  __shared__ double S[16 * 16 * 16];  // 16 x (up to 256) row-block scratch; larger nn handled in column chunks
+  // 16 x (up to 256) row-block scratch, needed by supernodes of more than 16 columns only: dynamic, sized by the launch
+  // (prep_lk_lds_bytes) -- as a static 32 KB array it capped the launch at four workgroups per CU on the 8064 small
+  // cliques of synth50k, whose supernodes have 5 and 15 columns
+  extern __shared__ __attribute__((aligned(16))) double S[];
   // zero the upper triangle of Li
   for (int e = threadIdx.x; e < nn * nn; e += blockDim.x) {
     int i = e % nn, j = e / nn;
