@@ -1748,7 +1748,8 @@ static int cholesky_impl(csp_ctx* c, double* x, void* stream, int set) {
     a0.LK = nullptr;
     for (int64_t l = 0; l < c->S.nlev; ++l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
-        if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(fact_threads(am, thr, 0)), bytes, st, am, x);
+        if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(fact_threads(am, thr, 0)),
+                            (size_t)mfma_lds_doubles_for(WK_CHOL, am.nnmax, am.namax) * sizeof(double), st, am, x);   // compact layout: front + update only
         else if (use_large() && c->D.gp_tptr) lf_chol(c, am, cnt, x, st);
         else launch_lds(c, KID_chol_mfma_hbm, k_chol_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
       }, set);
@@ -1812,7 +1813,8 @@ static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set) 
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
     for (int64_t l = c->S.nlev - 1; l >= 0; --l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
-        if (lds) launch_lds(c, KID_pinv_mfma, k_pinv_mfma<true>, dim3(cnt), dim3(fact_threads(am, thr, 1)), bytes, st, am, x);
+        if (lds) launch_lds(c, KID_pinv_mfma, k_pinv_mfma<true>, dim3(cnt), dim3(fact_threads(am, thr, 1)),
+                            (size_t)mfma_lds_doubles_for(WK_PINV, am.nnmax, am.namax) * sizeof(double), st, am, x);
         else if (use_large()) lf_pinv(c, am, cnt, x, st);
         else launch_lds(c, KID_pinv_mfma_hbm, k_pinv_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
       }, set);

@@ -111,6 +111,26 @@ __host__ __device__ inline int64_t mfma_lds_doubles(int nn, int na) {
   return lk * nnc + ll * nnc + lk * (int64_t)na + lf * nnc + ll * nnc + lk * nnc + lk * nnc + ll * nnc + lk * (int64_t)na + 16 * 16 + 8 + (na + 2) / 2;
 }
 
+// the LDS buffers a kernel uses (make_work / mfma_lds_doubles_for): kernels that need only some of them get a compact
+// layout, i.e. more resident workgroups per CU (the factorisation kernels on the small fronts are rounds x latency)
+enum : int { WK_K = 1, WK_LI = 2, WK_Y = 4, WK_F = 8, WK_FNN = 16, WK_E = 32, WK_G = 64, WK_T = 128, WK_U = 256, WK_ALL = 511 };
+constexpr int WK_CHOL = WK_F | WK_U;                       // k_chol_mfma: front, update block (+ the 16 x 16 scratch)
+constexpr int WK_PINV = WK_K | WK_LI | WK_E | WK_U;        // k_pinv_mfma: inverse-form factor, Y_AA, T = Y_AA K
+__host__ __device__ inline int64_t mfma_lds_doubles_for(int mask, int nn, int na) {
+  const int64_t lk = padld(na), ll = padld(nn), lf = padld(nn + na), nnc = nn;
+  int64_t t = 0;
+  if (mask & WK_K) t += lk * nnc;
+  if (mask & WK_LI) t += ll * nnc;
+  if (mask & WK_Y) t += lk * (int64_t)na;
+  if (mask & WK_F) t += lf * nnc;
+  if (mask & WK_FNN) t += ll * nnc;
+  if (mask & WK_E) t += lk * nnc;
+  if (mask & WK_G) t += lk * nnc;
+  if (mask & WK_T) t += ll * nnc;
+  if (mask & WK_U) t += lk * (int64_t)na;
+  return t + 16 * 16 + 8 + (na + 2) / 2;
+}
+
 struct Work {  // working-set pointers of one (clique, rhs) pair
   const double* K; int ldk;
   const double* Li; int ldl;
@@ -124,22 +144,23 @@ struct Work {  // working-set pointers of one (clique, rhs) pair
   double* D16;            // 16 x 16 scratch
 };
 
-template <bool LDS>
+template <bool LDS, int MASK = WK_ALL>
 __device__ inline Work make_work(const MfmaArgs& a, const CliqueDesc& d, double* smem, int k, int r) {
   Work w;
   const int nn = d.nn, na = d.na, nf = nn + na;
   if (LDS) {
     const int lk = padld(a.namax), ll = padld(a.nnmax), lf = padld(a.nnmax + a.namax);
     double* p = smem;
-    w.K = p; w.ldk = lk; p += (int64_t)lk * a.nnmax;
-    w.Li = p; w.ldl = ll; p += (int64_t)ll * a.nnmax;
-    w.Y = p; w.ldy = lk; p += (int64_t)lk * a.namax;
-    w.F = p; w.ldf = lf; p += (int64_t)lf * a.nnmax;
-    w.Fnn = p; w.ldn = ll; p += (int64_t)ll * a.nnmax;
-    w.E = p; w.lde = lk; p += (int64_t)lk * a.nnmax;
-    w.G = p; w.ldg = lk; p += (int64_t)lk * a.nnmax;
-    w.T = p; w.ldt = ll; p += (int64_t)ll * a.nnmax;
-    w.U = p; w.ldu = lk; p += (int64_t)lk * a.namax;
+    // a buffer outside MASK gets no room (its pointer aliases the next one and must not be used)
+    w.K = p; w.ldk = lk; if (MASK & WK_K) p += (int64_t)lk * a.nnmax;
+    w.Li = p; w.ldl = ll; if (MASK & WK_LI) p += (int64_t)ll * a.nnmax;
+    w.Y = p; w.ldy = lk; if (MASK & WK_Y) p += (int64_t)lk * a.namax;
+    w.F = p; w.ldf = lf; if (MASK & WK_F) p += (int64_t)lf * a.nnmax;
+    w.Fnn = p; w.ldn = ll; if (MASK & WK_FNN) p += (int64_t)ll * a.nnmax;
+    w.E = p; w.lde = lk; if (MASK & WK_E) p += (int64_t)lk * a.nnmax;
+    w.G = p; w.ldg = lk; if (MASK & WK_G) p += (int64_t)lk * a.nnmax;
+    w.T = p; w.ldt = ll; if (MASK & WK_T) p += (int64_t)ll * a.nnmax;
+    w.U = p; w.ldu = lk; if (MASK & WK_U) p += (int64_t)lk * a.namax;
     w.D16 = p;
   } else {
     w.Li = a.LK ? a.LK + d.blk : nullptr; w.ldl = nf;
@@ -661,7 +682,7 @@ __global__ void k_chol_mfma(MfmaArgs a, double* x) {
   if (*info_of(a.t, k)) return;
   const CliqueDesc d = a.t.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
-  Work w = make_work<LDS>(a, d, smem, k, 0);
+  Work w = make_work<LDS, WK_CHOL>(a, d, smem, k, 0);
   double* P = x + d.blk;
   double* UkG = a.t.upd + d.upd;
   double* UkP = a.t.updp + d.updp;
@@ -780,7 +801,7 @@ __global__ void k_pinv_mfma(MfmaArgs a, double* x) {
   const int k = a.t.lev[blockIdx.x];
   const CliqueDesc d = a.t.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
-  Work w = make_work<LDS>(a, d, smem, k, 0);
+  Work w = make_work<LDS, WK_PINV>(a, d, smem, k, 0);
   double* P = x + d.blk;
   double* UkG = a.t.upd + d.upd;
   const CliqueDesc par = a.t.cl[d.parent < 0 ? k : d.parent];
