@@ -969,6 +969,10 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
       if (lds) {
         // (fewer threads per workgroup do NOT help this kernel on the leaves: 0.302 ms per step with 256, 0.330 with 128)
+        if (ymode == 0) {     // no scaling operand: compact layout (the Y block is the largest buffer of the general one)
+          const size_t b0 = (size_t)mfma_lds_doubles_for(WK_DOWN0, a.nnmax, a.namax) * sizeof(double);
+          launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true, WK_DOWN0>, dim3(cnt, g), dim3(b0 > 48 * 1024 ? 512 : 256), b0, st, a, U, ldu);
+        } else
         launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
       }
       else if (use_large() && (ymode == 0 || ymode == 3 || ymode == 2)) {
@@ -1693,6 +1697,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       HIPCHK(hipFuncSetAttribute((const void*)k_lf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_factor_yaa_lds, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true, WK_DOWN0>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_chol_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_pinv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_inv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));

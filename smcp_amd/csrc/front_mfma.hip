@@ -116,6 +116,7 @@ __host__ __device__ inline int64_t mfma_lds_doubles(int nn, int na) {
 enum : int { WK_K = 1, WK_LI = 2, WK_Y = 4, WK_F = 8, WK_FNN = 16, WK_E = 32, WK_G = 64, WK_T = 128, WK_U = 256, WK_ALL = 511 };
 constexpr int WK_CHOL = WK_F | WK_U;                       // k_chol_mfma: front, update block (+ the 16 x 16 scratch)
 constexpr int WK_PINV = WK_K | WK_LI | WK_E | WK_U;        // k_pinv_mfma: inverse-form factor, Y_AA, T = Y_AA K
+constexpr int WK_DOWN0 = WK_ALL & ~(WK_Y | WK_FNN);        // k_hess_down_mfma without a scaling operand (ymode 0)
 __host__ __device__ inline int64_t mfma_lds_doubles_for(int mask, int nn, int na) {
   const int64_t lk = padld(na), ll = padld(nn), lf = padld(nn + na), nnc = nn;
   int64_t t = 0;
@@ -592,13 +593,13 @@ __global__ void k_hess_up_mfma(MfmaArgs a, double* u, int64_t ldu) {
 }
 
 // ------------------------------------------------------------------ Hessian, root -> leaves
-template <bool LDS>
+template <bool LDS, int MASK = WK_ALL>
 __global__ void k_hess_down_mfma(MfmaArgs a, double* u, int64_t ldu) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int k = a.t.lev[blockIdx.x];
   const CliqueDesc d = a.t.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
-  Work w = make_work<LDS>(a, d, smem, k, blockIdx.y);
+  Work w = make_work<LDS, MASK>(a, d, smem, k, blockIdx.y);
   if (LDS) { load_consts(a, d, w, a.ymode != 0); }
   const int ymode = a.ymode;
   const CliqueDesc par = a.t.cl[d.parent < 0 ? k : d.parent];
