@@ -1703,7 +1703,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_inv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_inv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_llt_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      HIPCHK(hipFuncSetAttribute((const void*)k_completion_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(mx - INV_STATIC_LDS)));
+      HIPCHK(hipFuncSetAttribute((const void*)k_completion_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     }
     if ((rc = dev_upload(&D.tmpptr, c->h_tmpptr, D.bytes))) return rc;
     if ((rc = dev_alloc(&D.yaa, S.updlen(), D.bytes))) return rc;
@@ -1855,8 +1855,11 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
     dim3 blk(256);
     for (int64_t l = 0; l < c->S.nlev; ++l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
-        if (lds && bytes + INV_STATIC_LDS <= LDS_LIMIT)
-          launch_lds(c, KID_completion_mfma, k_completion_mfma<true>, dim3(cnt), dim3(thr), bytes, st, am, x);
+        // compact layout (no inverse-form factor, no update block; the inversion scratch only for wide supernodes)
+        const size_t cb = lds ? (size_t)completion_lds_doubles(am.nnmax, am.namax) * sizeof(double) : 0;
+        if (lds && cb <= LDS_LIMIT) {
+          launch_lds(c, KID_completion_mfma, k_completion_mfma<true>, dim3(cnt), dim3(cb > 48 * 1024 ? 512 : 256), cb, st, am, x);
+        }
         else if (lds || !use_large())
           launch_lds(c, KID_completion_mfma_hbm, k_completion_mfma<false>, dim3(cnt), dim3(lds ? 256 : thr), 0, st, am, x);
       });

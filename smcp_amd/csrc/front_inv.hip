@@ -227,11 +227,14 @@ __global__ void k_hess_up_inv_mfma(MfmaArgs a, double* u, int64_t ldu) {
 template <bool LDS>
 __global__ void k_completion_mfma(MfmaArgs a, double* x) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ double S[16 * 128];
+  // row-block scratch of the triangular inversion (supernodes of more than 16 columns only): LDS = true: behind the
+  // compact working set, and only when the class has such supernodes (completion_lds_doubles); LDS = false: static
+  __shared__ double Sstat[LDS ? 1 : 16 * 128];
+  double* const S = LDS ? smem + mfma_lds_doubles_for(WK_COMPL, a.nnmax, a.namax) : Sstat;
   const int k = a.t.lev[blockIdx.x];
   const CliqueDesc d = a.t.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na;
-  Work w = make_work<LDS>(a, d, smem, k, 0);
+  Work w = make_work<LDS, WK_COMPL>(a, d, smem, k, 0);
   double* P = x + d.blk;
   double* D16 = w.D16;
   if (LDS) {

@@ -117,6 +117,7 @@ enum : int { WK_K = 1, WK_LI = 2, WK_Y = 4, WK_F = 8, WK_FNN = 16, WK_E = 32, WK
 constexpr int WK_CHOL = WK_F | WK_U;                       // k_chol_mfma: front, update block (+ the 16 x 16 scratch)
 constexpr int WK_PINV = WK_K | WK_LI | WK_E | WK_U;        // k_pinv_mfma: inverse-form factor, Y_AA, T = Y_AA K
 constexpr int WK_DOWN0 = WK_ALL & ~(WK_Y | WK_FNN);        // k_hess_down_mfma without a scaling operand (ymode 0)
+constexpr int WK_COMPL = WK_Y | WK_F | WK_FNN | WK_E | WK_G | WK_T;   // k_completion_mfma (no inverse-form factor, no update block)
 __host__ __device__ inline int64_t mfma_lds_doubles_for(int mask, int nn, int na) {
   const int64_t lk = padld(na), ll = padld(nn), lf = padld(nn + na), nnc = nn;
   int64_t t = 0;
@@ -130,6 +131,9 @@ __host__ __device__ inline int64_t mfma_lds_doubles_for(int mask, int nn, int na
   if (mask & WK_T) t += ll * nnc;
   if (mask & WK_U) t += lk * (int64_t)na;
   return t + 16 * 16 + 8 + (na + 2) / 2;
+}
+__host__ __device__ inline int64_t completion_lds_doubles(int nn, int na) {
+  return mfma_lds_doubles_for(WK_COMPL, nn, na) + (nn > 16 ? 16 * 128 : 0);
 }
 
 struct Work {  // working-set pointers of one (clique, rhs) pair
