@@ -661,7 +661,9 @@ def test_kkt_qr_nearly_dependent_constraints(eps, shifted):
     bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
     solve(bxd, byd, 1.0)
     x, y = host(bxd) * msk, byd.cpu().numpy()
-    assert (sys.qr_shift > 0.0) == shifted and sys.qr_passes == 3
+    # kappa(At^T At) ~ 4e18 at eps = 1e-9: whether its Cholesky goes through is decided by the last bits of the Gram
+    # matrix (the order of its partial sums), so only the breakdown at 1e-13 is asserted; three passes either way
+    assert sys.qr_passes == 3 and (sys.qr_shift > 0.0 or not shifted)
     res = lambda xx, yy: (np.sqrt(orc.dot(S, *(2 * [K.residual(L, Yh, xx, yy, bx, by, 1.0)[0]]))) / max(1, np.sqrt(orc.dot(S, bx, bx))),
                           np.linalg.norm(K.residual(L, Yh, xx, yy, bx, by, 1.0)[1]))
     xr, yr = K.qr_solve(L, Yh, F, bx, by, 1.0)
