@@ -691,7 +691,7 @@ static std::vector<std::pair<int64_t, int64_t>> gram_merge_ranges(int64_t nrange
 // chunking of a Gram accumulation over `total` rows: ~one resident wave of workgroups (2 per CU) over all ranges
 static int64_t gram_chunk_rows(int64_t total) {
   static int64_t minrows = 0;     // SMCP_GRAM_MINCHUNK (timing studies): smallest chunk of rows per workgroup
-  if (!minrows) { const char* e = getenv("SMCP_GRAM_MINCHUNK"); minrows = e ? atoll(e) : 2048; if (minrows < GRAM_KS) minrows = GRAM_KS; }   // (512: 0.202 -> 0.173 ms on one rank's share of an 8-rank job; not adopted -- the other summation order tips the marginal Cholesky of test_kkt_qr_nearly_dependent_constraints[1e-09] into the shifted route)
+  if (!minrows) { const char* e = getenv("SMCP_GRAM_MINCHUNK"); minrows = e ? atoll(e) : 512; if (minrows < GRAM_KS) minrows = GRAM_KS; }   // 512: one rank's share of an 8-rank job 0.202 -> 0.173 ms (with 2048 rows per workgroup two thirds of the chip idle); large problems are chunked by the second term
   return std::max<int64_t>(minrows, ((total / 512 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS);
 }
 static int gram_count_chunks(const std::vector<std::pair<int64_t, int64_t>>& rs, int64_t chunk) {
