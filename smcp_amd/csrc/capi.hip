@@ -21,6 +21,7 @@
 #include "front_fam.hip"
 #include "front_fam2.hip"
 #include "front_lfsp.hip"
+#include "front_leafgram.hip"
 
 using namespace smcp;
 
@@ -50,7 +51,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -68,7 +69,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_gram"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -697,7 +698,8 @@ bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   if (fixed + fam2_tail_doubles(4, 9) + 64 > lim) return false;          // room for a table of four passes at least
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)k_fam_sparse<NAT, KSN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)k_fam_sparse<NAT, KSN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)k_fam_sparse<NAT, KSN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
     if (hipFuncSetAttribute((const void*)k_fam2_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
     attr = true;
   }
@@ -735,8 +737,15 @@ bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
              a, D.famc, cnn, csa);
   MfmaArgs a2 = a;
   { static int stag = -1; if (stag < 0) { const char* e = getenv("SMCP_FAM2_STAG"); stag = e ? atoi(e) : 0; } a2.dn = stag; }
-  launch_lds(c, KID_hess_up_fam, k_fam_sparse<NAT, KSN>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a2, U, ldu,
-             (const double*)D.famc, cnn, csa, (const int32_t*)D.kc_ij, tabpasses, ecap);
+  // the children's panels are left out when the caller takes their Gram block from k_leaf_gram (D.lg_request)
+  if (D.lg_request) {
+    launch_lds(c, KID_hess_up_fam, k_fam_sparse<NAT, KSN, false>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a2, U, ldu,
+               (const double*)D.famc, cnn, csa, (const int32_t*)D.kc_ij, tabpasses, ecap);
+    D.lg_nochild = true;
+  } else {
+    launch_lds(c, KID_hess_up_fam, k_fam_sparse<NAT, KSN, true>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a2, U, ldu,
+               (const double*)D.famc, cnn, csa, (const int32_t*)D.kc_ij, tabpasses, ecap);
+  }
   return true;
 }
 // pipelined twelve-wave variant for parents with four row tiles (49..64 separator rows)
@@ -1387,7 +1396,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.gsl_start, D.gsl_len, D.lg_list, D.lg_part, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
     for (void* p : ptrs) if (p) hipFree(p);

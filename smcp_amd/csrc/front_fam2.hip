@@ -193,7 +193,9 @@ __host__ __device__ inline int fam2_tail_doubles(int T, int nmem) {
   return ((T * nmem + 1) & ~1) + (((T + 1) / 2 + 1) & ~1) + (((FAM2_NNCAP * T + 1) / 2 + 1) & ~1) + FAM2_NNCAP * T;
 }
 
-template <int NAT, int KSN>
+// CHP = false: the children's panels are NOT formed (their block of the Gram matrix comes from k_leaf_gram in closed
+// form, front_leafgram.hip); the children then only send their updates to the parent's front.
+template <int NAT, int KSN, bool CHP>
 __global__ void __launch_bounds__(512) k_fam_sparse(MfmaArgs a, double* u, int64_t ldu, const double* famc, int cnn, int csa,
                                                     const int32_t* kc_ij, int tabpasses, int ecap) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -388,6 +390,40 @@ __global__ void __launch_bounds__(512) k_fam_sparse(MfmaArgs a, double* u, int64
         const int ne = haschild ? trow[2 * (1 + cs)] : 0;
         const int where = haschild ? trow[2 * (1 + cs) + 1] : 0;
         const int nemax = max(__builtin_amdgcn_readlane(ne, 0), __builtin_amdgcn_readlane(ne, 32));
+        if constexpr (!CHP) {
+          // updates only: an entry v at (separator row iA, column jc) sends -v (K[:, jc] e_iA^T + e_iA K[:, jc]^T) to the
+          // parent's front (one LDS atomic per separator row, lane hl = row), an entry in the supernode block beyond the
+          // shared list the rank-2 update of the whole separator block
+          for (int t = 0; t < nemax; ++t) {
+            const bool valid = t < ne;
+            const int pk = lpk[valid ? where + t : 0];
+            const double v = lval[valid ? where + t : 0];
+            const int i = pk & 0xff, jc = valid ? ((pk >> 8) & 0xff) : 0, relA = (pk >> 16) & 0xff;
+            const bool isAN = valid && i >= nnc;
+            const int iA = isAN ? i - nnc : 0;
+            const double kv = smem[cbo + C.cK + jc * csa + hl];
+            if (isAN && hl < nac) {
+              const int hi = max(relr, relA), lo = min(relr, relA);
+              const int m2 = hi - nn, n2 = lo - nn;
+              const int pU = L.gU + n2 * na - ((n2 * (n2 - 1)) >> 1) + (m2 - n2);
+              const int pL = hi >= nn ? L.gFan + m2 + lo * LDA : L.gFnn + hi + lo * LDN;
+              unsafeAtomicAdd(&gb[lo >= nn ? pU : pL], -(hl == iA ? 2.0 : 1.0) * v * kv);
+            }
+            const bool isNN = valid && i < nnc;
+            if (__builtin_amdgcn_ballot_w64(isNN && !(pk & FAM2_COOP))) {
+              const double w = i == jc ? 0.5 * v : v;
+              const int ic = isNN ? i : 0;
+              const double* pK = smem + cbo + C.cK + ic * csa;
+              const double* qK = smem + cbo + C.cK + jc * csa;
+              const int* const crel = reinterpret_cast<const int*>(smem + cbo + C.cRel);
+              for (int c = 0; c < nacmax; ++c) {
+                const int rr2 = c + hl;
+                if (isNN && !(pk & FAM2_COOP) && rr2 < nac)
+                  unsafeAtomicAdd(&gb[fpos(crel[rr2], crel[c])], w * (pK[rr2] * qK[c] + qK[rr2] * pK[c]));
+              }
+            }
+          }
+        } else {
         double* const Pc = u + (int64_t)r * ldu + cblk;
         for (int e0 = 0; e0 < npanmax; e0 += 192) {
           double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -459,6 +495,7 @@ __global__ void __launch_bounds__(512) k_fam_sparse(MfmaArgs a, double* u, int64
           for (int x = 0; x < 6; ++x) { const int e = e0 + hl + 32 * x; if (e < npan && !(a.skip & 1)) FAM2_ST(&Pc[e], acc[x]); }
         }
       }
+        }
       STAMP(7);
       // supernode-block entries of the children, shared: wave gw takes a quarter of the na (na + 1) / 2 positions of
       // the update v (p q^T + q p^T) (halved for i == j), position p = (row r, column c <= r) in row-major order

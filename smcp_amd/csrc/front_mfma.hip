@@ -1337,17 +1337,16 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t l
 // processed in PAIRS with independent accumulator chains so that an MFMA never waits for the operands or the result
 // of the one before it -- with one dependent chain per tile the MFMA pipe was busy 45 % of the time, PMC
 // SQ_VALU_MFMA_BUSY_CYCLES).  Slots past the last tile of a wave recompute tile 0 and are not stored.
-// up to GRAM_MAXR blkval ranges per launch (the subtrees a rank owns): workgroups first[q] .. first[q + 1] - 1 take range q
-constexpr int GRAM_MAXR = 8;
-struct GramRanges { int64_t lo[GRAM_MAXR], hi[GRAM_MAXR]; int first[GRAM_MAXR + 1]; int n; };
+// The rows to accumulate are given as a table of SLICES of at most GRAM_KS consecutive blkval positions (sl_start,
+// sl_len): the host cuts the blkval ranges of a call -- a rank's subtrees, minus the cliques whose Gram block comes from
+// k_leaf_gram -- into slices once per set of ranges; workgroup w takes the slices w * spw .. (w + 1) * spw - 1.  A wave
+// keeps the descriptors of 64 slices in one register each (lane i: slice i of the window) and reads them with
+// v_readlane, so that walking the table costs no memory round trip.
 template <int NT, int NW>
-__global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(const double* G, int64_t ldg, int m, GramRanges rg,
-                                                      const double* sw, int64_t chunk, double* partial, int coff,
+__global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(const double* G, int64_t ldg, int m, const int64_t* sl_start,
+                                                      const int32_t* sl_len, int nsl, int spw,
+                                                      const double* sw, double* partial, int coff,
                                                       int nchunk_total, int skip) {
-  int rq = 0;
-  while (rq + 1 < rg.n && (int)blockIdx.x >= rg.first[rq + 1]) ++rq;
-  const int64_t e_lo = rg.lo[rq], e_hi = rg.hi[rq];
-  const int wg_in_range = (int)blockIdx.x - rg.first[rq];
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // LDS image [column][k = 64], ld GRAM_LDK = 66 doubles: the staging store is contiguous along k (no transpose)
   // and the operand reads (row = column l15, k = kq + 4 s) hit 32 distinct 8-byte bank pairs per half wave
@@ -1374,11 +1373,21 @@ __global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(co
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
   for (int e = threadIdx.x; e < GRAM_BLK * GRAM_LDK; e += 64 * NW) sA[e] = 0.0;   // columns >= m stay zero
-  const int64_t e_begin = e_lo + (int64_t)wg_in_range * chunk, e_end = min(e_hi, e_begin + chunk);
+  const int s_begin = (int)blockIdx.x * spw, s_end = min(nsl, s_begin + spw);
   double pre[NC], pre_sw = 0.0;
-  auto fetch = [&](int64_t e0) {
+  int64_t dstart = 0;          // descriptors of the window of 64 slices that holds the running one
+  int dlen = 0;
+  auto window = [&](int s0) {
+    const int s = s0 + lane;
+    dstart = s < s_end ? sl_start[s] : 0;
+    dlen = s < s_end ? sl_len[s] : 0;
+  };
+  auto fetch = [&](int s) {    // slice s (inside the loaded window)
+    const int i = (s - s_begin) & 63;
+    const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane((int)(dstart >> 32), i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)dstart, i);
+    const int len = __builtin_amdgcn_readlane(dlen, i);
     const int64_t e = e0 + lane;
-    const bool ein = e < e_end;
+    const bool ein = lane < len;
     pre_sw = ein ? sw[e] : 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -1386,13 +1395,13 @@ __global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(co
       pre[j] = (ein && cc < ni) ? ((skip & 2) ? 1.0 : G[(int64_t)cc * ldg + e]) : 0.0;
     }
   };
-  if (e_begin < e_end) fetch(e_begin);
+  if (s_begin < s_end) { window(s_begin); fetch(s_begin); }
   const double* const lbase = sA + l15 * GRAM_LDK + kq;
   const double* pa[NT];
   const double* pb[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) { pa[i] = lbase + 16 * GRAM_LDK * tms[i]; pb[i] = lbase + 16 * GRAM_LDK * tns[i]; }
-  for (int64_t e0 = e_begin; e0 < e_end; e0 += GRAM_KS) {
+  for (int sl = s_begin; sl < s_end; ++sl) {
     lds_barrier();                                 // the tiles of the previous slice have been consumed
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -1400,7 +1409,10 @@ __global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(co
       if (cc < ni) sA[cc * GRAM_LDK + lane] = pre_sw != 0.0 ? pre[j] * pre_sw : 0.0;   // weight 0: never-written entries
     }
     lds_barrier();
-    if (e0 + GRAM_KS < e_end) fetch(e0 + GRAM_KS); // in flight while the MFMAs below run
+    if (sl + 1 < s_end) {                          // in flight while the MFMAs below run
+      if (((sl + 1 - s_begin) & 63) == 0) window(sl + 1);
+      fetch(sl + 1);
+    }
     if (!(skip & 1))
 #pragma unroll
     for (int i = 0; i < NT; i += 2) {
@@ -1432,8 +1444,9 @@ __global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(co
   }
 }
 
-// H (m x m, ld ldh, both triangles) <- sum over chunks of the partial tiles
-__global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* H, int64_t ldh) {
+// H (m x m, ld ldh, both triangles) <- sum over chunks of the partial tiles (+ the nl packed lower triangles of
+// k_leaf_gram, front_leafgram.hip), every sum in a fixed order
+__global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* H, int64_t ldh, const double* lpart = nullptr, int nl = 0) {
   int bi = 0, rem = blockIdx.y;
   while (rem > bi) { rem -= bi + 1; ++bi; }
   const int bj = rem;
@@ -1454,8 +1467,21 @@ __global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* 
     for (int q = 0; q < 8; ++q) s8[q] += p[(int64_t)(c + q) * (64 * 256)];
   }
   for (; c < nchunk; ++c) s8[0] += p[(int64_t)c * (64 * 256)];
-  const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   const int i = ci0 + tm * 16 + (idx & 15), j = cj0 + tn * 16 + (idx >> 4);
+  if (nl > 0 && i < m && j < m) {
+    const int hi = max(i, j), lo = min(i, j);
+    const int64_t np = (int64_t)m * (m + 1) / 2;
+    const double* q = lpart + (int64_t)hi * (hi + 1) / 2 + lo;
+    double l8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int w = 0;
+    for (; w + 8 <= nl; w += 8) {
+#pragma unroll
+      for (int z = 0; z < 8; ++z) l8[z] += q[(int64_t)(w + z) * np];
+    }
+    for (; w < nl; ++w) l8[0] += q[(int64_t)w * np];
+    s += ((l8[0] + l8[1]) + (l8[2] + l8[3])) + ((l8[4] + l8[5]) + (l8[6] + l8[7]));
+  }
   if (i < ci0 + ni && j < cj0 + nj) {
     H[i + (int64_t)j * ldh] = s;
     H[j + (int64_t)i * ldh] = s;

@@ -315,6 +315,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   D.vbuf = D.hd = nullptr;
   D.kc_ptr = D.kc_off = nullptr; D.kc_val = nullptr; D.kc_ij = nullptr;
   D.md = D.ns = D.vcols = 0;
+  D.lg_children = 0; D.lg_nochild = false;
   if (D.qr_ws) { hipFree(D.qr_ws); D.bytes -= D.qr_len * 8; D.qr_ws = nullptr; D.qr_len = 0; }
   D.qr_valid = false;
   SetupClock clk("kkt_set_constraints");
@@ -482,6 +483,16 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
           const size_t q = (size_t)k * (m + 1) + j;
           D.kc_maxlist_large = std::max<int64_t>(D.kc_maxlist_large, kptr[q + 1] - kptr[q]);
         }
+    // closed-form Gram blocks of the family children (front_leafgram.hip): entries per child over all constraints
+    D.lg_children = 0; D.lg_maxent = 0; D.lg_pairs = 0; D.lg_rows = 0;
+    for (int64_t k = 0; k < S.nsn; ++k)
+      if (k < (int64_t)c->fam.size() && c->fam[k] == 1) {
+        const int64_t E = kptr[(size_t)k * (m + 1) + m] - kptr[(size_t)k * (m + 1)];
+        D.lg_children++;
+        D.lg_maxent = std::max(D.lg_maxent, E);
+        D.lg_pairs += E * (E + 1) / 2;
+        D.lg_rows += S.nf(k) * S.nn(k);
+      }
     std::vector<int32_t> fill(kptr.begin(), kptr.end() - 1);
     for (int64_t j = 0; j < m; ++j)
       for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
@@ -660,6 +671,7 @@ static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
   D.qr_valid = false;      // the stack is about to be rewritten
+  D.lg_nochild = false;    // ... by sweeps that decide anew whether the family children's panels are formed
   // the flag read after the sweeps must be theirs: a failed dense_potrf (Schur complement not positive definite) or
   // kkt_qr_factor leaves its own behind
   HIPCHK(zero_flag(c, st));
@@ -711,48 +723,117 @@ static int gram_reserve(csp_ctx* c, int64_t m, int nchunk) {
   }
   return 0;
 }
-// partial Gram tiles of the ranges rs (m <= GRAM_BLK: one block) into the chunk slots coff .. of D.gpart (nchunk slots in all)
-static void gram_partials_one_block(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& rs, int64_t m, int64_t chunk, int coff,
-                                    int nchunk, hipStream_t st) {
+// ---- slice table of a set of blkval ranges (k_gram_diag128) and the family children inside them (k_leaf_gram) ----------
+// Built on the host when the ranges (or the leaf switch) differ from the cached ones: a rank's ranges are the same at
+// every step.  leaf: the panels of the family children are not in the stack -- their rows are left out of the slices and
+// the cliques are listed for k_leaf_gram.
+static int gram_tables(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& rs, bool leaf, hipStream_t st) {
   DeviceCtx& D = c->D;
-  const int64_t bl = c->S.blklen();
-  // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
-  // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
-  static int nw = -1;
-  if (nw < 0) { const char* e = getenv("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
-  const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + nw - 1) / nw;   // lower tiles per wave
-  static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
-  if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
-  const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
-  for (size_t q0 = 0; q0 < rs.size(); q0 += GRAM_MAXR) {      // all ranges of a rank in one launch (up to GRAM_MAXR)
-    GramRanges rg;
-    rg.n = (int)std::min<size_t>(GRAM_MAXR, rs.size() - q0);
-    int nc = 0;
-    for (int q = 0; q < GRAM_MAXR; ++q) {
-      const bool on = q < rg.n;
-      rg.lo[q] = on ? rs[q0 + q].first : 0;
-      rg.hi[q] = on ? rs[q0 + q].second : 0;
-      rg.first[q] = nc;
-      if (on) nc += (int)((rg.hi[q] - rg.lo[q] + chunk - 1) / chunk);
+  const Symbolic& S = c->S;
+  std::vector<int64_t> key;
+  key.reserve(2 * rs.size() + 1);
+  for (auto& r : rs) { key.push_back(r.first); key.push_back(r.second); }
+  key.push_back(leaf ? 1 : 0);
+  if (key == c->gsl_key && D.gsl_start) return 0;
+  std::vector<int64_t> start;
+  std::vector<int32_t> len, list;
+  int nf = 0, nn = 0, na = 0;
+  auto add_segment = [&](int64_t lo, int64_t hi) {
+    for (int64_t e = lo; e < hi; e += GRAM_KS) { start.push_back(e); len.push_back((int32_t)std::min<int64_t>(GRAM_KS, hi - e)); }
+  };
+  for (auto& r : rs) {
+    if (!leaf) { add_segment(r.first, r.second); continue; }
+    int64_t k = (int64_t)(std::upper_bound(S.blkptr.begin(), S.blkptr.end(), r.first) - S.blkptr.begin()) - 1;
+    int64_t seg_lo = r.first;
+    for (; k < S.nsn && S.blkptr[k] < r.second; ++k) {
+      if (c->fam[k] != 1) continue;
+      const int64_t b = std::max(S.blkptr[k], r.first), e = std::min(S.blkptr[k + 1], r.second);
+      if (b != S.blkptr[k] || e != S.blkptr[k + 1]) return SMCP_EINVAL;     // ranges are unions of whole cliques
+      if (b > seg_lo) add_segment(seg_lo, b);
+      seg_lo = e;
+      list.push_back((int32_t)k);
+      nf = std::max(nf, (int)S.nf(k)); nn = std::max(nn, (int)S.nn(k)); na = std::max(na, (int)S.na(k));
     }
-    rg.first[GRAM_MAXR] = nc;
-#define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nc, 1), dim3(1024), lds, st, \
-               (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
-             else if (nw == 8) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nc, 1), dim3(512), lds, st, \
-               (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); \
-             else launch_lds(c, KID_gram_partial, k_gram_diag128<N, 4>, dim3(nc, 1), dim3(256), lds, st, \
-               (const double*)D.ustack, bl, (int)m, rg, (const double*)D.sw, chunk, D.gpart, coff, nchunk, gskip); break;
-    switch (npw) {
-      SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)
-      SMCP_GRAM_CASE(6) SMCP_GRAM_CASE(7) SMCP_GRAM_CASE(8) SMCP_GRAM_CASE(9)
-    }
-#undef SMCP_GRAM_CASE
-    coff += nc;
+    if (r.second > seg_lo) add_segment(seg_lo, r.second);
   }
+  auto grow = [&](auto** p, int64_t& cap, int64_t need) -> int {
+    if (cap >= need && *p) return 0;
+    if (*p) { if (hipFree(*p) != hipSuccess) return SMCP_EHIP; *p = nullptr; }
+    using T = typename std::remove_pointer<typename std::remove_pointer<decltype(p)>::type>::type;
+    T* q = nullptr;
+    if (hipMalloc((void**)&q, (size_t)std::max<int64_t>(need, 1) * sizeof(T)) != hipSuccess) return SMCP_ENOMEM;
+    *p = q; cap = need;
+    return 0;
+  };
+  HIPCHK(hipStreamSynchronize(st));             // the tables may be in use by launches still queued
+  int64_t cap_len = D.gsl_cap;
+  if (int rc = grow(&D.gsl_start, D.gsl_cap, (int64_t)start.size())) return rc;
+  if (int rc = grow(&D.gsl_len, cap_len, (int64_t)start.size())) return rc;
+  if (int rc = grow(&D.lg_list, D.lg_cap, (int64_t)list.size())) return rc;
+  if (!start.empty()) {
+    HIPCHK(hipMemcpy(D.gsl_start, start.data(), start.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(D.gsl_len, len.data(), len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  if (!list.empty()) HIPCHK(hipMemcpy(D.lg_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  D.gsl_n = (int)start.size();
+  D.lg_cnt = (int)list.size();
+  D.lg_nf = nf; D.lg_nn = nn; D.lg_na = na;
+  c->gsl_key = key;
+  return 0;
 }
-// H = sum over the given blkval ranges of G^T W G (ranges: host array of nranges (begin, end) pairs)
+
+// may the Schur sweep of mcols constraints leave the panels of the family children to k_leaf_gram?  (SMCP_LEAFGRAM=0: no)
+constexpr int LG_ECAP_MAX = 1024;
+static bool leafgram_ok(csp_ctx* c, int64_t mcols) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMCP_LEAFGRAM"); on = (e && e[0] == '0') ? 0 : 1; }
+  const DeviceCtx& D = c->D;
+  if (!on || use_generic() || !D.kc_ptr || !D.kc_ij || mcols > GRAM_BLK || mcols < 1 || D.lg_children <= 0) return false;
+  if (D.lg_maxent > LG_ECAP_MAX) return false;
+  // the pairs of entries cost ~ as much as half as many (row, constraint) pairs moved through HBM twice
+  if (D.lg_pairs > D.lg_rows * mcols) return false;
+  const int64_t np = mcols * (mcols + 1) / 2 + 1;
+  const int ecap = (int)((std::max<int64_t>(D.lg_maxent, 2) + 1) & ~1);
+  return np + leafgram_wave_doubles(48, 16, 32, ecap) <= (int64_t)(LDS_LIMIT / 8);
+}
+
+// partial triangles of the listed family children (gram_tables) -> D.lg_part; returns the number of partials
+static int leafgram_partials(csp_ctx* c, int64_t mcols, const int32_t* ids, hipStream_t st, int* nl) {
+  DeviceCtx& D = c->D;
+  *nl = 0;
+  if (!D.lg_cnt) return 0;
+  static int ncu = 0;
+  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  const int64_t np = mcols * (mcols + 1) / 2;
+  const int ecap = (int)((std::max<int64_t>(D.lg_maxent, 2) + 1) & ~1);
+  const int wd = leafgram_wave_doubles(D.lg_nf, D.lg_nn, D.lg_na, ecap);
+  const int64_t lim = (int64_t)(LDS_LIMIT / 8);
+  const int nw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (lim - ((np + 1) & ~1)) / wd));
+  const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(ncu, (D.lg_cnt + nw - 1) / nw));
+  if (D.lg_part_len < nwg * np) {
+    if (D.lg_part) { HIPCHK(hipFree(D.lg_part)); D.bytes -= D.lg_part_len * 8; D.lg_part = nullptr; D.lg_part_len = 0; }
+    if (int rc = dev_alloc(&D.lg_part, (int64_t)ncu * np, D.bytes)) return rc;
+    D.lg_part_len = (int64_t)ncu * np;
+  }
+  static bool attr = false;
+  if (!attr) { attr = hipFuncSetAttribute((const void*)k_leaf_gram, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess; }
+  if (!attr) return SMCP_EHIP;
+  LeafGramArgs a;
+  a.cl = D.cl; a.list = D.lg_list; a.cnt = D.lg_cnt; a.LK = D.lk; a.yaa = D.yaa;
+  a.kc_ptr = D.kc_ptr; a.kc_ij = D.kc_ij; a.kc_val = D.kc_val; a.ids = ids;
+  a.kc_stride = (int)(D.m + 1); a.nr = (int)mcols;
+  a.nfmax = D.lg_nf; a.nnmax = D.lg_nn; a.namax = D.lg_na; a.ecap = ecap;
+  a.part = D.lg_part; a.info = D.info;
+  const size_t lds = (size_t)(((np + 1) & ~1) + (int64_t)nw * wd) * sizeof(double);
+  launch_lds(c, KID_leaf_gram, k_leaf_gram, dim3(nwg), dim3(64 * nw), lds, st, a);
+  *nl = nwg;
+  return 0;
+}
+
+// H = sum over the given blkval ranges of G^T W G (ranges: host array of nranges (begin, end) pairs); leaf: the stack
+// lacks the panels of the family children (D.lg_nochild), whose Gram block k_leaf_gram supplies
 static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, hipStream_t st,
-                           int64_t mcols = -1) {
+                           int64_t mcols = -1, bool leaf = false, const int32_t* ids = nullptr) {
   DeviceCtx& D = c->D;
   const int64_t m = mcols < 0 ? D.m : mcols, bl = c->S.blklen();
   const std::vector<std::pair<int64_t, int64_t>> rs = gram_merge_ranges(nranges, ranges);
@@ -762,14 +843,47 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     HIPCHK(hipMemset2DAsync(H, ldh * sizeof(double), 0, m * sizeof(double), m, st));
     return 0;
   }
-  const int64_t chunk = gram_chunk_rows(total);
-  const int nchunk = gram_count_chunks(rs, chunk);
   const int nb = (int)((m + GRAM_BLK - 1) / GRAM_BLK);
   const int nblk = nb * (nb + 1) / 2;
+  if (nblk == 1) {
+    if (int rc = gram_tables(c, rs, leaf, st)) return rc;
+    const int64_t chunk = gram_chunk_rows((int64_t)D.gsl_n * GRAM_KS);
+    const int spw = (int)(chunk / GRAM_KS);
+    const int nchunk = std::max(1, (D.gsl_n + spw - 1) / spw);
+    if (int rc = gram_reserve(c, m, nchunk)) return rc;
+    int nl = 0;
+    if (leaf) { if (int rc = leafgram_partials(c, m, ids, st, &nl)) return rc; }
+    // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
+    // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
+    static int nw = -1;
+    if (nw < 0) { const char* e = getenv("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
+    const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + nw - 1) / nw;   // lower tiles per wave
+    static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
+    if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
+    const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
+    if (D.gsl_n > 0) {
+#define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nchunk, 1), dim3(1024), lds, st, \
+               (const double*)D.ustack, bl, (int)m, (const int64_t*)D.gsl_start, (const int32_t*)D.gsl_len, D.gsl_n, spw, (const double*)D.sw, D.gpart, 0, nchunk, gskip); \
+             else if (nw == 8) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nchunk, 1), dim3(512), lds, st, \
+               (const double*)D.ustack, bl, (int)m, (const int64_t*)D.gsl_start, (const int32_t*)D.gsl_len, D.gsl_n, spw, (const double*)D.sw, D.gpart, 0, nchunk, gskip); \
+             else launch_lds(c, KID_gram_partial, k_gram_diag128<N, 4>, dim3(nchunk, 1), dim3(256), lds, st, \
+               (const double*)D.ustack, bl, (int)m, (const int64_t*)D.gsl_start, (const int32_t*)D.gsl_len, D.gsl_n, spw, (const double*)D.sw, D.gpart, 0, nchunk, gskip); break;
+      switch (npw) {
+        SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)
+        SMCP_GRAM_CASE(6) SMCP_GRAM_CASE(7) SMCP_GRAM_CASE(8) SMCP_GRAM_CASE(9)
+      }
+#undef SMCP_GRAM_CASE
+    }
+    launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(256), st, (const double*)D.gpart, D.gsl_n > 0 ? nchunk : 0, (int)m, H, ldh,
+           (const double*)D.lg_part, nl);
+    HIPCHK(end_call(c));
+    return 0;
+  }
+  if (leaf) return SMCP_EINVAL;                 // leafgram_ok admits one block only
+  const int64_t chunk = gram_chunk_rows(total);
+  const int nchunk = gram_count_chunks(rs, chunk);
   if (int rc = gram_reserve(c, m, nchunk)) return rc;
   int coff = 0;
-  if (nblk == 1) gram_partials_one_block(c, rs, m, chunk, 0, nchunk, st);
-  else
   for (auto& r : rs) {
     const int64_t lo = r.first, hi = r.second;
     const int nc = (int)((hi - lo + chunk - 1) / chunk);
@@ -784,7 +898,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
       }
     coff += nc;
   }
-  launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
+  launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh, (const double*)nullptr, 0);
   HIPCHK(end_call(c));
   return 0;
 }
@@ -796,49 +910,16 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
   const int64_t m = D.m, bl = c->S.blklen();
   if (!D.ns) {
     if (int rc = gram_prepare(c, L, Y, st)) return rc;
-    // The rows of the swept stack that belong to the levels below the first large front are final as soon as those
-    // levels are swept: their Gram tiles (90 % of the rows on synth50k) are accumulated on a side stream while the
-    // large fronts at the top of the tree -- extend-adds that run one workgroup per CU, short phase kernels -- are
-    // still being swept; the rows of the top follow, and one reduction adds all partial tiles.  MEASURED AND LEFT OFF
-    // (SMCP_GRAM_OVERLAP=1 enables it): 5.92 ms per step against 5.61 with the accumulation after the sweep -- the Gram
-    // workgroups (two per CU, 70 KB of LDS each) and the extend-add's (one per CU, 148 KB) cannot share a CU, so the
-    // two stages only take CUs from each other, and each runs slower on a part of the chip than alone on all of it
-    // (the same outcome as the two-stream attempt of round 1).
-    static int ovl = -1;
-    if (ovl < 0) { const char* e = getenv("SMCP_GRAM_OVERLAP"); ovl = (e && e[0] == '1') ? 1 : 0; }
-    int64_t lc = c->S.nlev;
-    for (int64_t l = 0; l < c->S.nlev; ++l) if (c->lvl[l].nII > 0) { lc = l; break; }
-    // (lc >= 2: the childless members of a family sit at level 0 and are swept by their parents' launch at level 1)
-    if (ovl && Fork::enabled() && D.max_rhs >= m && m <= GRAM_BLK && lc >= 2 && lc < c->S.nlev) {
-      std::vector<int64_t> ra, rb;
-      for (int64_t l = 0; l < c->S.nlev; ++l)
-        for (int64_t q = c->S.levptr[l]; q < c->S.levptr[l + 1]; ++q) {
-          const int64_t k = c->S.levidx[q];
-          std::vector<int64_t>& r = l < lc ? ra : rb;
-          r.push_back(c->S.blkptr[k]); r.push_back(c->S.blkptr[k + 1]);
-        }
-      const auto rsA = gram_merge_ranges((int64_t)ra.size() / 2, ra.data()), rsB = gram_merge_ranges((int64_t)rb.size() / 2, rb.data());
-      const int64_t chunk = gram_chunk_rows(bl);
-      const int nA = gram_count_chunks(rsA, chunk), nB = gram_count_chunks(rsB, chunk);
-      if (int rc = gram_reserve(c, m, nA + nB)) return rc;
-      hess_up_fast(c, D.ustack, (int)m, bl, D.fac, 2, st, 0, D.kc_ptr ? 0 : -1, nullptr, 0, lc);
-      {
-        Fork f(c, st, 1);
-        gram_partials_one_block(c, rsA, m, chunk, 0, nA + nB, f.s);
-        hess_up_fast(c, D.ustack, (int)m, bl, D.fac, 2, st, 0, D.kc_ptr ? 0 : -1, nullptr, lc, -1);
-      }
-      gram_partials_one_block(c, rsB, m, chunk, nA, nA + nB, st);
-      launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(256), st, (const double*)D.gpart, nA + nB, (int)m, H, ldh);
-      HIPCHK(end_call(c));
-      if (int f = fetch_info(c, st)) return f;   // chol(Y_AA) failure
-      return 0;
-    }
+    // (Accumulating the Gram tiles of the lower levels on a side stream while the large fronts are still swept was
+    // measured in round 2 and dropped: 5.92 against 5.61 ms per step -- the two stages only take CUs from each other.)
+    D.lg_request = leafgram_ok(c, m);
     for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
       int nr = (int)std::min(D.max_rhs, m - jb);
       hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st, 0, D.kc_ptr ? jb : -1);     // G(A_j) = (G_NN, R^T G_AN)
     }
+    D.lg_request = false;
     const int64_t range[2] = {0, bl};
-    if (int rc = gram_accumulate(c, 1, range, H, ldh, st)) return rc;
+    if (int rc = gram_accumulate(c, 1, range, H, ldh, st, -1, D.lg_nochild)) return rc;
     if (int f = fetch_info(c, st)) return f;   // chol(Y_AA) failure
     return 0;
   }
@@ -853,12 +934,15 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
         launch(c, KID_scatter_constraints, k_scatter_constraints_ids, dim3(8, (unsigned)std::min<int64_t>(65535, md - jb)),
                dim3(256), st, (const int32_t*)D.dlist + jb, D.cptr, D.cidx, D.cval, D.ustack + jb * bl, bl);
     }
+    D.lg_nochild = false;
+    D.lg_request = leafgram_ok(c, md);
     for (int64_t jb = 0; jb < md; jb += D.max_rhs) {
       int nr = (int)std::min(D.max_rhs, md - jb);
       hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st, 0, D.kc_ptr ? jb : -1, D.kc_ptr ? D.dlist : nullptr);
     }
+    D.lg_request = false;
     const int64_t range[2] = {0, bl};
-    if (int rc = gram_accumulate(c, 1, range, D.hd, md, st, md)) return rc;
+    if (int rc = gram_accumulate(c, 1, range, D.hd, md, st, md, D.lg_nochild, D.kc_ptr ? D.dlist : nullptr)) return rc;
     launch(c, KID_scatter_constraints, k_scatter_hd, dim3((unsigned)std::min<int64_t>(1024, (md * md + 255) / 256)), dim3(256), st,
            (const int32_t*)D.dlist, (int)md, (const double*)D.hd, H, ldh);
   }
@@ -1005,6 +1089,7 @@ int kkt_gram_prepare_part(csp_ctx* c, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int64_t m = D.m, bl = c->S.blklen();
   D.qr_valid = false;
+  D.lg_nochild = false;
   if (!D.kc_ptr) {
     HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * m * bl, st));
     for (int64_t jb = 0; jb < m; jb += 65535)
@@ -1020,14 +1105,16 @@ int kkt_gram_sweep(csp_ctx* c, int set, int64_t j0, int64_t j1, void* stream) {
   if (set < 0 || set > 2 || j0 < 0 || j1 > D.m || j1 <= j0 || j1 - j0 > D.max_rhs) return SMCP_EINVAL;
   if (set && !c->sets[set].lev2) return SMCP_EINVAL;
   const int64_t bl = c->S.blklen();
+  D.lg_request = leafgram_ok(c, D.m);
   hess_up_fast(c, D.ustack + j0 * bl, (int)(j1 - j0), bl, D.fac, 2, (hipStream_t)stream, set, D.kc_ptr ? j0 : -1);
+  D.lg_request = false;
   HIPCHK(end_call(c));
   return 0;
 }
 int kkt_gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, void* stream) {
   if (int rc = ready(c)) return rc;
   if (!c->D.m || ldh < c->D.m || nranges < 0) return SMCP_EINVAL;
-  if (int rc = gram_accumulate(c, nranges, ranges, H, ldh, (hipStream_t)stream)) return rc;
+  if (int rc = gram_accumulate(c, nranges, ranges, H, ldh, (hipStream_t)stream, -1, c->D.lg_nochild)) return rc;
   return fetch_info(c, (hipStream_t)stream);
 }
 // ---- sharded factorisation and solve (every leaves->root / root->leaves sweep shards by subtree) ----
