@@ -109,9 +109,10 @@ struct DeviceCtx {
   // Gram accumulation over slices of the stack (k_gram_diag128) and closed-form blocks of the family children
   // (front_leafgram.hip): tables of the cached set of ranges (csp_ctx::gsl_key)
   int64_t* gsl_start = nullptr; int32_t* gsl_len = nullptr; int64_t gsl_cap = 0; int gsl_n = 0;
-  int32_t* lg_list = nullptr; int64_t lg_cap = 0; int lg_cnt = 0;     // family children inside the ranges
+  int32_t* lg_list = nullptr; int32_t* lg_slot = nullptr; int64_t lg_cap = 0; int lg_cnt = 0;     // family children inside the ranges, their index among all of them
+  int32_t* lg_eptr = nullptr; int32_t* lg_epk = nullptr; double* lg_ew = nullptr; int32_t* lg_remap = nullptr;   // static entry lists per family child
+  double* lg_tab = nullptr; int lg_rec = 0;                           // per-step tables (Psi, Omega), lg_rec doubles per child
   int lg_nf = 0, lg_nn = 0, lg_na = 0;                                // sizing over that list
-  double* lg_part = nullptr; int64_t lg_part_len = 0;                 // one packed lower triangle of H per workgroup
   int64_t lg_children = 0, lg_maxent = 0, lg_pairs = 0, lg_rows = 0;  // over all family children (kkt_set_constraints)
   bool lg_request = false;   // the running Schur sweep may leave the panels of the family children out
   bool lg_nochild = false;   // ... and did: the stack lacks them, their Gram block comes from k_leaf_gram
@@ -203,6 +204,7 @@ struct csp_ctx {
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status
   int launch_err = 0;                   // first failed kernel launch of the running call (launch helpers); read by end_call
   double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)
+  std::vector<int32_t> lg_slot_of;      // clique -> index among the family children (-1: not one)
   std::vector<int64_t> gsl_key;         // the ranges (+ leaf switch) the slice table in D.gsl_* was built for
   std::vector<int64_t> h_kptr;          // ns + 1 : offsets into kidx, host copy for chunk planning
   std::vector<int32_t> h_slist;

@@ -1444,9 +1444,9 @@ __global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(co
   }
 }
 
-// H (m x m, ld ldh, both triangles) <- sum over chunks of the partial tiles (+ the nl packed lower triangles of
-// k_leaf_gram, front_leafgram.hip), every sum in a fixed order
-__global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* H, int64_t ldh, const double* lpart = nullptr, int nl = 0) {
+// H (m x m, ld ldh, both triangles) <- sum over chunks of the partial tiles (those of k_gram_diag128 and those of
+// k_leaf_pairs, front_leafgram.hip), in a fixed order
+__global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* H, int64_t ldh) {
   int bi = 0, rem = blockIdx.y;
   while (rem > bi) { rem -= bi + 1; ++bi; }
   const int bj = rem;
@@ -1467,21 +1467,8 @@ __global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* 
     for (int q = 0; q < 8; ++q) s8[q] += p[(int64_t)(c + q) * (64 * 256)];
   }
   for (; c < nchunk; ++c) s8[0] += p[(int64_t)c * (64 * 256)];
-  double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   const int i = ci0 + tm * 16 + (idx & 15), j = cj0 + tn * 16 + (idx >> 4);
-  if (nl > 0 && i < m && j < m) {
-    const int hi = max(i, j), lo = min(i, j);
-    const int64_t np = (int64_t)m * (m + 1) / 2;
-    const double* q = lpart + (int64_t)hi * (hi + 1) / 2 + lo;
-    double l8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    int w = 0;
-    for (; w + 8 <= nl; w += 8) {
-#pragma unroll
-      for (int z = 0; z < 8; ++z) l8[z] += q[(int64_t)(w + z) * np];
-    }
-    for (; w < nl; ++w) l8[0] += q[(int64_t)w * np];
-    s += ((l8[0] + l8[1]) + (l8[2] + l8[3])) + ((l8[4] + l8[5]) + (l8[6] + l8[7]));
-  }
   if (i < ci0 + ni && j < cj0 + nj) {
     H[i + (int64_t)j * ldh] = s;
     H[j + (int64_t)i * ldh] = s;

@@ -306,7 +306,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   DeviceCtx& D = c->D;
   const Symbolic& S = c->S;
   HIPCHK(hipSetDevice(D.device));
-  void* old[] = {D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack,
+  void* old[] = {D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack,
                  D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.kc_ij};
   for (void* p : old) if (p) hipFree(p);
   D.cptr = nullptr; D.cidx = nullptr; D.cval = nullptr; D.cwval = nullptr; D.rpos = nullptr;
@@ -316,6 +316,8 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   D.kc_ptr = D.kc_off = nullptr; D.kc_val = nullptr; D.kc_ij = nullptr;
   D.md = D.ns = D.vcols = 0;
   D.lg_children = 0; D.lg_nochild = false;
+  D.lg_eptr = D.lg_epk = D.lg_remap = nullptr; D.lg_ew = D.lg_tab = nullptr;
+  c->gsl_key.clear();
   if (D.qr_ws) { hipFree(D.qr_ws); D.bytes -= D.qr_len * 8; D.qr_ws = nullptr; D.qr_len = 0; }
   D.qr_valid = false;
   SetupClock clk("kkt_set_constraints");
@@ -483,15 +485,21 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
           const size_t q = (size_t)k * (m + 1) + j;
           D.kc_maxlist_large = std::max<int64_t>(D.kc_maxlist_large, kptr[q + 1] - kptr[q]);
         }
-    // closed-form Gram blocks of the family children (front_leafgram.hip): entries per child over all constraints
-    D.lg_children = 0; D.lg_maxent = 0; D.lg_pairs = 0; D.lg_rows = 0;
+    // closed-form Gram blocks of the family children (front_leafgram.hip): per child its entries over all constraints
+    // in constraint order (row | column << 8 | constraint << 16, value halved on the diagonal) -- static, so the pair
+    // kernel reads them with one coalesced load -- and the record size of the per-step tables
+    D.lg_children = 0; D.lg_maxent = 0; D.lg_pairs = 0; D.lg_rows = 0; D.lg_rec = 0;
+    c->lg_slot_of.assign((size_t)S.nsn, -1);
+    std::vector<int32_t> lg_eptr(1, 0);
     for (int64_t k = 0; k < S.nsn; ++k)
       if (k < (int64_t)c->fam.size() && c->fam[k] == 1) {
         const int64_t E = kptr[(size_t)k * (m + 1) + m] - kptr[(size_t)k * (m + 1)];
-        D.lg_children++;
+        c->lg_slot_of[(size_t)k] = (int32_t)D.lg_children++;
         D.lg_maxent = std::max(D.lg_maxent, E);
         D.lg_pairs += E * (E + 1) / 2;
         D.lg_rows += S.nf(k) * S.nn(k);
+        D.lg_rec = std::max<int>(D.lg_rec, (int)(S.nf(k) * S.nf(k) + S.nf(k) * S.nn(k)));
+        lg_eptr.push_back(lg_eptr.back() + (int32_t)E);
       }
     std::vector<int32_t> fill(kptr.begin(), kptr.end() - 1);
     for (int64_t j = 0; j < m; ++j)
@@ -511,6 +519,27 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
           const int32_t q = fill2[(size_t)ek[e] * (m + 1) + j]++;
           kij[q] = (int32_t)((eoff[e] % nf) & 0xffff) | (int32_t)((eoff[e] / nf) << 16);
         }
+    }
+    if (D.lg_children > 0 && m < 32768) {
+      std::vector<int32_t> epk((size_t)lg_eptr.back()), remap((size_t)m, -1);
+      std::vector<double> ewv((size_t)lg_eptr.back());
+      for (int64_t k = 0; k < S.nsn; ++k) {
+        const int32_t g = c->lg_slot_of[(size_t)k];
+        if (g < 0) continue;
+        int32_t o = lg_eptr[(size_t)g];
+        for (int64_t j = 0; j < m; ++j)
+          for (int32_t q = kptr[(size_t)k * (m + 1) + j]; q < kptr[(size_t)k * (m + 1) + j + 1]; ++q, ++o) {
+            const int32_t i = kij[q] & 0xffff, jc = kij[q] >> 16;
+            epk[(size_t)o] = i | (jc << 8) | ((int32_t)j << 16);
+            ewv[(size_t)o] = i == jc ? 0.5 * kval[q] : kval[q];
+          }
+      }
+      for (size_t q = 0; q < dl.size(); ++q) remap[(size_t)dl[q]] = (int32_t)q;
+      if ((rc = dev_upload(&D.lg_eptr, lg_eptr, D.bytes))) return rc;
+      if ((rc = dev_upload(&D.lg_epk, epk, D.bytes))) return rc;
+      if ((rc = dev_upload(&D.lg_ew, ewv, D.bytes))) return rc;
+      if ((rc = dev_upload(&D.lg_remap, remap, D.bytes))) return rc;
+      if ((rc = dev_alloc(&D.lg_tab, D.lg_children * D.lg_rec, D.bytes))) return rc;
     }
     if ((rc = dev_upload(&D.kc_ij, kij, D.bytes))) return rc;
     if ((rc = dev_upload(&D.kc_ptr, kptr, D.bytes))) return rc;
@@ -736,7 +765,7 @@ static int gram_tables(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>
   key.push_back(leaf ? 1 : 0);
   if (key == c->gsl_key && D.gsl_start) return 0;
   std::vector<int64_t> start;
-  std::vector<int32_t> len, list;
+  std::vector<int32_t> len, list, slot;
   int nf = 0, nn = 0, na = 0;
   auto add_segment = [&](int64_t lo, int64_t hi) {
     for (int64_t e = lo; e < hi; e += GRAM_KS) { start.push_back(e); len.push_back((int32_t)std::min<int64_t>(GRAM_KS, hi - e)); }
@@ -752,6 +781,7 @@ static int gram_tables(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>
       if (b > seg_lo) add_segment(seg_lo, b);
       seg_lo = e;
       list.push_back((int32_t)k);
+      slot.push_back(c->lg_slot_of[(size_t)k]);
       nf = std::max(nf, (int)S.nf(k)); nn = std::max(nn, (int)S.nn(k)); na = std::max(na, (int)S.na(k));
     }
     if (r.second > seg_lo) add_segment(seg_lo, r.second);
@@ -769,12 +799,17 @@ static int gram_tables(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>
   int64_t cap_len = D.gsl_cap;
   if (int rc = grow(&D.gsl_start, D.gsl_cap, (int64_t)start.size())) return rc;
   if (int rc = grow(&D.gsl_len, cap_len, (int64_t)start.size())) return rc;
+  int64_t cap_slot = D.lg_cap;
   if (int rc = grow(&D.lg_list, D.lg_cap, (int64_t)list.size())) return rc;
+  if (int rc = grow(&D.lg_slot, cap_slot, (int64_t)list.size())) return rc;
   if (!start.empty()) {
     HIPCHK(hipMemcpy(D.gsl_start, start.data(), start.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(D.gsl_len, len.data(), len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
-  if (!list.empty()) HIPCHK(hipMemcpy(D.lg_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!list.empty()) {
+    HIPCHK(hipMemcpy(D.lg_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(D.lg_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   D.gsl_n = (int)start.size();
   D.lg_cnt = (int)list.size();
   D.lg_nf = nf; D.lg_nn = nn; D.lg_na = na;
@@ -792,40 +827,53 @@ static bool leafgram_ok(csp_ctx* c, int64_t mcols) {
   if (D.lg_maxent > LG_ECAP_MAX) return false;
   // the pairs of entries cost ~ as much as half as many (row, constraint) pairs moved through HBM twice
   if (D.lg_pairs > D.lg_rows * mcols) return false;
+  if (!D.lg_eptr || !D.lg_tab) return false;
   const int64_t np = mcols * (mcols + 1) / 2 + 1;
   const int ecap = (int)((std::max<int64_t>(D.lg_maxent, 2) + 1) & ~1);
-  return np + leafgram_wave_doubles(48, 16, 32, ecap) <= (int64_t)(LDS_LIMIT / 8);
+  return np + leafgram_wave_doubles(D.lg_rec, ecap) <= (int64_t)(LDS_LIMIT / 8);
 }
 
-// partial triangles of the listed family children (gram_tables) -> D.lg_part; returns the number of partials
-static int leafgram_partials(csp_ctx* c, int64_t mcols, const int32_t* ids, hipStream_t st, int* nl) {
+// partial tiles of the listed family children (gram_tables) -> the slots part[0 .. *nl) (at most leafgram_slots())
+static int leafgram_slots(csp_ctx* c) {
+  static int ncu = 0;
+  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, c->D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  return ncu;
+}
+static int leafgram_partials(csp_ctx* c, int64_t mcols, const int32_t* ids, hipStream_t st, double* part, int* nl) {
   DeviceCtx& D = c->D;
   *nl = 0;
   if (!D.lg_cnt) return 0;
-  static int ncu = 0;
-  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  const int ncu = leafgram_slots(c);
   const int64_t np = mcols * (mcols + 1) / 2;
   const int ecap = (int)((std::max<int64_t>(D.lg_maxent, 2) + 1) & ~1);
-  const int wd = leafgram_wave_doubles(D.lg_nf, D.lg_nn, D.lg_na, ecap);
+  const int wd = leafgram_wave_doubles(D.lg_rec, ecap);
   const int64_t lim = (int64_t)(LDS_LIMIT / 8);
   const int nw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (lim - ((np + 1) & ~1)) / wd));
   const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(ncu, (D.lg_cnt + nw - 1) / nw));
-  if (D.lg_part_len < nwg * np) {
-    if (D.lg_part) { HIPCHK(hipFree(D.lg_part)); D.bytes -= D.lg_part_len * 8; D.lg_part = nullptr; D.lg_part_len = 0; }
-    if (int rc = dev_alloc(&D.lg_part, (int64_t)ncu * np, D.bytes)) return rc;
-    D.lg_part_len = (int64_t)ncu * np;
-  }
-  static bool attr = false;
-  if (!attr) { attr = hipFuncSetAttribute((const void*)k_leaf_gram, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess; }
-  if (!attr) return SMCP_EHIP;
   LeafGramArgs a;
-  a.cl = D.cl; a.list = D.lg_list; a.cnt = D.lg_cnt; a.LK = D.lk; a.yaa = D.yaa;
-  a.kc_ptr = D.kc_ptr; a.kc_ij = D.kc_ij; a.kc_val = D.kc_val; a.ids = ids;
-  a.kc_stride = (int)(D.m + 1); a.nr = (int)mcols;
-  a.nfmax = D.lg_nf; a.nnmax = D.lg_nn; a.namax = D.lg_na; a.ecap = ecap;
-  a.part = D.lg_part; a.info = D.info;
+  a.cl = D.cl; a.list = D.lg_list; a.slot = D.lg_slot; a.cnt = D.lg_cnt; a.LK = D.lk; a.yaa = D.yaa;
+  a.tab = D.lg_tab; a.rec = D.lg_rec;
+  a.eptr = D.lg_eptr; a.epk = D.lg_epk; a.ew = D.lg_ew; a.remap = ids ? D.lg_remap : nullptr;
+  a.nr = (int)mcols; a.ecap = ecap;
+  a.part = part; a.info = D.info;
+  { static int sk = -1; if (sk < 0) { const char* e = getenv("SMCP_LGSKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
+  launch_lds(c, KID_leaf_tables, k_leaf_tables, dim3(D.lg_cnt), dim3(64), (size_t)leaftab_doubles(D.lg_nf, D.lg_nn, D.lg_na) * sizeof(double), st,
+             a, D.lg_nf, D.lg_nn, D.lg_na);
   const size_t lds = (size_t)(((np + 1) & ~1) + (int64_t)nw * wd) * sizeof(double);
-  launch_lds(c, KID_leaf_gram, k_leaf_gram, dim3(nwg), dim3(64 * nw), lds, st, a);
+  const int rt = (D.lg_rec + 63) / 64, et = (ecap + 63) / 64;
+  bool ok = false;
+#define SMCP_LG_CASE(RT, ET) \
+  if (!ok && rt <= RT && et <= ET) { \
+    static bool attr = false; \
+    if (!attr) attr = hipFuncSetAttribute((const void*)k_leaf_pairs<RT, ET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess; \
+    if (!attr) return SMCP_EHIP; \
+    launch_lds(c, KID_leaf_gram, k_leaf_pairs<RT, ET>, dim3(nwg), dim3(64 * nw), lds, st, a); \
+    ok = true; \
+  }
+  SMCP_LG_CASE(12, 2) SMCP_LG_CASE(12, 4) SMCP_LG_CASE(24, 2) SMCP_LG_CASE(24, 4) SMCP_LG_CASE(24, 16)
+  SMCP_LG_CASE(48, 4) SMCP_LG_CASE(48, 16)
+#undef SMCP_LG_CASE
+  if (!ok) return SMCP_EINVAL;
   *nl = nwg;
   return 0;
 }
@@ -850,9 +898,10 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     const int64_t chunk = gram_chunk_rows((int64_t)D.gsl_n * GRAM_KS);
     const int spw = (int)(chunk / GRAM_KS);
     const int nchunk = std::max(1, (D.gsl_n + spw - 1) / spw);
-    if (int rc = gram_reserve(c, m, nchunk)) return rc;
+    const int ngram = D.gsl_n > 0 ? nchunk : 0;
+    if (int rc = gram_reserve(c, m, nchunk + (leaf ? leafgram_slots(c) : 0))) return rc;
     int nl = 0;
-    if (leaf) { if (int rc = leafgram_partials(c, m, ids, st, &nl)) return rc; }
+    if (leaf) { if (int rc = leafgram_partials(c, m, ids, st, D.gpart + (int64_t)ngram * (64 * 256), &nl)) return rc; }
     // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
     // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
     static int nw = -1;
@@ -874,8 +923,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
       }
 #undef SMCP_GRAM_CASE
     }
-    launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(256), st, (const double*)D.gpart, D.gsl_n > 0 ? nchunk : 0, (int)m, H, ldh,
-           (const double*)D.lg_part, nl);
+    launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(256), st, (const double*)D.gpart, ngram + nl, (int)m, H, ldh);
     HIPCHK(end_call(c));
     return 0;
   }
@@ -898,7 +946,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
       }
     coff += nc;
   }
-  launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh, (const double*)nullptr, 0);
+  launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
   HIPCHK(end_call(c));
   return 0;
 }
