@@ -9,15 +9,17 @@ Inputs are synthetic (seeded numpy) and resident in HBM before the timed region.
 N = 1 workload: the configuration the metric is quoted on, "synth50k" (config 5: nested
 block-arrow chordal SDP, n = 50000, 8073 cliques, m = 100), which fits one GPU.
 N > 1 (strong scaling of ONE solve): the clique tree is cut into subtrees owned by single ranks plus a
-small replicated top (smcp_amd/shard.py).  Every rank sweeps all m constraints over its own subtrees,
-the packed update blocks of the subtree roots are exchanged with one RCCL all-gather, the top is swept
-redundantly, each rank forms the partial Gram matrix of its blkval ranges and one all-reduce of the
-m x m matrix H completes it.  Factorisation and solve_ are replicated.  (--shard columns selects the
-simpler column sharding of H.)
+small replicated top (smcp_amd/shard.py).  EVERY sweep of the step is sharded by subtree -- cholesky,
+projected_inverse, the Schur sweeps of all m constraints, both Hessians of solve_; the packed update blocks
+of the subtree roots are exchanged over RCCL, the top is swept redundantly, each rank forms the partial
+Gram matrix of its blkval ranges and one all-reduce of the m x m matrix H completes it; potrf / potrs of H
+are replicated.  (--shard columns selects the simpler column sharding of H.)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the
-dominant kernel (HIP-event timing inside the timed region) and `cpu_baseline` (the CPU
-oracle timed on a bounded sample on this host).
+dominant kernel (HIP-event timing inside the timed region), `cpu_baseline` (the CPU oracle timed on this
+host, median of three repeats), `back_solve` (the solve_ sub-rate of SURVEY 8d: two Hessians + potrs on
+the factored system) and, for the default N = 1 run, `secondary`: the GPU-only figures of BASELINE.json's
+configs 2, 3 and 4 (dense4096, arrow, maxcut; a few steps each, no CPU leg; --no-secondary skips them).
 """
 import argparse
 import ctypes
@@ -49,9 +51,23 @@ def build_workload(name, seed=0):
     elif name == "dense4096":
         pat = problems.band_pattern(4096, 4095)
         m, density, label = 16, 0.005, "single dense clique n=4096, m=16"
+    elif name == "maxcut":
+        # config 4: max-cut relaxation on a random 1000-node / 5909-edge graph (the size of SDPLIB maxG51), m = n
+        # constraints A_i = e_i e_i^T -- all column-sparse, so the Schur complement takes the trsm + SCMcolumn2 route
+        # (solvers.py:489-497, misc.c:620-663).  Pattern, embedding and constraints exactly as the drivers build them.
+        return None, 1000, None, "max-cut SDP, random graph n=1000, 5909 edges (maxG51 size), m=1000, SCMcolumn2 path"
     else:
         raise SystemExit("unknown workload " + name)
     return pat, m, density, label
+
+
+def maxcut_problem():
+    """(symbolic, cptr, cidx, cval) of the max-cut workload through the drivers' own index algebra (solvers._Problem)."""
+    from smcp_amd import base, solvers
+    P = base.maxcut_SDP(1000, 5909, seed=0)
+    pr = solvers._Problem(P._A, P._b)
+    cptr, cidx, cval = pr._con
+    return pr.symb, cptr, cidx, cval
 
 
 def lds_fits(nn, na):
@@ -83,87 +99,179 @@ def self_launch(ngpus):
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="synth50k")
-    ap.add_argument("--kktsolver", default="chol", choices=("chol", "qr"),
-                    help="'qr': the step factors with kkt_qr (Cholesky-QR of the swept stack) instead of kkt_chol; one GPU")
-    ap.add_argument("--m", type=int, default=None)
-    ap.add_argument("--max-rhs", type=int, default=None)
-    ap.add_argument("--cpu-cols", type=int, default=10 ** 9, help="Schur columns timed on the CPU oracle (default: all; at least one per thread)")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (a 1-GPU box has a 16-core share)")
-    ap.add_argument("--shard", default="subtree", choices=["subtree", "columns"],
-                    help="N > 1: subtree sharding + boundary exchange (default) or column sharding of H")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing")
-    ap.add_argument("--verbose", action="store_true")
-    args = ap.parse_args()
+def git_sha():
+    try:
+        import subprocess
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
 
-    world_env = os.environ.get("WORLD_SIZE")
-    if args.gpus > 1 and world_env is None:
-        # Not under a launcher: start the N ranks as fresh child processes (one per GPU, RCCL) BEFORE this process
-        # touches the GPU, relay rank 0's JSON line and exit with the launcher's code.  Nothing is exec'd.
-        raise SystemExit(self_launch(args.gpus))
-    if int(world_env or "1") != args.gpus:
-        print("bench.py: --gpus %d but WORLD_SIZE=%s; launch with `python bench.py --gpus N` or "
-              "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world_env),
-              file=sys.stderr)
-        raise SystemExit(2)
 
-    # RCCL prints a version banner on stdout when its first communicator comes up: everything but the result line goes
-    # to stderr (file descriptor 1 points at stderr from here on; rank 0 writes the JSON line to the saved stdout)
-    sys.stdout.flush()
-    real_stdout = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
+def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc, part, rank, world, label):
+    """roofline object of the dominant kernel `dom` (name as rocprofv3 shows it, without template arguments):
+    achieved = ALGORITHMIC bytes (or flops) of its launches in one step / their duration (HIP events).
+    B = sum (nn + na) nn (blkval), U = sum na^2, Up = sum na (na + 1) / 2 (packed update blocks)."""
+    nn_, na_ = symb.clique_sizes()
+    lds_ok = np.array([lds_fits(int(a), int(b)) for a, b in zip(nn_, na_)])
+    chunks = [min(max_rhs, mloc - c) for c in range(0, mloc, max_rhs)]
+    if part is not None:     # this rank sweeps only its own subtrees and the replicated top
+        lds_ok = lds_ok & ((part.owner == rank) | (part.owner == -1))
+        chunks = [min(max_rhs, m - c) for c in range(0, m, max_rhs)]
+    owned = np.ones(symb.Nsn, dtype=bool) if part is None else ((part.owner == rank) | (part.owner == -1))
+    Bk = ((nn_ + na_) * nn_).astype(np.float64)
+    Uk = (na_ * na_).astype(np.float64)
+    Upk = (na_ * (na_ + 1) // 2).astype(np.float64)
+    par = symb.snpar
+    Uch = np.zeros(symb.Nsn)
+    np.add.at(Uch, par[par >= 0], Uk[par >= 0])       # update volume a clique reads from its children
+    Upch = np.zeros(symb.Nsn)
+    np.add.at(Upch, par[par >= 0], Upk[par >= 0])
+    nch = np.diff(symb.chptr)
+    fam = symb.family_roles()
+    fam_mask = lds_ok & (fam > 0)
+    leaf_gram = "k_leaf_pairs" in breakdown           # the family children's panels are not formed (front_leafgram.hip)
+    B = Bk[owned].sum()
+    U = Uk[owned].sum()
+    solve_chunks = chunks + [1, 1]                    # the two single right-hand sides of solve_
 
+    def cls_bytes(mask):     # two-directional sweep kernels: panels read + written, updates written + read
+        return sum(8.0 * (r * (2 * Bk[mask].sum() + Uk[mask].sum() + Uch[mask].sum()) + Bk[mask].sum()) for r in solve_chunks)
+
+    def up_bytes(mask):      # Schur sweeps build their input from the entry lists (panels written only); solve_'s read them too
+        tot = 0.0
+        for i, r in enumerate(solve_chunks):
+            panel = (1 if i < len(chunks) else 2) * Bk[mask].sum()
+            tot += 8.0 * (r * (panel + Upk[mask].sum() + Upch[mask].sum()) + Bk[mask].sum())
+        return tot
+
+    note = None
+    extra = {}
+    alg = None
+    if dom == "k_fam_sparse":
+        # bytes the fused family kernel HAS to move: the parents' output panels (+ the children's when they are formed),
+        # the parents' packed updates, the constants of every member once per launch; the children's updates stay in LDS
+        panels = Bk[fam_mask & (fam == 2)].sum() + (0.0 if leaf_gram else Bk[fam_mask & (fam == 1)].sum())
+        alg = sum(8.0 * (r * (panels + Upk[fam_mask & (fam == 2)].sum()) + Bk[fam_mask].sum()) for r in chunks)
+        nnk, nak = nn_[fam_mask].astype(np.float64), na_[fam_mask].astype(np.float64)
+        flops = float((nnk ** 3 + 3 * nak * nnk ** 2 + 3 * nak ** 2 * nnk).sum()) * sum(chunks)
+        per_level = sum(8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask].sum() + Upch[fam_mask].sum()) + Bk[fam_mask].sum()) for r in chunks)
+        extra = {"per_level_bytes_per_launch": per_level / dom_launches,
+                 "mfma": {"flops_per_launch": flops / dom_launches,
+                          "achieved_tflops": round(flops / (1e-3 * dom_ms) / 1e12, 2),
+                          "frac": round(flops / (1e-3 * dom_ms) / 1e12 / FP64_PEAK_TFLOPS, 4)}}
+        note = ("bytes = the parents' output panels%s + the parents' packed updates + the members' constants (the children's "
+                "update matrices stay in LDS); per_level_bytes = SURVEY 8d's per-level figure for the same sweeps; mfma = "
+                "canonical dense-formulation flops" % (" (the children's panels are not formed: their Gram block comes from "
+                                                       "k_leaf_pairs in closed form)" if leaf_gram else " + the children's"))
+    elif dom == "k_hess_up_fam":
+        alg = sum(8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask & (fam == 2)].sum()) + Bk[fam_mask].sum()) for r in chunks)
+    elif dom == "k_gram_diag128":
+        rows = B - (Bk[owned & (fam == 1)].sum() if leaf_gram else 0.0)
+        alg = 8.0 * (m * rows + rows)                 # one read of the swept stack (+ the weights)
+        note = "bytes = one read of the swept constraint stack (m x rows) + the weights"
+    elif dom == "k_lf_assemble_lds":
+        big = (~lds_ok) & owned & (nch > 0)
+        nf_ = (nn_ + na_).astype(np.float64)
+        alg = sum(8.0 * r * (Upch[big].sum() + (nf_[big] * (nf_[big] + 1) / 2).sum()) for r in solve_chunks)
+        note = "bytes = the children's packed updates read once + the assembled lower triangle of every front written once, per right-hand side"
+    elif dom == "k_lfsp_up":
+        sp_mask = (~lds_ok) & (nch == 0) & (nn_ <= 64) & (na_ <= 128) & (na_ > 0)
+        alg = sum(8.0 * (r * (Bk[sp_mask].sum() + Upk[sp_mask].sum()) + 3 * (2 * Bk[sp_mask].sum() + Uk[sp_mask].sum())) for r in chunks)
+        note = ("three launches per chunk of right-hand sides (Q, update, G_NN) are timed under this name; bytes = output panels + "
+                "packed updates of every (front, constraint) + the fronts' constants once per launch, averaged over the launches")
+    elif dom in ("k_hess_up_level", "k_hess_down_level"):
+        alg = sum(8.0 * (r * (2 * B + 2 * U) + B) for r in solve_chunks)
+    elif dom == "k_hess_up_pad":
+        alg = up_bytes(lds_ok)
+    elif dom == "k_hess_up_n16":
+        alg = up_bytes(lds_ok & (nn_ <= 16) & (na_ <= 64))
+    elif dom in ("k_hess_up_mfma<true>", "k_hess_down_mfma<true>"):
+        alg = cls_bytes(lds_ok)
+    elif dom in ("k_hess_up_mfma<false>", "k_hess_down_mfma<false>"):
+        alg = cls_bytes(~lds_ok)
+    elif dom in ("k_chol_level", "k_pinv_level"):
+        alg = 8.0 * (2 * B + 2 * U)
+    elif dom in ("k_trsm_fwd_level", "k_trsm_bwd_level", "k_trsm_fwd_mfma", "k_trsm_bwd_mfma"):
+        # supernodal triangular solves with the n x |K| right-hand sides of the SCMcolumn2 route: the factor is read once
+        # per launch chain, every right-hand-side column is read and written once per sweep
+        ncols = float(m)       # one column of S^-1 per max-cut constraint
+        alg = 8.0 * (B + 2.0 * symb.n * ncols)
+        note = "bytes = the factor once + the n x m right-hand sides read and written once per sweep direction"
+    if alg is not None:
+        avg_s = 1e-3 * dom_ms / dom_launches
+        per_launch = alg / dom_launches
+        achieved = per_launch / avg_s / 1e9
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the gfx950
+        # guide prescribes), taken from the committed summary of the same command -- with its provenance, and dropped
+        # when that summary does not list this kernel for this workload
+        traffic, source = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
+            hits = [v for kname, v in tj.get("kernels", {}).items() if kname.split("<")[0] == dom.split("<")[0]]
+            if tj.get("workload") == label and hits and world == 1:
+                traffic = max(v["hbm_bytes_per_launch"] for v in hits)
+                source = "profiles/r03_hbm_traffic.json@%s" % tj.get("git_sha", "?")
+        except Exception:
+            traffic = None
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+                    "bytes_per_launch": per_launch, "avg_launch_us": round(1e6 * avg_s, 2),
+                    "launches_per_step": dom_launches}
+        roofline.update(extra)
+        if note:
+            roofline["note"] = note
+        return roofline
+    # large-front phase kernels (configs 2 and 3): MFMA-bound, canonical BLAS-3 flop counts per (front, rhs)
+    # (SURVEY 8d): up1 = E, T (2 na nn^2 + nn^3); up2 = update, G, G_NN (2 na^2 nn + na nn^2 + nn^3 / 3);
+    # up3 = scaling product (na^2 nn, triangular operand)
+    big = ~lds_ok
+    nnf, naf = nn_[big].astype(np.float64), na_[big].astype(np.float64)
+    # fronts of more than six 64-column tiles form G_NN = Li F_NN Li^T as Z = Li Fl (nn^3 / 3, phase 1) and
+    # Z Li^T + Li Z^T (2 nn^3 / 3, phase 2) instead of T = Li F_NN (nn^3) and T Li^T (nn^3 / 3): front_large.hip lf_sym_split
+    split = nnf > 6 * 64
+    lf_flops = {"k_lf_up1": (2 * naf * nnf ** 2 + np.where(split, nnf ** 3 / 3, nnf ** 3)).sum(),
+                "k_lf_up2": (2 * naf ** 2 * nnf + naf * nnf ** 2 + np.where(split, 2 * nnf ** 3 / 3, nnf ** 3 / 3)).sum(),
+                "k_lf_up3": (naf ** 2 * nnf).sum()}
+    if dom in lf_flops:
+        nr = sum(solve_chunks)
+        tfl = lf_flops[dom] * nr / (1e-3 * dom_ms) / 1e12
+        return {"kernel": dom, "bound": "mfma", "achieved": round(tfl, 2), "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tfl / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                "flops_per_step": lf_flops[dom] * nr, "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2),
+                "launches_per_step": dom_launches}
+    return {"kernel": dom, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+            "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2), "launches_per_step": dom_launches,
+            "note": "no byte / flop model for this kernel in bench.py"}
+
+
+def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
+    """One workload through the timed protocol; returns the result dict on rank 0 (None elsewhere)."""
     import torch
     import torch.distributed as dist
-    from smcp_amd import _lib, chordal, problems
+    from smcp_amd import chordal, problems
     from smcp_amd.cspmatrix import cspmatrix
     from smcp_amd.kkt import KKTSystem
     from smcp_amd.symbolic import Symbolic
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("SMCP_BENCH_BACKEND", "nccl")   # "gloo": functional check with ranks sharing a GPU
-        ndev = torch.cuda.device_count()
-        torch.cuda.set_device(local % ndev)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
-    # SMCP_BENCH_FORCE_SHARDED=1 (N = 1 only): the subtree-sharded route and its collectives over RCCL with a group of ONE
-    # rank -- what the host logic and the collective launches of the N-GPU step cost beside the plain single-GPU step
-    force_sharded = world == 1 and os.environ.get("SMCP_BENCH_FORCE_SHARDED") == "1"
-    if force_sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    dev = torch.device("cuda", torch.cuda.current_device())
-    lib = _lib.lib()
+    world, rank, dev, lib, force_sharded = env["world"], env["rank"], env["dev"], env["lib"], env["force_sharded"]
 
     # ---------------- problem (untimed) ----------------
-    pat, m, density, label = build_workload(args.workload)
-    if args.m:
+    pat, m, density, label = build_workload(workload)
+    if args.m and primary:
         m = args.m
     t0 = time.time()
-    symb = Symbolic(pat)
+    if workload == "maxcut":
+        symb, cptr, cidx, cval = maxcut_problem()
+    else:
+        symb = Symbolic(pat)
     t_sym = time.time() - t0
     fl = symb.flops()
     B, U = fl["B"], fl["U"]
     per_rhs = 8 * (U + 3 * B)
-    max_rhs = args.max_rhs or int(max(1, min(m, (48 << 30) // per_rhs)))
-    cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=1)
+    max_rhs = (args.max_rhs if primary else None) or int(max(1, min(m, (48 << 30) // per_rhs)))
+    if workload != "maxcut":
+        cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=1)
+    # the reference's default classification (tnzcols = 0.1): on the synthetic patterns every constraint touches more
+    # than n / 10 columns and is swept; the max-cut constraints are column-sparse
     kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs, tnzcols=0.0 if args.kktsolver == "qr" else None)
     part = None
     if (world > 1 or force_sharded) and args.shard == "subtree":
@@ -229,10 +337,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     prof = not args.no_profile
+    back_solve = None
     nk = int(lib.csp_profile_kinds())
     names = [lib.csp_profile_kernel_name(i).decode() for i in range(nk)]
 
@@ -259,7 +368,7 @@ def main():
         lib.csp_profile_filter(h, names.index(dom0))
         lib.csp_profile_read(h, None, None)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -267,7 +376,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
+    ms_per_step = 1e3 * elapsed / steps
     if lazy:
         chordal.lazy_status(symb, False)
 
@@ -275,154 +384,41 @@ def main():
     roofline = None
     breakdown = {}
     if prof:
-        timed = read_profile(args.steps)              # the dominant kernel only, from the timed steps above
+        timed = read_profile(steps)              # the dominant kernel only, from the timed steps above
         lib.csp_profile_enable(h, 0)
         lib.csp_profile_filter(h, -1)
         breakdown = dict(calib)
         breakdown.update(timed)
         dom = dom0
         dom_ms, dom_launches = breakdown[dom]
-        # algorithmic bytes of all launches of the dominant kernel in one step:
-        # one Hessian half-sweep over r right-hand sides touches 8*(r*(2B+2U)+B) bytes
-        # (U panels read+written, update matrices written once + read once, L read once).
-        mloc = j1 - j0
-        chunks = [min(max_rhs, mloc - c) for c in range(0, mloc, max_rhs)] + [1, 1]
-        sweep_bytes = sum(8.0 * (r * (2 * B + 2 * U) + B) for r in chunks)
-        # the LDS-class / HBM-class instantiations of a sweep kernel split the cliques of every level
-        # between them: the bytes of a sweep are apportioned by the cliques each instantiation owns
-        nn_, na_ = symb.clique_sizes()
-        from smcp_amd.symbolic import Symbolic as _S  # noqa: F401
-        lds_ok = np.array([lds_fits(int(a), int(b)) for a, b in zip(nn_, na_)])
-        if part is not None:     # this rank sweeps only its own subtrees and the replicated top
-            lds_ok = lds_ok & ((part.owner == rank) | (part.owner == -1))
-            chunks = [min(max_rhs, m - c) for c in range(0, m, max_rhs)] + [1, 1]
-        Bk = ((nn_ + na_) * nn_).astype(np.float64)
-        Uk = (na_ * na_).astype(np.float64)
-        par = symb.snpar
-        Uch = np.zeros(symb.Nsn)
-        np.add.at(Uch, par[par >= 0], Uk[par >= 0])   # update volume a clique reads from its children
-
-        def cls_bytes(mask):
-            return sum(8.0 * (r * (2 * Bk[mask].sum() + Uk[mask].sum() + Uch[mask].sum()) + Bk[mask].sum())
-                       for r in chunks)
-
-        # Gram formulation at N = 1: the m constraint sweeps are leaves->root only; the two Hessians of
-        # solve_ add one up- and one down-sweep each.  Update matrices are exchanged as packed lower
-        # triangles, so the algorithmic update volume of the fast up-sweep is Up = sum na(na+1)/2.
-        Upk = (na_ * (na_ + 1) // 2).astype(np.float64)
-        Upch = np.zeros(symb.Nsn)
-        np.add.at(Upch, par[par >= 0], Upk[par >= 0])
-        up_chunks = chunks if world == 1 else chunks
-
-        def up_bytes(mask):
-            # the sweeps of the Schur complement (all chunks but the two single right-hand sides of solve_) build
-            # their input panels from the constraints' own entries: panels are written once, not read
-            tot = 0.0
-            for i, r in enumerate(up_chunks):
-                panel = (1 if i < len(up_chunks) - 2 else 2) * Bk[mask].sum()
-                tot += 8.0 * (r * (panel + Upk[mask].sum() + Upch[mask].sum()) + Bk[mask].sum())
-            return tot
-
-        # family kernel: one launch sweeps the family parents AND their childless children for all the right-hand
-        # sides of the Schur complement.  Its algorithmic bytes are those of the per-level formulation (SURVEY 8d:
-        # every update matrix written once and read once) although the children's updates never reach HBM here.
-        fam = symb.family_roles()
-        fam_mask = lds_ok & (fam > 0)
-
-        def fam_bytes():
-            tot = 0.0
-            for r in up_chunks[:-2]:
-                tot += 8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask].sum() + Upch[fam_mask].sum()) + Bk[fam_mask].sum())
-            return tot
-
-        # sparse-input sweep of childless large fronts (front_lfsp.hip; three launches -- Q, update, G_NN -- per chunk):
-        # writes the output panel and the packed update of every (front, constraint), reads the constants of a front
-        # (Li, K, R^T K: 2 panels; R^T: na^2) once per launch
-        nch = np.diff(symb.chptr)
-        sp_mask = (~lds_ok) & (nch == 0) & (nn_ <= 64) & (na_ <= 128) & (na_ > 0)
-
-        def lfsp_bytes():
-            tot = 0.0
-            for r in up_chunks[:-2]:
-                tot += 8.0 * (r * (Bk[sp_mask].sum() + Upk[sp_mask].sum()) + 3 * (2 * Bk[sp_mask].sum() + Uk[sp_mask].sum()))
-            return tot
-
-        alg = {"k_hess_up_fam": fam_bytes(), "k_lfsp_up": lfsp_bytes(), "k_hess_up_level": sweep_bytes, "k_hess_down_level": sweep_bytes,
-               "k_hess_up_pad": up_bytes(lds_ok),
-               "k_hess_up_n16": up_bytes(lds_ok & (nn_ <= 16) & (na_ <= 64)),
-               "k_hess_up_mfma<true>": cls_bytes(lds_ok), "k_hess_down_mfma<true>": cls_bytes(lds_ok),
-               "k_hess_up_mfma<false>": cls_bytes(~lds_ok), "k_hess_down_mfma<false>": cls_bytes(~lds_ok),
-               "k_chol_level": 8.0 * (2 * B + 2 * U), "k_pinv_level": 8.0 * (2 * B + 2 * U)}.get(dom)
-        # large-front phase kernels (configs 2 and 3): MFMA-bound, canonical BLAS-3 flop counts per (front, rhs)
-        # (SURVEY 8d): up1 = E, T (2 na nn^2 + nn^3); up2 = update, G, G_NN (2 na^2 nn + na nn^2 + nn^3 / 3);
-        # up3 = scaling product (na^2 nn, triangular operand)
-        big = ~lds_ok
-        nnf, naf = nn_[big].astype(np.float64), na_[big].astype(np.float64)
-        # fronts of more than six 64-column tiles form G_NN = Li F_NN Li^T as Z = Li Fl (nn^3 / 3, phase 1) and
-        # Z Li^T + Li Z^T (2 nn^3 / 3, phase 2) instead of T = Li F_NN (nn^3) and T Li^T (nn^3 / 3): front_large.hip lf_sym_split
-        split = nnf > 6 * 64
-        lf_flops = {"k_lf_up1": (2 * naf * nnf ** 2 + np.where(split, nnf ** 3 / 3, nnf ** 3)).sum(),
-                    "k_lf_up2": (2 * naf ** 2 * nnf + naf * nnf ** 2 + np.where(split, 2 * nnf ** 3 / 3, nnf ** 3 / 3)).sum(),
-                    "k_lf_up3": (naf ** 2 * nnf).sum()}
-        if dom in lf_flops and alg is None:
-            nr = sum(chunks)
-            tfl = lf_flops[dom] * nr / (1e-3 * dom_ms) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tfl, 2), "peak": FP64_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(tfl / FP64_PEAK_TFLOPS, 4), "traffic": None,
-                        "flops_per_step": lf_flops[dom] * nr, "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2),
-                        "launches_per_step": dom_launches}
-        if alg is not None:
-            per_launch = alg / dom_launches
-            avg_s = 1e-3 * dom_ms / dom_launches
-            achieved = per_launch / avg_s / 1e9
-            # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled
-            # as the gfx950 guide prescribes), recorded in profiles/ for this kernel and workload -- or null
-            traffic = None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-                # the profiler's names carry template arguments; the sparse-input family kernel is timed under the
-                # same id as k_hess_up_fam
-                alias = {"k_hess_up_fam": ("k_fam_sparse", "k_hess_up_fam")}.get(dom, (dom,))
-                hits = [v for kname, v in tj.get("kernels", {}).items() if kname.startswith(alias)]
-                if tj.get("workload") == label and hits and world == 1:
-                    traffic = max(v["hbm_bytes_per_launch"] for v in hits)
-            except Exception:
-                traffic = None
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "bytes_per_launch": per_launch, "avg_launch_us": round(1e6 * avg_s, 2),
-                        "launches_per_step": dom_launches}
-            if dom == "k_lfsp_up":
-                roofline["note"] = ("three launches per chunk of right-hand sides (Q, update, G_NN) are timed under this "
-                                    "name; bytes = output panels + packed updates of every (front, constraint) + the "
-                                    "fronts' constants once per launch, averaged over the launches")
-            if dom == "k_hess_up_fam":
-                # The fused kernel keeps the children's update matrices in LDS, so the bytes it HAS to move are the
-                # output panels + the parents' packed updates + the constants (not SURVEY 8d's per-level figure, which
-                # counts every child update written once and read once).  The roofline is priced against the bytes of
-                # the formulation executed; the per-level figure and the MFMA view are given beside it.
-                moved = sum(8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask & (fam == 2)].sum()) + Bk[fam_mask].sum())
-                            for r in up_chunks[:-2]) / dom_launches
-                ach = moved / avg_s / 1e9
-                nnk, nak = nn_[fam_mask].astype(np.float64), na_[fam_mask].astype(np.float64)
-                flops = float((nnk ** 3 + 3 * nak * nnk ** 2 + 3 * nak ** 2 * nnk).sum()) * sum(up_chunks[:-2]) / dom_launches
-                roofline.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": moved,
-                                 "per_level_bytes_per_launch": per_launch,
-                                 "per_level_achieved": round(achieved, 2),
-                                 "mfma": {"flops_per_launch": flops, "achieved_tflops": round(flops / avg_s / 1e12, 2),
-                                          "frac": round(flops / avg_s / 1e12 / FP64_PEAK_TFLOPS, 4)},
-                                 "note": "bytes = output panels + parents' packed updates + constants (the children's update "
-                                         "matrices stay in LDS); per_level_* = SURVEY 8d's per-level formulation of the same "
-                                         "work (every child update written once and read once), which the per-level kernels "
-                                         "of state r01_f executed"})
+        roofline = kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, j1 - j0, part, rank, world, label)
         if args.verbose and rank == 0:
             for k, (t, c) in sorted(breakdown.items(), key=lambda kv: -kv[1][0]):
                 print("  %-26s %9.3f ms/step  %5d launches" % (k, t, c), file=sys.stderr)
 
+    # ---------------- back-solve sub-rate: solve_ alone on the factored system of the last step ------
+    # two Hessian applications + Amap / Aadj + potrs (solvers.py:506-541); an interior-point iteration issues ~9 of them
+    # per factorisation (solvers.py:907-913, 1035-1044)
+    if world == 1 and part is None and args.kktsolver == "chol":
+        nbs = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(nbs + 2):
+            if it == 2:
+                e0.record()
+            bx.blkval.copy_(bx0)
+            by.copy_(by0)
+            chk(lib.kkt_solve(h, L.blkval.data_ptr(), Y.blkval.data_ptr(), H.data_ptr(), m, 1.0,
+                              bx.blkval.data_ptr(), by.data_ptr(), st()), "solve")
+        e1.record()
+        torch.cuda.synchronize()
+        bs_ms = e0.elapsed_time(e1) / nbs
+        back_solve = {"ms": round(bs_ms, 4), "per_s": round(1e3 / bs_ms, 2), "calls": nbs,
+                      "what": "kkt_solve (solve_, solvers.py:506-541) on the factored system, right-hand sides reset per call"}
+
     # ---------------- CPU baseline: the oracle on a bounded sample (rank 0, N = 1 only) --------
     cpu = None
     # (the oracle leg times the reference's default kkt_chol path and needs the factored H: not run for --kktsolver qr)
-    if rank == 0 and world == 1 and not args.no_cpu and args.kktsolver == "chol":
+    if rank == 0 and world == 1 and want_cpu and args.kktsolver == "chol":
         from oracle import oracle as orc
         So = orc.Sym(symb)
         K = orc.KKT(So, cptr, cidx, cval)
@@ -432,10 +428,16 @@ def main():
         Hfac = np.asfortranarray(np.tril(H.cpu().numpy().T))   # factored H from the GPU (to time solve_ and potrf)
         Hfull = Hfac @ Hfac.T
 
+        scm = workload == "maxcut"      # every constraint column-sparse: the reference's trsm + SCMcolumn2 route
+        if scm:
+            nthr = 1
+            ncols = min(args.cpu_cols, m)
+
         def cpu_unit():
             """One Newton-KKT solve on the host: cholesky + projected_inverse (one thread: sequential over the cliques,
             as CHOMPACK is), the Schur columns (one Hessian application per column as in the reference's loop,
-            solvers.py:479-487; the independent columns spread over OpenMP threads), potrf(H) and one solve_."""
+            solvers.py:479-487, the independent columns spread over OpenMP threads -- or, for column-sparse constraints,
+            two supernodal triangular solves + SCMcolumn2 per column, solvers.py:489-497), potrf(H) and one solve_."""
             t0 = time.perf_counter()
             Lo = Sh.copy()
             orc.cholesky(So, Lo)
@@ -443,7 +445,10 @@ def main():
             orc.projected_inverse(So, Yo)
             t_fact = time.perf_counter() - t0
             t0 = time.perf_counter()
-            if nthr > 1:
+            if scm:
+                K.schur_scm_columns(Lo, np.zeros((m, m), order="F"), range(ncols))
+                t_cols = time.perf_counter() - t0
+            elif nthr > 1:
                 K.schur_columns_threaded(Lo, Yo, 0, ncols, nthr)
                 t_cols = K.last_seconds            # without the one-off allocation of the per-thread workspaces
             else:
@@ -458,29 +463,40 @@ def main():
             t_solve = time.perf_counter() - t0
             return t_fact, t_cols, t_potrf, t_solve, xo, yo
 
-        t_fact, t_cols, t_potrf, t_solve, xo, yo = cpu_unit()          # plain loops: the parity checker
-        t_loops = t_fact + t_cols * (m / ncols) + t_potrf + t_solve
+        def unit_seconds(t):
+            return t[0] + t[1] * (m / ncols) + t[2] + t[3]
+
+        first = cpu_unit()                                             # plain loops: the parity checker
+        xo, yo = first[4], first[5]
+        t_loops = unit_seconds(first)
         # the same run doubles as a full-size check of the GPU search direction
         ex = np.linalg.norm((bx.blkval.cpu().numpy() - xo)[msk]) / max(1e-300, np.linalg.norm(xo[msk]))
         ey = np.linalg.norm(by.cpu().numpy() - yo) / max(1e-300, np.linalg.norm(yo))
         blas_desc = orc.use_blas(True)                                  # per-clique BLAS-3 on the host BLAS from dimension 32 on
+        reps = [first]
         if blas_desc:
-            t_fact, t_cols, t_potrf, t_solve, _, _ = cpu_unit()
+            reps = [cpu_unit() for _ in range(max(1, args.cpu_repeats))]
             orc.use_blas(False)
-        t_unit = t_fact + t_cols * (m / ncols) + t_potrf + t_solve
-        cpu = {"value": round(1.0 / t_unit, 5), "unit": "KKT solves/s", "cores": nthr, "kind": "port",
+        reps.sort(key=unit_seconds)
+        med = reps[len(reps) // 2]                                      # the median repeat
+        t_fact, t_cols, t_potrf, t_solve = med[:4]
+        t_unit = unit_seconds(med)
+        cpu = {"value": round(1.0 / t_unit, 5), "unit": "KKT solves/s", "cores": nthr, "threads": nthr, "host_cores": os.cpu_count(),
+               "kind": "port", "repeats": len(reps), "value_min_max": [round(1.0 / unit_seconds(reps[-1]), 5), round(1.0 / unit_seconds(reps[0]), 5)],
                "blas": blas_desc or "none (plain loops)", "value_plain_loops": round(1.0 / t_loops, 5),
-               "sample": "cholesky+projected_inverse (%.3fs, 1 thread: sequential over the cliques as CHOMPACK is) + "
-                         "%d of %d Schur columns on %d threads (%.3fs%s) + potrf(H) (%.4fs) + 1 solve_ (%.3fs, 1 thread); "
-                         "oracle/chordal_oracle.c with per-clique dense operations of dimension >= 32 on %s, host has %d cores"
-                         % (t_fact, ncols, m, nthr, t_cols, "" if ncols == m else ", scaled x%.2f" % (m / ncols), t_potrf,
-                            t_solve, blas_desc or "plain loops", os.cpu_count())}
+               "sample": "median of %d repeats of: cholesky+projected_inverse (%.3fs, 1 thread: sequential over the cliques as CHOMPACK is) + "
+                         "%d of %d Schur columns on %d thread(s) of the host's %d cores (%.3fs%s%s) + potrf(H) (%.4fs) + 1 solve_ (%.3fs, 1 thread); "
+                         "oracle/chordal_oracle.c with per-clique dense operations of dimension >= 32 on %s"
+                         % (len(reps), t_fact, ncols, m, nthr, os.cpu_count(), t_cols, "" if ncols == m else ", scaled x%.2f" % (m / ncols),
+                            "; trsm x 2 + SCMcolumn2 per column, solvers.py:489-497" if scm else "", t_potrf,
+                            t_solve, blas_desc or "plain loops")}
         cpu["gpu_vs_oracle_relerr"] = [float("%.2e" % ex), float("%.2e" % ey)]
 
+    result = None
     if rank == 0:
         out = {
-            "metric": "Newton KKT solves/sec", "value": round(args.steps / elapsed, 4), "unit": "KKT solves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "metric": "Newton KKT solves/sec", "value": round(steps / elapsed, 4), "unit": "KKT solves/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": label, "kktsolver": args.kktsolver, "n": symb.n, "cliques": symb.Nsn, "m": m, "blkval_doubles": int(B),
@@ -488,12 +504,110 @@ def main():
                        "parallelism": ("single" if world == 1 else
                                        ("subtree-sharded Gram + boundary exchange/%d" % world if part is not None
                                         else "schur-columns/%d" % world))},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "back_solve": back_solve,
             "symbolic_s": round(t_sym, 3),
             # per-kernel HIP-event times: the dominant kernel from the timed steps, the others from the untimed
             # calibration pass that precedes them (events around every launch)
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
         }
+        result = out
+    # release the device context of this workload before the next one is built
+    if lazy:
+        pass
+    del kkt, L, Y, S, bx, by, H
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="synth50k")
+    ap.add_argument("--kktsolver", default="chol", choices=("chol", "qr"),
+                    help="'qr': the step factors with kkt_qr (Cholesky-QR of the swept stack) instead of kkt_chol; one GPU")
+    ap.add_argument("--m", type=int, default=None)
+    ap.add_argument("--max-rhs", type=int, default=None)
+    ap.add_argument("--cpu-cols", type=int, default=10 ** 9, help="Schur columns timed on the CPU oracle (default: all; at least one per thread)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (a 1-GPU box has a 16-core share)")
+    ap.add_argument("--shard", default="subtree", choices=["subtree", "columns"],
+                    help="N > 1: subtree sharding + boundary exchange (default) or column sharding of H")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the GPU-only figures of configs 2, 3 and 4 after the headline run")
+    ap.add_argument("--cpu-repeats", type=int, default=3, help="repeats of the CPU baseline (the median is reported)")
+    ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # Not under a launcher: start the N ranks as fresh child processes (one per GPU, RCCL) BEFORE this process
+        # touches the GPU, relay rank 0's JSON line and exit with the launcher's code.  Nothing is exec'd.
+        raise SystemExit(self_launch(args.gpus))
+    if int(world_env or "1") != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s; launch with `python bench.py --gpus N` or "
+              "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world_env),
+              file=sys.stderr)
+        raise SystemExit(2)
+
+    # RCCL prints a version banner on stdout when its first communicator comes up: everything but the result line goes
+    # to stderr (file descriptor 1 points at stderr from here on; rank 0 writes the JSON line to the saved stdout)
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    import torch
+    import torch.distributed as dist
+    from smcp_amd import _lib, chordal, problems
+    from smcp_amd.cspmatrix import cspmatrix
+    from smcp_amd.kkt import KKTSystem
+    from smcp_amd.symbolic import Symbolic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("SMCP_BENCH_BACKEND", "nccl")   # "gloo": functional check with ranks sharing a GPU
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local % ndev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
+        else:
+            dist.init_process_group(backend)
+    else:
+        torch.cuda.set_device(0)
+    # SMCP_BENCH_FORCE_SHARDED=1 (N = 1 only): the subtree-sharded route and its collectives over RCCL with a group of ONE
+    # rank -- what the host logic and the collective launches of the N-GPU step cost beside the plain single-GPU step
+    force_sharded = world == 1 and os.environ.get("SMCP_BENCH_FORCE_SHARDED") == "1"
+    if force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lib = _lib.lib()
+
+    env = {"world": world, "rank": rank, "dev": dev, "lib": lib, "force_sharded": force_sharded}
+    out = run_workload(args, args.workload, args.steps, args.warmup, not args.no_cpu, True, env)
+    # BASELINE.json's other single-GPU configurations, GPU only: config 2 (one dense 4096 front), config 3 (block-arrow),
+    # config 4 (max-cut, column-sparse constraints) -- a few steps each after the headline measurement
+    if world == 1 and not force_sharded and args.workload == "synth50k" and not args.no_secondary and args.kktsolver == "chol":
+        sec = {}
+        for name in ("dense4096", "arrow", "maxcut"):
+            try:
+                r = run_workload(args, name, 3, 1, name == "maxcut" and not args.no_cpu, False, env)
+                sec[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "back_solve", "cpu_baseline")}
+                sec[name]["top_kernels_ms_per_step"] = dict(list(r["kernel_ms_per_step"].items())[:6])
+            except Exception as e:      # a secondary workload must not take the headline line down
+                sec[name] = {"error": repr(e)}
+        if out is not None:
+            out["secondary"] = sec
+    if rank == 0 and out is not None:
         print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1 or force_sharded:
         dist.destroy_process_group()

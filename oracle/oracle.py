@@ -346,6 +346,37 @@ class KKT:
         self.last_seconds = sec.value          # compute time without the per-thread workspace allocation
         return H
 
+    def entry_coords(self):
+        """(row, col) of every constraint entry in permuted matrix coordinates (row >= col)."""
+        S = self.S
+        k = np.searchsorted(S.blkptr, self.cidx, side="right") - 1
+        nf = S.rowptr[k + 1] - S.rowptr[k]
+        off = self.cidx - S.blkptr[k]
+        row = S.rowidx[S.rowptr[k] + off % nf]
+        col = S.snptr[k] + off // nf
+        return np.ascontiguousarray(row, dtype=np.int64), np.ascontiguousarray(col, dtype=np.int64)
+
+    def schur_scm_columns(self, L, H, cols):
+        """Columns `cols` of lower(H) by the reference's route for column-sparse constraints (solvers.py:489-497):
+        V = unit columns of K_j, trsm(L, V), trsm(L, V, trans='T') -> S^-1[:, K_j], then misc.SCMcolumn2
+        (misc.c:620-663, restated as orc_scmcolumn2).  H: (m, m) Fortran-ordered, written in place (rows i >= j)."""
+        S, m, n = self.S, self.m, self.S.n
+        row, col = self.entry_coords()
+        ptr = np.ascontiguousarray(self.cptr, dtype=np.int64)
+        val = np.ascontiguousarray(self.cval, dtype=np.float64)
+        assert H.flags.f_contiguous and H.shape == (m, m)
+        for j in cols:
+            sl = slice(ptr[j], ptr[j + 1])
+            Kj = np.unique(np.concatenate([row[sl], col[sl]]))
+            V = np.zeros((len(Kj), n))
+            V[np.arange(len(Kj)), Kj] = 1.0
+            trsm(S, L, V, "N")
+            trsm(S, L, V, "T")
+            kl = np.zeros(n, dtype=np.int64)
+            kl[Kj] = np.arange(len(Kj))
+            lib().orc_scmcolumn2(m, n, _p(H), _p(ptr), _p(row), _p(col), _p(val), _p(V), _p(kl), int(j))
+        return H
+
     def solve(self, L, Y, H, bx, by, kk):
         r1 = bx.copy()
         hessian(self.S, L, Y, r1, adj=None, inv=False)

@@ -51,7 +51,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -69,7 +69,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -157,6 +157,21 @@ inline void launch(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, hipStream
     (void)hipEventRecord(P.next(), st);
     P.kids.push_back(kid);
   }
+}
+
+// host worker threads for the set-up phases: work(tix) for tix = 0 .. nth - 1.  Thread creation can fail
+// (std::system_error); nothing may propagate across the extern "C" boundary, so whatever did not start runs inline.
+template <class F>
+void run_threads(int nth, F work) {
+  if (nth <= 1) { work(0); return; }
+  std::vector<std::thread> pool;
+  int started = 0;
+  try {
+    for (; started < nth; ++started) pool.emplace_back(work, started);
+  } catch (...) {
+  }
+  for (int tix = started; tix < nth; ++tix) work(tix);
+  for (auto& th : pool) th.join();
 }
 
 template <class T>
@@ -403,7 +418,7 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
       static bool attr = false;
       if (!attr) { attr = hipFuncSetAttribute((const void*)k_lf_assemble_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess; }
       if (attr) {
-        launch_lds(c, KID_lf_assemble, k_lf_assemble_lds, dim3(cnt, nrhs), dim3(1024), bytes, st, a, U, ldu, sgn);
+        launch_lds(c, KID_lf_assemble_lds, k_lf_assemble_lds, dim3(cnt, nrhs), dim3(1024), bytes, st, a, U, ldu, sgn);
         return;
       }
     }
@@ -609,8 +624,7 @@ bool launch_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_hess_up_n16<NAT, CH>, thr, bytes) != hipSuccess || nb < 1) nb = 1;
     nb_bytes = bytes;
   }
-  static int ncu = 0;
-  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, c->D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  const int ncu = c->D.ncu;
   const int64_t slots = (int64_t)ncu * nb;
   const int rb = CH ? 1 : std::max(1, std::min(4, 16 / std::max(a.nnmax, 1)));
   int g = 1;
@@ -658,8 +672,7 @@ bool launch_fam(csp_ctx* c, MfmaArgs a, int cnt, int nrhs, double* U, int64_t ld
     if (hipFuncSetAttribute((const void*)k_hess_up_fam<NAT, NATC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
     attr = true;
   }
-  static int ncu = 0;
-  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, c->D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  const int ncu = c->D.ncu;
   // one workgroup per CU (LDS): split the right-hand sides so that the grid fills whole rounds; set-up ~ 3 passes
   int g = 1;
   int64_t best = -1;
@@ -710,8 +723,7 @@ bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
     if (dev_alloc(&D.famc, need, D.bytes)) return false;
     D.famc_len = need;
   }
-  static int ncu = 0;
-  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  const int ncu = D.ncu;
   // one workgroup per CU (LDS), two right-hand sides in flight per workgroup: split the right-hand sides so that the
   // grid fills whole rounds; set-up ~ 4 passes
   int g = 1;
@@ -739,57 +751,13 @@ bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   { static int stag = -1; if (stag < 0) { const char* e = getenv("SMCP_FAM2_STAG"); stag = e ? atoi(e) : 0; } a2.dn = stag; }
   // the children's panels are left out when the caller takes their Gram block from k_leaf_gram (D.lg_request)
   if (D.lg_request) {
-    launch_lds(c, KID_hess_up_fam, k_fam_sparse<NAT, KSN, false>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a2, U, ldu,
+    launch_lds(c, KID_fam_sparse, k_fam_sparse<NAT, KSN, false>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a2, U, ldu,
                (const double*)D.famc, cnn, csa, (const int32_t*)D.kc_ij, tabpasses, ecap);
     D.lg_nochild = true;
   } else {
-    launch_lds(c, KID_hess_up_fam, k_fam_sparse<NAT, KSN, true>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a2, U, ldu,
+    launch_lds(c, KID_fam_sparse, k_fam_sparse<NAT, KSN, true>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a2, U, ldu,
                (const double*)D.famc, cnn, csa, (const int32_t*)D.kc_ij, tabpasses, ecap);
   }
-  return true;
-}
-// pipelined twelve-wave variant for parents with four row tiles (49..64 separator rows)
-template <int KSN>
-bool launch_fam12(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
-  DeviceCtx& D = c->D;
-  const int cnn = std::max(1, a.famcnn), csa = 16 * std::max(1, (a.famcna + 15) / 16);
-  const int64_t lim = (160 * 1024 - 1024) / 8;
-  const int64_t fixed = fam12_layout(cnn, csa).oTab;
-  if (fixed + fam2_tail_doubles(4, 9) + 64 > lim) return false;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)k_fam_sparse12<KSN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
-    if (hipFuncSetAttribute((const void*)k_fam2_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
-    attr = true;
-  }
-  const int64_t need = (int64_t)cnt * fam2_const_doubles(cnn, csa);
-  if (D.famc_len < need) {
-    if (D.famc) { if (hipFree(D.famc) != hipSuccess) return false; D.bytes -= D.famc_len * 8; }
-    D.famc = nullptr; D.famc_len = 0;
-    if (dev_alloc(&D.famc, need, D.bytes)) return false;
-    D.famc_len = need;
-  }
-  static int ncu = 0;
-  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
-  int g = 1;
-  int64_t best = -1;
-  for (int gc = 1; gc <= std::min(nrhs, 32); ++gc) {
-    const int64_t rounds = ((int64_t)cnt * gc + ncu - 1) / ncu;
-    const int64_t passes = (nrhs + gc - 1) / gc;
-    const int64_t cost = rounds * (passes + 12);                        // set-up ~ 12 passes
-    if (best < 0 || cost < best) { best = cost; g = gc; }
-  }
-  const int passes = (nrhs + g - 1) / g;
-  const double avg = 9.0 * (double)D.cnnz / ((double)c->S.nsn * (double)std::max<int64_t>(1, D.m));
-  int tabpasses = std::min(passes, 113);
-  while (tabpasses > 4 && fixed + fam2_tail_doubles(tabpasses, 9) + (int64_t)(1.5 * avg * tabpasses) + 8 > lim) tabpasses = (tabpasses + 1) / 2;
-  const int64_t left = lim - fixed - fam2_tail_doubles(tabpasses, 9) - 4;
-  const int ecap = (int)std::max<int64_t>(0, (left * 2) / 3 - 2);
-  if (9 * D.kc_maxlist > ecap) return false;
-  launch_lds(c, KID_fam2_prep, k_fam2_prep, dim3(cnt), dim3(512), (size_t)8 * fam2_child_layout(cnn, csa).cstride * sizeof(double), st,
-             a, D.famc, cnn, csa);
-  launch_lds(c, KID_hess_up_fam, k_fam_sparse12<KSN>, dim3(cnt, g), dim3(768), (size_t)lim * 8, st, a, U, ldu,
-             (const double*)D.famc, cnn, csa, (const int32_t*)D.kc_ij, tabpasses, ecap);
   return true;
 }
 bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
@@ -800,9 +768,6 @@ bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64
   if (c->D.cnnz > (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m)) return false;
   const int nat = std::max(1, (a.famna + 15) / 16);
   const bool k2 = a.famnn <= 8;
-  static int f12 = -1;
-  if (f12 < 0) { const char* e = getenv("SMCP_FAM12"); f12 = (e && e[0] == '1') ? 1 : 0; }   // pipelined variant: measured slower
-  if (nat == 4 && f12 && (k2 ? launch_fam12<2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam12<4>(c, a, cnt, nrhs, U, ldu, st))) return true;
   switch (nat) {
     case 1: return k2 ? launch_fam2<1, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<1, 4>(c, a, cnt, nrhs, U, ldu, st);
     case 2: return k2 ? launch_fam2<2, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<2, 4>(c, a, cnt, nrhs, U, ldu, st);
@@ -922,8 +887,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         if (split_min < 0) { const char* e = getenv("SMCP_RHS_SPLIT"); split_min = e ? atoi(e) : 16; }
         static int parts = -1;
         if (parts < 0) { const char* e = getenv("SMCP_RHS_PARTS"); parts = (e && e[0] == '3') ? 3 : 2; }
-        static int ncu_split = 0;
-        if (!ncu_split) { hipDeviceProp_t p; ncu_split = (hipGetDeviceProperties(&p, c->D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+        const int ncu_split = c->D.ncu;
         // only when the extend-add needs more than one round of the chip: with fewer (front, right-hand side) pairs than
         // CUs (one rank's share of an 8-rank job: 100 pairs) there is no tail to fill and the halves only add launches
         // (measured on the partition of rank 0 of 8: 2.83 ms per step with the split, 2.67 without)
@@ -1383,9 +1347,9 @@ int csp_status(csp_ctx* c, void* stream) {
   if (int rc = ready(c)) return rc;
   hipStream_t st = (hipStream_t)stream;
   int v = 0;
-  HIPCHK(hipMemcpyAsync(c->D.info_host + 15, c->D.info + 16, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->D.info_host + 16, c->D.info + 16, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  v = c->D.info_host[15];
+  v = c->D.info_host[16];
   if (v) HIPCHK(hipMemsetAsync(c->D.info + 16, 0, sizeof(int), st));
   if (c->launch_err) { c->launch_err = 0; return SMCP_EHIP; }
   return v;
@@ -1598,12 +1562,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
             ntg[x] = nd;
           }
         };
-        if (nth == 1) work(0);
-        else {
-          std::vector<std::thread> pool;
-          for (int tix = 0; tix < nth; ++tix) pool.emplace_back(work, tix);
-          for (auto& th : pool) th.join();
-        }
+        run_threads(nth, work);
       }
       clk.mark("plan: sorted pairs");
       // targets (distinct codes) per clique were counted by the workers: the serial part only lays the pieces out
@@ -1626,12 +1585,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
             }
           }
         };
-        if (nth2 == 1) fill(0);
-        else {
-          std::vector<std::thread> pool;
-          for (int tix = 0; tix < nth2; ++tix) pool.emplace_back(fill, tix);
-          for (auto& th : pool) th.join();
-        }
+        run_threads(nth2, fill);
       }
       cptr[(size_t)nt1] = ns1;
       {
@@ -1726,8 +1680,11 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     if ((rc = dev_alloc(&D.red, 1024, D.bytes))) return rc;
     if ((rc = dev_alloc(&D.info, 32, D.bytes))) return rc;      // [0, 16): failure flags of the copies; [16]: status latch
     HIPCHK(hipMemset(D.info, 0, sizeof(int) * 32));
-    HIPCHK(hipHostMalloc((void**)&D.info_host, 64));
+    // pinned mirror: ints [0, 16) the trial flags (csp_trial_flags), [16] the status latch (csp_status), bytes [96, 104) the
+    // scalar of the reductions (csp_dot / csp_logdiagsum): separate slots, so that no call overwrites another's result
+    HIPCHK(hipHostMalloc((void**)&D.info_host, 128));
     clk.mark("attributes + buffers");
+    { hipDeviceProp_t p; D.ncu = (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     D.device = device;
   } else {
     if (D.upd) { hipFree(D.upd); D.bytes -= D.max_rhs * S.updlen() * 8; D.upd = nullptr; }
@@ -1961,7 +1918,7 @@ static int reduce_impl(csp_ctx* c, const double* X, const double* Y, int mode, d
   }
   launch(c, KID_reduce_final, k_reduce_final, dim3(1), dim3(NT), st, c->D.red, nb, c->D.red + 512);
   HIPCHK(end_call(c));
-  double* h = (double*)(c->D.info_host + 2);
+  double* h = (double*)(c->D.info_host + 24);
   HIPCHK(hipMemcpyAsync(h, c->D.red + 512, sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   *out = *h;

@@ -25,6 +25,7 @@ struct CliqueDesc {
 
 struct DeviceCtx {
   int device = -1;
+  int ncu = 256;           // compute units of the device (csp_device_init): launch heuristics
   int64_t max_rhs = 0;
   // index arrays
   CliqueDesc* cl = nullptr;

@@ -108,19 +108,6 @@ __device__ inline void fam2_barrier(int* cnt, int& target, int lane, int* info) 
   asm volatile("" ::: "memory");
 }
 
-// the same among eight waves
-__device__ inline void fam2_barrier8(int* cnt, int& target, int lane, int* info) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  target += 8;
-  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  int guard = 0;
-  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++guard > (1 << 22)) { if (lane == 0) atomicCAS(info, 0, -7); break; }
-  }
-  asm volatile("" ::: "memory");
-}
-
 // One workgroup per family parent, wave w = child w: the constants of the children in the layout k_fam_sparse
 // copies into LDS.  Runs once per sweep call (the factor may have changed since the last one).
 __global__ void __launch_bounds__(512) k_fam2_prep(MfmaArgs a, double* famc, int cnn, int csa) {
@@ -655,470 +642,5 @@ __global__ void __launch_bounds__(512) k_fam_sparse(MfmaArgs a, double* u, int64
 #undef SETUP
 }
 
-
-// =====================================================================================================================
-// k_fam_sparse12: the same sweep for parents with 49..64 separator rows (four row tiles), PIPELINED: twelve waves, of
-// which waves 8..11 assemble the front of right-hand side q (children by half-waves, shared supernode-block updates,
-// the parent's own entries) while waves 0..7 sweep the front of right-hand side q - 1 -- all eight on ONE right-hand
-// side, so that its dependent chain is as short as the tile structure allows:
-//   A: E_t, G_t by waves 0..3 (tile t), T and G_NN by wave 4            |  barrier among the eight (LDS counter)
-//   B: ten update tiles and four Q row tiles, sixteen products per wave (wave 7: eight), two tiles interleaved
-//   one workgroup barrier per right-hand side (s_barrier; the fronts are double buffered).
-// Measured against k_fam_sparse (two independent four-wave groups): the chain per right-hand side was 18 k cycles
-// there (children 5 k, products 8 k under contention, three group barriers) for two right-hand sides in flight.
-// =====================================================================================================================
-struct Fam12L { int oF0, fstride, gFnn, gFan, gU, oE, oG, oCh, oCnt, oTab; };
-__host__ __device__ inline Fam12L fam12_layout(int cnn, int csa) {
-  constexpr int NA = 64, LDA = NA + 1, LDN = 17;
-  Fam12L L{};
-  int g = 0;
-  L.gFnn = g; g += LDN * 16;
-  L.gFan = g; g += LDA * 16;
-  L.gU = g; g += NA * (NA + 1) / 2;
-  L.fstride = g;
-  int o = 0;
-  L.oF0 = o; o += 2 * g;
-  L.oE = o; o += LDA * 16;
-  L.oG = o; o += LDA * 16;
-  L.oCh = o; o += 8 * fam2_child_layout(cnn, csa).cstride;
-  L.oCnt = o; o += 6;
-  L.oTab = o;
-  return L;
-}
-
-template <int KSN>
-__global__ void __launch_bounds__(768) k_fam_sparse12(MfmaArgs a, double* u, int64_t ldu, const double* famc, int cnn, int csa,
-                                                      const int32_t* kc_ij, int tabpasses, int ecap) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int NA = 64, LDA = NA + 1, LDN = 17, NT = 768;
-  const Fam12L L = fam12_layout(cnn, csa);
-  const Fam2C C = fam2_child_layout(cnn, csa);
-  const double* const fc = famc + (int64_t)blockIdx.x * fam2_const_doubles(cnn, csa);
-  const int32_t* const hdr = reinterpret_cast<const int32_t*>(fc);
-  const int k = hdr[0], nn = hdr[1], na = hdr[2], nch = hdr[3], nf = nn + na;
-  const int64_t pblk = (int64_t)(uint32_t)hdr[4] | ((int64_t)hdr[5] << 32);
-  const int64_t pupd = (int64_t)(uint32_t)hdr[6] | ((int64_t)hdr[7] << 32);
-  const int64_t pupdp = (int64_t)(uint32_t)hdr[8] | ((int64_t)hdr[9] << 32);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool isP = wave < 8;
-  const int cw = wave - 8;                      // child wave 0..3: children cw (lanes 0..31) and cw + 4 (lanes 32..63)
-  const int nmem = nch + 1;
-  const int gy = (int)gridDim.y;
-  const int npass = ((int)a.nrhs - (int)blockIdx.y + gy - 1) / gy;
-  int* const cnt = reinterpret_cast<int*>(smem + L.oCnt);                    // barrier counter of the eight parent waves
-  int* const epfit = cnt + 2;
-  int* const cnac = cnt + 4;                                                 // separator sizes of the eight children
-  int* const tab = reinterpret_cast<int*>(smem + L.oTab);
-  int* const nncnt = reinterpret_cast<int*>(smem + L.oTab + ((tabpasses * nmem + 1) & ~1));
-  int* const nnpk = nncnt + 2 * (((tabpasses + 1) / 2 + 1) & ~1);
-  double* const nnv = reinterpret_cast<double*>(nnpk + 2 * (((FAM2_NNCAP * tabpasses + 1) / 2 + 1) & ~1));
-  double* const lval = nnv + FAM2_NNCAP * tabpasses;
-  int* const lpk = reinterpret_cast<int*>(lval + ecap);
-
-#ifdef SMCP_STAMPS   // diagnostic build only: waves 0 (update tiles), 3, 5 (Q), 8 (children) -> slots 8 * {0, 1, 2, 3}
-  const int sslot = wave == 0 ? 0 : (wave == 3 ? 1 : (wave == 5 ? 2 : (wave == 8 ? 3 : -1)));
-  const bool stamp = a.dbg && lane == 0 && sslot >= 0;
-  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamp ? clock64() : 0;
-#define STAMP(i) do { if (stamp) { unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; } } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-  // ---- set-up: fronts cleared, children's constants copied
-  for (int e = tid; e < L.oCh; e += NT) smem[e] = 0.0;
-  for (int e = tid; e < 8 * C.cstride; e += NT) smem[L.oCh + e] = fc[FAM2_HDR + e];
-  if (tid < 12) cnt[tid] = (tid >= 4 && tid - 4 < nch) ? hdr[16 + 6 * (tid - 4) + 2] : 0;
-  // Parent waves: operands of their tasks in registers.  Update tile (r, c) needs K_r (left operand) and K_c (right);
-  // Q row tile t needs the rows of M = R^T of that tile from its diagonal block on.
-  //   wave: 0 (3,0)(0,0) | 1 (3,1)(1,1) | 2 (3,2)(2,2) | 3 (3,3)(1,0) | 4 (2,0)(2,1) | 5 Q0 | 6 Q1, Q3 | 7 Q2
-  // and in phase A waves 0..3 form E_t, G_t of tile t = wave, wave 4 forms T and G_NN.
-  const int tr0 = wave < 4 ? 3 : 2, tc0 = wave < 4 ? wave : 0;              // first update tile of waves 0..4
-  const int tr1 = wave < 3 ? wave : (wave == 3 ? 1 : 2), tc1 = wave < 3 ? wave : (wave == 3 ? 0 : 1);   // second
-  // creg: waves 0..4: K_r0 | K_c0 | K_r1 | K_c1 (four values each); waves 5..7: sixteen values of M rows (see B)
-  double bdP[4], creg[16];
-  {
-    const double* lk = a.LK + pblk;
-    const double* ys = a.ysc + pupd;
-    auto ktile = [&](int t, int s) -> double {
-      const int kk = kq + 4 * s, mt = 16 * t + l15;
-      return (mt < na && kk < nn) ? lk[(nn + mt) + (int64_t)kk * nf] : 0.0;
-    };
-    auto mrow = [&](int t, int x) -> double {                // M[16 t + l15][kq + 4 x], M = R^T (upper triangular)
-      const int m = 16 * t + l15, kc = kq + 4 * x;
-      return (m < na && kc < na && kc >= m) ? ys[kc + (int64_t)m * na] : 0.0;
-    };
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int kk = kq + 4 * s;
-      bdP[s] = (l15 < nn && kk <= l15) ? lk[l15 + (int64_t)kk * nf] : 0.0;
-    }
-#pragma unroll
-    for (int x = 0; x < 16; ++x) {
-      // wave 5: row tile 0, blocks 0..3; wave 6: row tile 1, blocks 1..3 in [4..15] and row tile 3, block 3 in [0..3];
-      // wave 7: row tile 2, blocks 2..3 in [8..15]
-      double v = 0.0;
-      if (wave < 5) v = ktile(x < 4 ? tr0 : (x < 8 ? tc0 : (x < 12 ? tr1 : tc1)), x & 3);
-      else if (wave == 5) v = mrow(0, x);
-      else if (wave == 6) v = x < 4 ? mrow(3, 12 + x) : mrow(1, x);
-      else if (wave == 7) v = x >= 8 ? mrow(2, x) : 0.0;
-      creg[x] = v;
-    }
-  }
-  // Child waves: each HALF of a wave owns one child
-  const int hl = lane & 31, half = lane >> 5;
-  const int cs = (isP ? 0 : cw) + 4 * half;
-  const bool haschild = !isP && cs < nch;
-  const int nnc = haschild ? hdr[16 + 6 * cs + 1] : 1, nac = haschild ? hdr[16 + 6 * cs + 2] : 0;
-  const int nfc = nnc + nac, npan = haschild ? nfc * nnc : 0;
-  const int64_t cblk = haschild ? ((int64_t)(uint32_t)hdr[16 + 6 * cs + 4] | ((int64_t)hdr[16 + 6 * cs + 5] << 32)) : 0;
-  const int cbo = L.oCh + cs * C.cstride;
-  int pdec[6];
-#pragma unroll
-  for (int x = 0; x < 6; ++x) { const int e = hl + 32 * x; pdec[x] = (e % nfc) | ((e / nfc) << 16); }
-  const int npanmax = max(__builtin_amdgcn_readlane(npan, 0), __builtin_amdgcn_readlane(npan, 32));
-  const int nacmax = max(__builtin_amdgcn_readlane(nac, 0), __builtin_amdgcn_readlane(nac, 32));
-  double* const sE = smem + L.oE;
-  double* const sG = smem + L.oG;
-  int target = 0, relr = 0;
-
-  for (int q0 = 0; q0 < npass;) {
-    // ===================================================================================================
-    // epoch set-up (whole workgroup): entry lists of as many of the next tabpasses passes as fit -> LDS
-    // ===================================================================================================
-    const int epmax = min(tabpasses, npass - q0), npairs = epmax * nmem;
-    __syncthreads();
-    if (q0 == 0) relr = (haschild && hl < nac) ? reinterpret_cast<const int*>(smem + cbo + C.cRel)[hl] : 0;
-    if (tid == 0) *epfit = epmax;
-    for (int e = tid; e < epmax; e += NT) nncnt[e] = 0;
-    int myp0[2] = {0, 0};                                      // npairs <= 1024 (host): at most two pairs per thread
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int idx = tid + NT * h;
-      if (idx < npairs) {
-        const int qq = idx / nmem, mem = idx - qq * nmem;
-        const int r = (int)blockIdx.y + (q0 + qq) * gy;
-        const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
-        const int ck = mem ? hdr[16 + 6 * (mem - 1)] : k;
-        const int32_t* kp = a.kc_ptr + (int64_t)ck * a.kc_stride;
-        myp0[h] = kp[j];
-        tab[2 * idx] = kp[j + 1] - myp0[h];
-      }
-    }
-    __syncthreads();
-    if (wave == 0) {                                           // exclusive scan of the counts (one wave)
-      const int per = (npairs + 63) / 64, b = lane * per;
-      int sum = 0;
-      for (int x = 0; x < per; ++x) sum += (b + x < npairs) ? tab[2 * (b + x)] : 0;
-      int incl = sum;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-      int run = incl - sum;
-      for (int x = 0; x < per; ++x)
-        if (b + x < npairs) {
-          const int c = tab[2 * (b + x)];
-          tab[2 * (b + x) + 1] = run;
-          run += c;
-          if (run > ecap) atomicMin(epfit, (b + x) / nmem);
-        }
-    }
-    __syncthreads();
-    const int ep = max(1, *epfit);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int idx = tid + NT * h;
-      if (idx < ep * nmem) {
-        const int c = tab[2 * idx], p0 = myp0[h], off = tab[2 * idx + 1];
-        const int qq = idx / nmem, mem = idx - qq * nmem;
-        const int mnn = mem ? hdr[16 + 6 * (mem - 1) + 1] : 0;
-        const int* const mrel = reinterpret_cast<const int*>(smem + L.oCh + (mem - 1) * C.cstride + C.cRel);
-        for (int t = 0; t < c && off + t < ecap; ++t) {
-          const int ij = kc_ij[p0 + t];
-          const int i = ij & 0xffff, jc = ij >> 16;
-          const double v = a.kc_val[p0 + t];
-          int pk = i | (jc << 8);
-          if (mem && i >= mnn) pk |= mrel[i - mnn] << 16;
-          else if (mem) {
-            const int slot = atomicAdd(&nncnt[qq], 1);
-            if (slot < FAM2_NNCAP) {
-              nnpk[qq * FAM2_NNCAP + slot] = (mem - 1) | (i << 8) | (jc << 16);
-              nnv[qq * FAM2_NNCAP + slot] = v;
-              pk |= FAM2_COOP;
-            }
-          }
-          lpk[off + t] = pk;
-          lval[off + t] = v;
-        }
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) the compiler knows about (see k_fam_sparse)
-    __syncthreads();
-    STAMP(0);
-
-    if (!isP) {
-    for (int q = 0; q <= ep; ++q) {
-      {
-        // ===============================================================================================
-        // child waves: front of right-hand side q0 + q
-        // ===============================================================================================
-        if (q < ep && !(a.skip & 4)) {
-          const int r = (int)blockIdx.y + (q0 + q) * gy;
-          const int* const trow = tab + 2 * q * nmem;
-          double* const gb = smem + L.oF0 + (q & 1) * L.fstride;
-          auto fpos = [&](int hi, int lo) -> int {
-            if (lo >= nn) { const int m = hi - nn, n = lo - nn; return L.gU + n * na - ((n * (n - 1)) >> 1) + (m - n); }
-            return hi >= nn ? L.gFan + (hi - nn) + lo * LDA : L.gFnn + hi + lo * LDN;
-          };
-          const int ne = haschild ? trow[2 * (1 + cs)] : 0;
-          const int where = haschild ? trow[2 * (1 + cs) + 1] : 0;
-          const int nemax = max(__builtin_amdgcn_readlane(ne, 0), __builtin_amdgcn_readlane(ne, 32));
-          double* const Pc = u + (int64_t)r * ldu + cblk;
-          for (int e0 = 0; e0 < npanmax; e0 += 192) {
-            double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            int dec[6];
-#pragma unroll
-            for (int x = 0; x < 6; ++x) dec[x] = pdec[x];
-            if (e0)
-#pragma unroll
-              for (int x = 0; x < 6; ++x) { const int e = e0 + hl + 32 * x; dec[x] = (e % nfc) | ((e / nfc) << 16); }
-            for (int t = 0; t < nemax; ++t) {
-              const bool valid = t < ne;
-              const int pk = lpk[valid ? where + t : 0];
-              const double v = lval[valid ? where + t : 0];
-              const int i = pk & 0xff, jc = valid ? ((pk >> 8) & 0xff) : 0, relA = (pk >> 16) & 0xff;
-              const bool isAN = valid && i >= nnc;
-              const int iA = isAN ? i - nnc : 0;
-              const double kv = smem[cbo + C.cK + jc * csa + hl];
-              double rr[6], bb[6];
-              const double* rrow = smem + cbo + C.cR + iA * (iA + 1) / 2;
-              const double* bcol = smem + cbo + C.cLi + jc * 16;
-#pragma unroll
-              for (int x = 0; x < 6; ++x) {
-                const int m = (dec[x] & 0xffff) - nnc, n = dec[x] >> 16;
-                rr[x] = rrow[min(max(m, 0), iA)];
-                bb[x] = bcol[min(n, 15)];
-              }
-              if (isAN && e0 == 0 && hl < nac) {
-                const int hi = max(relr, relA), lo = min(relr, relA);
-                const int m2 = hi - nn, n2 = lo - nn;
-                const int pU = L.gU + n2 * na - ((n2 * (n2 - 1)) >> 1) + (m2 - n2);
-                const int pL = hi >= nn ? L.gFan + m2 + lo * LDA : L.gFnn + hi + lo * LDN;
-                unsafeAtomicAdd(&gb[lo >= nn ? pU : pL], -(hl == iA ? 2.0 : 1.0) * v * kv);
-              }
-#pragma unroll
-              for (int x = 0; x < 6; ++x) {
-                const int m = (dec[x] & 0xffff) - nnc, n = dec[x] >> 16;
-                acc[x] += (isAN && m >= 0 && m <= iA && n < nnc) ? v * rr[x] * bb[x] : 0.0;
-              }
-              const bool isNN = valid && i < nnc;
-              if (__builtin_amdgcn_ballot_w64(isNN)) {           // entries in the supernode block: rare
-                const double w = i == jc ? 0.5 * v : v;
-                const int ic = isNN ? i : 0;
-                const double* pK = smem + cbo + C.cK + ic * csa;
-                const double* qK = smem + cbo + C.cK + jc * csa;
-                if (e0 == 0 && __builtin_amdgcn_ballot_w64(isNN && !(pk & FAM2_COOP))) {   // beyond the shared list
-                  const int* const crel = reinterpret_cast<const int*>(smem + cbo + C.cRel);
-                  for (int c = 0; c < nacmax; ++c) {
-                    const int rr2 = c + hl;
-                    if (isNN && !(pk & FAM2_COOP) && rr2 < nac)
-                      unsafeAtomicAdd(&gb[fpos(crel[rr2], crel[c])], w * (pK[rr2] * qK[c] + qK[rr2] * pK[c]));
-                  }
-                }
-                if (isNN) {
-                  const double* acol = smem + cbo + C.cLi + ic * 16;
-                  const double* mp = smem + cbo + C.cMK + ic * csa;
-                  const double* mq = smem + cbo + C.cMK + jc * csa;
-#pragma unroll
-                  for (int x = 0; x < 6; ++x) {
-                    const int ie = dec[x] & 0xffff, n = dec[x] >> 16;
-                    if (n < nnc) {
-                      if (ie < nnc) { if (ie >= n) acc[x] += w * (acol[ie] * bcol[n] + bcol[ie] * acol[n]); }
-                      else { const int m = ie - nnc; acc[x] -= w * (mp[m] * bcol[n] + mq[m] * acol[n]); }
-                    }
-                  }
-                }
-              }
-            }
-#pragma unroll
-            for (int x = 0; x < 6; ++x) { const int e = e0 + hl + 32 * x; if (e < npan && !(a.skip & 1)) FAM2_ST(&Pc[e], acc[x]); }
-          }
-          // supernode-block entries of the children, shared by the four child waves (a quarter of the positions each)
-          {
-            const int nnn = min(__builtin_amdgcn_readfirstlane(nncnt[q]), FAM2_NNCAP);
-            for (int it = 0; it < nnn; ++it) {
-              const int pkk = __builtin_amdgcn_readfirstlane(nnpk[q * FAM2_NNCAP + it]);
-              const double v = nnv[q * FAM2_NNCAP + it];
-              const int c2 = pkk & 0xff, i = (pkk >> 8) & 0xff, jc = pkk >> 16;
-              const int nac2 = __builtin_amdgcn_readfirstlane(cnac[c2]);
-              const double* const cb2 = smem + L.oCh + c2 * C.cstride;
-              const int* const crel = reinterpret_cast<const int*>(cb2 + C.cRel);
-              const double* pK = cb2 + C.cK + i * csa;
-              const double* qK = cb2 + C.cK + jc * csa;
-              const double w = i == jc ? 0.5 * v : v;
-              const int np = nac2 * (nac2 + 1) / 2, per = (np + 3) / 4, pend = min(np, (cw + 1) * per);
-              for (int p = cw * per + lane; p < pend; p += 64) {
-                int r2 = (int)((__fsqrt_rn(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
-                if (r2 * (r2 + 1) / 2 > p) --r2;
-                else if ((r2 + 1) * (r2 + 2) / 2 <= p) ++r2;
-                const int c = p - r2 * (r2 + 1) / 2;
-                unsafeAtomicAdd(&gb[fpos(crel[r2], crel[c])], w * (pK[r2] * qK[c] + qK[r2] * pK[c]));
-              }
-            }
-          }
-          // the parent's own entries (child wave 3: it has the fewest children when a family is not full)
-          if (cw == 3) {
-            const int ne0 = __builtin_amdgcn_readfirstlane(trow[0]);
-            const int wh0 = __builtin_amdgcn_readfirstlane(trow[1]);
-            for (int t = lane; t < ne0; t += 64) {
-              const int pk = lpk[wh0 + t];
-              const double v = lval[wh0 + t];
-              const int i = pk & 0xff, n = (pk >> 8) & 0xff;
-              if (i >= nn) unsafeAtomicAdd(&gb[L.gFan + (i - nn) + n * LDA], v);
-              else if (i >= n) unsafeAtomicAdd(&gb[L.gFnn + i + n * LDN], v);
-            }
-          }
-        }
-      }
-      STAMP(1);
-      lds_barrier();        // stage boundary (whole workgroup): front q is assembled
-      STAMP(2);
-    }
-    } else {
-    for (int q = 0; q <= ep; ++q) {
-      if (q > 0 && !(a.skip & 8)) {
-        // ===============================================================================================
-        // parent waves: sweep of right-hand side q0 + q - 1
-        // ===============================================================================================
-        int opq = 0;
-        asm volatile("" : "+v"(opq));          // opaque zero: the per-lane addresses below are recomputed every pass instead
-                                                 // of living in ~60 registers across the loop (the kernel is capped at 168)
-        const int l15 = (lane & 15) + opq, kq = (lane >> 4) + opq;
-        const int r = (int)blockIdx.y + (q0 + q - 1) * gy;
-        double* const gb = smem + L.oF0 + ((q - 1) & 1) * L.fstride;
-        double* const sFnn = gb + L.gFnn;
-        double* const sFan = gb + L.gFan;
-        double* const sU = gb + L.gU;
-        double* const P = u + (int64_t)r * ldu + pblk;
-        double* const UkP = a.t.updp + (int64_t)r * a.t.updplen + pupdp;
-        // ---- A
-        if (wave < 4 && 16 * wave < na) {
-          const int m = 16 * wave + l15;
-          double fnn[4], fan[4];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int kr = kq + 4 * s;
-            fnn[s] = sFnn[kr >= l15 ? kr + l15 * LDN : l15 + kr * LDN];
-            fan[s] = sFan[m + kr * LDA];
-          }
-          d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int s = 0; s < KSN; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fnn[s], creg[4 + s], acc, 0, 0, 0);   // K_c0 = K of tile `wave`
-          double xv[4];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            xv[s] = fan[s] - acc[s];
-            sE[m + (kq + 4 * s) * LDA] = fan[s] - 0.5 * acc[s];
-            sFan[m + (kq + 4 * s) * LDA] = 0.0;
-          }
-          d4 g = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int s = 0; s < KSN; ++s) g = __builtin_amdgcn_mfma_f64_16x16x4f64(bdP[s], xv[s], g, 0, 0, 0);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) sG[m + (kq + 4 * s) * LDA] = g[s];
-        } else if (wave == 4) {
-          double fnn[4];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int kr = kq + 4 * s;
-            fnn[s] = sFnn[kr >= l15 ? kr + l15 * LDN : l15 + kr * LDN];
-          }
-          d4 tt = {0.0, 0.0, 0.0, 0.0}, gn = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int s = 0; s < KSN; ++s) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(fnn[s], bdP[s], tt, 0, 0, 0);
-#pragma unroll
-          for (int s = 0; s < KSN; ++s) gn = __builtin_amdgcn_mfma_f64_16x16x4f64(bdP[s], tt[s], gn, 0, 0, 0);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int jn = kq + 4 * s;
-            if (l15 < nn && jn <= l15 && !(a.skip & 2)) FAM2_ST(&P[l15 + (int64_t)jn * nf], gn[s]);
-          }
-        }
-        STAMP(1);
-        fam2_barrier8(cnt, target, lane, a.t.info);
-        STAMP(2);
-        // ---- B
-        if (wave < 5) {
-          if (wave == 4)
-            for (int e = lane; e < LDN * 16; e += 64) sFnn[e] = 0.0;
-          // two update tiles, their chains interleaved: tile (r, c) -= K_r E_c^T + E_r K_c^T
-          double eR0[4], eC0[4], eR1[4], eC1[4];
-          const int m0 = 16 * tr0 + l15, m1 = 16 * tr1 + l15;
-#pragma unroll
-          for (int s = 0; s < KSN; ++s) {
-            eR0[s] = sE[m0 + (kq + 4 * s) * LDA];
-            eC0[s] = sE[(16 * tc0 + l15) + (kq + 4 * s) * LDA];
-            eR1[s] = sE[m1 + (kq + 4 * s) * LDA];
-            eC1[s] = sE[(16 * tc1 + l15) + (kq + 4 * s) * LDA];
-          }
-          d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int s = 0; s < KSN; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(eC0[s], creg[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(eC1[s], creg[8 + s], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(creg[4 + s], eR0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(creg[12 + s], eR1[s], acc1, 0, 0, 0);
-          }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int n0 = 16 * tc0 + kq + 4 * s, n1 = 16 * tc1 + kq + 4 * s;
-            if (m0 >= n0 && m0 < na) {
-              const int po = n0 * na - ((n0 * (n0 - 1)) >> 1) + (m0 - n0);
-              const double uv = sU[po];
-              sU[po] = 0.0;
-              if (!(a.skip & 2)) UkP[po] = uv - acc0[s];
-            }
-            if (m1 >= n1 && m1 < na) {
-              const int po = n1 * na - ((n1 * (n1 - 1)) >> 1) + (m1 - n1);
-              const double uv = sU[po];
-              sU[po] = 0.0;
-              if (!(a.skip & 2)) UkP[po] = uv - acc1[s];
-            }
-          }
-        } else {
-          // Q row tiles: wave 5: tile 0 (blocks 0..3); wave 6: tile 1 (blocks 1..3) and tile 3 (block 3); wave 7: tile 2
-          const int tq = wave == 5 ? 0 : (wave == 6 ? 1 : 2);
-          d4 acc = {0.0, 0.0, 0.0, 0.0}, acc3 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int tb = 0; tb < 4; ++tb) {
-            if (tb < tq || 16 * tb >= na) continue;
-            double gv[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) gv[s] = sG[(kq + 4 * (4 * tb + s)) + l15 * LDA];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[s], creg[4 * tb + s], acc, 0, 0, 0);
-            if (wave == 6 && tb == 3)
-#pragma unroll
-              for (int s = 0; s < 4; ++s) acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[s], creg[s], acc3, 0, 0, 0);
-          }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int n = kq + 4 * s, m = 16 * tq + l15, m3 = 48 + l15;
-            if (m < na && n < nn && !(a.skip & 2)) FAM2_ST(&P[(nn + m) + (int64_t)n * nf], acc[s]);
-            if (wave == 6 && m3 < na && n < nn && !(a.skip & 2)) P[(nn + m3) + (int64_t)n * nf] = acc3[s];
-          }
-        }
-      }
-      STAMP(3);
-      lds_barrier();        // stage boundary (whole workgroup): front q - 1 is swept and clear
-      STAMP(4);
-    }
-    }
-    q0 += ep;
-  }
-#ifdef SMCP_STAMPS
-  if (stamp) for (int i = 0; i < 8; ++i) atomicAdd(a.dbg + 8 * sslot + i, tph[i]);
-#endif
-#undef STAMP
-}
 
 }  // namespace smcp

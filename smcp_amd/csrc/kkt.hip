@@ -382,12 +382,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
           }
         }
       };
-      if (nth == 1) work(0);
-      else {
-        std::vector<std::thread> pool;
-        for (int tix = 0; tix < nth; ++tix) pool.emplace_back(work, tix);
-        for (auto& th : pool) th.join();
-      }
+      run_threads(nth, work);
     }
     for (int64_t j = 0; j < m; ++j) {
       if (!is_sparse[(size_t)j]) { dl.push_back((int32_t)j); continue; }
@@ -835,9 +830,7 @@ static bool leafgram_ok(csp_ctx* c, int64_t mcols) {
 
 // partial tiles of the listed family children (gram_tables) -> the slots part[0 .. *nl) (at most leafgram_slots())
 static int leafgram_slots(csp_ctx* c) {
-  static int ncu = 0;
-  if (!ncu) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, c->D.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
-  return ncu;
+  return c->D.ncu;
 }
 static int leafgram_partials(csp_ctx* c, int64_t mcols, const int32_t* ids, hipStream_t st, double* part, int* nl) {
   DeviceCtx& D = c->D;
@@ -911,11 +904,11 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
     const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
     if (D.gsl_n > 0) {
-#define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nchunk, 1), dim3(1024), lds, st, \
+#define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_diag128, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nchunk, 1), dim3(1024), lds, st, \
                (const double*)D.ustack, bl, (int)m, (const int64_t*)D.gsl_start, (const int32_t*)D.gsl_len, D.gsl_n, spw, (const double*)D.sw, D.gpart, 0, nchunk, gskip); \
-             else if (nw == 8) launch_lds(c, KID_gram_partial, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nchunk, 1), dim3(512), lds, st, \
+             else if (nw == 8) launch_lds(c, KID_gram_diag128, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nchunk, 1), dim3(512), lds, st, \
                (const double*)D.ustack, bl, (int)m, (const int64_t*)D.gsl_start, (const int32_t*)D.gsl_len, D.gsl_n, spw, (const double*)D.sw, D.gpart, 0, nchunk, gskip); \
-             else launch_lds(c, KID_gram_partial, k_gram_diag128<N, 4>, dim3(nchunk, 1), dim3(256), lds, st, \
+             else launch_lds(c, KID_gram_diag128, k_gram_diag128<N, 4>, dim3(nchunk, 1), dim3(256), lds, st, \
                (const double*)D.ustack, bl, (int)m, (const int64_t*)D.gsl_start, (const int32_t*)D.gsl_len, D.gsl_n, spw, (const double*)D.sw, D.gpart, 0, nchunk, gskip); break;
       switch (npw) {
         SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)

@@ -367,6 +367,15 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
   hipStream_t st = (hipStream_t)stream;
   D.qr_valid = false;
   if (int rc = qr_alloc(c)) return rc;
+  // The breakdown of chol(G) below DECIDES control flow (shifted pass, clean-up passes): its flag must be read back at
+  // once even when the caller runs with deferred status (csp_lazy_status), where fetch_info only latches and returns 0
+  // -- the loop would then go on with a half-factored T.  Eager for the duration of this call; a failure that survives
+  // the retries is returned directly.
+  struct EagerStatus {
+    csp_ctx* c; bool was;
+    explicit EagerStatus(csp_ctx* c_) : c(c_), was(c_->lazy_status) { c->lazy_status = false; }
+    ~EagerStatus() { c->lazy_status = was; }
+  } eager(c);
   const int64_t ldr8 = (m + QR_JB - 1) / QR_JB * QR_JB, ldr16 = (m + QR_MB - 1) / QR_MB * QR_MB;
   double* G = D.qr_ws;
   double* T = G + m * m;

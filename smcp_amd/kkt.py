@@ -456,6 +456,12 @@ class KKTSystem(ShardedSchur):
         returns solve_(bx, by, kk)."""
         self.build_schur(L, Y, group)
         self._potrf()
+        # Deferred status (chordal.lazy_status): the sharded build reads the latch once before H's all-reduce; a
+        # failure of potrf(H) after it stays latched until the caller's chordal.check_status.  Every other route
+        # (one rank, column ranges) reads the latch here, so that factor() never hands out a solve_ on a factor
+        # whose failure was only latched.
+        if not (self.partition is not None and self._sharded_pair(L, Y)):
+            self._deferred_status()
         if self._sharded_pair(L, Y):
             def solve_sharded(bx, by, kk, complete=True):
                 """Overwrites bx (cspmatrix) with x and by (device vector) with y; sharded sweeps."""
