@@ -147,7 +147,7 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
     note = None
     extra = {}
     alg = None
-    if dom == "k_fam_sparse":
+    if dom in ("k_fam_sparse", "k_fam_terms"):
         # bytes the fused family kernel HAS to move: the parents' output panels (+ the children's when they are formed),
         # the parents' packed updates, the constants of every member once per launch; the children's updates stay in LDS
         panels = Bk[fam_mask & (fam == 2)].sum() + (0.0 if leaf_gram else Bk[fam_mask & (fam == 1)].sum())
@@ -159,8 +159,10 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
                  "mfma": {"flops_per_launch": flops / dom_launches,
                           "achieved_tflops": round(flops / (1e-3 * dom_ms) / 1e12, 2),
                           "frac": round(flops / (1e-3 * dom_ms) / 1e12 / FP64_PEAK_TFLOPS, 4)}}
+        if dom == "k_fam_terms":      # tables of the family (record of k_famt_prep) read once per workgroup instead of the constants
+            alg = sum(8.0 * r * (panels + Upk[fam_mask & (fam == 2)].sum()) for r in chunks) + 8.0 * Bk[fam_mask].sum()
         note = ("bytes = the parents' output panels%s + the parents' packed updates + the members' constants (the children's "
-                "update matrices stay in LDS); per_level_bytes = SURVEY 8d's per-level figure for the same sweeps; mfma = "
+                "update matrices never exist); per_level_bytes = SURVEY 8d's per-level figure for the same sweeps; mfma = "
                 "canonical dense-formulation flops" % (" (the children's panels are not formed: their Gram block comes from "
                                                        "k_leaf_pairs in closed form)" if leaf_gram else " + the children's"))
     elif dom == "k_hess_up_fam":

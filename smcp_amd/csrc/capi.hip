@@ -22,6 +22,7 @@
 #include "front_fam2.hip"
 #include "front_lfsp.hip"
 #include "front_leafgram.hip"
+#include "front_famt.hip"
 
 using namespace smcp;
 
@@ -51,7 +52,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -69,7 +70,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -760,6 +761,63 @@ bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   }
   return true;
 }
+// Entry-driven family sweep (front_famt.hip) for sweeps that leave the children's panels to k_leaf_gram: false = not
+// applicable (the caller falls back to k_fam_sparse).  SMCP_FAMT=0 disables.
+template <int NAT>
+bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("SMCP_FAMT"); off = (e && e[0] == '0') ? 1 : 0; }
+  if (off || !D.lg_request) return false;
+  const int cnn = std::max(1, a.famcnn);
+  const FamtL L = famt_layout<NAT>(8 * cnn);
+  const int64_t lim = (160 * 1024 - 1024) / 8;                          // doubles of LDS a workgroup may use
+  const int64_t fixed = L.total + 8 * famt_desc_doubles() + 6;
+  if (D.fam_maxterms > FAMT_TCAP / 2) return false;                      // pairs of one right-hand side: the descriptor area
+  if (fixed + 9 * 4 + 64 > lim) return false;
+  const int64_t prep_doubles = L.total + 8 * (16 * NAT + 16 + 32 * 16);
+  if (prep_doubles > lim) return false;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k_fam_terms<NAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)k_famt_prep<NAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return false;
+    attr = true;
+  }
+  const int64_t need = (int64_t)cnt * (FAMT_HDR + L.total);
+  if (D.famc_len < need) {
+    if (D.famc) { if (hipFree(D.famc) != hipSuccess) return false; D.bytes -= D.famc_len * 8; }
+    D.famc = nullptr; D.famc_len = 0;
+    if (dev_alloc(&D.famc, need, D.bytes)) return false;
+    D.famc_len = need;
+  }
+  const int ncu = D.ncu;
+  // one workgroup per CU (LDS), eight right-hand sides in flight per workgroup: split the right-hand sides so that the
+  // grid fills whole rounds; the set-up (tables, entry lists) costs about as much as sixteen passes
+  int g = 1;
+  int64_t best = -1;
+  for (int gc = 1; gc <= std::min(nrhs, 32); ++gc) {
+    const int64_t rounds = ((int64_t)cnt * gc + ncu - 1) / ncu;
+    const int64_t passes = (nrhs + gc - 1) / gc;
+    const int64_t cost = rounds * ((passes + 7) / 8 + 2);
+    if (best < 0 || cost < best) { best = cost; g = gc; }
+  }
+  static int genv = -1;
+  if (genv < 0) { const char* e = getenv("SMCP_FAMT_G"); genv = e ? atoi(e) : 0; }
+  if (genv > 0) g = std::min(genv, nrhs);
+  const int passes = (nrhs + g - 1) / g;
+  const double avg = 9.0 * (double)D.cnnz / ((double)c->S.nsn * (double)std::max<int64_t>(1, D.m));   // entries per (family, rhs)
+  int tabpasses = std::min(passes, 113);
+  auto tail = [&](int tp) { return (int64_t)2 * ((tp * 9 + 1) & ~1) / 2 + 2; };      // doubles of the (pass, member) table
+  while (tabpasses > 4 && fixed + tail(tabpasses) + (int64_t)(1.5 * 1.5 * avg * tabpasses) + 8 > lim) tabpasses = (tabpasses + 1) / 2;
+  const int64_t left = lim - fixed - tail(tabpasses) - 4;
+  const int ecap = (int)std::max<int64_t>(0, (left * 2) / 3 - 2);
+  if (9 * D.kc_maxlist > ecap) return false;
+  launch_lds(c, KID_famt_prep, k_famt_prep<NAT>, dim3(cnt), dim3(512), (size_t)prep_doubles * sizeof(double), st, a, D.famc, cnn);
+  launch_lds(c, KID_fam_terms, k_fam_terms<NAT>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a, U, ldu,
+             (const double*)D.famc, cnn, (const int32_t*)D.kc_ij, tabpasses, ecap);
+  D.lg_nochild = true;
+  return true;
+}
 bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   static int off = -1;
   if (off < 0) { const char* e = getenv("SMCP_FAM2"); off = (e && e[0] == '0') ? 1 : 0; }
@@ -768,6 +826,12 @@ bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64
   if (c->D.cnnz > (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m)) return false;
   const int nat = std::max(1, (a.famna + 15) / 16);
   const bool k2 = a.famnn <= 8;
+  switch (nat) {      // sweeps whose children's Gram block comes from k_leaf_gram: the entry-driven kernel
+    case 1: if (launch_famt<1>(c, a, cnt, nrhs, U, ldu, st)) return true; break;
+    case 2: if (launch_famt<2>(c, a, cnt, nrhs, U, ldu, st)) return true; break;
+    case 3: if (launch_famt<3>(c, a, cnt, nrhs, U, ldu, st)) return true; break;
+    case 4: if (launch_famt<4>(c, a, cnt, nrhs, U, ldu, st)) return true; break;
+  }
   switch (nat) {
     case 1: return k2 ? launch_fam2<1, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<1, 4>(c, a, cnt, nrhs, U, ldu, st);
     case 2: return k2 ? launch_fam2<2, 2>(c, a, cnt, nrhs, U, ldu, st) : launch_fam2<2, 4>(c, a, cnt, nrhs, U, ldu, st);

@@ -97,6 +97,7 @@ struct DeviceCtx {
   double* famc = nullptr;    // children's constants of the family parents of one sweep call, in LDS layout (k_fam2_prep)
   int64_t famc_len = 0;
   int64_t kc_maxlist = 0;    // longest entry list of a (clique, constraint) pair among possible family members
+  int64_t fam_maxterms = 0;  // most entries of a (family, constraint) pair: the parent's own + its children's
   double* vbuf = nullptr;    // n x vcols : S^-1[:, K_s] of the chunk in flight
   int64_t vcols = 0;
   double* hd = nullptr;      // md x md Gram block of the dense constraints (when ns > 0)

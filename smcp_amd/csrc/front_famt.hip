@@ -1,0 +1,394 @@
+// Entry-driven family sweep (round 3): the Schur-complement sweep of a small parent front (nn <= 16, na <= 64) with
+// its <= 8 childless children, for the right-hand sides whose children's panels are NOT formed (their Gram block comes
+// from front_leafgram.hip).  Replaces the LDS front, the atomics and the three barrier-separated phases of
+// k_fam_sparse (front_fam2.hip) by ONE set of independent rank-T products per (parent, right-hand side):
+//
+//   The front of a right-hand side is a short sum of symmetric dyads,  F = sum_t s_t (x_t y_t^T + y_t x_t^T):
+//     an own entry v at (i, j) of the parent's panel:        x = e_i, y = e_j,                 s = v  (v / 2 if i == j)
+//     an entry v at (separator row a, column j) of child c:  x = q~_{c,j}, y = e_{rel_c[a]},   s = -v
+//     an entry v at (i, j) of the supernode block of c:      x = q~_{c,i}, y = q~_{c,j},       s = v  (v / 2 if i == j)
+//   with q~_{c,j} = column j of K_c scattered to the parent's front rows (the closed forms of front_fam2.hip, fact 1).
+//   The sweep is linear in F:  with R_N = [Li 0], R_A = [-K I] (reference call site solvers.py:483
+//   through the Gram formulation of solvers.py:414-420)
+//     G_NN = R_N F R_N^T,   Q = R^T (R_A F R_N^T),   Upd = R_A F R_A^T,
+//   so with the images n(x) = R_N x, a(x) = R_A x, m(x) = R^T a(x) of the few distinct vectors x -- columns of Li, -K,
+//   -R^T K, R^T and unit vectors for the e_i, and per (child, column) constants for the q~ -- every output is
+//     G_NN = sum_t' s n(x') n(y')^T,   Q = sum_t' s m(x') n(y')^T,   Upd = sum_t' s a(x') a(y')^T
+//   over the 2 T ordered pairs t' = (x, y), (y, x): products with inner dimension 2 T ~ 26 whose operands are GATHERED
+//   from tables in LDS.  One wave owns a (parent, right-hand side) pair: per step of four t' it reads 14 operand values
+//   and issues 15 independent v_mfma_f64_16x16x4 (ten update tiles, four Q tiles, G_NN); the accumulators go straight
+//   to HBM.  No front in LDS, no atomics, no dependent product chain, no barrier after the set-up.
+//
+// k_famt_prep lays the tables of every family out once per sweep call (the factor may have changed); k_fam_terms copies
+// them to LDS, stages the entry lists of its right-hand sides there (as k_fam_sparse does: the steady-state loop issues
+// no vector load, which would wait behind the streaming stores -- vmcnt is one in-order counter) and sweeps.
+#include <hip/hip_runtime.h>
+
+namespace smcp {
+
+// tables of a family in LDS / in its global record (doubles): Li (16 x 16) | -K (NA x 16) | -R^T K (NA x 16) |
+// R^T (NA x NA, upper triangular, column-major) | NA zeros | per child column: n (16) | a (NA) | m (NA)
+struct FamtL { int oLi, onK, onMK, oRt, oZero, oCN, oCA, oCM, total; };
+template <int NAT>
+__host__ __device__ inline FamtL famt_layout(int ncol) {
+  constexpr int NA = 16 * NAT;
+  FamtL L{};
+  int o = 0;
+  L.oLi = o; o += 256;
+  L.onK = o; o += NA * 16;
+  L.onMK = o; o += NA * 16;
+  L.oRt = o; o += NA * NA;
+  L.oZero = o; o += NA;
+  L.oCN = o; o += ncol * 16;
+  L.oCA = o; o += ncol * NA;
+  L.oCM = o; o += ncol * NA;
+  L.total = o;
+  return L;
+}
+constexpr int FAMT_HDR = 32;        // doubles: the header of a record (ints, as FAM2: [0] clique, [1] nn, [2] na, [3] children,
+                                    // [4,5] panel offset, [8,9] packed-update offset; child c at 16 + 6 c: clique, nn, na,
+                                    // first column in the child tables, -, -)
+constexpr int FAMT_TCAP = 96;       // ordered pairs t' per (parent, right-hand side): 48 entries (host-checked)
+constexpr int FAMT_CHILD = 128;     // vector ids: < 128 unit vector e_id of the parent's front, >= 128 child column id - 128
+
+template <int NAT>
+__global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int cnn) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NA = 16 * NAT;
+  const int ncol = 8 * cnn;
+  const FamtL L = famt_layout<NAT>(ncol);
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na, nch = d.chend - d.chbeg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* const T = smem;
+  double* const scr = smem + L.total + wave * (NA + 16 + 32 * 16);     // per wave: q~ (16 + NA) | K_c (<= 32 x 16)
+  double* const out = famt + (int64_t)blockIdx.x * (FAMT_HDR + L.total);
+  for (int e = tid; e < L.total; e += 512) T[e] = 0.0;
+  __syncthreads();
+  {
+    const double* lk = a.LK + d.blk;
+    const double* ys = a.ysc + d.upd;                  // R: lower, column-major na x na
+    for (int e = tid; e < nf * nn; e += 512) {
+      const int i = e % nf, j = e / nf;
+      if (i >= nn) T[L.onK + (i - nn) + j * NA] = -lk[e];
+      else if (i >= j) T[L.oLi + i + j * 16] = lk[e];
+    }
+    for (int e = tid; e < na * na; e += 512) {
+      const int i = e % na, p = e / na;                // R[i][p], i >= p  ->  R^T[p][i]
+      if (i >= p) T[L.oRt + p + i * NA] = ys[e];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < na * nn; e += 512) {           // -(R^T K)[p][c] = sum_{q >= p} R^T[p][q] (-K)[q][c]
+    const int p = e % na, c = e / na;
+    double s = 0.0;
+    for (int q = p; q < na; ++q) s += T[L.oRt + p + q * NA] * T[L.onK + q + c * NA];
+    T[L.onMK + p + c * NA] = s;
+  }
+  // children: wave w = child w
+  int colbase = 0;
+  for (int c = 0; c < wave && c < nch; ++c) colbase += a.t.cl[a.t.chidx[d.chbeg + c]].nn;
+  if (wave < nch) {
+    const int ck = a.t.chidx[d.chbeg + wave];
+    const CliqueDesc cd = a.t.cl[ck];
+    const int nnc = cd.nn, nac = cd.na, nfc = nnc + nac;
+    const double* lkc = a.LK + cd.blk;
+    double* const qt = scr;                            // q~: rows of the parent's front (nn then na)
+    double* const Kc = scr + NA + 16;
+    for (int e = lane; e < nac * nnc; e += 64) { const int h = e % nac, j = e / nac; Kc[h + j * 32] = lkc[(nnc + h) + (int64_t)j * nfc]; }
+    const int rel = lane < nac ? a.t.relidx[cd.rel + lane] : 0;
+    for (int j = 0; j < nnc; ++j) {
+      for (int e = lane; e < NA + 16; e += 64) qt[e] = 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < nac) qt[rel < nn ? rel : 16 + (rel - nn)] = Kc[lane + j * 32];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int g = colbase + j;
+      // n = Li q~_N ; a = q~_A + (-K) q~_N
+      if (lane < nn) {
+        double s = 0.0;
+        for (int q = 0; q <= lane; ++q) s += T[L.oLi + lane + q * 16] * qt[q];
+        T[L.oCN + g * 16 + lane] = s;
+      }
+      for (int p = lane; p < na; p += 64) {
+        double s = qt[16 + p];
+        for (int q = 0; q < nn; ++q) s += T[L.onK + p + q * NA] * qt[q];
+        T[L.oCA + g * NA + p] = s;
+      }
+    }
+    if (lane == 0) {
+      int* const hdr = reinterpret_cast<int*>(out) + 16 + 6 * wave;
+      hdr[0] = ck; hdr[1] = nnc; hdr[2] = nac; hdr[3] = colbase; hdr[4] = 0; hdr[5] = 0;
+    }
+  } else if (wave < 8 && lane == 0) {
+    int* const hdr = reinterpret_cast<int*>(out) + 16 + 6 * wave;
+    hdr[0] = -1; hdr[1] = 1; hdr[2] = 0; hdr[3] = 0; hdr[4] = 0; hdr[5] = 0;
+  }
+  __syncthreads();
+  // m = R^T a for all child columns at once, by the whole workgroup: thread (p, column group) keeps up to eight sums;
+  // R^T[p][q] is read once per q, the a values by broadcast
+  {
+    const int p = tid & 63, grp = tid >> 6;             // eight groups of columns g = gb + grp, gb + grp + 8, ...
+    for (int gb = 0; gb < ncol; gb += 64)
+      if (p < na) {
+        double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int q = p; q < na; ++q) {
+          const double rt = T[L.oRt + p + q * NA];
+#pragma unroll
+          for (int x = 0; x < 8; ++x) { const int g = gb + grp + 8 * x; if (g < ncol) s8[x] += rt * T[L.oCA + g * NA + q]; }
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { const int g = gb + grp + 8 * x; if (g < ncol) T[L.oCM + g * NA + p] = s8[x]; }
+      }
+  }
+  if (tid == 0) {
+    int* const hdr = reinterpret_cast<int*>(out);
+    hdr[0] = k; hdr[1] = nn; hdr[2] = na; hdr[3] = nch;
+    hdr[4] = (int)(d.blk & 0xffffffffll); hdr[5] = (int)(d.blk >> 32);
+    hdr[6] = 0; hdr[7] = 0;
+    hdr[8] = (int)(d.updp & 0xffffffffll); hdr[9] = (int)(d.updp >> 32);
+  }
+  __syncthreads();
+  for (int e = tid; e < L.total; e += 512) out[FAMT_HDR + e] = T[e];
+}
+
+// LDS of k_fam_terms behind the tables (doubles): per wave the descriptors of FAMT_TCAP ordered pairs (scale: 1 double,
+// offsets: 4 ints), then the entry table of k_fam_sparse: per (pass, member) two ints, then the staged entries
+__host__ __device__ inline int famt_desc_doubles() { return FAMT_TCAP * 3; }
+
+template <int NAT>
+__global__ void __launch_bounds__(512) k_fam_terms(MfmaArgs a, double* u, int64_t ldu, const double* famt, int cnn,
+                                                   const int32_t* kc_ij, int tabpasses, int ecap) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NA = 16 * NAT, NW = 8;
+  const int ncol = 8 * cnn;
+  const FamtL L = famt_layout<NAT>(ncol);
+  const double* const fc = famt + (int64_t)blockIdx.x * (FAMT_HDR + L.total);
+  const int32_t* const hdr = reinterpret_cast<const int32_t*>(fc);
+  const int k = hdr[0], nn = hdr[1], na = hdr[2], nch = hdr[3], nf = nn + na;
+  const int64_t pblk = (int64_t)(uint32_t)hdr[4] | ((int64_t)hdr[5] << 32);
+  const int64_t pupdp = (int64_t)(uint32_t)hdr[8] | ((int64_t)hdr[9] << 32);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nmem = nch + 1;                     // members with entry lists: 0 = the parent, 1 + c = child c
+  const int gy = (int)gridDim.y;
+  const int npass = ((int)a.nrhs - (int)blockIdx.y + gy - 1) / gy;
+  double* const dS = smem + L.total + wave * famt_desc_doubles();              // scale of pair t'
+  int* const dI = reinterpret_cast<int*>(dS + FAMT_TCAP);                       // four words per pair
+  int* const misc = reinterpret_cast<int*>(smem + L.total + NW * famt_desc_doubles());
+  int* const epfit = misc;                                                     // passes of the running epoch whose entries are staged
+  int* const cdim = misc + 2;                                                  // per child: nn | colbase << 8
+  int* const tab = misc + 12;                                                  // [pass in epoch][member] -> (count, where)
+  double* const lval = reinterpret_cast<double*>(tab + 2 * ((tabpasses * nmem + 1) & ~1));
+  int* const lpk = reinterpret_cast<int*>(lval + ecap);
+
+  for (int e = tid; e < L.total; e += 512) smem[e] = fc[FAMT_HDR + e];
+  if (tid < 8) cdim[tid] = tid < nch ? (hdr[16 + 6 * tid + 1] | (hdr[16 + 6 * tid + 3] << 8)) : 1;
+
+  for (int q0 = 0; q0 < npass;) {
+    // ===================================================================================================
+    // epoch set-up (whole workgroup): the entry lists of the passes q0 .. q0 + ep - 1 -> LDS, as in k_fam_sparse
+    // (word = row | column << 8 | parent front row of a child's separator row << 16)
+    // ===================================================================================================
+    const int epmax = min(tabpasses, npass - q0), npairs = epmax * nmem;
+    __syncthreads();
+    if (tid == 0) *epfit = epmax;
+    int myp0[2] = {0, 0};                                      // npairs <= 1024 (host): at most two pairs per thread
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int idx = tid + 512 * h;
+      if (idx < npairs) {
+        const int qq = idx / nmem, mem = idx - qq * nmem;
+        const int r = (int)blockIdx.y + (q0 + qq) * gy;
+        const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
+        const int ck = mem ? hdr[16 + 6 * (mem - 1)] : k;
+        const int32_t* kp = a.kc_ptr + (int64_t)ck * a.kc_stride;
+        myp0[h] = kp[j];
+        tab[2 * idx] = kp[j + 1] - myp0[h];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {                                           // exclusive scan of the counts (one wave)
+      const int per = (npairs + 63) / 64, b = lane * per;
+      int sum = 0;
+      for (int x = 0; x < per; ++x) sum += (b + x < npairs) ? tab[2 * (b + x)] : 0;
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+      int run = incl - sum;
+      for (int x = 0; x < per; ++x)
+        if (b + x < npairs) {
+          const int c = tab[2 * (b + x)];
+          tab[2 * (b + x) + 1] = run;
+          run += c;
+          if (run > ecap) atomicMin(epfit, (b + x) / nmem);    // this pass does not fit any more
+        }
+    }
+    __syncthreads();
+    const int ep = max(1, *epfit);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int idx = tid + 512 * h;
+      if (idx < ep * nmem) {
+        const int c = tab[2 * idx], p0 = myp0[h], off = tab[2 * idx + 1];
+        const int qq = idx / nmem, mem = idx - qq * nmem;
+        (void)qq;
+        const int mnn = mem ? hdr[16 + 6 * (mem - 1) + 1] : 0;
+        const int mck = mem ? hdr[16 + 6 * (mem - 1)] : 0;
+        const int32_t* const mrel = a.t.relidx + a.t.cl[mem ? mck : k].rel;
+        for (int t = 0; t < c && off + t < ecap; ++t) {
+          const int ij = kc_ij[p0 + t];
+          const int i = ij & 0xffff, jc = ij >> 16;
+          int pk = i | (jc << 8);
+          if (mem && i >= mnn) pk |= mrel[i - mnn] << 16;
+          lpk[off + t] = pk;
+          lval[off + t] = a.kc_val[p0 + t];
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) the compiler's wait-count pass knows about (see k_fam_sparse)
+    __syncthreads();
+
+    for (int qq = wave; qq < ep; qq += NW) {
+      const int r = (int)blockIdx.y + (q0 + qq) * gy;
+      const int* const trow = tab + 2 * qq * nmem;
+      // =================================================================================================
+      // the ordered pairs of this right-hand side: lane e <-> entry e of the concatenated member lists
+      // =================================================================================================
+      int cntm = lane < nmem ? trow[2 * lane] : 0;
+      int incl = cntm;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+      const int T = min(__builtin_amdgcn_readlane(incl, 15), FAMT_TCAP / 2);
+      {
+        int mem = 0, base = 0;
+#pragma unroll
+        for (int mm = 0; mm < 8; ++mm) {
+          const int up = __builtin_amdgcn_readlane(incl, mm);
+          if (lane >= up) { mem = mm + 1; base = up; }
+        }
+        if (lane < T) {
+          const int where = trow[2 * mem + 1];
+          const int pk = lpk[where + (lane - base)];
+          const double v = lval[where + (lane - base)];
+          const int i = pk & 0xff, jc = (pk >> 8) & 0xff, rl = (pk >> 16) & 0xff;
+          int vx, vy;
+          double s;
+          if (mem == 0) { vx = i; vy = jc; s = i == jc ? 0.5 * v : v; }
+          else {
+            const int cd = cdim[mem - 1], nnc = cd & 0xff, cb = cd >> 8;
+            if (i >= nnc) { vx = FAMT_CHILD + cb + jc; vy = rl; s = -v; }
+            else { vx = FAMT_CHILD + cb + i; vy = FAMT_CHILD + cb + jc; s = i == jc ? 0.5 * v : v; }
+          }
+          // images of a vector id: offsets of n, a, m in LDS and the index of the unit part of a (255: none)
+          auto img = [&](int vid, int& on, int& oa, int& om, int& ui) {
+            if (vid >= FAMT_CHILD) { const int g = vid - FAMT_CHILD; on = L.oCN + 16 * g; oa = L.oCA + NA * g; om = L.oCM + NA * g; ui = 255; }
+            else if (vid < nn) { on = L.oLi + 16 * vid; oa = L.onK + NA * vid; om = L.onMK + NA * vid; ui = 255; }
+            else { on = L.oZero; oa = L.oZero; om = L.oRt + NA * (vid - nn); ui = vid - nn; }
+          };
+          int nx, ax, mx, ux, ny, ay, my, uy;
+          img(vx, nx, ax, mx, ux);
+          img(vy, ny, ay, my, uy);
+          dS[2 * lane] = s; dS[2 * lane + 1] = s;
+          int4 w0 = {nx | (ax << 16), mx | (ux << 16), ny | (ay << 16), uy};
+          int4 w1 = {ny | (ay << 16), my | (uy << 16), nx | (ax << 16), ux};
+          reinterpret_cast<int4*>(dI)[2 * lane] = w0;
+          reinterpret_cast<int4*>(dI)[2 * lane + 1] = w1;
+        }
+        // pad to a multiple of four pairs
+        if (lane < 4 && 2 * T + lane < ((2 * T + 3) & ~3)) {
+          dS[2 * T + lane] = 0.0;
+          int4 z = {L.oZero | (L.oZero << 16), L.oZero | (255 << 16), L.oZero | (L.oZero << 16), 255};
+          reinterpret_cast<int4*>(dI)[2 * T + lane] = z;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // =================================================================================================
+      // products: step s takes the pairs t' = kq + 4 s.  Accumulator register x of lane (l15, kq) of a tile holds
+      // (row l15 of the b operand's tile, column kq + 4 x of the a operand's tile)
+      // =================================================================================================
+      // Row tiles in two passes when there are four of them (rows 0..2, then row 3 + G_NN): 15 live accumulator tiles
+      // plus the operands of a step exceed the 256 registers of a wave at two waves per SIMD (measured: 35 spilled
+      // registers, i.e. scratch loads behind the streaming stores); the operands are re-read from LDS, which is cheap.
+      const int ks = (2 * T + 3) >> 2;
+      double* const P = u + (int64_t)r * ldu + pblk;
+      double* const UkP = a.t.updp + (int64_t)r * a.t.updplen + pupdp;
+      auto pass = [&](auto LOc, auto HIc, auto Gc) {
+        constexpr int LO = decltype(LOc)::value, HI = decltype(HIc)::value;      // row tiles LO .. HI - 1
+        constexpr bool WITHG = decltype(Gc)::value;
+        constexpr int NTU = HI * (HI + 1) / 2 - LO * (LO + 1) / 2;
+        d4 accU[NTU], accQ[HI - LO], accG = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < NTU; ++x) accU[x] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < HI - LO; ++x) accQ[x] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < ks; ++s) {
+          const int tp = kq + 4 * s;
+          const double sc = dS[tp];
+          const int4 w = reinterpret_cast<const int4*>(dI)[tp];
+          const int nx = w.x & 0xffff, ax = w.x >> 16, mx = w.y & 0xffff, ux = w.y >> 16;
+          const int ny = w.z & 0xffff, ay = w.z >> 16, uy = w.w;
+          double bA[HI - LO], bM[HI - LO], aA[HI];
+#pragma unroll
+          for (int t = 0; t < HI; ++t) {
+            const int row = 16 * t + l15;
+            aA[t] = sc * (smem[ay + row] + (row == uy ? 1.0 : 0.0));
+            if (t >= LO) {
+              bA[t - LO] = smem[ax + row] + (row == ux ? 1.0 : 0.0);
+              bM[t - LO] = smem[mx + row];
+            }
+          }
+          const double aN = sc * smem[ny + l15];
+#pragma unroll
+          for (int rt = LO; rt < HI; ++rt) {
+#pragma unroll
+            for (int ct = 0; ct <= rt; ++ct) {
+              constexpr int base = LO * (LO + 1) / 2;
+              const int x = rt * (rt + 1) / 2 + ct - base;
+              accU[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[ct], bA[rt - LO], accU[x], 0, 0, 0);
+            }
+            accQ[rt - LO] = __builtin_amdgcn_mfma_f64_16x16x4f64(aN, bM[rt - LO], accQ[rt - LO], 0, 0, 0);
+          }
+          if constexpr (WITHG) {
+            const double bN = smem[nx + l15];
+            accG = __builtin_amdgcn_mfma_f64_16x16x4f64(aN, bN, accG, 0, 0, 0);
+          }
+        }
+        // results straight from the accumulators: packed update (column-major lower), Q and G_NN into the panel
+#pragma unroll
+        for (int rt = LO; rt < HI; ++rt) {
+          const int m = 16 * rt + l15;
+#pragma unroll
+          for (int ct = 0; ct <= rt; ++ct)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const int n = 16 * ct + kq + 4 * x;
+              if (m >= n && m < na) FAM2_ST(&UkP[n * na - ((n * (n - 1)) >> 1) + (m - n)], accU[rt * (rt + 1) / 2 + ct - LO * (LO + 1) / 2][x]);
+            }
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int n = kq + 4 * x;
+            if (m < na && n < nn) FAM2_ST(&P[(nn + m) + (int64_t)n * nf], accQ[rt - LO][x]);
+          }
+        }
+        if constexpr (WITHG) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int jn = kq + 4 * x;
+            if (l15 < nn && jn <= l15) FAM2_ST(&P[l15 + (int64_t)jn * nf], accG[x]);
+          }
+        }
+      };
+      if constexpr (NAT == 4) {
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, std::false_type{});
+        pass(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::true_type{});
+      } else {
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NAT>{}, std::true_type{});
+      }
+    }
+    q0 += ep;
+  }
+}
+
+}  // namespace smcp

@@ -473,6 +473,19 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
           const size_t q = (size_t)k * (m + 1) + j;
           D.kc_maxlist = std::max<int64_t>(D.kc_maxlist, kptr[q + 1] - kptr[q]);
         }
+    // most entries of a (family, constraint) pair: the parent's own + its children's (the entry-driven family sweep of
+    // front_famt.hip turns every entry into one term of a rank-T product)
+    D.fam_maxterms = 0;
+    for (int64_t k = 0; k < S.nsn; ++k)
+      if (k < (int64_t)c->fam.size() && c->fam[k] == 2)
+        for (int64_t j = 0; j < m; ++j) {
+          int64_t tot = kptr[(size_t)k * (m + 1) + j + 1] - kptr[(size_t)k * (m + 1) + j];
+          for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) {
+            const size_t q = (size_t)S.chidx[q2] * (m + 1) + j;
+            tot += kptr[q + 1] - kptr[q];
+          }
+          D.fam_maxterms = std::max(D.fam_maxterms, tot);
+        }
     D.kc_maxlist_large = 0;       // over the childless fronts beyond the small classes (sparse-input sweep of large fronts)
     for (int64_t k = 0; k < S.nsn; ++k)
       if ((S.nn(k) > 16 || S.na(k) > 64) && S.nn(k) <= 64 && S.na(k) <= 128 && S.chptr[k + 1] == S.chptr[k])

@@ -453,15 +453,14 @@ class KKTSystem(ShardedSchur):
 
     def factor(self, L, Y, group=None):
         """kkt_chol(L, Y): builds (sharded over `group` if given) and factors the Schur complement;
-        returns solve_(bx, by, kk)."""
+        returns solve_(bx, by, kk).
+        Under the deferred regime (chordal.lazy_status) a failure -- chol(Y_AA) inside the sweeps, potrf(H) -- is
+        only LATCHED on the device: this call still returns a solve_, whose results are meaningless after a failure
+        (safe: no index depends on a value), and the caller must read the verdict with chordal.check_status before
+        it trusts them.  (The sharded build reads the latch itself, once, before H's all-reduce, because every rank
+        has to agree on the outcome.)  The interior-point drivers run eagerly."""
         self.build_schur(L, Y, group)
         self._potrf()
-        # Deferred status (chordal.lazy_status): the sharded build reads the latch once before H's all-reduce; a
-        # failure of potrf(H) after it stays latched until the caller's chordal.check_status.  Every other route
-        # (one rank, column ranges) reads the latch here, so that factor() never hands out a solve_ on a factor
-        # whose failure was only latched.
-        if not (self.partition is not None and self._sharded_pair(L, Y)):
-            self._deferred_status()
         if self._sharded_pair(L, Y):
             def solve_sharded(bx, by, kk, complete=True):
                 """Overwrites bx (cspmatrix) with x and by (device vector) with y; sharded sweeps."""
