@@ -4,10 +4,10 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-python3 bench.py --steps 10 > $out/bench.json 2> $out/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --steps 5 --no-cpu > $out/stats.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 bench.py --steps 2 --no-cpu --no-profile > $out/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python3 bench.py --steps 2 --no-cpu --no-profile > $out/pmc_write.log 2>&1
+python3 bench.py --no-secondary --steps 10 > $out/bench.json 2> $out/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --no-secondary --steps 5 --no-cpu > $out/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 bench.py --no-secondary --steps 2 --no-cpu --no-profile > $out/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python3 bench.py --no-secondary --steps 2 --no-cpu --no-profile > $out/pmc_write.log 2>&1
 python3 - $out <<'PY'
 import csv, glob, sys, json, collections
 out=sys.argv[1]

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tr -o tr -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-profile > gpurun_out/tr.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tr -o tr -- python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile > gpurun_out/tr.log 2>&1
 python3 - <<'PY'
 import csv
 rows=list(csv.DictReader(open('gpurun_out/tr/tr_kernel_trace.csv')))

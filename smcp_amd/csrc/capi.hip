@@ -775,7 +775,7 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   const int64_t fixed = L.total + 8 * famt_desc_doubles() + 6;
   if (D.fam_maxterms > FAMT_TCAP / 2) return false;                      // pairs of one right-hand side: the descriptor area
   if (fixed + 9 * 4 + 64 > lim) return false;
-  const int64_t prep_doubles = L.total + 8 * (16 * NAT + 16 + 32 * 16);
+  const int64_t prep_doubles = famt_prep_doubles<NAT>(cnn);
   if (prep_doubles > lim) return false;
   static bool attr = false;
   if (!attr) {

@@ -45,12 +45,32 @@ __host__ __device__ inline FamtL famt_layout(int ncol) {
   L.total = o;
   return L;
 }
+// Results leave through raw buffer stores: an element that is not to be written (above the diagonal of a diagonal
+// tile, beyond na / nn) gets the byte offset 0xffffffff, which the hardware range check of the buffer drops -- one
+// v_cndmask per store instead of an exec-mask region with its branch (the per-element if () form compiled to ~8
+// instructions per store, masks spilled to VGPR lanes, and made the kernel's run time depend on where its code
+// landed in memory: 0.86 to 1.05 ms for the same instructions at four 256-byte offsets, scratch/famt_place.sh).
+typedef unsigned int famt_u2 __attribute__((ext_vector_type(2)));
+__device__ inline __amdgpu_buffer_rsrc_t famt_rsrc(double* base, int doubles) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, doubles * 8, 0x00020000);      // raw buffer, 32-bit data format (gfx9)
+}
+__device__ inline void famt_store(__amdgpu_buffer_rsrc_t r, bool ok, int pos, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(famt_u2, v), r, ok ? pos * 8 : -1, 0, 0);
+}
 constexpr int FAMT_HDR = 32;        // doubles: the header of a record (ints, as FAM2: [0] clique, [1] nn, [2] na, [3] children,
                                     // [4,5] panel offset, [8,9] packed-update offset; child c at 16 + 6 c: clique, nn, na,
                                     // first column in the child tables, -, -)
 constexpr int FAMT_TCAP = 96;       // ordered pairs t' per (parent, right-hand side): 48 entries (host-checked)
 constexpr int FAMT_CHILD = 128;     // vector ids: < 128 unit vector e_id of the parent's front, >= 128 child column id - 128
 
+// LDS of k_famt_prep (doubles): R^T | -K | Li | per wave q~ (16 + NA) and the a images of its child's columns (cnn x NA)
+template <int NAT>
+__host__ __device__ inline int famt_prep_doubles(int cnn) { constexpr int NA = 16 * NAT; return NA * NA + NA * 16 + 256 + 8 * (NA + 16 + cnn * NA); }
+
+// One workgroup per family, wave w = child w.  Only what later steps of the kernel read again is kept in LDS (R^T, -K, Li:
+// 42 KB for NA = 64 + 9 KB per wave), the tables themselves go straight to the record -- with the whole record staged in
+// LDS (136 KB, one workgroup per CU) the chain of dependent global loads of every workgroup was exposed and the launch
+// took 0.16 ms on synth50k.
 template <int NAT>
 __global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int cnn) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -61,61 +81,93 @@ __global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int
   const CliqueDesc d = a.t.cl[k];
   const int nn = d.nn, na = d.na, nf = nn + na, nch = d.chend - d.chbeg;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* const T = smem;
-  double* const scr = smem + L.total + wave * (NA + 16 + 32 * 16);     // per wave: q~ (16 + NA) | K_c (<= 32 x 16)
+  double* const sRt = smem;                    // R^T[p][q] at p + q NA (upper triangular)
+  double* const snK = sRt + NA * NA;           // -K[p][c] at p + c NA
+  double* const sLi = snK + NA * 16;           // Li[i][j] at i + j 16 (lower)
+  double* const qt = sLi + 256 + wave * (NA + 16 + cnn * NA);     // q~: rows of the parent's front (16 then NA)
+  double* const sCA = qt + NA + 16;                                // a images of this wave's columns: [j][p]
   double* const out = famt + (int64_t)blockIdx.x * (FAMT_HDR + L.total);
-  for (int e = tid; e < L.total; e += 512) T[e] = 0.0;
+  double* const T = out + FAMT_HDR;
+  // (the children's descriptors in one round trip: lane c loads child c, the column bases come from a wave scan)
+  const int myck = lane < nch ? a.t.chidx[d.chbeg + lane] : 0;
+  const int mynn = lane < nch ? a.t.cl[myck].nn : 0;
+  int inc = mynn;
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+  const int colbase = __shfl(inc - mynn, min(wave, 7));
+  const int ck = __shfl(myck, min(wave, 7));
+  for (int e = tid; e < NA * NA + NA * 16 + 256; e += 512) smem[e] = 0.0;
   __syncthreads();
   {
     const double* lk = a.LK + d.blk;
     const double* ys = a.ysc + d.upd;                  // R: lower, column-major na x na
     for (int e = tid; e < nf * nn; e += 512) {
       const int i = e % nf, j = e / nf;
-      if (i >= nn) T[L.onK + (i - nn) + j * NA] = -lk[e];
-      else if (i >= j) T[L.oLi + i + j * 16] = lk[e];
+      if (i >= nn) snK[(i - nn) + j * NA] = -lk[e];
+      else if (i >= j) sLi[i + j * 16] = lk[e];
     }
     for (int e = tid; e < na * na; e += 512) {
       const int i = e % na, p = e / na;                // R[i][p], i >= p  ->  R^T[p][i]
-      if (i >= p) T[L.oRt + p + i * NA] = ys[e];
+      if (i >= p) sRt[p + i * NA] = ys[e];
     }
   }
   __syncthreads();
-  for (int e = tid; e < na * nn; e += 512) {           // -(R^T K)[p][c] = sum_{q >= p} R^T[p][q] (-K)[q][c]
-    const int p = e % na, c = e / na;
+  // the parent's own tables -> record (zero-padded to the fixed strides)
+  for (int e = tid; e < 256; e += 512) T[L.oLi + e] = sLi[e];
+  for (int e = tid; e < NA * 16; e += 512) T[L.onK + e] = snK[e];
+  for (int e = tid; e < NA * NA; e += 512) T[L.oRt + e] = sRt[e];
+  for (int e = tid; e < NA; e += 512) T[L.oZero + e] = 0.0;
+  for (int e = tid; e < NA * 16; e += 512) {           // -(R^T K)[p][c] = sum_{q >= p} R^T[p][q] (-K)[q][c]
+    const int p = e % NA, c = e / NA;
     double s = 0.0;
-    for (int q = p; q < na; ++q) s += T[L.oRt + p + q * NA] * T[L.onK + q + c * NA];
-    T[L.onMK + p + c * NA] = s;
+    if (p < na && c < nn)
+      for (int q = p; q < na; ++q) s += sRt[p + q * NA] * snK[q + c * NA];
+    T[L.onMK + e] = s;
   }
-  // children: wave w = child w
-  int colbase = 0;
-  for (int c = 0; c < wave && c < nch; ++c) colbase += a.t.cl[a.t.chidx[d.chbeg + c]].nn;
+  // children: wave w = child w; columns of absent children stay zero
   if (wave < nch) {
-    const int ck = a.t.chidx[d.chbeg + wave];
     const CliqueDesc cd = a.t.cl[ck];
     const int nnc = cd.nn, nac = cd.na, nfc = nnc + nac;
     const double* lkc = a.LK + cd.blk;
-    double* const qt = scr;                            // q~: rows of the parent's front (nn then na)
-    double* const Kc = scr + NA + 16;
-    for (int e = lane; e < nac * nnc; e += 64) { const int h = e % nac, j = e / nac; Kc[h + j * 32] = lkc[(nnc + h) + (int64_t)j * nfc]; }
     const int rel = lane < nac ? a.t.relidx[cd.rel + lane] : 0;
     for (int j = 0; j < nnc; ++j) {
+      const double kv = lane < nac ? lkc[(nnc + lane) + (int64_t)j * nfc] : 0.0;     // K_c[lane][j]
       for (int e = lane; e < NA + 16; e += 64) qt[e] = 0.0;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < nac) qt[rel < nn ? rel : 16 + (rel - nn)] = Kc[lane + j * 32];
+      if (lane < nac) qt[rel < nn ? rel : 16 + (rel - nn)] = kv;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int g = colbase + j;
       // n = Li q~_N ; a = q~_A + (-K) q~_N
-      if (lane < nn) {
+      if (lane < 16) {
         double s = 0.0;
-        for (int q = 0; q <= lane; ++q) s += T[L.oLi + lane + q * 16] * qt[q];
+        if (lane < nn)
+          for (int q = 0; q <= lane; ++q) s += sLi[lane + q * 16] * qt[q];
         T[L.oCN + g * 16 + lane] = s;
       }
-      for (int p = lane; p < na; p += 64) {
-        double s = qt[16 + p];
-        for (int q = 0; q < nn; ++q) s += T[L.onK + p + q * NA] * qt[q];
+      for (int p = lane; p < NA; p += 64) {
+        double s = 0.0;
+        if (p < na) {
+          s = qt[16 + p];
+          for (int q = 0; q < nn; ++q) s += snK[p + q * NA] * qt[q];
+        }
+        sCA[j * NA + p] = s;
         T[L.oCA + g * NA + p] = s;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // m = R^T a for the columns of this child: lane = row p, R^T[p][q] read once per q, the a values by broadcast
+    for (int j0 = 0; j0 < nnc; j0 += 8)
+      for (int p = lane; p < NA; p += 64) {
+        double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (p < na)
+          for (int q = p; q < na; ++q) {
+            const double rt = sRt[p + q * NA];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) s8[x] += rt * sCA[min(j0 + x, cnn - 1) * NA + q];
+          }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) if (j0 + x < nnc) T[L.oCM + (colbase + j0 + x) * NA + p] = s8[x];
+      }
     if (lane == 0) {
       int* const hdr = reinterpret_cast<int*>(out) + 16 + 6 * wave;
       hdr[0] = ck; hdr[1] = nnc; hdr[2] = nac; hdr[3] = colbase; hdr[4] = 0; hdr[5] = 0;
@@ -124,22 +176,11 @@ __global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int
     int* const hdr = reinterpret_cast<int*>(out) + 16 + 6 * wave;
     hdr[0] = -1; hdr[1] = 1; hdr[2] = 0; hdr[3] = 0; hdr[4] = 0; hdr[5] = 0;
   }
-  __syncthreads();
-  // m = R^T a for all child columns at once, by the whole workgroup: thread (p, column group) keeps up to eight sums;
-  // R^T[p][q] is read once per q, the a values by broadcast
+  // table columns no child owns (fewer than 8 cnn columns in all): zero
   {
-    const int p = tid & 63, grp = tid >> 6;             // eight groups of columns g = gb + grp, gb + grp + 8, ...
-    for (int gb = 0; gb < ncol; gb += 64)
-      if (p < na) {
-        double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int q = p; q < na; ++q) {
-          const double rt = T[L.oRt + p + q * NA];
-#pragma unroll
-          for (int x = 0; x < 8; ++x) { const int g = gb + grp + 8 * x; if (g < ncol) s8[x] += rt * T[L.oCA + g * NA + q]; }
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x) { const int g = gb + grp + 8 * x; if (g < ncol) T[L.oCM + g * NA + p] = s8[x]; }
-      }
+    const int used = __shfl(inc, 7);                    // columns of all children
+    for (int e = tid; e < (ncol - used) * 16; e += 512) T[L.oCN + used * 16 + e] = 0.0;
+    for (int e = tid; e < (ncol - used) * NA; e += 512) { T[L.oCA + used * NA + e] = 0.0; T[L.oCM + used * NA + e] = 0.0; }
   }
   if (tid == 0) {
     int* const hdr = reinterpret_cast<int*>(out);
@@ -148,8 +189,6 @@ __global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int
     hdr[6] = 0; hdr[7] = 0;
     hdr[8] = (int)(d.updp & 0xffffffffll); hdr[9] = (int)(d.updp >> 32);
   }
-  __syncthreads();
-  for (int e = tid; e < L.total; e += 512) out[FAMT_HDR + e] = T[e];
 }
 
 // LDS of k_fam_terms behind the tables (doubles): per wave the descriptors of FAMT_TCAP ordered pairs (scale: 1 double,
@@ -312,8 +351,8 @@ __global__ void __launch_bounds__(512) k_fam_terms(MfmaArgs a, double* u, int64_
       // plus the operands of a step exceed the 256 registers of a wave at two waves per SIMD (measured: 35 spilled
       // registers, i.e. scratch loads behind the streaming stores); the operands are re-read from LDS, which is cheap.
       const int ks = (2 * T + 3) >> 2;
-      double* const P = u + (int64_t)r * ldu + pblk;
-      double* const UkP = a.t.updp + (int64_t)r * a.t.updplen + pupdp;
+      const __amdgpu_buffer_rsrc_t rP = famt_rsrc(u + (int64_t)r * ldu + pblk, nf * nn);
+      const __amdgpu_buffer_rsrc_t rU = famt_rsrc(a.t.updp + (int64_t)r * a.t.updplen + pupdp, (na * (na + 1)) >> 1);
       auto pass = [&](auto LOc, auto HIc, auto Gc) {
         constexpr int LO = decltype(LOc)::value, HI = decltype(HIc)::value;      // row tiles LO .. HI - 1
         constexpr bool WITHG = decltype(Gc)::value;
@@ -359,24 +398,26 @@ __global__ void __launch_bounds__(512) k_fam_terms(MfmaArgs a, double* u, int64_
 #pragma unroll
         for (int rt = LO; rt < HI; ++rt) {
           const int m = 16 * rt + l15;
+          const bool mok = m < na;
 #pragma unroll
           for (int ct = 0; ct <= rt; ++ct)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               const int n = 16 * ct + kq + 4 * x;
-              if (m >= n && m < na) FAM2_ST(&UkP[n * na - ((n * (n - 1)) >> 1) + (m - n)], accU[rt * (rt + 1) / 2 + ct - LO * (LO + 1) / 2][x]);
+              const int cb = (n * (2 * na - 1 - n)) >> 1;                      // packed column start minus the column index
+              famt_store(rU, ct < rt ? mok : (mok && m >= n), cb + m, accU[rt * (rt + 1) / 2 + ct - LO * (LO + 1) / 2][x]);
             }
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
             const int n = kq + 4 * x;
-            if (m < na && n < nn) FAM2_ST(&P[(nn + m) + (int64_t)n * nf], accQ[rt - LO][x]);
+            famt_store(rP, mok && n < nn, (nn + m) + n * nf, accQ[rt - LO][x]);
           }
         }
         if constexpr (WITHG) {
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
             const int jn = kq + 4 * x;
-            if (l15 < nn && jn <= l15) FAM2_ST(&P[l15 + (int64_t)jn * nf], accG[x]);
+            famt_store(rP, l15 < nn && jn <= l15, l15 + jn * nf, accG[x]);
           }
         }
       };
