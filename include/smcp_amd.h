@@ -27,7 +27,8 @@ typedef struct csp_ctx csp_ctx;
 #define SMCP_ENODEV (-2)
 #define SMCP_EHIP (-3)
 #define SMCP_ENOMEM (-4)
-#define SMCP_ESTALE (-5)  /* the prepared sharded factor was overwritten by another call: kkt_prepare_part again */
+#define SMCP_ESTALE (-5)  /* the prepared sharded factor was overwritten by another call (kkt_prepare_part again), or -- with
+                             CSP_TUNE_VERIFY_CACHE -- a cached quantity is older than the matrix it was derived from */
 
 /* ---- symbolic layer (host only, no GPU needed) ------------------------------------- */
 
@@ -215,6 +216,21 @@ int csp_hessian_sweep_part(csp_ctx* ctx, double* U, int64_t nrhs, int64_t ldu, i
  * to a buffer drops the cache entries derived from it.  A caller that changes the contents of L or
  * Y by any other means (its own kernels, memcpy) must call csp_cache_reset() before the next call. */
 int csp_cache_reset(csp_ctx* ctx);
+/* The explicit form of that contract: the caller has written to the matrix (or right-hand side) stored at `ptr` by
+ * means the library cannot see -- the reference does so with blas.scal(a, X.blkval) (solvers.py:407, 905) -- and
+ * whatever was derived from the old contents at that address is dropped (cheaper than csp_cache_reset: quantities
+ * derived from other matrices stay). */
+int csp_touch(csp_ctx* ctx, const void* ptr);
+
+/* ---- tuning / debugging knobs ------------------------------------------------------------ */
+#define CSP_TUNE_LEAFGRAM 1       /* closed-form Gram blocks of childless small cliques (front_leafgram.hip): 0 never,
+                                     1 when the entry lists are short enough to beat the panel route (default), 2 always */
+#define CSP_TUNE_VERIFY_CACHE 2   /* 1: every reuse of a cached derived quantity first checks a fingerprint of the matrix
+                                     it was derived from (one small kernel + a stream synchronisation per reuse); a
+                                     caller that forgot csp_touch gets SMCP_ESTALE instead of stale factors */
+#define CSP_TUNE_DETERMINISTIC 3  /* 1: every sum in a fixed order (no floating-point atomics): results are bit-identical
+                                     from run to run; slower */
+int csp_tune(csp_ctx* ctx, int what, int64_t value);
 
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on its own stream. */

@@ -18,7 +18,8 @@ def _chk(rc, what):
     if rc < 0:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, {
             -1: "invalid argument", -2: "no MI355X device initialised (no CPU fallback)",
-            -3: "HIP error", -4: "out of memory", -5: "prepared sharded factor overwritten"}.get(rc, "?")))
+            -3: "HIP error", -4: "out of memory",
+            -5: "stale derived quantities (prepared sharded factor overwritten, or a matrix changed without csp_touch)"}.get(rc, "?")))
 
 
 def _ensure(symb, nrhs=1):
@@ -37,6 +38,28 @@ def lazy_status(symb, on=True):
     _ensure(symb)
     _chk(_lib.lib().csp_lazy_status(symb.handle, 1 if on else 0), "csp_lazy_status")
     symb.__dict__["_lazy_status"] = bool(on)
+
+
+TUNE_LEAFGRAM, TUNE_VERIFY_CACHE, TUNE_DETERMINISTIC = 1, 2, 3
+
+
+def tune(symb, what, value):
+    """include/smcp_amd.h: csp_tune -- TUNE_LEAFGRAM (0 never / 1 when cheaper / 2 whenever possible: closed-form Gram
+    blocks of childless small cliques), TUNE_VERIFY_CACHE (1: every reuse of a cached derived quantity checks a
+    fingerprint of the matrix it came from; a forgotten ``touch`` raises instead of serving stale factors),
+    TUNE_DETERMINISTIC (1: fixed-order summation, bit-identical results from run to run)."""
+    _ensure(symb)
+    _chk(_lib.lib().csp_tune(symb.handle, int(what), int(value)), "csp_tune")
+
+
+def touch(X):
+    """Tell the library that X.blkval was rewritten by means it cannot see (torch arithmetic on the tensor, a copy into
+    it): whatever it had derived from the old contents at that address is dropped (csp_touch).  The wrappers of this
+    module track torch's in-place version counter and do this themselves; the call is for code that goes through raw
+    pointers, as the reference does with blas.scal(a, X.blkval) (solvers.py:407, 905)."""
+    if X.symb._device is not None:
+        _chk(_lib.lib().csp_touch(X.symb.handle, X.blkval.data_ptr()), "csp_touch")
+    X.touched()
 
 
 def check_status(symb, what="factorisation (deferred status)"):

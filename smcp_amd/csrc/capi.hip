@@ -553,6 +553,51 @@ void lf_prep(csp_ctx* c, const MfmaArgs& a, int cnt, const double* L, hipStream_
 // dynamic LDS of k_prep_lk: the row-block scratch of supernodes wider than 16 columns (none otherwise)
 static size_t prep_lk_lds_bytes(int nnmax) { return nnmax > 16 ? (size_t)16 * 16 * 16 * sizeof(double) : 0; }
 static int prep_lk_threads(int nnmax) { return nnmax > 16 ? NT : 128; }
+// ---- cache verification (csp_tune(ctx, CSP_TUNE_VERIFY_CACHE, 1); debug aid) ------------------------------------
+// The derived-quantity caches are keyed by the ADDRESS of the matrix they came from; a caller that rewrites the
+// matrix in place without telling the library (csp_touch) would be served stale factors.  With verification on, a
+// fingerprint of the matrix -- the wrap-around sum of the bit patterns of its diagonal entries, each multiplied by an
+// odd number that depends on its column, so exact and independent of the summation order -- is latched on the device
+// when a cache entry is created and compared when the entry is reused; a mismatch makes the call return SMCP_ESTALE.
+__global__ void k_diag_fingerprint(const CliqueDesc* cl, int nsn, const double* x, unsigned long long* slot, int* bad, int check) {
+  __shared__ unsigned long long part[256];
+  unsigned long long s = 0;
+  for (int k = blockIdx.x; k < nsn; k += gridDim.x) {
+    const CliqueDesc d = cl[k];
+    const int nf = d.nn + d.na;
+    for (int i = threadIdx.x; i < d.nn; i += blockDim.x)
+      s += (unsigned long long)__double_as_longlong(x[d.blk + i + (int64_t)i * nf]) * (2ull * (unsigned long long)(d.first + i) + 1ull);
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(slot + (check ? 4 : 0), part[0]);
+  (void)bad;
+}
+__global__ void k_fingerprint_compare(unsigned long long* slots, int which, int* bad) {
+  if (threadIdx.x == 0) { if (slots[which] != slots[which + 4]) *bad = 1 + which; slots[which + 4] = 0; }
+}
+// which: 0 = LK derived from L at this address, 1 = LK valid for the pair (L, Y) with Y at this address, 2 = Y_AA blocks of Y
+static void fp_record(csp_ctx* c, int which, const double* x, hipStream_t st) {
+  if (!c->verify_cache || !c->D.fp) return;
+  (void)hipMemsetAsync(c->D.fp + which, 0, sizeof(unsigned long long), st);
+  hipLaunchKernelGGL(k_diag_fingerprint, dim3(64), dim3(256), 0, st, c->D.cl, (int)c->S.nsn, x, c->D.fp + which, c->D.fp_bad, 0);
+}
+static int fp_check(csp_ctx* c, int which, const double* x, hipStream_t st) {
+  if (!c->verify_cache || !c->D.fp) return 0;
+  hipLaunchKernelGGL(k_diag_fingerprint, dim3(64), dim3(256), 0, st, c->D.cl, (int)c->S.nsn, x, c->D.fp + which, c->D.fp_bad, 1);
+  hipLaunchKernelGGL(k_fingerprint_compare, dim3(1), dim3(64), 0, st, c->D.fp, which, c->D.fp_bad);
+  int bad = 0;
+  if (hipMemcpyAsync(&bad, c->D.fp_bad, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return SMCP_EHIP;
+  if (bad) {
+    (void)hipMemsetAsync(c->D.fp_bad, 0, sizeof(int), st);
+    fprintf(stderr, "smcp_amd: stale cache: the matrix at %p changed since the quantities cached for it (kind %d) were derived; "
+                    "call csp_touch after writing to a matrix outside the library\n", (const void*)x, which);
+    return SMCP_ESTALE;
+  }
+  return 0;
+}
+
 void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
   TreeArgs t = tree_args(c);
   if (use_large()) {
@@ -575,6 +620,7 @@ void prep_lk(csp_ctx* c, const double* L, hipStream_t st) {
   c->D.lk_tag_Y = nullptr;
   c->D.part_valid = false;
   c->D.lk_gen++;
+  fp_record(c, 0, L, st);
 }
 // the same for the cliques of one set of the partition (clique-local: no order among the levels needed)
 void prep_lk_set(csp_ctx* c, int set, const double* L, hipStream_t st) {
@@ -590,10 +636,12 @@ void prep_lk_set(csp_ctx* c, int set, const double* L, hipStream_t st) {
 // The KKT entry points are called with (L, Y) where either LK was just prepared from this very L,
 // or Y = projected_inverse(L) was produced by csp_projected_inverse (which prepares LK from L
 // before overwriting it).  In both cases the cached LK is still the inverse form of L.
-void prep_lk_cached(csp_ctx* c, const double* L, const double* Y, hipStream_t st) {
+int prep_lk_cached(csp_ctx* c, const double* L, const double* Y, hipStream_t st) {
   const bool nocache = cache_off();
-  if (!nocache && ((c->D.lk_tag_L && c->D.lk_tag_L == L) || (c->D.lk_tag_Y && c->D.lk_tag_Y == Y))) return;
+  if (!nocache && c->D.lk_tag_L && c->D.lk_tag_L == L) return fp_check(c, 0, L, st);
+  if (!nocache && c->D.lk_tag_Y && c->D.lk_tag_Y == Y) return fp_check(c, 1, Y, st);
   prep_lk(c, L, st);
+  return 0;
 }
 // an in-place operation is about to change the matrix stored at p: forget what was derived from it
 void invalidate_tags(csp_ctx* c, const void* p) {
@@ -1048,7 +1096,8 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
     c->D.yaa_tag = Y;
     c->D.fac_tag = c->D.faci_tag = nullptr;
     c->D.part_valid = false;
-  }
+    if (Y) fp_record(c, 2, Y, st);
+  } else if (int rc = fp_check(c, 2, Y, st)) return rc;
   const bool fast = !use_generic() && use_large();
   if (need_fac && c->D.fac_tag != Y) {
     if (fast) {
@@ -1424,7 +1473,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.fp, D.fp_bad, D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1845,6 +1894,7 @@ static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set) 
     c->D.lk_tag_L = nullptr;   // x is about to be overwritten by Y: LK stays valid for the pair (L, Y = x)
     c->D.lk_tag_Y = x;
     }
+    const bool whole = !set;
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
     // The root->leaves pass gathers the separator block Y_AA of every clique into the update workspace (each clique's
     // children read it from there).  With yaa AS that workspace the blocks are where the sweeps that follow look for
@@ -1862,7 +1912,9 @@ static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set) 
       c->D.yaa_tag = x;
       c->D.fac_tag = c->D.faci_tag = nullptr;
       c->D.part_valid = false;
+      fp_record(c, 2, x, st);
     }
+    if (whole) fp_record(c, 1, x, st);
   } else
   for_levels_down(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
@@ -1937,7 +1989,7 @@ int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t
   HIPCHK(zero_flag(c, st));
   const bool refactor = need_fac && (cache_off() || c->D.fac_tag != Y);
   prepare_yaa(c, Y, need_fac, st, inv && !use_generic());
-  if (!inv && !use_generic()) prep_lk_cached(c, L, Y, st);
+  if (!inv && !use_generic()) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
   for (int64_t r0 = 0; r0 < nrhs; r0 += c->D.max_rhs) {
     int64_t nr = std::min(c->D.max_rhs, nrhs - r0);
     hessian_impl(c, L, U + r0 * ldu, nr, ldu, adj, inv, st);
@@ -2011,6 +2063,37 @@ int csp_cache_reset(csp_ctx* c) {
   if (!c) return SMCP_EINVAL;
   c->D.lk_tag_L = c->D.lk_tag_Y = c->D.yaa_tag = c->D.fac_tag = c->D.faci_tag = nullptr;
   return 0;
+}
+
+int csp_touch(csp_ctx* c, const void* p) {
+  if (!c) return SMCP_EINVAL;
+  invalidate_tags(c, p);
+  return 0;
+}
+
+int csp_tune(csp_ctx* c, int what, int64_t value) {
+  if (!c) return SMCP_EINVAL;
+  switch (what) {
+    case CSP_TUNE_LEAFGRAM:
+      if (value < 0 || value > 2) return SMCP_EINVAL;
+      c->leafgram_policy = (int)value;
+      return 0;
+    case CSP_TUNE_VERIFY_CACHE:
+      if (c->D.device < 0) return SMCP_ENODEV;
+      if (value && !c->D.fp) {
+        if (hipMalloc((void**)&c->D.fp, 8 * sizeof(unsigned long long)) != hipSuccess) return SMCP_ENOMEM;
+        if (hipMalloc((void**)&c->D.fp_bad, sizeof(int)) != hipSuccess) return SMCP_ENOMEM;
+        if (hipMemset(c->D.fp, 0, 8 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->D.fp_bad, 0, sizeof(int)) != hipSuccess) return SMCP_EHIP;
+      }
+      c->verify_cache = value != 0;
+      // entries created while verification was off carry no fingerprint: start from an empty cache
+      c->D.lk_tag_L = c->D.lk_tag_Y = c->D.yaa_tag = c->D.fac_tag = c->D.faci_tag = nullptr;
+      return 0;
+    case CSP_TUNE_DETERMINISTIC:
+      c->deterministic = value != 0;
+      return 0;
+  }
+  return SMCP_EINVAL;
 }
 
 int csp_profile_enable(csp_ctx* c, int on) {

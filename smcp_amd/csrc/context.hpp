@@ -65,6 +65,7 @@ struct DeviceCtx {
   int64_t tmplen = 0;
   double* red = nullptr;   // reduction scratch
   int* info = nullptr;     // device failure flag
+  unsigned long long* fp = nullptr; int* fp_bad = nullptr;   // cache verification: latched fingerprints [0..3], scratch [4..7], mismatch flag
   int* info_host = nullptr;  // pinned host mirror
   // constraints
   int64_t m = 0, cnnz = 0;
@@ -206,6 +207,9 @@ struct csp_ctx {
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status
   int launch_err = 0;                   // first failed kernel launch of the running call (launch helpers); read by end_call
   double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)
+  int leafgram_policy = 1;              // csp_tune: closed-form Gram blocks of the family children: 0 never, 1 when cheaper, 2 whenever possible
+  bool verify_cache = false;            // csp_tune: fingerprints of the matrices the caches were derived from are checked on reuse
+  bool deterministic = false;           // csp_tune: fixed-order summation everywhere (bit-identical results from run to run)
   std::vector<int32_t> lg_slot_of;      // clique -> index among the family children (-1: not one)
   std::vector<int64_t> gsl_key;         // the ranges (+ leaf switch) the slice table in D.gsl_* was built for
   std::vector<int64_t> h_kptr;          // ns + 1 : offsets into kidx, host copy for chunk planning

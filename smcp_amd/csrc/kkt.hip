@@ -713,7 +713,7 @@ static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_
   // kkt_qr_factor leaves its own behind
   HIPCHK(zero_flag(c, st));
   prepare_yaa(c, Y, true, st);
-  prep_lk_cached(c, L, Y, st);
+  if (int rc = prep_lk_cached(c, L, Y, st)) return rc;
   if (!D.kc_ptr) {   // the sweeps read their input from the stack: clear it and scatter the constraints into it
     HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * m * bl, st));
     for (int64_t jb = 0; jb < m; jb += 65535)
@@ -831,10 +831,10 @@ static bool leafgram_ok(csp_ctx* c, int64_t mcols) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("SMCP_LEAFGRAM"); on = (e && e[0] == '0') ? 0 : 1; }
   const DeviceCtx& D = c->D;
-  if (!on || use_generic() || !D.kc_ptr || !D.kc_ij || mcols > GRAM_BLK || mcols < 1 || D.lg_children <= 0) return false;
+  if (!on || !c->leafgram_policy || use_generic() || !D.kc_ptr || !D.kc_ij || mcols > GRAM_BLK || mcols < 1 || D.lg_children <= 0) return false;
   if (D.lg_maxent > LG_ECAP_MAX) return false;
   // the pairs of entries cost ~ as much as half as many (row, constraint) pairs moved through HBM twice
-  if (D.lg_pairs > D.lg_rows * mcols) return false;
+  if (c->leafgram_policy < 2 && D.lg_pairs > D.lg_rows * mcols) return false;
   if (!D.lg_eptr || !D.lg_tab) return false;
   const int64_t np = mcols * (mcols + 1) / 2 + 1;
   const int ecap = (int)((std::max<int64_t>(D.lg_maxent, 2) + 1) & ~1);
@@ -981,7 +981,7 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
   const int64_t md = D.md, n = c->S.n;
   if (md) {
     prepare_yaa(c, Y, true, st);
-    prep_lk_cached(c, L, Y, st);
+    if (int rc = prep_lk_cached(c, L, Y, st)) return rc;
     if (!D.kc_ptr) {
       HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * md * bl, st));
       for (int64_t jb = 0; jb < md; jb += 65535)
@@ -1041,7 +1041,7 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
   HIPCHK(zero_flag(c, st));
   if (j0 == 0 && j1 == m && use_gram()) return schur_gram(c, L, Y, H, ldh, st);
   prepare_yaa(c, Y, false, st);
-  if (!use_generic()) prep_lk_cached(c, L, Y, st);
+  if (!use_generic()) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
   for (int64_t jb = j0; jb < j1; jb += D.max_rhs) {
     int nr = (int)std::min(D.max_rhs, j1 - jb);
     HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * nr * bl, st));
@@ -1077,7 +1077,7 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   HIPCHK(zero_flag(c, st));
   // the Y_AA cache must correspond to (L, Y): recompute (cheap, one gather sweep)
   if (!(c->D.yaa_tag == Y && c->D.yaa_tag)) prepare_yaa(c, Y, false, st);
-  if (!use_generic()) prep_lk_cached(c, L, Y, st);
+  if (!use_generic()) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
   HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
   hessian_impl(c, L, r1, 1, bl, 2, 0, st);                      // r1 = W(bx)
   amap_impl(c, r1, 0, 1, ytmp, 0, st);                          // Amap(r1)

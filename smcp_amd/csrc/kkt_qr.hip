@@ -490,7 +490,7 @@ int kkt_qr_solve(csp_ctx* c, const double* L, const double* Y, double kk, double
   // factorisation between kkt_qr_factor and this call (a line-search completion, say) leaves the cache with its own
   HIPCHK(zero_flag(c, st));
   prepare_yaa(c, Y, true, st);
-  prep_lk_cached(c, L, Y, st);
+  if (int rc = prep_lk_cached(c, L, Y, st)) return rc;
   HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
   hessian_impl(c, L, r1, 1, bl, 0, 0, st);                                   // r1 = G(bx)           (solvers.py:444-447)
   // x = Q^T r1 in the weighted inner product (solvers.py:449-450); rw = sw^2 r1 in the partial-sum scratch's tail

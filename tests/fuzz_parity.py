@@ -109,6 +109,9 @@ def run(ncases, seed0=0, verbose=False, patterns=None):
         xr, yr = K.solve(Lr, Yr, Href, bx, by, kk)
         if not np.isfinite(xr).all() or np.linalg.cond(np.tril(Href)) > 1e6:
             continue
+        # closed-form Gram blocks of family children + the entry-driven family sweep (round 3): forced on every other case
+        # (the cost rule would rarely pick them on trees this small), off otherwise
+        chordal.tune(symb, chordal.TUNE_LEAFGRAM, 2 if case % 2 == 0 else 1)
         for tnz in (None, 0.0, 1.0):
             sysk = KKTSystem(symb, cptr, cidx, cval, max_rhs=symb._max_rhs, tnzcols=tnz)
             solve = sysk.factor(dev(Lr), dev(Yr))

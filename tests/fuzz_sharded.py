@@ -48,6 +48,7 @@ def worker(rank, world, port, ncases, seed0, out):
             cx, cy = cspmatrix(symb, b0.clone()), y0.clone()
             solve1(cx, cy, 0.6)
             sh = KKTSystem(symb, cptr, cidx, cval, max_rhs=mr, tnzcols=0.0)
+            chordal.tune(symb, chordal.TUNE_LEAFGRAM, 2 if case % 2 == 0 else 1)     # closed-form leaf Gram blocks, sharded too
             P = sh.set_partition(dist.group.WORLD)
             if os.environ.get("SMCP_FS_MODE") == "gram":        # replicated factor, sharded Schur complement only
                 L, Y = L1, Y1

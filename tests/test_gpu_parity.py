@@ -234,6 +234,101 @@ def test_kkt_factor_and_solve(name):
         assert np.linalg.norm(rr) / max(1, np.linalg.norm(by)) < 1e-10
 
 
+def _launch_counts(symb, fn):
+    """kernel name -> launches while fn() runs (csp_profile_*: HIP events around every launch)"""
+    import ctypes
+    from smcp_amd import _lib
+    lib = _lib.lib()
+    h = symb.handle
+    nk = int(lib.csp_profile_kinds())
+    names = [lib.csp_profile_kernel_name(i).decode() for i in range(nk)]
+    lib.csp_profile_filter(h, -1)
+    lib.csp_profile_enable(h, 1)
+    lib.csp_profile_read(h, None, None)
+    try:
+        fn()
+        torch.cuda.synchronize()
+        ms = (ctypes.c_double * nk)()
+        cnt = (ctypes.c_int64 * nk)()
+        lib.csp_profile_read(h, ms, cnt)
+    finally:
+        lib.csp_profile_enable(h, 0)
+    return {names[i]: int(cnt[i]) for i in range(nk) if cnt[i]}
+
+
+@pytest.mark.parametrize("name,m,density", [("nested_mid", 12, 0.002), ("fam_odd", 10, 0.03), ("nested", 8, 0.03)])
+def test_family_children_closed_form_gram_and_entry_driven_sweep(name, m, density):
+    """Round 3: the Schur complement of a tree with families is built WITHOUT the children's panels -- k_fam_terms sweeps
+    the parents from the entry lists (front_famt.hip), k_leaf_pairs supplies the children's Gram block in closed form
+    (front_leafgram.hip), k_gram_diag128 walks a slice table that leaves the children's rows out.  H, x, y against the
+    oracle, and the launch counters show that these kernels are the ones that ran."""
+    symb, S, A, msk = setup(name, 11)
+    rng = np.random.default_rng(12)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=13)
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+    chordal.tune(symb, chordal.TUNE_LEAFGRAM, 2)          # the test problems are too small for the cost rule to pick the route
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    box = {}
+    counts = _launch_counts(symb, lambda: box.setdefault("solve", sys.factor(Ld, Yd)))
+    assert counts.get("k_fam_terms", 0) >= 1 and counts.get("k_leaf_pairs", 0) >= 1 and counts.get("k_leaf_tables", 0) >= 1, counts
+    assert counts.get("k_gram_diag128", 0) >= 1, counts
+    Hg = np.tril(sys.H.cpu().numpy().T)
+    assert rel(Hg, np.tril(Href)) < 1e-9
+    bx = rng.standard_normal(symb.blklen) * msk
+    by = rng.standard_normal(m)
+    xr, yr = K.solve(L, Yh, Href, bx, by, 0.5)
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    box["solve"](bxd, byd, 0.5)
+    assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+    # the QR route needs the whole stack: the children's panels are formed again (k_fam_sparse), same H through Q^T Q
+    sysq = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+    counts_q = _launch_counts(symb, lambda: sysq.factor_qr(Ld, Yd))
+    assert counts_q.get("k_fam_terms", 0) == 0 and counts_q.get("k_leaf_pairs", 0) == 0, counts_q
+
+
+def test_stale_cache_is_detected_and_touch_repairs_it():
+    """the derived-quantity caches are keyed by device address; a C caller that rescales a factor in
+    place (the reference's blas.scal(a, X.blkval), solvers.py:407) and forgets csp_touch used to get results from the
+    OLD factor.  With CSP_TUNE_VERIFY_CACHE the reuse is refused (SMCP_ESTALE); after csp_touch the call is right."""
+    from smcp_amd import _lib
+    from smcp_amd.cspmatrix import _stream
+    symb, S, A, msk = setup("nested_mid", 3)
+    lib = _lib.lib()
+    chordal.tune(symb, chordal.TUNE_VERIFY_CACHE, 1)
+    try:
+        L = dev(symb, A)
+        chordal.cholesky(L)
+        Y = L.copy()
+        chordal.projected_inverse(Y)
+        rng = np.random.default_rng(5)
+        u0 = rng.standard_normal(symb.blklen) * msk
+
+        def raw_hessian(U):      # the C ABI directly: nothing between the caller's pointers and the library
+            return lib.csp_hessian(symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), U.blkval.data_ptr(), 1,
+                                   symb.blklen, 2, 0, _stream())
+
+        U1 = dev(symb, u0)
+        assert raw_hessian(U1) == 0
+        # rescale the scaling point in place behind the library's back: S -> S / 4, i.e. L -> L / 2, Y -> 4 Y
+        L.blkval.mul_(0.5)
+        Y.blkval.mul_(4.0)
+        U2 = dev(symb, u0)
+        assert raw_hessian(U2) == -5                      # SMCP_ESTALE: refused, not silently wrong
+        assert lib.csp_touch(symb.handle, L.blkval.data_ptr()) == 0 and lib.csp_touch(symb.handle, Y.blkval.data_ptr()) == 0
+        U3 = dev(symb, u0)
+        assert raw_hessian(U3) == 0
+        # H(U) = P_V(S^-1 U S^-1): S / 4 gives 16 times the first result
+        assert rel(host(U3)[msk], 16.0 * host(U1)[msk]) < 1e-12
+    finally:
+        chordal.tune(symb, chordal.TUNE_VERIFY_CACHE, 0)
+
+
 def test_two_kkt_systems_on_one_symbolic_do_not_share_constraints():
     """The constraint set lives in the Symbolic's native context; a KKTSystem re-installs its own set when another
     system has used the context in between (the first system silently ran on the second one's constraints).
