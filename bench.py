@@ -319,7 +319,9 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
             # N > 1: every sweep of the step sharded by subtree (cholesky, projected_inverse, Schur sweeps, the two
             # Hessians of solve_); boundary update blocks + H + Amap + the completed x travel over RCCL
             Ls, Ys = kkt.factor_scaling(S, dist.group.WORLD, defer_status=True)   # status agreed with H's all-reduce
-            kkt.factor(Ls, Ys, dist.group.WORLD)(bx, by, 1.0)
+            # x stays sharded (valid on this rank's cliques and the top: what a sharded consumer reads); SMCP_BENCH_COMPLETE_X=1
+            # adds the all-gather that completes it on every rank
+            kkt.factor(Ls, Ys, dist.group.WORLD)(bx, by, 1.0, complete=os.environ.get("SMCP_BENCH_COMPLETE_X") == "1")
             return
         L.blkval.copy_(S.blkval)
         chordal.cholesky(L)                  # csp_cholesky

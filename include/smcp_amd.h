@@ -187,6 +187,14 @@ int kkt_gram_accumulate(csp_ctx* ctx, int64_t nranges, const int64_t* ranges, do
 int csp_exchange_sizes(csp_ctx* ctx, int64_t world, int64_t* sizes_per_rhs);
 int csp_exchange_pack(csp_ctx* ctx, int64_t nrhs, double* buf, void* stream);
 int csp_exchange_unpack(csp_ctx* ctx, int64_t nrhs, const double* buf, int64_t width, void* stream);
+/* The boundary blocks of a sweep whose input is a linear combination of inputs that were swept (and exchanged) before
+ * need no collective: the second Hessian of solve_ is applied to Aadj(y) - bx (solvers.py:528-531), so the other
+ * ranks' root blocks are sum_i y_i (blocks gathered for constraint i during the Schur sweeps) - (blocks gathered for
+ * bx).  gbuf: the gathered buffer of a chunk of nrhs constraints (region width gwidth per rank), y: its nrhs
+ * multipliers (device), out: a buffer in the layout of a one-right-hand-side gather (region width owidth);
+ * mode 0: out <- sum - out (out holds the blocks of bx), mode 1: out <- out + sum (further chunks). */
+int csp_exchange_combine(csp_ctx* ctx, int64_t nrhs, const double* y, const double* gbuf, int64_t gwidth, double* out,
+                         int64_t owidth, int mode, void* stream);
 
 /* ---- subtree-sharded factorisation and solve (every leaves->root / root->leaves sweep of the path
  * shards; reference call sites of the sweeps: solvers.py:881-891 cholesky + projected_inverse, 521-532 the two

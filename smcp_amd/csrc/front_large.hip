@@ -1361,6 +1361,27 @@ __global__ void k_exchange_roots(const CliqueDesc* cl, const int32_t* roots, con
   }
 }
 
+// Boundary blocks of a sweep whose input is a linear combination of inputs swept before (the second Hessian of solve_:
+// Aadj(y) - bx, solvers.py:528-531): for every subtree root of ANOTHER rank
+//   out[root] = sum_i y[i] g[root][i] - out[root]   (mode 0: out holds the blocks received for bx)
+//   out[root] += sum_i y[i] g[root][i]               (mode 1: a further chunk of constraints)
+// with g the buffer gathered during the Schur sweeps of the constraints (region of rank o at o * gwidth, root q at
+// bptr[q] * nrhs, right-hand side i at + i * np) -- no collective for this sweep.
+__global__ void k_exchange_combine(const CliqueDesc* cl, const int32_t* roots, const int32_t* owner, const int64_t* bptr, int me,
+                                   int nrhs, const double* y, const double* g, int64_t gwidth, double* out, int64_t owidth, int mode) {
+  const int q = blockIdx.y;
+  if (owner[q] == me) return;
+  const CliqueDesc d = cl[roots[q]];
+  const int np = d.na * (d.na + 1) / 2;
+  const double* gq = g + owner[q] * gwidth + bptr[q] * nrhs;
+  double* oq = out + owner[q] * owidth + bptr[q];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < np; e += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int i = 0; i < nrhs; ++i) s += y[i] * gq[(int64_t)i * np + e];
+    oq[e] = mode ? oq[e] + s : s - oq[e];
+  }
+}
+
 // dst <- src on the update-layout blocks (na x na at d.upd) of the cliques of a launch list
 __global__ void k_copy_upd_blocks(TreeArgs a, const double* src, double* dst) {
   const CliqueDesc d = a.cl[a.lev[blockIdx.x]];

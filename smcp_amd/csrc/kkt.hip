@@ -1248,6 +1248,17 @@ static int exchange_roots(csp_ctx* c, int64_t nrhs, double* buf, int64_t width, 
   HIPCHK(end_call(c));
   return 0;
 }
+int csp_exchange_combine(csp_ctx* c, int64_t nrhs, const double* y, const double* gbuf, int64_t gwidth, double* out, int64_t owidth,
+                         int mode, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (c->xr_me < 0 || nrhs < 1 || !y || !gbuf || !out || mode < 0 || mode > 1) return SMCP_EINVAL;
+  if (!c->xr_n) return 0;
+  launch(c, KID_axpby, k_exchange_combine, dim3((unsigned)std::min<int64_t>(32, (c->xr_npmax + 255) / 256), (unsigned)c->xr_n),
+         dim3(256), (hipStream_t)stream, (const CliqueDesc*)c->D.cl, (const int32_t*)c->xr_roots, (const int32_t*)c->xr_owner,
+         (const int64_t*)c->xr_bptr, c->xr_me, (int)nrhs, y, gbuf, gwidth, out, owidth, mode);
+  HIPCHK(end_call(c));
+  return 0;
+}
 int csp_exchange_pack(csp_ctx* c, int64_t nrhs, double* buf, void* stream) { return exchange_roots(c, nrhs, buf, 0, 0, stream); }
 int csp_exchange_unpack(csp_ctx* c, int64_t nrhs, const double* buf, int64_t width, void* stream) {
   return exchange_roots(c, nrhs, const_cast<double*>(buf), width, 1, stream);

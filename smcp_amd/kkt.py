@@ -102,26 +102,54 @@ class ShardedSchur:
             return 1, 0
         return dist.get_world_size(group), dist.get_rank(group)
 
-    def _exchange(self, group, nrhs, live=True):
-        """Boundary exchange of a leaves->root sweep: the packed update blocks of the subtree roots of every rank
-        (nrhs right-hand sides) travel in ONE all-gather on buffers that are allocated once per width."""
+    def _exchange_plan(self, group, nrhs):
         world, rank = self._world(group)
         P = self.partition
         bufs = self.__dict__.setdefault("_xchg", {})
         if ("sizes", nrhs) not in bufs:
             bufs[("sizes", nrhs)] = [self._exchange_size(P.roots_by_rank[r], nrhs) for r in range(world)]
         sizes = bufs[("sizes", nrhs)]
-        width = max(max(sizes), 1)
-        if width not in bufs:
-            bufs[width] = (torch.zeros(width, dtype=torch.float64, device=self.dev),
-                           torch.empty(width * world, dtype=torch.float64, device=self.dev))
-        send, recv = bufs[width]
+        return bufs, sizes, max(max(sizes), 1)
+
+    def _exchange(self, group, nrhs, live=True, keep=None):
+        """Boundary exchange of a leaves->root sweep: the packed update blocks of the subtree roots of every rank
+        (nrhs right-hand sides) travel in ONE all-gather on buffers that are allocated once per width.
+        keep: a key under which the gathered buffer stays untouched by later exchanges (the Schur sweeps' blocks are
+        combined again by the second Hessian of solve_, _exchange_local)."""
+        world, rank = self._world(group)
+        P = self.partition
+        bufs, sizes, width = self._exchange_plan(group, nrhs)
+        key = width if keep is None else ("keep", keep, width)
+        if key not in bufs:
+            bufs[key] = (torch.zeros(width, dtype=torch.float64, device=self.dev),
+                         torch.empty(width * world, dtype=torch.float64, device=self.dev))
+        send, recv = bufs[key]
         if sizes[rank] and live:
             self._exchange_pack(P.roots_by_rank[rank], nrhs, send[:sizes[rank]])
         _all_gather_into(recv, send, group)
         self.collectives += 1
         if live:       # a rank whose sweep has failed only keeps the collective matched
             self._exchange_unpack_all(P, rank, nrhs, recv, width, sizes)
+        return recv, width
+
+    # most doubles kept from the Schur sweeps for the collective-free exchange of solve_'s second Hessian
+    KEEP_LIMIT = 1 << 28
+
+    def _exchange_local(self, group, y):
+        """The boundary blocks of the second Hessian of solve_ WITHOUT a collective: its input is Aadj(y) - bx
+        (solvers.py:528-531), so the other ranks' root blocks are sum_i y_i (blocks gathered for constraint i by the
+        Schur sweeps) - (blocks gathered for bx by the first Hessian) -- both are on this rank already."""
+        world, rank = self._world(group)
+        P = self.partition
+        bufs, sizes1, width1 = self._exchange_plan(group, 1)
+        recv1 = bufs[width1][1]                       # what the first Hessian's exchange gathered
+        if ("local", width1) not in bufs:
+            bufs[("local", width1)] = torch.empty(width1 * world, dtype=torch.float64, device=self.dev)
+        out = bufs[("local", width1)]
+        out.copy_(recv1)
+        for n, (j0, j1, recv, width) in enumerate(self._kept):
+            self._exchange_combine(P, rank, j1 - j0, y[j0:j1], recv, width, out, width1, 0 if n == 0 else 1)
+        self._exchange_unpack_all(P, rank, 1, out, width1, sizes1)
 
     def _exchange_unpack_all(self, P, rank, nrhs, recv, width, sizes):
         for r in range(len(sizes)):
@@ -163,11 +191,20 @@ class ShardedSchur:
         else:
             guarded(self._gram_prepare, L, Y)
         step = self._gram_chunk()
-        for j0 in range(0, self.m, step):
+        # the gathered root blocks of every chunk are kept (if they fit KEEP_LIMIT doubles): solve_'s second Hessian
+        # forms its own boundary blocks from them instead of a third exchange
+        _, sizes_m, width_m = self._exchange_plan(group, min(step, self.m))
+        keep = width_m * world * ((self.m + step - 1) // step) <= self.KEEP_LIMIT
+        self._kept = []
+        for n, j0 in enumerate(range(0, self.m, step)):
             j1 = min(self.m, j0 + step)
             guarded(self._gram_sweep, 1, j0, j1)                         # owned subtrees
-            self._exchange(group, j1 - j0, live=err[0] is None)
+            recv, width = self._exchange(group, j1 - j0, live=err[0] is None, keep=n if keep else None)
+            if keep:
+                self._kept.append((j0, j1, recv, width))
             guarded(self._gram_sweep, 2, j0, j1)                         # replicated top
+        if not keep:
+            self._kept = None
         ranges = list(P.ranges_by_rank[rank]) + (list(P.top_ranges) if rank == 0 else [])
         guarded(self._gram_accumulate, ranges)
         guarded(self._deferred_status)               # chordal.lazy_status: the one read-back of the step happens here
@@ -240,9 +277,12 @@ class ShardedSchur:
         top (up), top -> owned (down); Amap sums over the blkval ranges this rank accounts for and ONE all-reduce
         completes it; the m x m solve is replicated.  With complete=True one all-gather of the owned ranges fills x in on every
         rank, otherwise x is valid on the owned cliques and the top (what the next sharded sweep needs)."""
-        def W(U):
+        def W(U, y=None):
             self._hess_part(U, 1, 0)
-            self._exchange(group, 1)
+            if y is not None and getattr(self, "_kept", None):
+                self._exchange_local(group, y)       # no collective: Aadj(y) - bx is a combination of swept inputs
+            else:
+                self._exchange(group, 1)
             self._hess_part(U, 2, 0)
             self._hess_part(U, 2, 1)
             self._hess_part(U, 1, 1)
@@ -257,7 +297,7 @@ class ShardedSchur:
         x = self.aadj(by)
         bx.blkval.neg_().add_(x.blkval)
         bx.touched()
-        W(bx)
+        W(bx, by)
         bx.blkval.mul_(1.0 / kk)
         if complete:
             self._complete_owned(bx, group)
@@ -413,6 +453,10 @@ class KKTSystem(ShardedSchur):
     def _exchange_pack(self, cliques, nrhs, out):
         # this rank's subtree roots (the list csp_set_partition derived from the owner array: the same cliques)
         _chk(_lib.lib().csp_exchange_pack(self.symb.handle, int(nrhs), out.data_ptr(), _stream()), "csp_exchange_pack")
+
+    def _exchange_combine(self, P, rank, nrhs, y, recv, width, out, owidth, mode):
+        _chk(_lib.lib().csp_exchange_combine(self.symb.handle, int(nrhs), y.data_ptr(), recv.data_ptr(), int(width),
+                                             out.data_ptr(), int(owidth), int(mode), _stream()), "csp_exchange_combine")
 
     def _exchange_unpack_all(self, P, rank, nrhs, recv, width, sizes):
         _chk(_lib.lib().csp_exchange_unpack(self.symb.handle, int(nrhs), recv.data_ptr(), int(width), _stream()),

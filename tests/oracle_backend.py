@@ -81,6 +81,21 @@ class OracleKKT(kkt.ShardedSchur):
                 u[S.updptr[k]:S.updptr[k + 1]] = b[o:o + n]
                 o += n
 
+    def _exchange_combine(self, P, rank, nrhs, y, recv, width, out, owidth, mode):
+        """numpy form of csp_exchange_combine on the oracle's exchange layout ([clique][rhs][square block])"""
+        S = self.K.S
+        g, o, yv = recv.numpy(), out.numpy(), y.numpy()
+        for r, cliques in enumerate(P.roots_by_rank):
+            if r == rank:
+                continue
+            og, oo = r * width, r * owidth
+            for k in cliques:
+                n = int(S.updptr[k + 1] - S.updptr[k])
+                acc = yv @ g[og:og + nrhs * n].reshape(nrhs, n)
+                o[oo:oo + n] = (o[oo:oo + n] + acc) if mode else (acc - o[oo:oo + n])
+                og += nrhs * n
+                oo += n
+
     # ---- sharded factorisation / solve, emulated with the oracle's masked sweeps
     def _upd1(self):
         if "_u1" not in self.__dict__:
