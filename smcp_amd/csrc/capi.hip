@@ -312,10 +312,12 @@ bool cache_off() {
   return nocache == 1;
 }
 
-bool use_generic() {
+// the any-size, fixed-order kernels of front_generic.hip for every tree operation: SMCP_GENERIC=1 (process-wide) or
+// csp_tune(ctx, CSP_TUNE_DETERMINISTIC, 1) -- no floating-point atomics anywhere, results bit-identical from run to run
+bool use_generic(const csp_ctx* c) {
   static int g = -1;
   if (g < 0) { const char* e = getenv("SMCP_GENERIC"); g = (e && e[0] == '1') ? 1 : 0; }
-  return g == 1;
+  return g == 1 || (c && c->deterministic);
 }
 
 MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
@@ -414,12 +416,24 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
     static int alds = -1;
     if (alds < 0) { const char* e = getenv("SMCP_ALDS"); alds = (e && e[0] == '0') ? 0 : 1; }
     const int nfmax = a.nnmax + a.namax;
-    const size_t bytes = (size_t)(lf_alds_doubles(nfmax) + 3 * a.nchmax + 2) * sizeof(double);   // front + child table
-    if (alds && a.nchmax > 0 && (int64_t)cnt * nrhs >= 32 && nfmax <= LF_ALDS_MAXNF && bytes <= LDS_LIMIT) {   // enough workgroups to fill the chip
+    // workgroups per (front, right-hand side): one, unless a front has so many children that one CU would stream them
+    // for long (config 3: 1999 children of the root, 100 pairs) -- then the children are dealt over nz workgroups whose
+    // partial fronts meet in global memory (atomics; the update blocks are cleared first).  SMCP_ALDS_Z overrides.
+    static int zenv = -1;
+    if (zenv < 0) { const char* e = getenv("SMCP_ALDS_Z"); zenv = e ? atoi(e) : 0; }
+    const int64_t pairs = std::max<int64_t>(1, (int64_t)cnt * nrhs);
+    int nz = 1;
+    if (zenv > 0) nz = zenv;
+    else if (a.nchmax >= 256) nz = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)a.nchmax / 16, (int64_t)64, (4 * (int64_t)c->D.ncu + pairs - 1) / pairs}));
+    nz = std::max(1, std::min(nz, std::max(1, a.nchmax)));
+    const size_t bytes = (size_t)(lf_alds_doubles(nfmax) + 3 * ((a.nchmax + nz - 1) / nz) + 2) * sizeof(double);   // front + child table
+    if (alds && a.nchmax > 0 && pairs * nz >= 32 && nfmax <= LF_ALDS_MAXNF && bytes <= LDS_LIMIT) {   // enough workgroups to fill the chip
       static bool attr = false;
       if (!attr) { attr = hipFuncSetAttribute((const void*)k_lf_assemble_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess; }
       if (attr) {
-        launch_lds(c, KID_lf_assemble_lds, k_lf_assemble_lds, dim3(cnt, nrhs), dim3(1024), bytes, st, a, U, ldu, sgn);
+        if (nz > 1 && sgn == 0)
+          launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), dim3(256), st, a);
+        launch_lds(c, KID_lf_assemble_lds, k_lf_assemble_lds, dim3(cnt, nrhs, nz), dim3(1024), bytes, st, a, U, ldu, sgn);
         return;
       }
     }
@@ -1098,7 +1112,7 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
     c->D.part_valid = false;
     if (Y) fp_record(c, 2, Y, st);
   } else if (int rc = fp_check(c, 2, Y, st)) return rc;
-  const bool fast = !use_generic() && use_large();
+  const bool fast = !use_generic(c) && use_large();
   if (need_fac && c->D.fac_tag != Y) {
     if (fast) {
       // k_factor_yaa_lds reads yaa and writes the lower triangle of fac (what every reader of fac uses; the strict upper
@@ -1234,7 +1248,7 @@ int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t l
   auto scale = [&](int mode) {
     launch(c, KID_scale_an, k_scale_an, dim3(nsn, (int)nrhs), dim3(NT), st, a, c->D.yaa, c->D.fac, U, ldu, mode);
   };
-  if (!inv && !use_generic()) {
+  if (!inv && !use_generic(c)) {
     // LK must have been prepared for this L (prep_lk) by the caller
     if (adj == 0) hess_up_fast(c, U, (int)nrhs, ldu, c->D.fac, 2, st);
     else if (adj == 1) hess_down_fast(c, U, (int)nrhs, ldu, c->D.fac, 3, st);
@@ -1243,7 +1257,7 @@ int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t l
     if (adj == 0) { up(); scale(0); }
     else if (adj == 1) { scale(1); down(); }
     else { up(); scale(4); down(); }
-  } else if (!use_generic()) {
+  } else if (!use_generic(c)) {
     if (adj == 0) hess_up_inv_fast(c, L, U, (int)nrhs, ldu, 3, st);
     else if (adj == 1) hess_down_inv_fast(c, L, U, (int)nrhs, ldu, 2, st);
     else { hess_down_inv_fast(c, L, U, (int)nrhs, ldu, 1, st); hess_up_inv_fast(c, L, U, (int)nrhs, ldu, 0, st); }
@@ -1818,7 +1832,7 @@ int64_t csp_device_bytes(const csp_ctx* c) { return c ? c->D.bytes : 0; }
 static int cholesky_impl(csp_ctx* c, double* x, void* stream, int set);
 int csp_cholesky(csp_ctx* c, double* x, void* stream) { return cholesky_impl(c, x, stream, 0); }
 int csp_cholesky_part(csp_ctx* c, double* x, int set, void* stream) {
-  if (set < 1 || set > 2 || !c || !c->sets[set].lev2 || use_generic()) return SMCP_EINVAL;
+  if (set < 1 || set > 2 || !c || !c->sets[set].lev2 || use_generic(c)) return SMCP_EINVAL;
   return cholesky_impl(c, x, stream, set);
 }
 static int cholesky_impl(csp_ctx* c, double* x, void* stream, int set) {
@@ -1827,7 +1841,7 @@ static int cholesky_impl(csp_ctx* c, double* x, void* stream, int set) {
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
   HIPCHK(zero_flag(c, st));
-  if (!use_generic()) {
+  if (!use_generic(c)) {
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
     a0.LK = nullptr;
     for (int64_t l = 0; l < c->S.nlev; ++l)
@@ -1851,7 +1865,7 @@ int csp_llt(csp_ctx* c, double* x, void* stream) {
   invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
-  if (!use_generic()) {
+  if (!use_generic(c)) {
     MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
     a0.LK = nullptr;
     dim3 blk(256);
@@ -1879,7 +1893,7 @@ int csp_llt(csp_ctx* c, double* x, void* stream) {
 static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set);
 int csp_projected_inverse(csp_ctx* c, double* x, void* stream) { return projected_inverse_impl(c, x, stream, 0); }
 int csp_projected_inverse_part(csp_ctx* c, double* x, int set, void* stream) {
-  if (set < 1 || set > 2 || !c || !c->sets[set].lev2 || use_generic()) return SMCP_EINVAL;
+  if (set < 1 || set > 2 || !c || !c->sets[set].lev2 || use_generic(c)) return SMCP_EINVAL;
   return projected_inverse_impl(c, x, stream, set);
 }
 static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set) {
@@ -1887,7 +1901,7 @@ static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set) 
   invalidate_tags(c, x);
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
-  if (!use_generic()) {
+  if (!use_generic(c)) {
     if (set) { prep_lk_set(c, set, x, st); c->D.lk_tag_L = nullptr; c->D.lk_tag_Y = nullptr; }   // partial: no cache claim
     else {
     prep_lk(c, x, st);
@@ -1930,7 +1944,7 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   TreeArgs a = tree_args(c);
   HIPCHK(zero_flag(c, st));
-  if (!use_generic()) {
+  if (!use_generic(c)) {
     // clique-local given chol(X_AA) and its inverse of every clique (taken from the input before it is overwritten)
     prepare_yaa(c, x, true, st, true);
     MfmaArgs a0 = mfma_args(c, c->D.faci, 0, 1);
@@ -1988,8 +2002,8 @@ int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t
   invalidate_tags(c, U);
   HIPCHK(zero_flag(c, st));
   const bool refactor = need_fac && (cache_off() || c->D.fac_tag != Y);
-  prepare_yaa(c, Y, need_fac, st, inv && !use_generic());
-  if (!inv && !use_generic()) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
+  prepare_yaa(c, Y, need_fac, st, inv && !use_generic(c));
+  if (!inv && !use_generic(c)) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
   for (int64_t r0 = 0; r0 < nrhs; r0 += c->D.max_rhs) {
     int64_t nr = std::min(c->D.max_rhs, nrhs - r0);
     hessian_impl(c, L, U + r0 * ldu, nr, ldu, adj, inv, st);
@@ -2026,7 +2040,7 @@ int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, 
 
 static int reduce_impl(csp_ctx* c, const double* X, const double* Y, int mode, double* out, hipStream_t st) {
   int nb = 512;
-  if (c->D.sw && !use_generic()) {
+  if (c->D.sw && !use_generic(c)) {
     launch(c, KID_reduce_cliques, k_reduce_flat, dim3(nb), dim3(NT), st, c->S.blklen(), (const double*)c->D.sw, X, Y, mode, c->D.red);
   } else {
     nb = (int)std::min<int64_t>(c->S.nsn, 512);

@@ -230,12 +230,17 @@ __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u,
   // child table in LDS (packed-update offset, separator size, relative-index offset): a wave starting on a child
   // then pays one memory latency (its relative indices and first columns together), not a chain of four
   const int nch = d.chend - d.chbeg;
+  // (gridDim.z workgroups share the children of the pair: this one takes the children wz, wz + nz, ... -- its table
+  // holds only those)
+  const int wz = (int)blockIdx.z, nz = (int)gridDim.z;
+  const int nmine = (nch - wz + nz - 1) / nz;
+  const int tcap = (a.nchmax + nz - 1) / nz;
   int64_t* const sCu = reinterpret_cast<int64_t*>(T + lf_alds_doubles(a.nnmax + a.namax));
-  int64_t* const sCr = sCu + a.nchmax;
-  int* const sCn = reinterpret_cast<int*>(sCr + a.nchmax);
-  for (int q = tid; q < nch; q += nthr) {
-    const CliqueDesc c = a.t.cl[a.t.chidx[d.chbeg + q]];
-    sCu[q] = c.updp; sCr[q] = c.rel; sCn[q] = c.na;
+  int64_t* const sCr = sCu + tcap;
+  int* const sCn = reinterpret_cast<int*>(sCr + tcap);
+  for (int qi = tid; qi < nmine; qi += nthr) {
+    const CliqueDesc c = a.t.cl[a.t.chidx[d.chbeg + wz + qi * nz]];
+    sCu[qi] = c.updp; sCr[qi] = c.rel; sCn[qi] = c.na;
   }
   for (int e = tid; e < ntot; e += nthr) T[e] = 0.0;
   __syncthreads();
@@ -244,18 +249,34 @@ __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u,
   auto cb = [nf](int j) { return j * nf - ((j * (j - 1)) >> 1) - j; };
   // fewer children than waves: `parts` waves share a child and take its column batches round-robin (eight children
   // on sixteen waves left half of the workgroup idle)
-  const int parts = nch < nw ? max(1, nw / nch) : 1;
-  const int part = parts > 1 ? wave / nch : 0;
-  for (int q = parts > 1 ? wave % nch : wave; q < nch && part < parts; q += nw) {
-    const int nac = sCn[q];
-    const int32_t* rel = a.t.relidx + sCr[q];
-    const double* Uc = ubase + sCu[q];
+  // gridDim.z workgroups share the children of a (front, right-hand side) pair (child q belongs to workgroup
+  // q mod gridDim.z) and add their partial fronts into the panel / the cleared update block with global atomics: a
+  // front with very many children (config 3: 1999 under the root, i.e. 100 workgroups for 13 GB of child blocks) or a
+  // launch whose workgroup count leaves a poor last round is spread finer this way
+  const int parts = nmine < nw ? max(1, nw / max(nmine, 1)) : 1;
+  const int part = parts > 1 ? wave / max(nmine, 1) : 0;
+  for (int qi = parts > 1 ? wave % max(nmine, 1) : wave; qi < nmine && part < parts; qi += nw) {
+    const int nac = sCn[qi];
+    const int32_t* rel = a.t.relidx + sCr[qi];
+    const double* Uc = ubase + sCu[qi];
     if (nac <= 64) lf_add_child<16, false>(T, nf, Uc, rel, nac, lane, part, parts);
     else lf_add_child<8, true>(T, nf, Uc, rel, nac, lane, part, parts);
   }
   __syncthreads();
   double* P = u + (int64_t)r * ldu + d.blk;
   double* U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+  if (nz > 1) {        // partial front: atomics into the panel and the (pre-cleared or accumulating) update block
+    const double spz = (sgn == 1) ? -1.0 : 1.0;
+    for (int e = tid; e < nf * nn; e += nthr) {
+      const int i = e % nf, j = e / nf;
+      if (i >= j) { const double v = T[cb(j) + i]; if (v != 0.0) unsafeAtomicAdd(&P[e], spz * v); }
+    }
+    for (int e = tid; e < na * na; e += nthr) {
+      const int i = e % na, j = e / na;
+      if (i >= j) { const double v = T[cb(nn + j) + nn + i]; if (v != 0.0) unsafeAtomicAdd(&U[e], v); }
+    }
+    return;
+  }
   // write-out: flat loops over the rectangular panel / the square update block with eight read-modify-writes in
   // flight per thread (a column-by-column loop would pay one memory latency per column)
   const double sp = (sgn == 1) ? -1.0 : 1.0;

@@ -360,7 +360,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
     // (synth50k: 100 sorts of 23 k indices, 65 ms on one thread); the lists are then joined in constraint order
     std::vector<std::vector<int32_t>> kss((size_t)m);
     std::vector<char> is_sparse((size_t)m, 0);
-    const bool scm_on = !off && !use_generic();
+    const bool scm_on = !off && !use_generic(c);
     const int64_t cap = std::min(kcap, trsm_cap);
     {
       const unsigned hw = std::thread::hardware_concurrency();
@@ -604,7 +604,7 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
     HIPCHK(end_call(c));
     return fetch_info(c, st);
   }
-  if (!use_generic() && n <= 2 * LB) {
+  if (!use_generic(c) && n <= 2 * LB) {
     const int64_t need = 8 * 256 + 2 * n;
     if (c->D.hinv_cap < need) {
       if (c->D.hinv) { HIPCHK(hipFree(c->D.hinv)); c->D.bytes -= c->D.hinv_cap * 8; }
@@ -619,7 +619,7 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
       attr_set = true;
     }
     launch_lds(c, KID_dense_potrf, k_dense_potrf_small, dim3(1), potrf_blk(), lds, st, A, (int)n, lda, c->D.info, c->D.hinv);
-  } else if (use_generic()) {
+  } else if (use_generic(c)) {
     launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
   } else {
     // blocked right-looking Cholesky, 64-wide block columns: diagonal block by one workgroup, panel and
@@ -649,7 +649,7 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
   }
   HIPCHK(end_call(c));
   int rc = fetch_info(c, st);
-  if (!rc && !use_generic()) { c->D.hinv_tag = A; c->D.hinv_n = n; }
+  if (!rc && !use_generic(c)) { c->D.hinv_tag = A; c->D.hinv_n = n; }
   return rc;
 }
 // potrs with the factor of dense_potrf.  A single right-hand side of a factor produced by the blocked dense_potrf
@@ -695,10 +695,10 @@ int dense_potrs(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, 
   return 0;
 }
 
-static bool use_gram() {
+static bool use_gram(const csp_ctx* c) {
   static int g = -1;
   if (g < 0) { const char* e = getenv("SMCP_GRAM"); g = (e && e[0] == '0') ? 0 : 1; }
-  return g == 1 && !use_generic();
+  return g == 1 && !use_generic(c);
 }
 
 // Gram formulation of the whole Schur complement (what kkt_qr implies, solvers.py:414-420):
@@ -831,7 +831,7 @@ static bool leafgram_ok(csp_ctx* c, int64_t mcols) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("SMCP_LEAFGRAM"); on = (e && e[0] == '0') ? 0 : 1; }
   const DeviceCtx& D = c->D;
-  if (!on || !c->leafgram_policy || use_generic() || !D.kc_ptr || !D.kc_ij || mcols > GRAM_BLK || mcols < 1 || D.lg_children <= 0) return false;
+  if (!on || !c->leafgram_policy || use_generic(c) || !D.kc_ptr || !D.kc_ij || mcols > GRAM_BLK || mcols < 1 || D.lg_children <= 0) return false;
   if (D.lg_maxent > LG_ECAP_MAX) return false;
   // the pairs of entries cost ~ as much as half as many (row, constraint) pairs moved through HBM twice
   if (c->leafgram_policy < 2 && D.lg_pairs > D.lg_rows * mcols) return false;
@@ -1039,9 +1039,9 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
   hipStream_t st = (hipStream_t)stream;
   D.qr_valid = false;
   HIPCHK(zero_flag(c, st));
-  if (j0 == 0 && j1 == m && use_gram()) return schur_gram(c, L, Y, H, ldh, st);
+  if (j0 == 0 && j1 == m && use_gram(c)) return schur_gram(c, L, Y, H, ldh, st);
   prepare_yaa(c, Y, false, st);
-  if (!use_generic()) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
+  if (!use_generic(c)) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
   for (int64_t jb = j0; jb < j1; jb += D.max_rhs) {
     int nr = (int)std::min(D.max_rhs, j1 - jb);
     HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * nr * bl, st));
@@ -1077,7 +1077,7 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   HIPCHK(zero_flag(c, st));
   // the Y_AA cache must correspond to (L, Y): recompute (cheap, one gather sweep)
   if (!(c->D.yaa_tag == Y && c->D.yaa_tag)) prepare_yaa(c, Y, false, st);
-  if (!use_generic()) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
+  if (!use_generic(c)) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
   HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
   hessian_impl(c, L, r1, 1, bl, 2, 0, st);                      // r1 = W(bx)
   amap_impl(c, r1, 0, 1, ytmp, 0, st);                          // Amap(r1)
@@ -1130,7 +1130,7 @@ int csp_set_partition(csp_ctx* c, const int32_t* owner, int rank) {
 }
 int kkt_gram_prepare(csp_ctx* c, const double* L, const double* Y, void* stream) {
   if (int rc = ready(c)) return rc;
-  if (!c->D.m || use_generic()) return SMCP_EINVAL;
+  if (!c->D.m || use_generic(c)) return SMCP_EINVAL;
   return gram_prepare(c, L, Y, (hipStream_t)stream);
 }
 // the same when the factor (L, Y) is valid on the owned cliques and the top only: kkt_prepare_part has been called
@@ -1138,7 +1138,7 @@ int kkt_gram_prepare(csp_ctx* c, const double* L, const double* Y, void* stream)
 int kkt_gram_prepare_part(csp_ctx* c, void* stream) {
   if (int rc = ready(c)) return rc;
   DeviceCtx& D = c->D;
-  if (!D.m || use_generic()) return SMCP_EINVAL;
+  if (!D.m || use_generic(c)) return SMCP_EINVAL;
   if (!D.part_valid) return SMCP_ESTALE;
   hipStream_t st = (hipStream_t)stream;
   const int64_t m = D.m, bl = c->S.blklen();
@@ -1176,7 +1176,7 @@ int kkt_gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, doub
 // a subtree root gathers from its parent's panel, which lies in the top); with_lk: also the inverse-form factor of L.
 int kkt_prepare_part(csp_ctx* c, const double* L, const double* Y, int set, int with_lk, void* stream) {
   if (int rc = ready(c)) return rc;
-  if (set < 1 || set > 2 || !c->sets[set].lev2 || use_generic() || !use_large()) return SMCP_EINVAL;
+  if (set < 1 || set > 2 || !c->sets[set].lev2 || use_generic(c) || !use_large()) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   DeviceCtx& D = c->D;
   D.yaa_tag = D.fac_tag = D.faci_tag = nullptr;        // partial content: nothing to claim for the caches
@@ -1222,7 +1222,7 @@ int kkt_prepare_part(csp_ctx* c, const double* L, const double* Y, int set, int 
 // between the owned and the top pass of dir 0 (csp_exchange_pack / unpack); dir 1 needs no exchange.
 int csp_hessian_sweep_part(csp_ctx* c, double* U, int64_t nrhs, int64_t ldu, int set, int dir, void* stream) {
   if (int rc = ready(c)) return rc;
-  if (set < 1 || set > 2 || !c->sets[set].lev2 || use_generic() || nrhs < 1 || nrhs > c->D.max_rhs) return SMCP_EINVAL;
+  if (set < 1 || set > 2 || !c->sets[set].lev2 || use_generic(c) || nrhs < 1 || nrhs > c->D.max_rhs) return SMCP_EINVAL;
   if (!c->D.part_valid) return SMCP_ESTALE;
   hipStream_t st = (hipStream_t)stream;
   if (dir == 0) hess_up_fast(c, U, (int)nrhs, ldu, c->D.yaa, 1, st, set);

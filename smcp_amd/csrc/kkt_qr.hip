@@ -360,7 +360,7 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
   if (int rc = ready(c)) return rc;
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
-  if (!m || use_generic()) return SMCP_EINVAL;
+  if (!m || use_generic(c)) return SMCP_EINVAL;
   if (D.ns) return SMCP_EINVAL;                 // every constraint must be swept (kkt_set_tnzcols(0) before the constraints)
   if (D.max_rhs < 1 || D.ustack_cols < m) return SMCP_EINVAL;
   if (m > 320) return SMCP_ENOMEM;              // k_stack_trsm keeps m / 8 rows per wave in registers: m <= 320 in this build

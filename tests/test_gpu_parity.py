@@ -329,6 +329,39 @@ def test_stale_cache_is_detected_and_touch_repairs_it():
         chordal.tune(symb, chordal.TUNE_VERIFY_CACHE, 0)
 
 
+def test_deterministic_mode_is_bit_identical_from_run_to_run():
+    """csp_tune(CSP_TUNE_DETERMINISTIC, 1) routes every tree operation through the fixed-order kernels
+    (no floating-point atomics: the default extend-adds sum children with ds_add_f64 in arrival order): H, x and y of
+    five whole KKT solves are bit-identical, and agree with the default (atomic) route to rounding."""
+    symb, S, A, msk = setup("nested_mid", 21)
+    rng = np.random.default_rng(22)
+    m = 9
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.01, seed=23)
+    b0 = rng.standard_normal(symb.blklen) * msk
+    y0 = rng.standard_normal(m)
+
+    def whole_solve():
+        sysk = KKTSystem(symb, cptr, cidx, cval, max_rhs=4, tnzcols=0.0)
+        L = dev(symb, A)
+        chordal.cholesky(L)
+        Y = L.copy()
+        chordal.projected_inverse(Y)
+        f = sysk.factor(L, Y)
+        bx, by = dev(symb, b0), torch.from_numpy(y0.copy()).cuda()
+        f(bx, by, 0.7)
+        return sysk.H.cpu().numpy().copy(), host(bx).copy(), by.cpu().numpy().copy()
+
+    Hd, xd, yd = whole_solve()                                  # default route
+    chordal.tune(symb, chordal.TUNE_DETERMINISTIC, 1)
+    try:
+        runs = [whole_solve() for _ in range(5)]
+    finally:
+        chordal.tune(symb, chordal.TUNE_DETERMINISTIC, 0)
+    for H, x, y in runs[1:]:
+        assert np.array_equal(H, runs[0][0]) and np.array_equal(x, runs[0][1]) and np.array_equal(y, runs[0][2])
+    assert rel(runs[0][0], Hd) < 1e-12 and rel(runs[0][1][msk], xd[msk]) < 1e-11 and rel(runs[0][2], yd) < 1e-11
+
+
 def test_two_kkt_systems_on_one_symbolic_do_not_share_constraints():
     """The constraint set lives in the Symbolic's native context; a KKTSystem re-installs its own set when another
     system has used the context in between (the first system silently ran on the second one's constraints).
