@@ -1487,7 +1487,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.fp, D.fp_bad, D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.trsm_x, D.fp, D.fp_bad, D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -2017,10 +2017,40 @@ int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t
   return 0;
 }
 
-int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, int trans, void* stream) {
-  if (int rc = ready(c)) return rc;
-  if (nrhs < 1 || ldb < c->S.n) return SMCP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
+// Y: the matrix whose pair (L, Y) the cached inverse-form factor may belong to (null: only a factor cached for L itself
+// is reused, otherwise it is formed from L)
+int trsm_impl(csp_ctx* c, const double* L, const double* Y, double* B, int64_t nrhs, int64_t ldb, int trans, hipStream_t st) {
+  static int mm = -1;
+  if (mm < 0) { const char* e = getenv("SMCP_TRSM_MM"); mm = (e && e[0] == '0') ? 0 : 1; }
+  if (mm && !use_generic(c) && use_large() && nrhs >= 8) {
+    // tile products with the inverse-form factor (front_large.hip: k_trsm_mm_*): the generic kernels below solve every
+    // clique's triangle by substitution in one workgroup per sixteen columns -- 0.48 ms per level on config 4
+    if (int rc = prep_lk_cached(c, L, Y, st)) return rc;
+    const int64_t need = ldb * nrhs;
+    DeviceCtx& D = c->D;
+    if (D.trsm_x_len < need) {
+      if (D.trsm_x) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(D.trsm_x)); D.bytes -= D.trsm_x_len * 8; D.trsm_x = nullptr; D.trsm_x_len = 0; }
+      if (int rc = dev_alloc(&D.trsm_x, need, D.bytes)) return rc;
+      D.trsm_x_len = need;
+    }
+    MfmaArgs a0 = mfma_args(c, nullptr, 0, (int)nrhs);
+    const unsigned ct = (unsigned)tiles64((int)nrhs);
+    auto level = [&](int64_t l) {
+      const LevelClass& Lc = c->lvl[l];
+      const int cnt = (int)(Lc.nI + Lc.nII);
+      if (!cnt) return;
+      MfmaArgs a = a0;
+      a.t.lev = c->D.lev2idx + c->S.levptr[l];
+      const int nnm = std::max(Lc.nnmaxI, Lc.nnmaxII), nfm = std::max(Lc.nnmaxI + Lc.namaxI, Lc.nnmaxII + Lc.namaxII);
+      if (!trans) launch(c, KID_trsm_fwd_level, k_trsm_mm_fwd, dim3(umax1(tiles64(nfm)), cnt, ct), dim3(256), st, a, B, (int)nrhs, ldb, (const int32_t*)c->D.rowidx, D.trsm_x);
+      else launch(c, KID_trsm_bwd_level, k_trsm_mm_bwd, dim3(umax1(tiles64(nnm)), cnt, ct), dim3(256), st, a, B, (int)nrhs, ldb, (const int32_t*)c->D.rowidx, D.trsm_x);
+      launch(c, KID_axpby, k_trsm_mm_copy, dim3((unsigned)std::min<int64_t>(64, ((int64_t)nnm * nrhs + 255) / 256), cnt), dim3(256), st, a, B, (int)nrhs, ldb, (const double*)D.trsm_x);
+    };
+    if (!trans) for (int64_t l = 0; l < c->S.nlev; ++l) level(l);
+    else for (int64_t l = c->S.nlev - 1; l >= 0; --l) level(l);
+    HIPCHK(end_call(c));
+    return 0;
+  }
   if (c->S.sepptr[c->S.nsn] * nrhs > c->D.max_rhs * c->D.tmplen) return SMCP_ENOMEM;
   TreeArgs a = tree_args(c);
   if (!trans) {
@@ -2036,6 +2066,11 @@ int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, 
   }
   HIPCHK(end_call(c));
   return 0;
+}
+int csp_trsm(csp_ctx* c, const double* L, double* B, int64_t nrhs, int64_t ldb, int trans, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (nrhs < 1 || ldb < c->S.n) return SMCP_EINVAL;
+  return trsm_impl(c, L, nullptr, B, nrhs, ldb, trans, (hipStream_t)stream);
 }
 
 static int reduce_impl(csp_ctx* c, const double* X, const double* Y, int mode, double* out, hipStream_t st) {

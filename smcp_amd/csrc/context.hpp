@@ -100,6 +100,7 @@ struct DeviceCtx {
   int64_t kc_maxlist = 0;    // longest entry list of a (clique, constraint) pair among possible family members
   int64_t fam_maxterms = 0;  // most entries of a (family, constraint) pair: the parent's own + its children's
   double* vbuf = nullptr;    // n x vcols : S^-1[:, K_s] of the chunk in flight
+  double* trsm_x = nullptr; int64_t trsm_x_len = 0;   // scratch image of the right-hand sides of csp_trsm (tile-product route)
   int64_t vcols = 0;
   double* hd = nullptr;      // md x md Gram block of the dense constraints (when ns > 0)
   // blocked dense Cholesky of the Schur complement: inverses of its 64 x 64 diagonal blocks (for the blocked potrs)

@@ -572,6 +572,64 @@ __global__ void __launch_bounds__(256) k_lf_down3(MfmaArgs a, double* u, int64_t
   tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
 }
 
+// ---- supernodal triangular solves with a dense n x nrhs right-hand side (chompack.trsm; the S^-1[:, K_j] columns of the
+// SCMcolumn2 route, solvers.py:490-492) as tile products with the inverse-form factor LK = [Li; K]:
+//   forward  (B <- L^-1 B), per clique:  x_N = Li b_N,  B[rows_A] -= K b_N        (L_AN x_N = K b_N)
+//   backward (B <- L^-T B), per clique:  x_N = Li^T b_N - K^T x_A                (L_NN^-T L_AN^T = K^T)
+// One workgroup per (64 front rows, clique, 64 columns of B); the cliques of a level are independent, the separator
+// rows of different cliques of a level may coincide (global atomics in the forward sweep).  x_N goes to a scratch image
+// X of B first: other tiles of the same clique still read b_N.
+__global__ void __launch_bounds__(256) k_trsm_mm_fwd(MfmaArgs a, double* B, int nrhs, int64_t ldb, const int32_t* rowidx, double* X) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  const int m0 = blockIdx.x * LT, n0 = blockIdx.z * LT;
+  if (m0 >= nf) return;
+  const double* LK = a.LK + d.blk;
+  const double* Bn = B + d.first;
+  const int kend = (m0 + LT <= nn) ? min(nn, m0 + LT) : nn;     // Li(m, k) = 0 for k > m
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64(acc, nf, nrhs, kend, m0, n0, [=](int m, int kk) { return LK[m + (int64_t)kk * nf]; },
+              [=](int kk, int n) { return Bn[kk + (int64_t)n * ldb]; }, sA, sB);
+  const int32_t* rows = rowidx + d.rows;
+  double* Xn = X + d.first;
+  tile64_foreach(acc, m0, n0, nf, nrhs, [=](int m, int n, double v) {
+    if (m < nn) Xn[m + (int64_t)n * ldb] = v;
+    else if (v != 0.0) unsafeAtomicAdd(&B[rows[m] + (int64_t)n * ldb], -v);
+  });
+}
+__global__ void k_trsm_mm_copy(MfmaArgs a, double* B, int nrhs, int64_t ldb, const double* X) {
+  const CliqueDesc d = a.t.cl[a.t.lev[blockIdx.y]];
+  const int nn = d.nn;
+  const int64_t tot = (int64_t)nn * nrhs;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % nn, col = e / nn;
+    B[d.first + i + col * ldb] = X[d.first + i + col * ldb];
+  }
+}
+__global__ void __launch_bounds__(256) k_trsm_mm_bwd(MfmaArgs a, double* B, int nrhs, int64_t ldb, const int32_t* rowidx, double* X) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const int k = a.t.lev[blockIdx.y];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  const int m0 = blockIdx.x * LT, n0 = blockIdx.z * LT;
+  if (m0 >= nn) return;
+  const double* LK = a.LK + d.blk;
+  const int32_t* rows = rowidx + d.rows;
+  const double* Bc = B;
+  const int first = d.first;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  // [Li^T | -K^T](m, kk) = +-LK[kk + m nf] (zero for kk < m: Li is stored with zeros above its diagonal)
+  gemm_tile64(acc, nn, nrhs, nf, m0, n0,
+              [=](int m, int kk) { const double v = LK[kk + (int64_t)m * nf]; return kk < nn ? v : -v; },
+              [=](int kk, int n) { return Bc[(kk < nn ? first + kk : rows[kk]) + (int64_t)n * ldb]; }, sA, sB, m0);
+  double* Xn = X + d.first;
+  tile64_foreach(acc, m0, n0, nn, nrhs, [=](int m, int n, double v) { Xn[m + (int64_t)n * ldb] = v; });
+}
+
 // ---- projected inverse, large fronts: E = Y_AA K ; Y_NN = Li^T Li + K^T E (lower) ; Y_AN = -E
 __global__ void __launch_bounds__(256) k_lf_pinv1(MfmaArgs a, double* x) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];

@@ -1014,8 +1014,8 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     HIPCHK(hipMemsetAsync(D.vbuf, 0, sizeof(double) * cols * n, st));
     launch(c, KID_scatter_constraints, k_unit_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), st,
            (const int32_t*)D.kidx + c->h_kptr[q0], cols, D.vbuf, n);
-    if (int rc = csp_trsm(c, L, D.vbuf, cols, n, 0, st)) return rc;      // V = L^-T L^-1 E_K  (solvers.py:491-492)
-    if (int rc = csp_trsm(c, L, D.vbuf, cols, n, 1, st)) return rc;
+    if (int rc = trsm_impl(c, L, Y, D.vbuf, cols, n, 0, st)) return rc;      // V = L^-T L^-1 E_K  (solvers.py:491-492)
+    if (int rc = trsm_impl(c, L, Y, D.vbuf, cols, n, 1, st)) return rc;
     // chunk offsets: a small device array behind the reduction scratch would not fit 65535 entries; use tmp's head
     int64_t* dvoff = reinterpret_cast<int64_t*>(D.tmp);
     HIPCHK(hipMemcpyAsync(dvoff, voff.data(), sizeof(int64_t) * voff.size(), hipMemcpyHostToDevice, st));

@@ -142,13 +142,16 @@ def test_trsm(name):
     rng = np.random.default_rng(6)
     L = A.copy()
     orc.cholesky(S, L)
-    for trans in ("N", "T"):
-        B = rng.standard_normal((4, symb.n))
-        ref = B.copy()
-        orc.trsm(S, L, ref, trans)
-        Bd = torch.from_numpy(B).cuda()
-        chordal.trsm(dev(symb, L), Bd, trans)
-        assert rel(Bd.cpu().numpy(), ref) < TOL
+    # 4 right-hand sides: the substitution kernels (front_generic.hip); 8 and 70: tile products with the inverse-form
+    # factor (k_trsm_mm_*, front_large.hip; 70 columns = two column tiles, the second one ragged)
+    for nrhs in (4, 8, 70):
+        for trans in ("N", "T"):
+            B = rng.standard_normal((nrhs, symb.n))
+            ref = B.copy()
+            orc.trsm(S, L, ref, trans)
+            Bd = torch.from_numpy(B).cuda()
+            chordal.trsm(dev(symb, L), Bd, trans)
+            assert rel(Bd.cpu().numpy(), ref) < TOL, (nrhs, trans)
 
 
 @pytest.mark.parametrize("name", ["arrow", "nested_mid", "fam_odd"])
