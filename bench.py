@@ -403,7 +403,7 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
     # ---------------- back-solve sub-rate: solve_ alone on the factored system of the last step ------
     # two Hessian applications + Amap / Aadj + potrs (solvers.py:506-541); an interior-point iteration issues ~9 of them
     # per factorisation (solvers.py:907-913, 1035-1044)
-    if world == 1 and part is None and args.kktsolver == "chol":
+    if world == 1 and part is None and args.kktsolver == "chol" and not args.no_back_solve:
         nbs = 20
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(nbs + 2):
@@ -540,6 +540,7 @@ def main():
     ap.add_argument("--shard", default="subtree", choices=["subtree", "columns"],
                     help="N > 1: subtree sharding + boundary exchange (default) or column sharding of H")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-back-solve", action="store_true", help="skip the solve_-only timing loop (kernel traces of exactly the timed steps)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the GPU-only figures of configs 2, 3 and 4 after the headline run")
     ap.add_argument("--cpu-repeats", type=int, default=3, help="repeats of the CPU baseline (the median is reported)")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing")

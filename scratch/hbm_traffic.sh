@@ -5,8 +5,8 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc_f gpurun_out/pmc_w
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o p -- python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile > gpurun_out/pmc_f.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o p -- python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile > gpurun_out/pmc_w.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o p -- python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile --no-back-solve > gpurun_out/pmc_f.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o p -- python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile --no-back-solve > gpurun_out/pmc_w.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, json
 def collect(d, name):
@@ -34,7 +34,7 @@ for k in sorted(set(F) | set(W)):
               "hbm_bytes_per_launch": int(1024 * (2 * fk + wk))}
 top = sorted(ker.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
 json.dump({"_comment": "HBM traffic per launch from rocprofv3 PMC counters, two separate passes (--pmc FETCH_SIZE ; --pmc WRITE_SIZE) of "
-           "`python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile` on MI355X; FETCH_SIZE doubled per "
+           "`python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile --no-back-solve` on MI355X; FETCH_SIZE doubled per "
            "/opt/skills/guides/MI355X_MICROARCH.md (HBM section), WRITE_SIZE as is; counters in KB",
            "workload": "synth50k nested block-arrow SDP n=50000, 8073 cliques, m=100",
            "kernels": dict(top)}, open('gpurun_out/r02_hbm_traffic.json', 'w'), indent=1)

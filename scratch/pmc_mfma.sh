@@ -3,8 +3,8 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmc_mfma
 rm -rf $out; mkdir -p $out
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/a -o p -- python3 bench.py --no-secondary --steps 2 --no-cpu --no-profile > $out/a.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY --output-format csv -d $out/b -o p -- python3 bench.py --no-secondary --steps 2 --no-cpu --no-profile > $out/b.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/a -o p -- python3 bench.py --no-secondary --steps 2 --no-cpu --no-profile --no-back-solve > $out/a.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY --output-format csv -d $out/b -o p -- python3 bench.py --no-secondary --steps 2 --no-cpu --no-profile --no-back-solve > $out/b.log 2>&1
 python3 - $out <<'PY'
 import csv, glob, sys, collections
 out=sys.argv[1]

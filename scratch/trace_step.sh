@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/trace_step
 rm -rf $out; mkdir -p $out
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile > $out/run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile --no-back-solve > $out/run.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/trace_step/**/*kernel_trace.csv", recursive=True)[0]

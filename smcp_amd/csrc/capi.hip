@@ -433,6 +433,21 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
       if (attr) {
         if (nz > 1 && sgn == 0)
           launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), dim3(256), st, a);
+        // more tasks than CUs (one workgroup per CU: the front fills LDS): a persistent grid draws them from a counter, so
+        // that the last round does not leave most of the chip idle.  SMCP_ALDS_DYN=0: one workgroup per task.
+        static int dyn = -1;
+        if (dyn < 0) { const char* e = getenv("SMCP_ALDS_DYN"); dyn = (e && e[0] == '0') ? 0 : 1; }
+        const int64_t tasks = pairs * nz;
+        if (dyn && tasks > c->D.ncu && tasks < ((int64_t)1 << 30) && c->D.info) {
+          static bool attr2 = false;
+          if (!attr2) attr2 = hipFuncSetAttribute((const void*)k_lf_assemble_lds_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
+          if (attr2) {
+            int* counter = c->D.info + 24 + (st == c->aux_stream[0] ? 1 : (st == c->aux_stream[1] ? 2 : 0));      // one counter per stream in use
+            (void)hipMemsetAsync(counter, 0, sizeof(int), st);
+            launch_lds(c, KID_lf_assemble_lds, k_lf_assemble_lds_dyn, dim3(c->D.ncu), dim3(1024), bytes, st, a, U, ldu, sgn, cnt, nrhs, nz, counter);
+            return;
+          }
+        }
         launch_lds(c, KID_lf_assemble_lds, k_lf_assemble_lds, dim3(cnt, nrhs, nz), dim3(1024), bytes, st, a, U, ldu, sgn);
         return;
       }

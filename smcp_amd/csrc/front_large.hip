@@ -211,18 +211,19 @@ __device__ inline void lf_add_child(double* T, int nf, const double* Uc, const i
       for (int h = 0; h < NR; ++h) cur[x][h] = nxt[x][h];
   }
 }
-__global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u, int64_t ldu, int sgn) {
-  extern __shared__ __attribute__((aligned(16))) double T[];
-  const int k = a.t.lev[blockIdx.x];
+// (body of one (front, right-hand side, share of the children) task; bx / by / bz and nz: block index and z-extent of the grid
+// in the plain launch)
+__device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, int sgn, int bx, int by, int bz, int nz, double* T) {
+  const int k = a.t.lev[bx];
   const CliqueDesc d = a.t.cl[k];
   if (d.chend == d.chbeg) {
     if (!sgn) {      // a childless front among fronts with children: its update block is assigned too (zero)
-      double* U0 = a.t.upd + (int64_t)blockIdx.y * a.t.updlen + d.upd;
+      double* U0 = a.t.upd + (int64_t)by * a.t.updlen + d.upd;
       for (int e = threadIdx.x; e < d.na * d.na; e += blockDim.x) U0[e] = 0.0;
     }
     return;
   }
-  const int r = blockIdx.y;
+  const int r = by;
   const int nn = d.nn, na = d.na, nf = nn + na;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
@@ -232,7 +233,7 @@ __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u,
   const int nch = d.chend - d.chbeg;
   // (gridDim.z workgroups share the children of the pair: this one takes the children wz, wz + nz, ... -- its table
   // holds only those)
-  const int wz = (int)blockIdx.z, nz = (int)gridDim.z;
+  const int wz = bz;
   const int nmine = (nch - wz + nz - 1) / nz;
   const int tcap = (a.nchmax + nz - 1) / nz;
   int64_t* const sCu = reinterpret_cast<int64_t*>(T + lf_alds_doubles(a.nnmax + a.namax));
@@ -296,6 +297,28 @@ __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u,
       const int i = e % na, j = e / na;
       if (i >= j) U[e] = T[cb(nn + j) + nn + i];                       // full assignment of the lower triangle
     }
+  }
+}
+__global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u, int64_t ldu, int sgn) {
+  extern __shared__ __attribute__((aligned(16))) double T[];
+  lf_alds_task(a, u, ldu, sgn, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.z, T);
+}
+// The same with the tasks dealt out dynamically: a grid of one workgroup per CU draws (front, right-hand side, share)
+// triples from a device counter until they are used up.  A plain launch of 800 workgroups on 256 CUs (synth50k: 8
+// fronts x 100 right-hand sides, one workgroup per CU because of the 148 KB front) runs 3.125 rounds, i.e. four, the
+// last one on an eighth of the chip; here every CU stays busy until the last task is taken.  Every workgroup leaves the
+// loop as soon as the counter passes the number of tasks: no workgroup waits for another.
+__global__ void __launch_bounds__(1024) k_lf_assemble_lds_dyn(MfmaArgs a, double* u, int64_t ldu, int sgn, int cnt, int nrhs, int nz, int* counter) {
+  extern __shared__ __attribute__((aligned(16))) double T[];
+  __shared__ int stask;
+  const int total = cnt * nrhs * nz;
+  for (;;) {
+    __syncthreads();                                  // the previous task's write-out has read the front
+    if (threadIdx.x == 0) stask = atomicAdd(counter, 1);
+    __syncthreads();
+    const int t = stask;
+    if (t >= total) break;
+    lf_alds_task(a, u, ldu, sgn, t % cnt, (t / cnt) % nrhs, t / (cnt * nrhs), nz, T);
   }
 }
 // Tiled extend-add: one workgroup owns an LF_TR x LF_TW tile of the front of (clique, rhs) in LDS and streams the

@@ -31,7 +31,8 @@ struct Symbolic {
   std::vector<int32_t> relidx;  // |A_k| entries at sepptr[k]: position of each A_k row inside rows(parent(k))
   std::vector<int64_t> blkptr;  // nsn+1 : offset of the (nn+na) x nn column-major block of clique k in blkval
   std::vector<int64_t> updptr;  // nsn+1 : offset of the na x na update matrix of clique k in the update workspace
-  std::vector<int64_t> updpptr; // nsn+1 : offset of the PACKED lower triangle (na(na+1)/2) in the child->parent exchange buffer
+  std::vector<int64_t> updpptr; // nsn+1 : OFFSET of the packed lower triangle (na(na+1)/2) of clique k in the child->parent exchange
+                                //           buffer, siblings side by side (not monotone in k); [nsn] = total length
   std::vector<int64_t> chptr;   // nsn+1 : children lists
   std::vector<int64_t> chidx;   // nsn-#roots
   std::vector<int64_t> level;   // nsn   : height-based level (leaves = 0, parent > all children)
