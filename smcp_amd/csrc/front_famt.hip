@@ -54,8 +54,11 @@ typedef unsigned int famt_u2 __attribute__((ext_vector_type(2)));
 __device__ inline __amdgpu_buffer_rsrc_t famt_rsrc(double* base, int doubles) {
   return __builtin_amdgcn_make_buffer_rsrc(base, 0, doubles * 8, 0x00020000);      // raw buffer, 32-bit data format (gfx9)
 }
+#ifndef SMCP_FAMT_AUX
+#define SMCP_FAMT_AUX 0          // cache-policy bits of the result stores (2 = nt: streamed once, read ~1 ms later by other kernels)
+#endif
 __device__ inline void famt_store(__amdgpu_buffer_rsrc_t r, bool ok, int pos, double v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(famt_u2, v), r, ok ? pos * 8 : -1, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(famt_u2, v), r, ok ? pos * 8 : -1, 0, SMCP_FAMT_AUX);
 }
 constexpr int FAMT_HDR = 32;        // doubles: the header of a record (ints, as FAM2: [0] clique, [1] nn, [2] na, [3] children,
                                     // [4,5] panel offset, [8,9] packed-update offset; child c at 16 + 6 c: clique, nn, na,

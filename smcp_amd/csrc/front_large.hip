@@ -182,8 +182,13 @@ __device__ inline void lf_add_child(double* T, int nf, const double* Uc, const i
       for (int h = 0; h < NR; ++h) v[x][h] = 0.0;
       if (j < nac) {
         const double* col = Uc + pk_col(j, nac) - j;               // col[i] = U_c(i, j), i >= j
+#ifdef SMCP_ALDS_NT
+        if (iA >= j && iA < nac) v[x][0] = __builtin_nontemporal_load(&col[iA]);
+        if (TWO && iB >= j && iB < nac) v[x][NR - 1] = __builtin_nontemporal_load(&col[iB]);
+#else
         if (iA >= j && iA < nac) v[x][0] = col[iA];
         if (TWO && iB >= j && iB < nac) v[x][NR - 1] = col[iB];
+#endif
       }
     }
   };
