@@ -171,7 +171,7 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
         rows = B - (Bk[owned & (fam == 1)].sum() if leaf_gram else 0.0)
         alg = 8.0 * (m * rows + rows)                 # one read of the swept stack (+ the weights)
         note = "bytes = one read of the swept constraint stack (m x rows) + the weights"
-    elif dom == "k_lf_assemble_lds":
+    elif dom in ("k_lf_assemble_lds", "k_lf_assemble_lds_dyn"):
         big = (~lds_ok) & owned & (nch > 0)
         nf_ = (nn_ + na_).astype(np.float64)
         alg = sum(8.0 * r * (Upch[big].sum() + (nf_[big] * (nf_[big] + 1) / 2).sum()) for r in solve_chunks)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the kernels of one bench step from the PMC counters (separate passes, as the MI355X guide prescribes):
-# writes gpurun_out/r02_hbm_traffic.json (copy to profiles/).  FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B
+# writes gpurun_out/r03_hbm_traffic.json (copy to profiles/).  FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B
 # request of wide coalesced reads), WRITE_SIZE taken as is; both are reported in KB by rocprofv3.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -37,7 +37,8 @@ json.dump({"_comment": "HBM traffic per launch from rocprofv3 PMC counters, two 
            "`python3 bench.py --no-secondary --steps 2 --warmup 1 --no-cpu --no-profile --no-back-solve` on MI355X; FETCH_SIZE doubled per "
            "/opt/skills/guides/MI355X_MICROARCH.md (HBM section), WRITE_SIZE as is; counters in KB",
            "workload": "synth50k nested block-arrow SDP n=50000, 8073 cliques, m=100",
-           "kernels": dict(top)}, open('gpurun_out/r02_hbm_traffic.json', 'w'), indent=1)
+           "git_sha": __import__("subprocess").run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or __import__("os").environ.get("SMCP_GIT_SHA", "?"),
+           "kernels": dict(top)}, open('gpurun_out/r03_hbm_traffic.json', 'w'), indent=1)
 for k, v in top:
     print(k, v)
 PY

@@ -52,7 +52,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -70,7 +70,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -444,7 +444,7 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
           if (attr2) {
             int* counter = c->D.info + 24 + (st == c->aux_stream[0] ? 1 : (st == c->aux_stream[1] ? 2 : 0));      // one counter per stream in use
             (void)hipMemsetAsync(counter, 0, sizeof(int), st);
-            launch_lds(c, KID_lf_assemble_lds, k_lf_assemble_lds_dyn, dim3(c->D.ncu), dim3(1024), bytes, st, a, U, ldu, sgn, cnt, nrhs, nz, counter);
+            launch_lds(c, KID_lf_assemble_lds_dyn, k_lf_assemble_lds_dyn, dim3(c->D.ncu), dim3(1024), bytes, st, a, U, ldu, sgn, cnt, nrhs, nz, counter);
             return;
           }
         }
@@ -1032,7 +1032,13 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         // only when the extend-add needs more than one round of the chip: with fewer (front, right-hand side) pairs than
         // CUs (one rank's share of an 8-rank job: 100 pairs) there is no tail to fill and the halves only add launches
         // (measured on the partition of rank 0 of 8: 2.83 ms per step with the split, 2.67 without)
-        if (split_min > 0 && a.nchmax > 0 && nrhs >= split_min && (int64_t)cnt * nrhs > ncu_split && Fork::enabled()) {
+        // (with the task-drawing extend-add -- lf_assemble, SMCP_ALDS_DYN -- one launch keeps every CU busy to the last task
+        // and a second one on another stream could not start before it ends, both holding the whole LDS of a CU: the split
+        // is for the plain launch only.  Measured with both: 4.50 against 4.55 ms per step -- and the second launch's
+        // duration would count its wait for CUs.)
+        static int dynsplit = -1;
+        if (dynsplit < 0) { const char* e = getenv("SMCP_ALDS_DYN"); const char* f = getenv("SMCP_RHS_SPLIT_DYN"); dynsplit = ((e && e[0] == '0') || (f && f[0] == '1')) ? 1 : 0; }
+        if (dynsplit && split_min > 0 && a.nchmax > 0 && nrhs >= split_min && (int64_t)cnt * nrhs > ncu_split && Fork::enabled()) {
           auto part = [&](int r0, int nr, hipStream_t s) {       // right-hand sides r0 .. r0 + nr - 1 on stream s
             MfmaArgs ap = a;
             ap.nrhs = nr;
