@@ -160,7 +160,7 @@ int kkt_solve(csp_ctx* ctx, const double* L, const double* Y, const double* H, i
  * lower-triangular matrix.  *passes (optional) receives the number of passes taken, *shift the relative shift of
  * the first pass (0: none).  Returns 0, a negative error, or j+1 > 0 when chol(Y_AA) of a clique or the Gram
  * matrix is not positive definite (lapack.geqrf's ArithmeticError at solvers.py:425-428 has no counterpart: a
- * rank-deficient stack shows up here).  m <= 320 in this build (SMCP_ENOMEM beyond).
+ * rank-deficient stack shows up here).  any m (factors wider than 320 columns are processed in panels of 256).
  * kkt_qr_solve is its solve_ closure (solvers.py:430-471): overwrites bx (blkval) with x and by (length m) with y;
  * valid until the next call that rewrites the stack (kkt_qr_factor, kkt_schur_*, kkt_solve, kkt_gram_*). */
 int kkt_qr_factor(csp_ctx* ctx, const double* L, const double* Y, int64_t* passes, double* shift, void* stream);

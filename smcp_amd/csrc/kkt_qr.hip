@@ -123,14 +123,14 @@ __global__ void __launch_bounds__(64 * QR_NW) k_stack_trsm(double* W, int64_t ld
 constexpr int QR_MB = 16;
 template <int NB>
 __global__ void __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 2 ? 3 : 2))) k_stack_trsm_mfma(double* W, int64_t ldw, int64_t len, int m,
-                                                         const double* __restrict__ Rp, int ldr) {
+                                                         const double* __restrict__ Rp, int ldr, int nblk) {
   __shared__ double sT[QR_MB][64 + 1];          // the owner's block, [row][position]
   __shared__ double sQ[2][QR_MB][64];           // finished rows of the block step, double buffered
   __shared__ double sR[2][QR_MB][QR_MB + 1];    // diagonal block of R of the block step (reciprocals on its diagonal)
   const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t p0 = (int64_t)blockIdx.x * 64;
-  const int nblk = ldr / QR_MB;
+  const int64_t p0 = (int64_t)blockIdx.x * 64;      // nblk: blocks of 16 rows of this call (a panel of a larger factor: Rp points at its
+                                                    // diagonal block, ldr stays the stride of the whole packed factor)
   d4 D[NB][4];
 #pragma unroll
   for (int s = 0; s < NB; ++s) {
@@ -226,6 +226,58 @@ __global__ void __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 2 ? 3 : 2))) k_stac
           for (int g = 0; g < 4; ++g) D[s][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[s][st], aq[g][st], D[s][g], 0, 0, 0);
       }
     }
+  }
+}
+// Panels of a factor with more than 320 columns (k_stack_trsm_mfma keeps a panel's rows as accumulators: at most five
+// blocks of 64 rows): before the substitution inside the panel of rows [c0, c0 + 16 ntile) the finished rows above it
+// are eliminated,  W[j][p] -= sum_{i < c0} W[i][p] R[i][j]  -- a tall product on the matrix pipe: 64 positions per
+// workgroup, wave w the column tiles w, w + 4, ... (NT per wave), every finished row read once per panel.
+template <int NT>
+__global__ void __launch_bounds__(256) k_stack_gemm_panel(double* W, int64_t ldw, int64_t len, int c0, int ntile, int m,
+                                                          const double* __restrict__ Rp, int ldr) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  d4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[t][g] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int i0 = 0; i0 < c0; i0 += 8) {            // two k-steps per trip: eight loads of W in flight
+    double b[2][4], a[2][NT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = i0 + 4 * h + kq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t p = p0 + 16 * g + l15;
+        b[h][g] = (i < c0 && p < len) ? W[(int64_t)i * ldw + p] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int tile = wave + 4 * t;
+        a[h][t] = (i < c0 && tile < ntile) ? Rp[(int64_t)i * ldr + c0 + 16 * tile + l15] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[t][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h][t], b[h][g], acc[t][g], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tile = wave + 4 * t;
+    if (tile >= ntile) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int col = c0 + 16 * tile + kq + 4 * x;
+        const int64_t p = p0 + 16 * g + l15;
+        if (col < m && p < len) W[(int64_t)col * ldw + p] -= acc[t][g][x];
+      }
   }
 }
 // Rp (row-major upper, ldr x ldr, RECIPROCALS on the diagonal, unit diagonal in the padding) <- transpose of the lower
@@ -363,7 +415,6 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
   if (!m || use_generic(c)) return SMCP_EINVAL;
   if (D.ns) return SMCP_EINVAL;                 // every constraint must be swept (kkt_set_tnzcols(0) before the constraints)
   if (D.max_rhs < 1 || D.ustack_cols < m) return SMCP_EINVAL;
-  if (m > 320) return SMCP_ENOMEM;              // k_stack_trsm keeps m / 8 rows per wave in registers: m <= 320 in this build
   hipStream_t st = (hipStream_t)stream;
   D.qr_valid = false;
   if (int rc = qr_alloc(c)) return rc;
@@ -433,15 +484,27 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
     if (!vfma) {
       const dim3 grid((unsigned)((bl + 63) / 64)), blk(256);
       const int nb = (int)((ldr / QR_MB + 3) / 4);
-#define SMCP_TRSM_CASE(N) case N: launch(c, KID_qr_rmul, k_stack_trsm_mfma<N>, grid, blk, st, D.ustack, bl, bl, (int)m, (const double*)X, (int)ldr); break;
-      switch (nb) {
-        SMCP_TRSM_CASE(1) SMCP_TRSM_CASE(2) SMCP_TRSM_CASE(3) SMCP_TRSM_CASE(4) SMCP_TRSM_CASE(5)
-        default: return SMCP_ENOMEM;
-      }
+      // panels of at most 256 rows (320 when the whole factor fits one): rows above a panel are eliminated by a tall
+      // product first (k_stack_gemm_panel), then the substitution runs inside the panel
+      const int PB = ldr <= 320 ? (int)ldr : 256;
+      for (int c0 = 0; c0 < (int)ldr; c0 += PB) {
+        const int pc = std::min(PB, (int)ldr - c0), rows = std::max(0, std::min(pc, (int)m - c0));
+        if (!rows) break;
+        if (c0 > 0) launch(c, KID_qr_rmul, k_stack_gemm_panel<4>, grid, blk, st, D.ustack, bl, bl, c0, pc / QR_MB, (int)m, (const double*)X, (int)ldr);
+        double* Wp = D.ustack + (int64_t)c0 * bl;
+        const double* Xp = X + (int64_t)c0 * ldr + c0;
+        const int nbp = (pc / QR_MB + 3) / 4;
+#define SMCP_TRSM_CASE(N) case N: launch(c, KID_qr_rmul, k_stack_trsm_mfma<N>, grid, blk, st, Wp, bl, bl, rows, Xp, (int)ldr, pc / QR_MB); break;
+        switch (nbp) {
+          SMCP_TRSM_CASE(1) SMCP_TRSM_CASE(2) SMCP_TRSM_CASE(3) SMCP_TRSM_CASE(4) SMCP_TRSM_CASE(5)
+          default: return SMCP_ENOMEM;
+        }
 #undef SMCP_TRSM_CASE
+      }
     } else {
       // SMCP_QR_P=2: two positions per lane (halves the scalar loads per FMA; measured no faster).  Eight waves per
       // workgroup and four positions per lane were measured too (1.75-2.4 ms per pass) and are not instantiated any more.
+      if (m > 320) return SMCP_ENOMEM;            // the vector-FMA variant keeps all rows of a position in registers
       static int pv = -1;
       const int nwv = 4;
       if (pv < 0) { const char* e = getenv("SMCP_QR_P"); pv = (e && e[0] == '2') ? 2 : 1; }

@@ -763,6 +763,29 @@ def test_kkt_qr_many_constraints():
     assert rel(byd.cpu().numpy(), yr) < 1e-8
 
 
+def test_kkt_qr_more_than_320_constraints():
+    """the triangular solve of the stack kept a row block per wave in registers (m <= 320); wider
+    factors now go through panels of 256 rows -- the rows above a panel are eliminated by a tall product on the matrix
+    pipe (k_stack_gemm_panel), the substitution runs inside the panel.  m = 420: two panels, the second one ragged."""
+    m = 420
+    symb, S, msk, L, Yh, cptr, cidx, cval = _kkt_qr_case("nested_mid", m, 51, density=0.004)
+    rng = np.random.default_rng(52)
+    K = orc.KKT(S, cptr, cidx, cval)
+    F = K.qr_factor(L, Yh)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=32, tnzcols=0.0)
+    solve = sys.factor_qr(dev(symb, L), dev(symb, Yh))
+    Rt, G = sys.qr_inspect()
+    assert np.abs(G.cpu().numpy() - np.eye(m)).max() < 1e-11
+    assert rel(np.tril(Rt) @ np.tril(Rt).T, 2.0 * F["R"].T @ F["R"]) < 1e-10
+    bx = rng.standard_normal(symb.blklen) * msk
+    by = rng.standard_normal(m)
+    xr, yr = K.qr_solve(L, Yh, F, bx, by, 0.5)
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    solve(bxd, byd, 0.5)
+    assert rel(host(bxd)[msk], xr[msk]) < 1e-8
+    assert rel(byd.cpu().numpy(), yr) < 1e-8
+
+
 @pytest.mark.parametrize("eps,shifted", [(1e-9, False), (1e-13, True)])
 def test_kkt_qr_nearly_dependent_constraints(eps, shifted):
     """Two constraints that differ by eps times a third, independent one: kappa(At) ~ 2 / eps.  At 1e-9 chol(At^T At)
