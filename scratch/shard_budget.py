@@ -101,7 +101,7 @@ def main():
         print("world %d: owned %.3f ms  replicated %.3f ms  (top cliques %d, owned by rank 0: %d)"
               % (world, own, top, out[world]["top_cliques"], out[world]["owned_cliques"]), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(out, open("gpurun_out/r02_shard_budget.json", "w"), indent=1)
+    json.dump(out, open("gpurun_out/r03_shard_budget.json", "w"), indent=1)
     print(json.dumps(out[max(out)]["phases"]))
 
 

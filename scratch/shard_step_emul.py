@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--rank", type=int, default=0)
-    ap.add_argument("--defer", type=int, default=0)
+    ap.add_argument("--defer", type=int, default=1, help="1: the regime bench.py runs with N > 1 (status with H's all-reduce, deferred failure reports, x left sharded)")
     args = ap.parse_args()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -76,8 +76,12 @@ def main():
                 Ls, Ys = kkt.factor_scaling(S, G, defer_status=True)
             else:
                 Ls, Ys = kkt.factor_scaling(S, G)
-            kkt.factor(Ls, Ys, G)(bx, by, 1.0)
+            kkt.factor(Ls, Ys, G)(bx, by, 1.0, complete=not args.defer)
+            if args.defer:
+                chordal.check_status(symb)
 
+        if args.defer:
+            chordal.lazy_status(symb, True)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -89,6 +93,8 @@ def main():
         ms = 1e3 * (time.perf_counter() - t0) / args.steps
         out[world] = dict(ms_per_step=round(ms, 3), collectives_per_step=(kkt.collectives - c0) / args.steps,
                           rank=state["rank"])
+        if args.defer:
+            chordal.lazy_status(symb, False)
         print("world %d rank %d: %.3f ms per step (%.1f collectives)" % (world, state["rank"], ms, out[world]["collectives_per_step"]),
               flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
