@@ -1,6 +1,7 @@
 // C-ABI implementation (include/smcp_amd.h): host-side drivers that walk the clique tree
 // level by level and launch the HIP kernels.  No CPU compute fallback exists here.
 #include <hip/hip_runtime.h>
+#include <memory>
 
 #include <algorithm>
 #include <chrono>
@@ -283,7 +284,15 @@ void for_levels_down(csp_ctx* c, F f) {
 }
 
 // workgroups per clique of a gather launch whose largest separator is namax
-inline unsigned gather_parts(int namax) { return (unsigned)std::max(1, std::min(64, (namax * namax) / (NT * 32))); }
+// (a launch over a few cliques -- `pairs` (clique, right-hand side) pairs on a chip of ncu CUs -- is a chain of dependent
+// index loads per thread: more, shorter workgroups then; k_gather_level on the eight mid fronts of synth50k, one
+// right-hand side: 21 us with 2 parts)
+inline unsigned gather_parts(int namax, int64_t pairs = (int64_t)1 << 40, int ncu = 0) {
+  const int base = std::max(1, std::min(64, (namax * namax) / (NT * 32)));
+  if (pairs * base >= 2 * (int64_t)ncu) return (unsigned)base;
+  const int cap = std::max(1, std::min(64, (namax * namax) / (NT * 2)));
+  return (unsigned)std::max<int64_t>(base, std::min<int64_t>(cap, (2 * (int64_t)ncu + pairs - 1) / std::max<int64_t>(1, pairs)));
+}
 inline int namax_of(csp_ctx* c, const int32_t* lev) {   // lev points into D.levidx at the start of a level
   const int64_t off = lev - c->D.levidx;
   const auto& lp = c->S.levptr;
@@ -296,7 +305,7 @@ void gather_all(csp_ctx* c, const double* x, int64_t ldx, int nrhs, double* updb
   TreeArgs a = tree_args(c);
   for_levels_down(c, [&](const int32_t* lev, int cnt) {
     a.lev = lev;
-    launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(namax_of(c, lev))), dim3(NT), st, a, x, ldx, updbase);
+    launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(namax_of(c, lev), (int64_t)cnt * nrhs, c->D.ncu)), dim3(NT), st, a, x, ldx, updbase);
   });
 }
 
@@ -456,7 +465,11 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   if (clear_first)
     launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), dim3(256), st, a);
   if (plan && a.t.gp_tptr) {
-    launch(c, KID_lf_assemble, k_lf_assemble, dim3(32, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
+    // a thread per front position when the launch is small (few fronts, one right-hand side): each position is a chain of
+    // dependent loads, and 32 workgroups per front leave two or three positions per thread
+    const int nfm = a.nnmax + a.namax;
+    const int gx = (int64_t)cnt * nrhs * 32 < 2 * (int64_t)c->D.ncu ? std::max(32, std::min(128, (nfm * (nfm + 1) / 2 + 255) / 256)) : 32;
+    launch(c, KID_lf_assemble, k_lf_assemble, dim3(gx, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
     return;
   }
   const int nfmax = a.nnmax + a.namax;
@@ -464,32 +477,47 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   launch(c, KID_lf_assemble, k_lf_assemble_tiled, dim3(ncb * nrb, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
 }
 
+// Phase kernels of the large fronts come in two shapes (gemm_tile64<PD>, front_large.hip): sixteen waves per 64 x 64 tile
+// for launches of at most one workgroup per CU (a few tiles: one right-hand side on the top fronts), four waves otherwise
+// (the batched sweeps, where the workgroups sharing a CU keep its four SIMDs busy).  SMCP_PD=1: four waves everywhere.
+static bool pd_deep() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMCP_PD"); on = (e && e[0] == '1') ? 0 : 1; }
+  return on == 1;
+}
+#define LAUNCH_PD(c, kid, kern, grid, blk, ...)                                                        \
+  do {                                                                                                 \
+    const dim3 g_ = (grid);                                                                            \
+    if (pd_deep() && (int64_t)g_.x * g_.y * g_.z <= (int64_t)(c)->D.ncu) launch(c, kid, kern<4>, g_, dim3(1024), __VA_ARGS__); \
+    else launch(c, kid, kern<1>, g_, blk, __VA_ARGS__);                                                \
+  } while (0)
+
 void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
   if (a.nchmax > 0) {     // a level of childless large fronts has nothing to assemble (k_lf_up2 does not read their update blocks)
     lf_assemble(c, a, cnt, nrhs, U, ldu, 0, st, true);
   }
-  launch(c, KID_lf_up1, k_lf_up1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
-  launch(c, KID_lf_up2, k_lf_up2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
-  if (a.namax) launch(c, KID_lf_up3, k_lf_up3, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
+  LAUNCH_PD(c, KID_lf_up1, k_lf_up1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
+  LAUNCH_PD(c, KID_lf_up2, k_lf_up2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
+  if (a.namax) LAUNCH_PD(c, KID_lf_up3, k_lf_up3, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
 }
 void lf_down(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
-  if (a.namax) launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(a.namax)), dim3(NT), st, a.t, (const double*)U, ldu, a.t.upd);
-  launch(c, KID_lf_down1, k_lf_down1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
-  if (a.namax) launch(c, KID_lf_down2, k_lf_down2, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
-  launch(c, KID_lf_down3, k_lf_down3, dim3(umax1(ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
+  if (a.namax) launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(a.namax, (int64_t)cnt * nrhs, c->D.ncu)), dim3(NT), st, a.t, (const double*)U, ldu, a.t.upd);
+  LAUNCH_PD(c, KID_lf_down1, k_lf_down1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
+  if (a.namax) LAUNCH_PD(c, KID_lf_down2, k_lf_down2, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
+  LAUNCH_PD(c, KID_lf_down3, k_lf_down3, dim3(umax1(ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
 }
 void lf_pinv(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) {
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
   if (a.namax) {
-    launch(c, KID_gather_level, k_gather_level, dim3(cnt, 1, gather_parts(a.namax)), dim3(NT), st, a.t, (const double*)x, (int64_t)0, a.t.upd);
-    launch(c, KID_lf_pinv1, k_lf_pinv1, dim3(umax1(mtA * ntN), cnt, 1), blk, st, a, x);
+    launch(c, KID_gather_level, k_gather_level, dim3(cnt, 1, gather_parts(a.namax, cnt, c->D.ncu)), dim3(NT), st, a.t, (const double*)x, (int64_t)0, a.t.upd);
+    LAUNCH_PD(c, KID_lf_pinv1, k_lf_pinv1, dim3(umax1(mtA * ntN), cnt, 1), blk, st, a, x);
   }
-  launch(c, KID_lf_pinv2, k_lf_pinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, 1), blk, st, a, x);
+  LAUNCH_PD(c, KID_lf_pinv2, k_lf_pinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, 1), blk, st, a, x);
 }
 
 constexpr size_t LF_DIAG_LDS = (size_t)(2 * LB * LBD + 256 + 16 * LB) * sizeof(double);
@@ -985,9 +1013,14 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
     a.kc_ptr = nullptr;
   };
   auto dense_input = [&](MfmaArgs& a, int cnt) { dense_input_on(a, cnt, U, nrhs, st); };
+  // (A handful of level-0 fronts outside the families -- synth50k: ONE leaf hangs off a mid front directly -- is a launch of
+  // its own in the chain, 15 us for one workgroup.  On a side stream next to the family launch of level 1 it costs as
+  // much in event waits: 6 us before and after the family launch, measured.)
   for (int64_t l = lev_lo; l < (lev_hi < 0 ? c->S.nlev : lev_hi); ++l)     // [lev_lo, lev_hi): the caller may sweep in two parts
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
-      if (lds && a.nS > 0 && (sparse || nrhs >= 4)) {
+      static int fam_minrhs = -1;
+      if (fam_minrhs < 0) { const char* e = getenv("SMCP_FAM_MINRHS"); fam_minrhs = e ? atoi(e) : 1; }
+      if (lds && a.nS > 0 && (sparse || nrhs >= fam_minrhs)) {
         // families: the childless members (level 0) are swept inside their parents' workgroups (k_hess_up_fam);
         // for one or two dense right-hand sides the per-workgroup set-up outweighs the saved exchange (measured)
         const int nS = a.nS;
@@ -1007,16 +1040,17 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
       }
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
       if (lds) {
+        hipStream_t ls = st;
         static int oldk = -1;
         if (oldk < 0) { const char* e = getenv("SMCP_OLDLDS"); oldk = (e && e[0] == '1') ? 1 : 0; }
         size_t pbytes = (size_t)pad_layout(a.nnmax, a.namax, a.nchmax, a.panmax, a.pkmax, a.plansum).total * sizeof(double);
-        if (!oldk && try_n16(c, a, cnt, nrhs, U, ldu, st)) {
+        if (!oldk && try_n16(c, a, cnt, nrhs, U, ldu, ls)) {
         } else if (!oldk && pbytes <= LDS_LIMIT) {
-          dense_input(a, cnt);
-          launch_lds(c, KID_hess_up_pad, k_hess_up_pad, dim3(cnt, g), dim3(pbytes > 48 * 1024 ? 512 : 256), pbytes, st, a, U, ldu);
+          dense_input_on(a, cnt, U, nrhs, ls);
+          launch_lds(c, KID_hess_up_pad, k_hess_up_pad, dim3(cnt, g), dim3(pbytes > 48 * 1024 ? 512 : 256), pbytes, ls, a, U, ldu);
         } else {
-          dense_input(a, cnt);
-          launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+          dense_input_on(a, cnt, U, nrhs, ls);
+          launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, ls, a, U, ldu);
         }
       } else if (use_large() && c->D.gp_tptr) {
         if (sparse && try_lfsp(c, a, cnt, nrhs, U, ldu, st)) return;
@@ -1079,7 +1113,7 @@ void gather_set(csp_ctx* c, int set, const double* x, int64_t ldx, int nrhs, dou
     const int cnt = (int)(L.nI + L.nII);
     if (!cnt) continue;
     a.lev = LS.lev2 + LS.off[l];
-    launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(std::max(L.namaxI, L.namaxII))), dim3(NT), st, a, x, ldx, updbase);
+    launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(std::max(L.namaxI, L.namaxII), (int64_t)cnt * nrhs, c->D.ncu)), dim3(NT), st, a, x, ldx, updbase);
   }
 }
 void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0) {
@@ -1098,7 +1132,7 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
       else if (use_large() && (ymode == 0 || ymode == 3 || ymode == 2)) {
         if (ymode && a.namax) {   // Q = R Ghat_AN (ymode 3) / R^T Ghat_AN (ymode 2) first, then the unscaled sweep
           const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
-          launch(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), dim3(256), st, a, U, ldu, ymode == 2 ? 1 : 0);
+          LAUNCH_PD(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), dim3(256), st, a, U, ldu, ymode == 2 ? 1 : 0);
           launch(c, KID_lf_copy_an, k_lf_copy_an, dim3(umax1(std::min(64, (a.namax * a.nnmax + 255) / 256)), cnt, nrhs), dim3(256), st, a, U, ldu, 0);
         }
         MfmaArgs a2 = a;
@@ -1204,10 +1238,10 @@ void hess_down_inv_fast(csp_ctx* c, const double* L, double* U, int nrhs, int64_
   if (use_large())
     for_all_large(c, a0, [&](MfmaArgs a, int cnt) {   // clique-local: all large fronts of the tree in one set of launches
       const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
-      launch(c, KID_lf_dinv1, k_lf_dinv1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
-      launch(c, KID_lf_dinv2, k_lf_dinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
+      LAUNCH_PD(c, KID_lf_dinv1, k_lf_dinv1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
+      LAUNCH_PD(c, KID_lf_dinv2, k_lf_dinv2, dim3(umax1(ntN * (ntN + 1) / 2 + mtA * ntN), cnt, nrhs), blk, st, a, U, ldu);
       if (ymode == 1 && a.namax) {
-        launch(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu, 1);
+        LAUNCH_PD(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu, 1);
         launch(c, KID_lf_copy_an, k_lf_copy_an, dim3(umax1(std::min(64, (a.namax * a.nnmax + 255) / 256)), cnt, nrhs), blk, st, a, U, ldu, 0);
       }
     });
@@ -1226,11 +1260,11 @@ void hess_up_inv_fast(csp_ctx* c, const double* L, double* U, int nrhs, int64_t 
         const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
         const dim3 gcopy(umax1(std::min(64, (a.namax * a.nnmax + 255) / 256)), cnt, nrhs);
         if (ymode == 3 && a.namax) {
-          launch(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu, 1);
+          LAUNCH_PD(c, KID_lf_ri_an, k_lf_ri_an, dim3(umax1(mtA * ntN), cnt, nrhs), blk, st, a, U, ldu, 1);
           launch(c, KID_lf_copy_an, k_lf_copy_an, gcopy, blk, st, a, U, ldu, 0);
         }
-        launch(c, KID_lf_uinv1, k_lf_uinv1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
-        launch(c, KID_lf_uinv2, k_lf_uinv2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
+        LAUNCH_PD(c, KID_lf_uinv1, k_lf_uinv1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
+        LAUNCH_PD(c, KID_lf_uinv2, k_lf_uinv2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
         if (a.namax) launch(c, KID_lf_copy_an, k_lf_copy_an, gcopy, blk, st, a, U, ldu, 0);
         lf_assemble(c, a, cnt, nrhs, U, ldu, 1, st);
         if (a.namax) launch(c, KID_lf_pack_upd, k_lf_pack_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 255) / 256)), cnt, nrhs), blk, st, a);

@@ -5,6 +5,7 @@
 // chip and the 192-fronts of config 3 run as batched GEMMs.  Intermediates (E, G, T) live in the
 // per-(clique, rhs) scratch, which stays L2 / Infinity-Cache resident between phases.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace smcp {
 
@@ -17,26 +18,77 @@ constexpr int LSA = LT + 1, LSB = LKC + 1;
 // The products run over k in [kbeg, Kd): a caller whose operand is triangular passes the range where it is nonzero
 // (kbeg is rounded down to a slice boundary; Li is stored with explicit zeros above its diagonal, so the bounds only
 // skip slices of zeros -- half of T = Li F_NN, G = X Li^T ... on a big front).
-template <class LA, class LB>
+// Two shapes of the same tile product.  PD = 1 (256 threads): four waves, 2 x 2 MFMA tiles each -- the batched sweeps, where
+// several workgroups share a CU.  PD = 4 (1024 threads, "W16"): sixteen waves, ONE 16 x 16 MFMA tile each, for launches of
+// a few tiles (one right-hand side on the top fronts: the solves of the interior-point iteration).  In-kernel stamps
+// (scratch/stamps_lf.py) showed a slice of the 256-thread shape to cost ~1.3 us on an otherwise idle CU -- 16 MFMAs (64 cycles
+// each), the address arithmetic of 8 loads and two barriers, all on ONE wave per SIMD, instruction bound, not latency
+// bound (deeper prefetch and batched loads changed nothing); with sixteen waves a slice is 4 MFMAs and 2 loads per wave.
+// Every load is issued unconditionally at an index clamped into the operand and masked afterwards: a load under a
+// branch makes the number of loads in flight unknown to the compiler and every wait becomes vmcnt(0).
+template <int PD = 1, class LA, class LB>
 __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0, int n0, LA la, LB lb,
                                    double* sA, double* sB, int kbeg = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, kq = lane >> 4, wm = wave & 1, wn = wave >> 1;
-  // the operands of slice k0 + LKC are fetched into registers while the MFMAs of slice k0 run (the products here
-  // are short -- K = 64 is four slices -- so an exposed memory latency per slice is most of a tile's time)
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int kfirst = (kbeg / LKC) * LKC;
+  if (kfirst >= Kd) return;
+  if constexpr (PD == 4) {
+    const int wm = wave & 3, wn = wave >> 2;
+    const int ia = tid & 63, ka = tid >> 6, kb = tid & 15, jb = tid >> 4;
+    const int mi = max(0, min(m0 + ia, M - 1)), nj = max(0, min(n0 + jb, N - 1));
+    const bool inA = m0 + ia < M, inB = n0 + jb < N;
+    // Two slices in flight.  The operands were written by the previous launch, on some other XCD: every first touch is a
+    // trip to the memory side of the fabric.  Requests past the last slice would be waited for at the end of the product
+    // (one more such trip), and a request under a run-time condition makes every wait a wait for all loads -- so the main
+    // loop requests unconditionally and the last (up to three) slices are peeled without requests.
+    double va[2], vb[2];
+    auto fetch = [&](int p, int k0) {
+      const double av = la(mi, min(k0 + ka, Kd - 1)), bv = lb(min(k0 + kb, Kd - 1), nj);
+      va[p] = (inA && k0 + ka < Kd) ? av : 0.0;
+      vb[p] = (inB && k0 + kb < Kd) ? bv : 0.0;
+    };
+    auto slice = [&](int p, int k0, auto ahead) {
+      __syncthreads();
+      sA[ia + ka * LSA] = va[p];
+      sB[kb + jb * LSB] = vb[p];
+      __syncthreads();
+      if constexpr (decltype(ahead)::value) fetch(p, k0 + 2 * LKC);
+#pragma unroll
+      for (int ks = 0; ks < LKC / 4; ++ks) {
+        const int kk = 4 * ks + kq;
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[kk + (16 * wn + l15) * LSB], sA[(16 * wm + l15) + kk * LSA], acc[0][0], 0, 0, 0);
+      }
+    };
+    constexpr std::integral_constant<bool, true> yes{};
+    constexpr std::integral_constant<bool, false> no{};
+    const int nsl = (Kd - kfirst + LKC - 1) / LKC;
+    fetch(0, kfirst);
+    fetch(1, kfirst + LKC);            // (a product of one slice: clamped, masked, waited for at the end)
+    int sl = 0, k0 = kfirst;
+    for (; sl + 3 < nsl; sl += 2, k0 += 2 * LKC) { slice(0, k0, yes); slice(1, k0 + LKC, yes); }
+    const int rest = nsl - sl;         // 1 .. 3
+    if (rest == 3) { slice(0, k0, yes); slice(1, k0 + LKC, no); slice(0, k0 + 2 * LKC, no); }
+    else if (rest == 2) { slice(0, k0, no); slice(1, k0 + LKC, no); }
+    else slice(0, k0, no);
+    return;
+  } else {
+  const int wm = wave & 1, wn = wave >> 1;
+  // the operands of slice k0 + LKC are fetched into registers while the MFMAs of slice k0 run
   double va[4], vb[4];
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + 256 * u;
       const int i = e & 63, kk = e >> 6;
-      va[u] = (m0 + i < M && k0 + kk < Kd) ? la(m0 + i, k0 + kk) : 0.0;
+      const double av = la(max(0, min(m0 + i, M - 1)), min(k0 + kk, Kd - 1));
+      va[u] = (m0 + i < M && k0 + kk < Kd) ? av : 0.0;
       const int kb = e & 15, j = e >> 4;
-      vb[u] = (n0 + j < N && k0 + kb < Kd) ? lb(k0 + kb, n0 + j) : 0.0;
+      const double bv = lb(min(k0 + kb, Kd - 1), max(0, min(n0 + j, N - 1)));
+      vb[u] = (n0 + j < N && k0 + kb < Kd) ? bv : 0.0;
     }
   };
-  const int kfirst = (kbeg / LKC) * LKC;
-  if (kfirst < Kd) fetch(kfirst);
+  fetch(kfirst);
   for (int k0 = kfirst; k0 < Kd; k0 += LKC) {
     __syncthreads();
 #pragma unroll
@@ -46,7 +98,7 @@ __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0
       sB[(e & 15) + (e >> 4) * LSB] = vb[u];
     }
     __syncthreads();
-    if (k0 + LKC < Kd) fetch(k0 + LKC);
+    fetch(k0 + LKC);      // (past the last slice: clamped addresses, masked values)
 #pragma unroll
     for (int ks = 0; ks < LKC / 4; ++ks) {
       const int kk = 4 * ks + kq;
@@ -58,20 +110,63 @@ __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
     }
   }
+  }
+}
+// accumulator element (a, b, r) of this lane -> (m, n) inside the 64 x 64 tile; false: the lane has no such element
+// (the sixteen-wave shape keeps one MFMA tile per wave in acc[0][0])
+__device__ inline bool tile64_pos(int a, int b, int r, int& m, int& n) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  if (blockDim.x == 1024) {
+    m = 16 * (wave & 3) + l15; n = 16 * (wave >> 2) + kq + 4 * r;
+    return a == 0 && b == 0;
+  }
+  m = 32 * (wave & 1) + 16 * a + l15; n = 32 * (wave >> 1) + 16 * b + kq + 4 * r;
+  return true;
 }
 // visit the accumulator elements of this lane: f(m, n, value)
 template <class F>
 __device__ inline void tile64_foreach(const d4 (&acc)[2][2], int m0, int n0, int M, int N, F f) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l15 = lane & 15, kq = lane >> 4, wm = wave & 1, wn = wave >> 1;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 32 * wm + 16 * a + l15, n = n0 + 32 * wn + 16 * b + kq + 4 * r;
-        if (m < M && n < N) f(m, n, acc[a][b][r]);
+        int m, n;
+        const bool has = tile64_pos(a, b, r, m, n);
+        m += m0; n += n0;
+        if (has && m < M && n < N) f(m, n, acc[a][b][r]);
+      }
+}
+// The same for results that are combined with values already in memory: ld(m, n) is called for ALL sixteen elements of the
+// lane first (unconditionally, at indices clamped into the M x N operand), then st(m, n, value, loaded) for those inside.
+// A load inside the guarded visit is a load under a branch: the compiler waits for each before it issues the next, and
+// sixteen dependent memory round trips were most of the time of a launch of a few tiles (k_lf_up1 / up2 / down2 for
+// one right-hand side on the top fronts of synth50k: 13 - 17 us each).
+template <class LD, class ST>
+__device__ inline void tile64_rmw(const d4 (&acc)[2][2], int m0, int n0, int M, int N, LD ld, ST st) {
+  double old[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m, n;
+        tile64_pos(a, b, r, m, n);
+        old[a][b][r] = ld(max(0, min(m0 + m, M - 1)), max(0, min(n0 + n, N - 1)));
+      }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m, n;
+        const bool has = tile64_pos(a, b, r, m, n);
+        m += m0; n += n0;
+        if (has && m < M && n < N) st(m, n, acc[a][b][r], old[a][b][r]);
       }
 }
 __device__ inline void tile64_zero(d4 (&acc)[2][2]) {
@@ -136,14 +231,20 @@ __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
   for (int64_t tt = t0 + gid; tt < t1; tt += stride) {
     const int32_t code = a.t.gp_tgt[tt];
     const int64_t c0 = a.t.gp_cptr[tt], c1 = a.t.gp_cptr[tt + 1];
+    // sixteen contributions per round of two dependent loads (source index, value), issued unconditionally at clamped
+    // positions: a position of the (64,128) fronts of synth50k sums 12.6 children on average, and with four per round
+    // and a tail loop the chain was ~9 memory round trips (24 us for one right-hand side); the sum keeps its fixed order
     double acc = 0.0;
-    int64_t cc = c0;
-    for (; cc + 4 <= c1; cc += 4) {
-      const int32_t s0 = a.t.gp_src[cc], s1 = a.t.gp_src[cc + 1], s2 = a.t.gp_src[cc + 2], s3 = a.t.gp_src[cc + 3];
-      const double v0 = ubase[s0], v1 = ubase[s1], v2 = ubase[s2], v3 = ubase[s3];
-      acc += v0; acc += v1; acc += v2; acc += v3;
+    for (int64_t cc = c0; cc < c1; cc += 16) {
+      int32_t sx[16];
+      double vx[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sx[q] = a.t.gp_src[min(cc + q, c1 - 1)];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) vx[q] = ubase[sx[q]];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc += (cc + q < c1) ? vx[q] : 0.0;
     }
-    for (; cc < c1; ++cc) acc += ubase[a.t.gp_src[cc]];
     const int i = code & 0x7fff, j = (code >> 15) & 0x7fff;
     if (sgn) {
       if (code & (1 << 30)) U[i + (int64_t)j * na] += acc; else P[i + (int64_t)j * nf] += (sgn == 2 ? acc : -acc);
@@ -399,7 +500,8 @@ __global__ void k_lf_clear_upd(MfmaArgs a) {
 // at eight, 25 % less in the limit
 __host__ __device__ inline bool lf_sym_split(int nn) { return nn > 6 * LT; }
 // ---- up-sweep phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place) ; Z = Li Fl (into T)
-__global__ void __launch_bounds__(256) k_lf_up1(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up1(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -408,19 +510,19 @@ __global__ void __launch_bounds__(256) k_lf_up1(MfmaArgs a, double* u, int64_t l
   const int t = blockIdx.x;
   if (t >= nE + nT) return;
   const double* P = c.P;
-  auto fsym = [=](int kk, int n) { return kk >= n ? P[kk + (int64_t)n * nf] : P[n + (int64_t)kk * nf]; };
+  auto fsym = [=](int kk, int n) { return P[max(kk, n) + (int64_t)min(kk, n) * nf]; };
   d4 acc[2][2];
   tile64_zero(acc);
   if (t < nE) {
     const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
     const double* K = c.K;
-    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return K[m + (int64_t)kk * nf]; }, fsym, sA, sB);
+    gemm_tile64<PD>(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return K[m + (int64_t)kk * nf]; }, fsym, sA, sB);
     double* E = c.E; double* Pw = c.P;
-    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) {
-      const double f = Pw[nn + m + (int64_t)n * nf];
-      E[m + (int64_t)n * na] = f - 0.5 * v;
-      Pw[nn + m + (int64_t)n * nf] = f - v;
-    });
+    tile64_rmw(acc, m0, n0, na, nn, [=](int m, int n) { return Pw[nn + m + (int64_t)n * nf]; },
+               [=](int m, int n, double v, double f) {
+                 E[m + (int64_t)n * na] = f - 0.5 * v;
+                 Pw[nn + m + (int64_t)n * nf] = f - v;
+               });
   } else {
     // Z = Li Fl with Fl = the lower triangle of F_NN, its diagonal halved (F_NN = Fl + Fl^T): a product of two lower
     // triangular matrices -- only the lower tiles, k from the tile's first column to its last row (nn^3 / 3 flops where
@@ -429,18 +531,19 @@ __global__ void __launch_bounds__(256) k_lf_up1(MfmaArgs a, double* u, int64_t l
     const double* Li = c.Li;
     if (lf_sym_split(nn)) {
       if (n0 > m0) return;
-      gemm_tile64(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
-                  [=](int kk, int n) { return kk > n ? P[kk + (int64_t)n * nf] : (kk == n ? 0.5 * P[kk + (int64_t)n * nf] : 0.0); },
+      gemm_tile64<PD>(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
+                  [=](int kk, int n) { const double v_ = P[kk + (int64_t)n * nf]; return kk > n ? v_ : (kk == n ? 0.5 * v_ : 0.0); },
                   sA, sB, n0);
     } else {
-      gemm_tile64(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; }, fsym, sA, sB);   // Li(m, k) = 0 for k > m
+      gemm_tile64<PD>(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; }, fsym, sA, sB);   // Li(m, k) = 0 for k > m
     }
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
   }
 }
 // ---- up-sweep phase 2: U -= K E^T + E K^T (lower tiles) ; G = X Li^T ; G_NN = Z Li^T + Li Z^T (lower, in place)
-__global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up2(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -455,9 +558,9 @@ __global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t l
     int tm, tn;
     lower_pair(t, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return K[m + (int64_t)kk * nf]; },
+    gemm_tile64<PD>(acc, na, na, nn, m0, n0, [=](int m, int kk) { return K[m + (int64_t)kk * nf]; },
                 [=](int kk, int n) { return E[n + (int64_t)kk * na]; }, sA, sB);
-    gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return E[m + (int64_t)kk * na]; },
+    gemm_tile64<PD>(acc, na, na, nn, m0, n0, [=](int m, int kk) { return E[m + (int64_t)kk * na]; },
                 [=](int kk, int n) { return K[n + (int64_t)kk * nf]; }, sA, sB);
     // The parent takes the update from the packed exchange buffer only; the square block is read (what the extend-add
     // assembled) but never written back, and a childless front does not even read it: its assembled block is zero
@@ -465,16 +568,15 @@ __global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t l
     // right-hand sides) that is 26 GB of reads + 26 GB of writes + 26 GB of clears per sweep less.
     const double* U = c.U; double* UP = c.UP;
     if (c.hasch)
-      tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) {
-        if (m >= n) UP[pk_idx(m, n, na)] = U[m + (int64_t)n * na] - v;
-      });
+      tile64_rmw(acc, m0, n0, na, na, [=](int m, int n) { return U[m + (int64_t)n * na]; },
+                 [=](int m, int n, double v, double uo) { if (m >= n) UP[pk_idx(m, n, na)] = uo - v; });
     else
       tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) {
         if (m >= n) UP[pk_idx(m, n, na)] = -v;
       });
   } else if (t < nU + nG) {
     const int tt = t - nU, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
-    gemm_tile64(acc, na, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; },
+    gemm_tile64<PD>(acc, na, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; },
                 [=](int kk, int n) { return Li[n + (int64_t)kk * nf]; }, sA, sB);      // Li(n, k) = 0 for k > n
     double* G = c.G;
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { G[m + (int64_t)n * na] = v; });
@@ -482,18 +584,23 @@ __global__ void __launch_bounds__(256) k_lf_up2(MfmaArgs a, double* u, int64_t l
     int tm, tn;
     lower_pair(t - nU - nG, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64(acc, nn, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return T[m + (int64_t)kk * nn]; },
+    gemm_tile64<PD>(acc, nn, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return T[m + (int64_t)kk * nn]; },
                 [=](int kk, int n) { return Li[n + (int64_t)kk * nf]; }, sA, sB);                 // Z Li^T  (T holds Z, phase 1)
     if (lf_sym_split(nn))
-      gemm_tile64(acc, nn, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
+      gemm_tile64<PD>(acc, nn, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
                   [=](int kk, int n) { return T[n + (int64_t)kk * nn]; }, sA, sB);               // + Li Z^T
     double* Pw = c.P;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
   }
 }
 // ---- up-sweep phase 3: Q = Ysc G into the AN rows of the panel (X is dead)
-__global__ void __launch_bounds__(256) k_lf_up3(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up3(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
+#ifdef SMCP_STAMPS
+  const bool stamp = a.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && a.nrhs == 1;
+  unsigned long long ts0 = stamp ? wall_clock64() : 0, ts1 = 0, ts2 = 0;
+#endif
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
   const int mtA = tiles64(na), ntN = tiles64(nn);
@@ -507,17 +614,32 @@ __global__ void __launch_bounds__(256) k_lf_up3(MfmaArgs a, double* u, int64_t l
   tile64_zero(acc);
   if (ymode) {
     // ymode 2: R^T(m, k) = 0 for k < m; any other mode but 1 (symmetric Y_AA): R(m, k) = 0 for k > m
-    gemm_tile64(acc, na, nn, (ymode == 1 || ymode == 2) ? na : min(na, m0 + LT), m0, n0,
+#ifdef SMCP_STAMPS
+    if (stamp) ts1 = wall_clock64();
+#endif
+    gemm_tile64<PD>(acc, na, nn, (ymode == 1 || ymode == 2) ? na : min(na, m0 + LT), m0, n0,
                 [=](int m, int kk) { return yacc(Y, na, ymode, m, kk); },
                 [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB, ymode == 2 ? m0 : 0);
+#ifdef SMCP_STAMPS
+    if (stamp) ts2 = wall_clock64();
+#endif
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = v; });
+#ifdef SMCP_STAMPS
+    if (stamp) {
+      __builtin_amdgcn_s_waitcnt(0);
+      const unsigned long long ts3 = wall_clock64();
+      atomicAdd(a.dbg + 26, ts1 - ts0); atomicAdd(a.dbg + 27, ts2 - ts1); atomicAdd(a.dbg + 28, ts3 - ts2); atomicAdd(a.dbg + 29, 1ull);
+    }
+#endif
   } else {
-    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = G[m + (int64_t)n * na]; });
+    tile64_rmw(acc, m0, n0, na, nn, [=](int m, int n) { return G[m + (int64_t)n * na]; },
+               [=](int m, int n, double, double g) { Pw[nn + m + (int64_t)n * nf] = g; });
   }
 }
 
 // ---- down-sweep phase 1: QL = Q Li (into E) ; T = G_NN Li        (Q = AN rows of the panel)
-__global__ void __launch_bounds__(256) k_lf_down1(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down1(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -531,7 +653,7 @@ __global__ void __launch_bounds__(256) k_lf_down1(MfmaArgs a, double* u, int64_t
   tile64_zero(acc);
   if (t < nE) {
     const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
-    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, li, sA, sB, n0);   // Li(k, n) = 0 for k < n
+    gemm_tile64<PD>(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, li, sA, sB, n0);   // Li(k, n) = 0 for k < n
     double* E = c.E;
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = v; });
   } else {
@@ -540,18 +662,19 @@ __global__ void __launch_bounds__(256) k_lf_down1(MfmaArgs a, double* u, int64_t
       // wide fronts: Z' = Gl Li with Gl = the lower triangle of G_NN, diagonal halved (lower tiles only, k from the tile's
       // first column to its last row); phase 3 forms Li^T G_NN Li = Li^T Z' + Z'^T Li  (see k_lf_up1)
       if (n0 > m0) return;
-      gemm_tile64(acc, nn, nn, min(nn, m0 + LT), m0, n0,
-                  [=](int m, int kk) { return m > kk ? P[m + (int64_t)kk * nf] : (m == kk ? 0.5 * P[m + (int64_t)kk * nf] : 0.0); }, li, sA, sB, n0);
+      gemm_tile64<PD>(acc, nn, nn, min(nn, m0 + LT), m0, n0,
+                  [=](int m, int kk) { const double v_ = P[m + (int64_t)kk * nf]; return m > kk ? v_ : (m == kk ? 0.5 * v_ : 0.0); }, li, sA, sB, n0);
     } else {
-      gemm_tile64(acc, nn, nn, nn, m0, n0,
-                  [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : P[kk + (int64_t)m * nf]; }, li, sA, sB, n0);
+      gemm_tile64<PD>(acc, nn, nn, nn, m0, n0,
+                  [=](int m, int kk) { return P[max(m, kk) + (int64_t)min(m, kk) * nf]; }, li, sA, sB, n0);
     }
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
   }
 }
 // ---- down-sweep phase 2: D = QL - Z_AA K / 2 (into G) ; Z_AN = 2D - QL (into the panel)
-__global__ void __launch_bounds__(256) k_lf_down2(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down2(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -562,19 +685,20 @@ __global__ void __launch_bounds__(256) k_lf_down2(MfmaArgs a, double* u, int64_t
   const double* Z = c.U; const double* K = c.K; const double* E = c.E;
   d4 acc[2][2];
   tile64_zero(acc);
-  gemm_tile64(acc, na, nn, na, m0, n0,
-              [=](int m, int kk) { return m >= kk ? Z[m + (int64_t)kk * na] : Z[kk + (int64_t)m * na]; },
+  gemm_tile64<PD>(acc, na, nn, na, m0, n0,
+              [=](int m, int kk) { return Z[max(m, kk) + (int64_t)min(m, kk) * na]; },
               [=](int kk, int n) { return K[kk + (int64_t)n * nf]; }, sA, sB);
   double* G = c.G; double* Pw = c.P;
-  tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) {
-    const double ql = E[m + (int64_t)n * na];
-    const double dd = ql - 0.5 * v;
-    G[m + (int64_t)n * na] = dd;
-    Pw[nn + m + (int64_t)n * nf] = 2.0 * dd - ql;
-  });
+  tile64_rmw(acc, m0, n0, na, nn, [=](int m, int n) { return E[m + (int64_t)n * na]; },
+             [=](int m, int n, double v, double ql) {
+               const double dd = ql - 0.5 * v;
+               G[m + (int64_t)n * na] = dd;
+               Pw[nn + m + (int64_t)n * nf] = 2.0 * dd - ql;
+             });
 }
 // ---- down-sweep phase 3: Z_NN = Li^T T - K^T D - D^T K (lower tiles, into the panel)
-__global__ void __launch_bounds__(256) k_lf_down3(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down3(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -587,14 +711,14 @@ __global__ void __launch_bounds__(256) k_lf_down3(MfmaArgs a, double* u, int64_t
   const double* Li = c.Li; const double* K = c.K; const double* T = c.T; const double* D = c.G;
   d4 acc[2][2];
   tile64_zero(acc);
-  gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
+  gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
               [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB, m0);                 // Li(k, m) = 0 for k < m
   if (lf_sym_split(nn))
-    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return T[kk + (int64_t)m * nn]; },
+    gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return T[kk + (int64_t)m * nn]; },
                 [=](int kk, int n) { return Li[kk + (int64_t)n * nf]; }, sA, sB, m0);             // + Z'^T Li (T holds Z')
-  gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -K[kk + (int64_t)m * nf]; },
+  gemm_tile64<PD>(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -K[kk + (int64_t)m * nf]; },
               [=](int kk, int n) { return D[kk + (int64_t)n * na]; }, sA, sB);
-  gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -D[kk + (int64_t)m * na]; },
+  gemm_tile64<PD>(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -D[kk + (int64_t)m * na]; },
               [=](int kk, int n) { return K[kk + (int64_t)n * nf]; }, sA, sB);
   double* Pw = c.P;
   tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
@@ -659,7 +783,8 @@ __global__ void __launch_bounds__(256) k_trsm_mm_bwd(MfmaArgs a, double* B, int 
 }
 
 // ---- projected inverse, large fronts: E = Y_AA K ; Y_NN = Li^T Li + K^T E (lower) ; Y_AN = -E
-__global__ void __launch_bounds__(256) k_lf_pinv1(MfmaArgs a, double* x) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_pinv1(MfmaArgs a, double* x) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, x, 0);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -670,13 +795,14 @@ __global__ void __launch_bounds__(256) k_lf_pinv1(MfmaArgs a, double* x) {
   const double* Y = c.U; const double* K = c.K;
   d4 acc[2][2];
   tile64_zero(acc);
-  gemm_tile64(acc, na, nn, na, m0, n0,
-              [=](int m, int kk) { return m >= kk ? Y[m + (int64_t)kk * na] : Y[kk + (int64_t)m * na]; },
+  gemm_tile64<PD>(acc, na, nn, na, m0, n0,
+              [=](int m, int kk) { return Y[max(m, kk) + (int64_t)min(m, kk) * na]; },
               [=](int kk, int n) { return K[kk + (int64_t)n * nf]; }, sA, sB);
   double* E = c.E;
   tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = v; });
 }
-__global__ void __launch_bounds__(256) k_lf_pinv2(MfmaArgs a, double* x) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_pinv2(MfmaArgs a, double* x) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, x, 0);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -693,9 +819,9 @@ __global__ void __launch_bounds__(256) k_lf_pinv2(MfmaArgs a, double* x) {
     const double* Li = c.Li; const double* K = c.K;
     d4 acc[2][2];
     tile64_zero(acc);
-    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
+    gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
                 [=](int kk, int n) { return Li[kk + (int64_t)n * nf]; }, sA, sB, max(m0, n0));
-    gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return K[kk + (int64_t)m * nf]; },
+    gemm_tile64<PD>(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return K[kk + (int64_t)m * nf]; },
                 [=](int kk, int n) { return E[kk + (int64_t)n * na]; }, sA, sB);
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
   } else {
@@ -872,7 +998,8 @@ __global__ void __launch_bounds__(256) k_lf_chol_trail(MfmaArgs a, double* x, do
     gemm_tile64(acc, mrem, ncr, w, m0, n0, [=](int m, int kk) { return Pj[m + kk * ld]; },
                 [=](int kk, int n) { return Pj[n + kk * ld]; }, sA, sB);
     double* Tr = M.A + (jb + w) + (int64_t)(jb + w) * M.ld;
-    tile64_foreach(acc, m0, n0, mrem, ncr, [=](int m, int n, double v) { if (m >= n) Tr[m + n * ld] -= v; });
+    tile64_rmw(acc, m0, n0, mrem, ncr, [=](int m, int n) { return Tr[m + n * ld]; },
+               [=](int m, int n, double v, double o) { if (m >= n) Tr[m + n * ld] = o - v; });
   } else {
     int tm, tn;
     lower_pair(t - nP, tm, tn);
@@ -882,7 +1009,8 @@ __global__ void __launch_bounds__(256) k_lf_chol_trail(MfmaArgs a, double* x, do
     gemm_tile64(acc, na, na, w, m0, n0, [=](int m, int kk) { return Pa[m + kk * ld]; },
                 [=](int kk, int n) { return Pa[n + kk * ld]; }, sA, sB);
     double* U = M.upd;
-    tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) { if (m >= n) U[m + (int64_t)n * na] -= v; });
+    tile64_rmw(acc, m0, n0, na, na, [=](int m, int n) { return U[m + (int64_t)n * na]; },
+               [=](int m, int n, double v, double o) { if (m >= n) U[m + (int64_t)n * na] = o - v; });
   }
 }
 // after the last step of a front's Cholesky: publish the update block as packed lower triangle
@@ -1018,7 +1146,7 @@ __global__ void __launch_bounds__(256) k_lf_prep_s(MfmaArgs a, const double* L, 
   d4 acc[2][2];
   tile64_zero(acc);
   gemm_tile64(acc, w, ib, ib, 0, n0, [=](int m, int kk) { return Lk[(ib + m) + (int64_t)kk * nf]; },
-              [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB, n0);
+              [=](int kk, int n) { const double v_ = Li[kk + (int64_t)n * nf]; return kk >= n ? v_ : 0.0; }, sA, sB, n0);
   tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { S[s0 + m * sm + n * sn] = v; });
 }
 // hoisted != 0: the inverses of ALL diagonal blocks are already in place in dst (k_lf_diag_inv)
@@ -1119,11 +1247,11 @@ __global__ void __launch_bounds__(256) k_lf_trtri(MfmaArgs a, const double* L, d
     const double* Bm = Lk + (r0 + b) + (int64_t)r0 * nf;
     const double* Ai = Li + r0 + (int64_t)r0 * nf;
     gemm_tile64(acc, b2, b, b, m0, n0, [=](int m, int kk) { return Bm[m + (int64_t)kk * nf]; },
-                [=](int kk, int n) { return kk >= n ? Ai[kk + (int64_t)n * nf] : 0.0; }, sA, sB, n0);       // Ai(k, n) = 0 for k < n
+                [=](int kk, int n) { const double v_ = Ai[kk + (int64_t)n * nf]; return kk >= n ? v_ : 0.0; }, sA, sB, n0);       // Ai(k, n) = 0 for k < n
     tile64_foreach(acc, m0, n0, b2, b, [=](int m, int n, double v) { W[m + (int64_t)n * b] = v; });
   } else {
     const double* Ci = Li + (r0 + b) + (int64_t)(r0 + b) * nf;
-    gemm_tile64(acc, b2, b, min(b2, m0 + LT), m0, n0, [=](int m, int kk) { return m >= kk ? Ci[m + (int64_t)kk * nf] : 0.0; },
+    gemm_tile64(acc, b2, b, min(b2, m0 + LT), m0, n0, [=](int m, int kk) { const double v_ = Ci[m + (int64_t)kk * nf]; return m >= kk ? v_ : 0.0; },
                 [=](int kk, int n) { return W[kk + (int64_t)n * b]; }, sA, sB);                               // Ci(m, k) = 0 for k > m
     double* X = Li + (r0 + b) + (int64_t)r0 * nf;
     tile64_foreach(acc, m0, n0, b2, b, [=](int m, int n, double v) { X[m + (int64_t)n * nf] = -v; });
@@ -1144,7 +1272,7 @@ __global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, 
   d4 acc[2][2];
   tile64_zero(acc);
   gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return Lk[(nn + m) + (int64_t)kk * nf]; },
-              [=](int kk, int n) { return kk >= n ? Li[kk + (int64_t)n * nf] : 0.0; }, sA, sB, n0);
+              [=](int kk, int n) { const double v_ = Li[kk + (int64_t)n * nf]; return kk >= n ? v_ : 0.0; }, sA, sB, n0);
   tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Kk[m + (int64_t)n * nf] = v; });
 }
 
@@ -1155,16 +1283,16 @@ __global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, 
 // ---------------------------------------------------------------------------------------------
 template <class F>
 __device__ inline void tile64_foreach2(const d4 (&a1)[2][2], const d4 (&a2)[2][2], int m0, int n0, int M, int N, F f) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l15 = lane & 15, kq = lane >> 4, wm = wave & 1, wn = wave >> 1;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 32 * wm + 16 * a + l15, n = n0 + 32 * wn + 16 * b + kq + 4 * r;
-        if (m < M && n < N) f(m, n, a1[a][b][r], a2[a][b][r]);
+        int m, n;
+        const bool has = tile64_pos(a, b, r, m, n);
+        m += m0; n += n0;
+        if (has && m < M && n < N) f(m, n, a1[a][b][r], a2[a][b][r]);
       }
 }
 // AN rows of the panel <-> G scratch.  dir 0: panel = G, 1: G = panel
@@ -1177,7 +1305,8 @@ __global__ void k_lf_copy_an(MfmaArgs a, double* u, int64_t ldu, int dir) {
   }
 }
 // G = Ri^T (AN rows of the panel)  (tr = 1)   or   G = Ri (AN rows)  (tr = 0)
-__global__ void __launch_bounds__(256) k_lf_ri_an(MfmaArgs a, double* u, int64_t ldu, int tr) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_ri_an(MfmaArgs a, double* u, int64_t ldu, int tr) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1189,17 +1318,18 @@ __global__ void __launch_bounds__(256) k_lf_ri_an(MfmaArgs a, double* u, int64_t
   d4 acc[2][2];
   tile64_zero(acc);
   if (tr)
-    gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return kk >= m ? Y[kk + (int64_t)m * na] : 0.0; },
+    gemm_tile64<PD>(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[kk + (int64_t)m * na]; return kk >= m ? v_ : 0.0; },
                 [=](int kk, int n) { return P[nn + kk + (int64_t)n * nf]; }, sA, sB);
   else
-    gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return m >= kk ? Y[m + (int64_t)kk * na] : 0.0; },
+    gemm_tile64<PD>(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[m + (int64_t)kk * na]; return m >= kk ? v_ : 0.0; },
                 [=](int kk, int n) { return P[nn + kk + (int64_t)n * nf]; }, sA, sB);
   double* G = c.G;
   tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { G[m + (int64_t)n * na] = v; });
 }
 
 // ---- G^-adj phase 1: Q = Z_AN L_NN + Z_AA L_AN (into G) ; Q'' = Z_AN L_NN + Z_AA L_AN / 2 (into E) ; T = Z_NN L_NN
-__global__ void __launch_bounds__(256) k_lf_dinv1(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_dinv1(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1215,9 +1345,9 @@ __global__ void __launch_bounds__(256) k_lf_dinv1(MfmaArgs a, double* u, int64_t
     const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
     d4 acc2[2][2];
     tile64_zero(acc2);
-    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, lnn, sA, sB);
-    gemm_tile64(acc2, na, nn, na, m0, n0,
-                [=](int m, int kk) { return m >= kk ? Z[m + (int64_t)kk * na] : Z[kk + (int64_t)m * na]; },
+    gemm_tile64<PD>(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, lnn, sA, sB);
+    gemm_tile64<PD>(acc2, na, nn, na, m0, n0,
+                [=](int m, int kk) { return Z[max(m, kk) + (int64_t)min(m, kk) * na]; },
                 [=](int kk, int n) { return Lan[kk + (int64_t)n * nf]; }, sA, sB);
     double* E = c.E; double* G = c.G;
     tile64_foreach2(acc, acc2, m0, n0, na, nn, [=](int m, int n, double v1, double v2) {
@@ -1226,14 +1356,15 @@ __global__ void __launch_bounds__(256) k_lf_dinv1(MfmaArgs a, double* u, int64_t
     });
   } else {
     const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
-    gemm_tile64(acc, nn, nn, nn, m0, n0,
-                [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : P[kk + (int64_t)m * nf]; }, lnn, sA, sB);
+    gemm_tile64<PD>(acc, nn, nn, nn, m0, n0,
+                [=](int m, int kk) { return P[max(m, kk) + (int64_t)min(m, kk) * nf]; }, lnn, sA, sB);
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
   }
 }
 // ---- G^-adj phase 2: G_NN = L_NN^T T + L_AN^T Q'' + Q''^T L_AN (lower, into the panel) ; AN rows = Q or Ri Q
-__global__ void __launch_bounds__(256) k_lf_dinv2(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_dinv2(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1249,27 +1380,29 @@ __global__ void __launch_bounds__(256) k_lf_dinv2(MfmaArgs a, double* u, int64_t
     int tm, tn;
     lower_pair(t, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Lnn[kk + (int64_t)m * nf]; },
+    gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Lnn[kk + (int64_t)m * nf]; },
                 [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB);
-    gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return Lan[kk + (int64_t)m * nf]; },
+    gemm_tile64<PD>(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return Lan[kk + (int64_t)m * nf]; },
                 [=](int kk, int n) { return E[kk + (int64_t)n * na]; }, sA, sB);
-    gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return E[kk + (int64_t)m * na]; },
+    gemm_tile64<PD>(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return E[kk + (int64_t)m * na]; },
                 [=](int kk, int n) { return Lan[kk + (int64_t)n * nf]; }, sA, sB);
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
   } else {
     const int tt = t - nN, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
     if (a.ymode) {
       const double* Y = c.Ys;
-      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return m >= kk ? Y[m + (int64_t)kk * na] : 0.0; },
+      gemm_tile64<PD>(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[m + (int64_t)kk * na]; return m >= kk ? v_ : 0.0; },
                   [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB);
       tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = v; });
     } else {
-      tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = G[m + (int64_t)n * na]; });
+      tile64_rmw(acc, m0, n0, na, nn, [=](int m, int n) { return G[m + (int64_t)n * na]; },
+               [=](int m, int n, double, double g) { Pw[nn + m + (int64_t)n * nf] = g; });
     }
   }
 }
 // ---- G^-1 phase 1: V = G_AN + L_AN G_NN / 2 (into E) ; T = G_NN L_NN^T
-__global__ void __launch_bounds__(256) k_lf_uinv1(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_uinv1(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1278,23 +1411,25 @@ __global__ void __launch_bounds__(256) k_lf_uinv1(MfmaArgs a, double* u, int64_t
   const int t = blockIdx.x;
   if (t >= nE + nT) return;
   const double* P = c.P; const double* Lnn = c.Li; const double* Lan = c.K;
-  auto gsym = [=](int i, int j) { return i >= j ? P[i + (int64_t)j * nf] : P[j + (int64_t)i * nf]; };
+  auto gsym = [=](int i, int j) { return P[max(i, j) + (int64_t)min(i, j) * nf]; };
   d4 acc[2][2];
   tile64_zero(acc);
   if (t < nE) {
     const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
-    gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return Lan[m + (int64_t)kk * nf]; }, gsym, sA, sB);
+    gemm_tile64<PD>(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return Lan[m + (int64_t)kk * nf]; }, gsym, sA, sB);
     double* E = c.E;
-    tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = P[nn + m + (int64_t)n * nf] + 0.5 * v; });
+    tile64_rmw(acc, m0, n0, na, nn, [=](int m, int n) { return P[nn + m + (int64_t)n * nf]; },
+               [=](int m, int n, double v, double f) { E[m + (int64_t)n * na] = f + 0.5 * v; });
   } else {
     const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
-    gemm_tile64(acc, nn, nn, nn, m0, n0, gsym, [=](int kk, int n) { return Lnn[n + (int64_t)kk * nf]; }, sA, sB);
+    gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, gsym, [=](int kk, int n) { return Lnn[n + (int64_t)kk * nf]; }, sA, sB);
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
   }
 }
 // ---- G^-1 phase 2: U = -(V L_AN^T + L_AN V^T) (lower) ; G = (2V - G_AN) L_NN^T ; F_NN = L_NN T (lower, into the panel)
-__global__ void __launch_bounds__(256) k_lf_uinv2(MfmaArgs a, double* u, int64_t ldu) {
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_uinv2(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1309,15 +1444,15 @@ __global__ void __launch_bounds__(256) k_lf_uinv2(MfmaArgs a, double* u, int64_t
     int tm, tn;
     lower_pair(t, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return E[m + (int64_t)kk * na]; },
+    gemm_tile64<PD>(acc, na, na, nn, m0, n0, [=](int m, int kk) { return E[m + (int64_t)kk * na]; },
                 [=](int kk, int n) { return Lan[n + (int64_t)kk * nf]; }, sA, sB);
-    gemm_tile64(acc, na, na, nn, m0, n0, [=](int m, int kk) { return Lan[m + (int64_t)kk * nf]; },
+    gemm_tile64<PD>(acc, na, na, nn, m0, n0, [=](int m, int kk) { return Lan[m + (int64_t)kk * nf]; },
                 [=](int kk, int n) { return E[n + (int64_t)kk * na]; }, sA, sB);
     double* U = c.U;
     tile64_foreach(acc, m0, n0, na, na, [=](int m, int n, double v) { if (m >= n) U[m + (int64_t)n * na] = -v; });
   } else if (t < nU + nG) {
     const int tt = t - nU, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
-    gemm_tile64(acc, na, nn, nn, m0, n0,
+    gemm_tile64<PD>(acc, na, nn, nn, m0, n0,
                 [=](int m, int kk) { return 2.0 * E[m + (int64_t)kk * na] - P[nn + m + (int64_t)kk * nf]; },
                 [=](int kk, int n) { return Lnn[n + (int64_t)kk * nf]; }, sA, sB);
     double* G = c.G;
@@ -1326,7 +1461,7 @@ __global__ void __launch_bounds__(256) k_lf_uinv2(MfmaArgs a, double* u, int64_t
     int tm, tn;
     lower_pair(t - nU - nG, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Lnn[m + (int64_t)kk * nf]; },
+    gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Lnn[m + (int64_t)kk * nf]; },
                 [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB);
     __syncthreads();
     double* Pw = c.P;
@@ -1351,10 +1486,10 @@ __global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, in
     if (t >= mtA * ntN) return;
     const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
     if (step == 0)
-      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return m >= kk ? Y[m + (int64_t)kk * na] : 0.0; },
+      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[m + (int64_t)kk * na]; return m >= kk ? v_ : 0.0; },
                   [=](int kk, int n) { return P[nn + kk + (int64_t)n * nf]; }, sA, sB);
     else
-      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return kk >= m ? Y[kk + (int64_t)m * na] : 0.0; },
+      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[kk + (int64_t)m * na]; return kk >= m ? v_ : 0.0; },
                   [=](int kk, int n) { return E[kk + (int64_t)n * na]; }, sA, sB);
     double* O = step == 0 ? E : G;
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { O[m + (int64_t)n * na] = v; });
@@ -1363,10 +1498,8 @@ __global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, in
     const int m0 = (t % ntN) * LT, n0 = (t / ntN) * LT;
     gemm_tile64(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return P[nn + kk + (int64_t)m * nf]; },
                 [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB);
-    tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) {
-      const double f = m >= n ? P[m + (int64_t)n * nf] : P[n + (int64_t)m * nf];
-      T[(nn - 1 - m) + (int64_t)(nn - 1 - n) * nn] = f - v;
-    });
+    tile64_rmw(acc, m0, n0, nn, nn, [=](int m, int n) { return P[max(m, n) + (int64_t)min(m, n) * nf]; },
+               [=](int m, int n, double v, double f) { T[(nn - 1 - m) + (int64_t)(nn - 1 - n) * nn] = f - v; });
   } else {
     const int nN = ntN * ntN, nA = mtA * ntN;
     if (t >= nN + nA) return;
@@ -1380,7 +1513,7 @@ __global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, in
     } else {
       const int tt = t - nN, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
       gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return G[m + (int64_t)kk * na]; },
-                  [=](int kk, int n) { return kk >= n ? T[(nn - 1 - n) + (int64_t)(nn - 1 - kk) * nn] : 0.0; }, sA, sB);
+                  [=](int kk, int n) { const double v_ = T[(nn - 1 - n) + (int64_t)(nn - 1 - kk) * nn]; return kk >= n ? v_ : 0.0; }, sA, sB);
       tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = -v; });
     }
   }
@@ -1410,14 +1543,14 @@ __global__ void __launch_bounds__(256) k_lf_llt(MfmaArgs a, double* x, int step)
     return;
   }
   const double* P = c.P;
-  auto lnnT = [=](int kk, int n) { return n >= kk ? P[n + (int64_t)kk * nf] : 0.0; };
+  auto lnnT = [=](int kk, int n) { const double v_ = P[n + (int64_t)kk * nf]; return n >= kk ? v_ : 0.0; };
   d4 acc[2][2];
   tile64_zero(acc);
   if (t < nT) {
     int tm, tn;
     lower_pair(t, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return m >= kk ? P[m + (int64_t)kk * nf] : 0.0; }, lnnT, sA, sB);
+    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { const double v_ = P[m + (int64_t)kk * nf]; return m >= kk ? v_ : 0.0; }, lnnT, sA, sB);
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) T[m + (int64_t)n * nn] = v; });
   } else if (t < nT + nG) {

@@ -208,9 +208,13 @@ __device__ inline void load_consts(const MfmaArgs& a, const CliqueDesc& d, const
 }
 
 __device__ inline double yacc(const double* Y, int ld, int mode, int m, int k) {
-  if (mode == 1) return m >= k ? Y[m + k * ld] : Y[k + m * ld];
-  if (mode == 2) return k >= m ? Y[k + m * ld] : 0.0;   // R^T
-  return m >= k ? Y[m + k * ld] : 0.0;                    // R
+  // one unconditional load (the mirrored position of a triangular factor is allocated memory: zeros or scratch) and a
+  // mask: no branch around the load (see gemm_tile64)
+  const bool tr = mode == 1 ? m < k : mode == 2;           // read (k, m) instead of (m, k)
+  const int i = tr ? k : m, j = tr ? m : k;
+  const double v = Y[i + j * ld];
+  if (mode == 1) return v;
+  return i >= j ? v : 0.0;                                  // R^T (mode 2) / R
 }
 
 // children's update matrices (global, lower) scatter-added into the front [F | U].
@@ -620,7 +624,9 @@ __global__ void k_hess_down_mfma(MfmaArgs a, double* u, int64_t ldu) {
         batched_loop<8>(threadIdx.x, nf * nn, blockDim.x, [=](int e) { return P[e]; },
                         [=](int e, double v) { Fl[(e % nf) + (e / nf) * ldfl] = v; });
       }
-      gather_front(d, par, rel, ur, ub, w.U, w.ldu, UkG);
+      // (the copy of Z_AA in global memory is what the CHILDREN gather from: a childless clique -- 7168 of the 8073 of
+      // synth50k, 27 MB of stores per right-hand side -- keeps it in LDS only)
+      gather_front(d, par, rel, ur, ub, w.U, w.ldu, d.chend > d.chbeg ? UkG : nullptr);
     } else {
       w.F = P;
       w.U = UkG;
