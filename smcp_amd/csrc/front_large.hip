@@ -81,11 +81,11 @@ __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0
     for (int u = 0; u < 4; ++u) {
       const int e = tid + 256 * u;
       const int i = e & 63, kk = e >> 6;
-      const double av = la(max(0, min(m0 + i, M - 1)), min(k0 + kk, Kd - 1));
-      va[u] = (m0 + i < M && k0 + kk < Kd) ? av : 0.0;
+      // (guarded loads here: with clamped, unconditional ones -- what the sixteen-wave shape needs -- the batched sweeps
+      // lost 10 - 45 %: k_lf_up1 on the root of synth50k, 100 right-hand sides, 76 -> 110 us)
+      va[u] = (m0 + i < M && k0 + kk < Kd) ? la(m0 + i, k0 + kk) : 0.0;
       const int kb = e & 15, j = e >> 4;
-      const double bv = lb(min(k0 + kb, Kd - 1), max(0, min(n0 + j, N - 1)));
-      vb[u] = (n0 + j < N && k0 + kb < Kd) ? bv : 0.0;
+      vb[u] = (n0 + j < N && k0 + kb < Kd) ? lb(k0 + kb, n0 + j) : 0.0;
     }
   };
   fetch(kfirst);
@@ -98,7 +98,7 @@ __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0
       sB[(e & 15) + (e >> 4) * LSB] = vb[u];
     }
     __syncthreads();
-    fetch(k0 + LKC);      // (past the last slice: clamped addresses, masked values)
+    if (k0 + LKC < Kd) fetch(k0 + LKC);
 #pragma unroll
     for (int ks = 0; ks < LKC / 4; ++ks) {
       const int kk = 4 * ks + kq;
