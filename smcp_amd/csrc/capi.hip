@@ -53,7 +53,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn, KID_lf_zsp,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -71,7 +71,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn", "k_lf_zsp"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -346,6 +346,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.kc_ptr = nullptr; a.kc_off = nullptr; a.kc_val = nullptr; a.kc_ids = nullptr;
   a.sp_rt = c->D.sp_rt; a.sp_mk = c->D.sp_mk;
   a.kc_stride = 0; a.kc_j0 = 0;
+  a.nnmin = 0;
   a.level = 0; a.nS = 0; a.famna = a.fampan = a.fampk = a.famcna = a.famnn = a.famcnn = 0;
   return a;
 }
@@ -375,6 +376,7 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f, int set = 0) {
   if (L.nII) {
     a.t.lev = base + L.nI;
     a.nnmax = L.nnmaxII;
+    a.nnmin = L.nnminII;
     a.namax = L.namaxII;
     a.nchmax = L.nchmaxII;
     f(false, a, (int)L.nII, (size_t)0, 1024);
@@ -1098,6 +1100,18 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
           part(0, h, st);
           return;
         }
+        // Wide childless fronts without separator (config 2: ONE dense 4096 clique) whose right-hand sides are sparse
+        // constraints: the first phase, Z = Li Fl, is a sparse combination of columns of Li per column of Z (k_lf_zsp)
+        // instead of a product of two dense triangles, the second phase never reads the input panel -- no dense panel is built
+        // at all.  SMCP_ZSP=0: the dense route.
+        static int zsp = -1;
+        if (zsp < 0) { const char* e = getenv("SMCP_ZSP"); zsp = (e && e[0] == '0') ? 0 : 1; }
+        if (zsp && sparse && c->D.kc_sorted && a.nchmax == 0 && a.namax == 0 && lf_sym_split(a.nnmin) && a.nnmax <= LF_ZSP_MAXNN) {
+          const int ntN = tiles64(a.nnmax);
+          launch_lds(c, KID_lf_zsp, k_lf_zsp, dim3(a.nnmax, cnt, nrhs), dim3(256), (size_t)a.nnmax * sizeof(double), st, a, U, ldu);
+          LAUNCH_PD(c, KID_lf_up2, k_lf_up2, dim3(umax1(ntN * (ntN + 1) / 2), cnt, nrhs), dim3(256), st, a, U, ldu);
+          return;
+        }
         dense_input(a, cnt);
         lf_up(c, a, cnt, nrhs, U, ldu, st);
       }
@@ -1435,6 +1449,7 @@ void classify_levels(const Symbolic& S, Keep keep, std::vector<LevelClass>& lvl,
         } else {
           L.nII++;
           L.nnmaxII = std::max<int>(L.nnmaxII, (int)S.nn(k));
+          L.nnminII = std::min<int>(L.nnminII, (int)S.nn(k));
           L.namaxII = std::max<int>(L.namaxII, (int)S.na(k));
           L.nchmaxII = std::max<int>(L.nchmaxII, (int)(S.chptr[k + 1] - S.chptr[k]));
         }

@@ -118,6 +118,7 @@ struct DeviceCtx {
   double* lg_tab = nullptr; int lg_rec = 0;                           // per-step tables (Psi, Omega), lg_rec doubles per child
   int lg_nf = 0, lg_nn = 0, lg_na = 0;                                // sizing over that list
   int64_t lg_children = 0, lg_maxent = 0, lg_pairs = 0, lg_rows = 0;  // over all family children (kkt_set_constraints)
+  bool kc_sorted = false;    // every per-(clique, constraint) entry list ascends in panel position (columns are contiguous runs)
   bool lg_request = false;   // the running Schur sweep may leave the panels of the family children out
   bool lg_nochild = false;   // ... and did: the stack lacks them, their Gram block comes from k_leaf_gram
   // kkt_qr (csrc/kkt_qr.hip): m x m work matrices, the inverse of the triangular factor, G(bx) and reduction scratch;
@@ -165,6 +166,7 @@ struct LevelClass {
   int nnmaxI = 0, namaxI = 0;  // LDS layout sizing for the LDS class
   int nchmaxI = 0, panmaxI = 0, pkmaxI = 0, plansumI = 0;  // index tables of the padded kernels (see pad_layout)
   int nnmaxII = 0, namaxII = 0;  // tile-grid sizing for the large-front (HBM) class
+  int nnminII = 1 << 30;         // narrowest supernode of the class (the sparse first phase of wide childless fronts needs all of them wide)
   int nchmaxII = 0;              // most children of a large front (child table of k_lf_assemble_lds)
   // Families (front_fam.hip): the LAST nS cliques of the LDS class of this level are either childless cliques whose
   // parent is a family parent (level 0) or family parents (levels >= 1: small fronts all of whose children are such

@@ -18,6 +18,13 @@ constexpr int LSA = LT + 1, LSB = LKC + 1;
 // The products run over k in [kbeg, Kd): a caller whose operand is triangular passes the range where it is nonzero
 // (kbeg is rounded down to a slice boundary; Li is stored with explicit zeros above its diagonal, so the bounds only
 // skip slices of zeros -- half of T = Li F_NN, G = X Li^T ... on a big front).
+// masked operand element: the sixteen-wave shape loads unconditionally and masks (see gemm_tile64), the four-wave shape
+// keeps the load under its condition (the masked half of a triangular operand is not fetched at all)
+template <int PD>
+__device__ inline double ldm(bool c, const double* p) {
+  if constexpr (PD == 4) { const double v = *p; return c ? v : 0.0; }
+  else return c ? *p : 0.0;
+}
 // Two shapes of the same tile product.  PD = 1 (256 threads): four waves, 2 x 2 MFMA tiles each -- the batched sweeps, where
 // several workgroups share a CU.  PD = 4 (1024 threads, "W16"): sixteen waves, ONE 16 x 16 MFMA tile each, for launches of
 // a few tiles (one right-hand side on the top fronts: the solves of the interior-point iteration).  In-kernel stamps
@@ -532,7 +539,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up1(MfmaArgs a, dou
     if (lf_sym_split(nn)) {
       if (n0 > m0) return;
       gemm_tile64<PD>(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
-                  [=](int kk, int n) { const double v_ = P[kk + (int64_t)n * nf]; return kk > n ? v_ : (kk == n ? 0.5 * v_ : 0.0); },
+                  [=](int kk, int n) { const double v_ = ldm<PD>(kk >= n, &P[kk + (int64_t)n * nf]); return kk == n ? 0.5 * v_ : v_; },
                   sA, sB, n0);
     } else {
       gemm_tile64<PD>(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; }, fsym, sA, sB);   // Li(m, k) = 0 for k > m
@@ -540,6 +547,65 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up1(MfmaArgs a, dou
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
   }
+}
+// ---- up-sweep phase 1 of a wide childless front WITHOUT separator whose right-hand side is a sparse constraint A_j (entry
+// list of the clique, ascending in panel position: the entries of a column are one run):
+//   Z[:, c] = sum over the entries (r, c), r >= c, of column c:  w Li[:, r]      (w halved on the diagonal; rows >= r)
+// i.e. 2 nnz(A_j) n / 3 multiply-adds instead of the n^3 / 3 of the product of two dense triangles -- 3.4e8 against 2.3e10
+// per constraint on the 4096 clique of config 2 at 0.5 % density -- and no dense input panel.  One workgroup per column of Z:
+// the column is accumulated in LDS (row i belongs to thread (i - r0) mod 256 throughout: no synchronisation between entries),
+// every read of Li is a contiguous run of one of its columns.  Rows r0 .. c - 1 of the column (r0 = the first row of its
+// diagonal tile) are written as zeros: phase 2 reads whole lower tiles of Z.
+constexpr int LF_ZSP_MAXNN = 7168;        // the column buffer: 56 KB of LDS
+__global__ void __launch_bounds__(256) k_lf_zsp(MfmaArgs a, double* u, int64_t ldu) {
+  extern __shared__ __attribute__((aligned(16))) double zc[];
+  __shared__ int s_row[64];
+  __shared__ double s_w[64];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, nf = c.nf;
+  const int col = blockIdx.x;
+  if (col >= nn) return;
+  const int tid = threadIdx.x;
+  const int r0 = (col / LT) * LT;
+  const int r = blockIdx.z;
+  const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
+  const int32_t* kp = a.kc_ptr + (int64_t)c.k * a.kc_stride;
+  const int e0 = kp[j], e1 = kp[j + 1];
+  // the run of column `col`: first entry at or after col * nf, first at or after (col + 1) * nf   (uniform binary searches)
+  auto lower = [&](int64_t key) {
+    int lo = e0, hi = e1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)a.kc_off[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  const int b0 = lower((int64_t)col * nf), b1 = lower((int64_t)(col + 1) * nf);
+  for (int i = r0 + tid; i < nn; i += 256) zc[i] = 0.0;
+  const double* Li = c.Li;
+  for (int base = b0; base < b1; base += 64) {
+    __syncthreads();
+    if (tid < 64 && base + tid < b1) {
+      const int off = a.kc_off[base + tid];
+      const int row = off - col * nf;                   // < nn: the front has no separator rows
+      s_row[tid] = row;
+      s_w[tid] = row == col ? 0.5 * a.kc_val[base + tid] : a.kc_val[base + tid];
+    }
+    __syncthreads();
+    const int ne = min(64, b1 - base);
+    for (int q = 0; q < ne; ++q) {
+      const int row = s_row[q];
+      const double w = s_w[q];
+      const double* Lc = Li + (int64_t)row * nf;
+      // first row i >= row owned by this thread: i = r0 + tid (mod 256)
+      int i = r0 + tid;
+      if (i < row) i += ((row - i + 255) >> 8) << 8;
+      for (; i + 768 < nn; i += 1024) {
+        const double v0 = Lc[i], v1 = Lc[i + 256], v2 = Lc[i + 512], v3 = Lc[i + 768];
+        zc[i] += w * v0; zc[i + 256] += w * v1; zc[i + 512] += w * v2; zc[i + 768] += w * v3;
+      }
+      for (; i < nn; i += 256) zc[i] += w * Lc[i];
+    }
+  }
+  double* T = c.T + (int64_t)col * nn;
+  for (int i = r0 + tid; i < nn; i += 256) T[i] = zc[i];
 }
 // ---- up-sweep phase 2: U -= K E^T + E K^T (lower tiles) ; G = X Li^T ; G_NN = Z Li^T + Li Z^T (lower, in place)
 template <int PD>
@@ -618,7 +684,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up3(MfmaArgs a, dou
     if (stamp) ts1 = wall_clock64();
 #endif
     gemm_tile64<PD>(acc, na, nn, (ymode == 1 || ymode == 2) ? na : min(na, m0 + LT), m0, n0,
-                [=](int m, int kk) { return yacc(Y, na, ymode, m, kk); },
+                [=](int m, int kk) { return yacc<PD>(Y, na, ymode, m, kk); },
                 [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB, ymode == 2 ? m0 : 0);
 #ifdef SMCP_STAMPS
     if (stamp) ts2 = wall_clock64();
@@ -663,7 +729,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down1(MfmaArgs a, d
       // first column to its last row); phase 3 forms Li^T G_NN Li = Li^T Z' + Z'^T Li  (see k_lf_up1)
       if (n0 > m0) return;
       gemm_tile64<PD>(acc, nn, nn, min(nn, m0 + LT), m0, n0,
-                  [=](int m, int kk) { const double v_ = P[m + (int64_t)kk * nf]; return m > kk ? v_ : (m == kk ? 0.5 * v_ : 0.0); }, li, sA, sB, n0);
+                  [=](int m, int kk) { const double v_ = ldm<PD>(m >= kk, &P[m + (int64_t)kk * nf]); return m == kk ? 0.5 * v_ : v_; }, li, sA, sB, n0);
     } else {
       gemm_tile64<PD>(acc, nn, nn, nn, m0, n0,
                   [=](int m, int kk) { return P[max(m, kk) + (int64_t)min(m, kk) * nf]; }, li, sA, sB, n0);
@@ -1146,7 +1212,7 @@ __global__ void __launch_bounds__(256) k_lf_prep_s(MfmaArgs a, const double* L, 
   d4 acc[2][2];
   tile64_zero(acc);
   gemm_tile64(acc, w, ib, ib, 0, n0, [=](int m, int kk) { return Lk[(ib + m) + (int64_t)kk * nf]; },
-              [=](int kk, int n) { const double v_ = Li[kk + (int64_t)n * nf]; return kk >= n ? v_ : 0.0; }, sA, sB, n0);
+              [=](int kk, int n) { return ldm<1>(kk >= n, &Li[kk + (int64_t)n * nf]); }, sA, sB, n0);
   tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { S[s0 + m * sm + n * sn] = v; });
 }
 // hoisted != 0: the inverses of ALL diagonal blocks are already in place in dst (k_lf_diag_inv)
@@ -1247,11 +1313,11 @@ __global__ void __launch_bounds__(256) k_lf_trtri(MfmaArgs a, const double* L, d
     const double* Bm = Lk + (r0 + b) + (int64_t)r0 * nf;
     const double* Ai = Li + r0 + (int64_t)r0 * nf;
     gemm_tile64(acc, b2, b, b, m0, n0, [=](int m, int kk) { return Bm[m + (int64_t)kk * nf]; },
-                [=](int kk, int n) { const double v_ = Ai[kk + (int64_t)n * nf]; return kk >= n ? v_ : 0.0; }, sA, sB, n0);       // Ai(k, n) = 0 for k < n
+                [=](int kk, int n) { return ldm<1>(kk >= n, &Ai[kk + (int64_t)n * nf]); }, sA, sB, n0);       // Ai(k, n) = 0 for k < n
     tile64_foreach(acc, m0, n0, b2, b, [=](int m, int n, double v) { W[m + (int64_t)n * b] = v; });
   } else {
     const double* Ci = Li + (r0 + b) + (int64_t)(r0 + b) * nf;
-    gemm_tile64(acc, b2, b, min(b2, m0 + LT), m0, n0, [=](int m, int kk) { const double v_ = Ci[m + (int64_t)kk * nf]; return m >= kk ? v_ : 0.0; },
+    gemm_tile64(acc, b2, b, min(b2, m0 + LT), m0, n0, [=](int m, int kk) { return ldm<1>(m >= kk, &Ci[m + (int64_t)kk * nf]); },
                 [=](int kk, int n) { return W[kk + (int64_t)n * b]; }, sA, sB);                               // Ci(m, k) = 0 for k > m
     double* X = Li + (r0 + b) + (int64_t)r0 * nf;
     tile64_foreach(acc, m0, n0, b2, b, [=](int m, int n, double v) { X[m + (int64_t)n * nf] = -v; });
@@ -1272,7 +1338,7 @@ __global__ void __launch_bounds__(256) k_lf_prep_k(MfmaArgs a, const double* L, 
   d4 acc[2][2];
   tile64_zero(acc);
   gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return Lk[(nn + m) + (int64_t)kk * nf]; },
-              [=](int kk, int n) { const double v_ = Li[kk + (int64_t)n * nf]; return kk >= n ? v_ : 0.0; }, sA, sB, n0);
+              [=](int kk, int n) { return ldm<1>(kk >= n, &Li[kk + (int64_t)n * nf]); }, sA, sB, n0);
   tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Kk[m + (int64_t)n * nf] = v; });
 }
 
@@ -1318,10 +1384,10 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_ri_an(MfmaArgs a, d
   d4 acc[2][2];
   tile64_zero(acc);
   if (tr)
-    gemm_tile64<PD>(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[kk + (int64_t)m * na]; return kk >= m ? v_ : 0.0; },
+    gemm_tile64<PD>(acc, na, nn, na, m0, n0, [=](int m, int kk) { return ldm<PD>(kk >= m, &Y[kk + (int64_t)m * na]); },
                 [=](int kk, int n) { return P[nn + kk + (int64_t)n * nf]; }, sA, sB);
   else
-    gemm_tile64<PD>(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[m + (int64_t)kk * na]; return m >= kk ? v_ : 0.0; },
+    gemm_tile64<PD>(acc, na, nn, na, m0, n0, [=](int m, int kk) { return ldm<PD>(m >= kk, &Y[m + (int64_t)kk * na]); },
                 [=](int kk, int n) { return P[nn + kk + (int64_t)n * nf]; }, sA, sB);
   double* G = c.G;
   tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { G[m + (int64_t)n * na] = v; });
@@ -1391,7 +1457,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_dinv2(MfmaArgs a, d
     const int tt = t - nN, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
     if (a.ymode) {
       const double* Y = c.Ys;
-      gemm_tile64<PD>(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[m + (int64_t)kk * na]; return m >= kk ? v_ : 0.0; },
+      gemm_tile64<PD>(acc, na, nn, na, m0, n0, [=](int m, int kk) { return ldm<PD>(m >= kk, &Y[m + (int64_t)kk * na]); },
                   [=](int kk, int n) { return G[kk + (int64_t)n * na]; }, sA, sB);
       tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = v; });
     } else {
@@ -1486,10 +1552,10 @@ __global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, in
     if (t >= mtA * ntN) return;
     const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
     if (step == 0)
-      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[m + (int64_t)kk * na]; return m >= kk ? v_ : 0.0; },
+      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return ldm<1>(m >= kk, &Y[m + (int64_t)kk * na]); },
                   [=](int kk, int n) { return P[nn + kk + (int64_t)n * nf]; }, sA, sB);
     else
-      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { const double v_ = Y[kk + (int64_t)m * na]; return kk >= m ? v_ : 0.0; },
+      gemm_tile64(acc, na, nn, na, m0, n0, [=](int m, int kk) { return ldm<1>(kk >= m, &Y[kk + (int64_t)m * na]); },
                   [=](int kk, int n) { return E[kk + (int64_t)n * na]; }, sA, sB);
     double* O = step == 0 ? E : G;
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { O[m + (int64_t)n * na] = v; });
@@ -1513,7 +1579,7 @@ __global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, in
     } else {
       const int tt = t - nN, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
       gemm_tile64(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return G[m + (int64_t)kk * na]; },
-                  [=](int kk, int n) { const double v_ = T[(nn - 1 - n) + (int64_t)(nn - 1 - kk) * nn]; return kk >= n ? v_ : 0.0; }, sA, sB);
+                  [=](int kk, int n) { return ldm<1>(kk >= n, &T[(nn - 1 - n) + (int64_t)(nn - 1 - kk) * nn]); }, sA, sB);
       tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { Pw[nn + m + (int64_t)n * nf] = -v; });
     }
   }
@@ -1543,14 +1609,14 @@ __global__ void __launch_bounds__(256) k_lf_llt(MfmaArgs a, double* x, int step)
     return;
   }
   const double* P = c.P;
-  auto lnnT = [=](int kk, int n) { const double v_ = P[n + (int64_t)kk * nf]; return n >= kk ? v_ : 0.0; };
+  auto lnnT = [=](int kk, int n) { return ldm<1>(n >= kk, &P[n + (int64_t)kk * nf]); };
   d4 acc[2][2];
   tile64_zero(acc);
   if (t < nT) {
     int tm, tn;
     lower_pair(t, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { const double v_ = P[m + (int64_t)kk * nf]; return m >= kk ? v_ : 0.0; }, lnnT, sA, sB);
+    gemm_tile64(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return ldm<1>(m >= kk, &P[m + (int64_t)kk * nf]); }, lnnT, sA, sB);
     double* T = c.T;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) T[m + (int64_t)n * nn] = v; });
   } else if (t < nT + nG) {

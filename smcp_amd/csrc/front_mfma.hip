@@ -99,6 +99,7 @@ struct MfmaArgs {
   const double* sp_rt; const double* sp_mk;
   // host-side only (level loop of hess_up_fast): level index and the family tail of the LDS class (LevelClass::nS ...)
   int level, nS, famna, fampan, fampk, famcna, famnn, famcnn;
+  int nnmin;     // narrowest supernode of a large-front class
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }
@@ -207,14 +208,21 @@ __device__ inline void load_consts(const MfmaArgs& a, const CliqueDesc& d, const
   }
 }
 
+// UNC: one unconditional load and a mask (the mirrored position of a triangular factor is allocated memory: zeros or
+// scratch) -- what the sixteen-wave tile products of front_large.hip need (no branch around a load: see gemm_tile64)
+template <int UNC = 1>
 __device__ inline double yacc(const double* Y, int ld, int mode, int m, int k) {
-  // one unconditional load (the mirrored position of a triangular factor is allocated memory: zeros or scratch) and a
-  // mask: no branch around the load (see gemm_tile64)
-  const bool tr = mode == 1 ? m < k : mode == 2;           // read (k, m) instead of (m, k)
-  const int i = tr ? k : m, j = tr ? m : k;
-  const double v = Y[i + j * ld];
-  if (mode == 1) return v;
-  return i >= j ? v : 0.0;                                  // R^T (mode 2) / R
+  if constexpr (UNC == 4) {
+    const bool tr = mode == 1 ? m < k : mode == 2;           // read (k, m) instead of (m, k)
+    const int i = tr ? k : m, j = tr ? m : k;
+    const double v = Y[i + j * ld];
+    if (mode == 1) return v;
+    return i >= j ? v : 0.0;                                  // R^T (mode 2) / R
+  } else {
+    if (mode == 1) return m >= k ? Y[m + k * ld] : Y[k + m * ld];
+    if (mode == 2) return k >= m ? Y[k + m * ld] : 0.0;   // R^T
+    return m >= k ? Y[m + k * ld] : 0.0;                    // R
+  }
 }
 
 // children's update matrices (global, lower) scatter-added into the front [F | U].

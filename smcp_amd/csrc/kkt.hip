@@ -517,6 +517,10 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
         kval[q] = cval[e];
       }
     kptr.pop_back();
+    D.kc_sorted = true;           // (CCS columns with ascending rows give ascending panel positions per clique)
+    for (size_t q = 0; q + 1 < kptr.size() && D.kc_sorted; ++q)
+      for (int32_t e = kptr[q] + 1; e < kptr[q + 1]; ++e)
+        if (koff[(size_t)e] <= koff[(size_t)e - 1]) { D.kc_sorted = false; break; }
     // the same positions as (row | column << 16) of the clique's panel, for k_fam_sparse (its members have < 2^16 rows)
     std::vector<int32_t> kij(nnz);
     {

@@ -527,6 +527,38 @@ def test_kkt_wide_separators_stream_through_lds_front():
         assert rel(got[r][msk], ref[r][msk]) < 1e-9
 
 
+def test_kkt_wide_dense_clique_sparse_first_phase():
+    """Config-2 shape at test size: ONE dense clique of 450 columns (wide enough for the symmetric split of the large-front
+    sweep, seven column tiles with a ragged last one) and sparse constraints -- the first phase of the Schur sweep is
+    k_lf_zsp (Z = Li Fl as a sparse combination of columns of Li), no dense panel is built; H against the oracle and
+    against the dense route (SMCP_ZSP has no run-time switch: the launch counts tell which route ran)."""
+    symb = Symbolic(problems.band_pattern(450, 449))
+    symb.device_init(0, 5)
+    S = orc.Sym(symb)
+    A = problems.random_factor_blkval(symb, 41)
+    orc.llt(S, A)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    m = 5
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.01, seed=42)
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=3, tnzcols=0.0)
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    counts = _launch_counts(symb, lambda: sys_.factor(Ld, Yd))
+    assert counts.get("k_lf_zsp", 0) >= 1 and counts.get("k_lf_up1", 0) == 0, counts
+    assert rel(np.tril(sys_.H.cpu().numpy().T), np.tril(Href)) < 1e-9
+    rng = np.random.default_rng(43)
+    msk = lowmask(symb)
+    bx, by = rng.standard_normal(symb.blklen) * msk, rng.standard_normal(m)
+    xr, yr = K.solve(L, Yh, Href, bx, by, 1.0)
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    sys_.factor(Ld, Yd)(bxd, byd, 1.0)
+    assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+
+
 def test_kkt_family_kernel_dense_constraints():
     """Family kernel with long entry lists: constraints dense on V give a (5,31) child 180 entries (more than the 64
     prefetched per wave) and a (15,64) parent 1185 (more than the 256 prefetched per group): the direct-load tails
