@@ -347,6 +347,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.sp_rt = c->D.sp_rt; a.sp_mk = c->D.sp_mk;
   a.kc_stride = 0; a.kc_j0 = 0;
   a.nnmin = 0;
+  a.grp_ptr = nullptr; a.grp_list = nullptr; a.chskip = nullptr;
   a.level = 0; a.nS = 0; a.famna = a.fampan = a.fampk = a.famcna = a.famnn = a.famcnn = 0;
   return a;
 }
@@ -464,6 +465,9 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
       }
     }
   }
+  // (the gather plan and the tiled kernel read every child slot: members of sibling groups that did not write theirs in
+  // this sweep -- MfmaArgs::chskip -- get them cleared first; the streaming kernel above skips them instead)
+  if (a.chskip) launch(c, KID_lf_clear_upd, k_lf_zero_skipped, dim3(cnt, nrhs), dim3(256), st, a);
   if (clear_first)
     launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), dim3(256), st, a);
   if (plan && a.t.gp_tptr) {
@@ -954,7 +958,7 @@ bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_
 
 // childless fronts beyond the LDS class with nn <= 64, na <= 128, sparse input, R^T scaling: swept from their entry lists
 // (front_lfsp.hip).  R^T and R^T K are formed when fac or lk have changed since they were formed last.  SMCP_LFSP=0 disables.
-bool try_lfsp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+bool try_lfsp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st, const csp_ctx::LfspGroups* grp = nullptr) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("SMCP_LFSP"); on = (e && e[0] == '0') ? 0 : 1; }
   DeviceCtx& D = c->D;
@@ -978,16 +982,30 @@ bool try_lfsp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64
   const int g = std::max(1, (nrhs + gdiv - 1) / gdiv);            // right-hand sides per workgroup: gdiv
   // one launch per phase (Q, Upd, G_NN): fewer live accumulators per wave, three to four waves per SIMD
   const dim3 grid(g, cnt), blk(256);
+  // the update phase by sibling groups (one summed update per group; the caller hands MfmaArgs::chskip to the levels above)
+  const bool grouped = grp && grp->ngroups > 0;
+  MfmaArgs bg = b;
+  if (grouped) { bg.grp_ptr = grp->ptr; bg.grp_list = grp->list; }
+  const dim3 ggrid(g, grouped ? grp->ngroups : cnt);
   if (exact) {
     launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 1, 3, 1, false, true>, grid, blk, st, b, U, ldu);
-    launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 2, 1, false, true>, grid, blk, st, b, U, ldu);
+    if (grouped) launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 2, 1, false, true, true>, ggrid, blk, st, bg, U, ldu);
+    else launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 2, 1, false, true>, grid, blk, st, b, U, ldu);
     launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 4, 4, 1, false, true>, grid, blk, st, b, U, ldu);
   } else {
     launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 1, 3, 1, false, false>, grid, blk, st, b, U, ldu);
-    launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 2, 1, false, false>, grid, blk, st, b, U, ldu);
+    if (grouped) launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 2, 1, false, false, true>, ggrid, blk, st, bg, U, ldu);
+    else launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 2, 1, false, false>, grid, blk, st, b, U, ldu);
     launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 4, 4, 1, false, false>, grid, blk, st, b, U, ldu);
   }
   return true;
+}
+// would try_lfsp take a class whose static shape qualifies (the conditions that do not depend on the class)
+bool lfsp_dynamic_ok(csp_ctx* c, const MfmaArgs& a) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMCP_LFSP"); on = (e && e[0] == '0') ? 0 : 1; }
+  const DeviceCtx& D = c->D;
+  return on && a.kc_ptr && a.ymode == 2 && a.ysc && D.kc_maxlist_large > 0 && D.kc_maxlist_large <= LFSP_ECAP && D.lfsp_cnt;
 }
 
 // sparse_j0 >= 0: the right-hand sides are the constraints sparse_j0 .. (through `ids` if given) and are taken from
@@ -1000,6 +1018,10 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
     a0.kc_ptr = c->D.kc_ptr; a0.kc_off = c->D.kc_off; a0.kc_val = c->D.kc_val; a0.kc_ids = ids;
     a0.kc_stride = (int)(c->D.m + 1); a0.kc_j0 = (int)sparse_j0;
   }
+  // sibling groups of the sparse-input sweep of childless large fronts: when they are in use the non-leaders' slots of the
+  // exchange buffer stay unwritten, and every extend-add above must know (MfmaArgs::chskip)
+  const bool groups_on = sparse && set == 0 && c->lfsp_any_groups && c->D.lfsp_skip && lfsp_dynamic_ok(c, a0);
+  if (groups_on) a0.chskip = c->D.lfsp_skip;
   // kernels that read their input from U get dense panels built first (zeros + the constraint's entries)
   auto dense_input_on = [&](MfmaArgs& a, int cnt, double* Ub, int nr, hipStream_t s) {
     if (!sparse) return;
@@ -1055,7 +1077,14 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
           launch_lds(c, KID_hess_up_mfma, k_hess_up_mfma<true>, dim3(cnt, g), dim3(thr), bytes, ls, a, U, ldu);
         }
       } else if (use_large() && c->D.gp_tptr) {
-        if (sparse && try_lfsp(c, a, cnt, nrhs, U, ldu, st)) return;
+        {
+          const csp_ctx::LfspGroups* grp = groups_on && (size_t)l < c->lfsp_grp.size() && c->lfsp_grp[(size_t)l].ngroups > 0 ? &c->lfsp_grp[(size_t)l] : nullptr;
+          if (sparse && try_lfsp(c, a, cnt, nrhs, U, ldu, st, grp)) return;
+          if (grp) {      // the parents would skip slots that the dense route is about to leave ... written, but the sums would be missing
+            fprintf(stderr, "smcp_amd: sparse-input sweep of a grouped level not launchable\n");
+            if (!c->launch_err) c->launch_err = -1;
+          }
+        }
         // Many right-hand sides on a few large fronts with children (the Schur sweeps over the top of synth50k: 8 fronts
         // x 100): the extend-add runs one workgroup per CU (LDS front) and leaves a partial last round, the three phase
         // kernels after it are short.  The right-hand sides are independent: two halves on two streams fill each
@@ -1557,10 +1586,11 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.trsm_x, D.fp, D.fp_bad, D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.lfsp_skip, D.trsm_x, D.fp, D.fp_bad, D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (auto& G : c->lfsp_grp) { if (G.ptr) hipFree(G.ptr); if (G.list) hipFree(G.list); }
     for (int q = 0; q < 2; ++q) {
       if (c->aux_stream[q]) { (void)hipStreamSynchronize(c->aux_stream[q]); (void)hipStreamDestroy(c->aux_stream[q]); }
       if (c->aux_join[q]) (void)hipEventDestroy(c->aux_join[q]);
@@ -1707,6 +1737,60 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
         D.lfsp_exact = !sp.empty();
         for (int32_t k : sp) if (S.nn(k) != 64 || S.na(k) != 128) D.lfsp_exact = false;
         if (!sp.empty() && (rc = dev_upload(&D.lfsp_list, sp, D.bytes))) return rc;
+      }
+      {
+        // sibling groups for the sparse-input sweep (front_lfsp.hip, k_lfsp_up<..., GRP>): members of a large-front class all
+        // of whose fronts that sweep can take (childless, nn <= 64, 0 < na <= 128), under one LARGE parent, with identical
+        // relative indices; at most eight per group, in list order.  SMCP_LFSP_GROUP=0: none.
+        const char* ge = getenv("SMCP_LFSP_GROUP");
+        const bool gon = !(ge && ge[0] == '0');
+        std::vector<uint8_t> is_large((size_t)S.nsn, 0), skip((size_t)S.nsn, 0);
+        for (int32_t k : large) is_large[(size_t)k] = 1;
+        c->lfsp_grp.assign((size_t)S.nlev, csp_ctx::LfspGroups());
+        c->lfsp_any_groups = false;
+        for (int64_t l = 0; l < S.nlev && gon; ++l) {
+          const LevelClass& L = c->lvl[l];
+          if (!L.nII || L.nchmaxII != 0 || L.nnmaxII > 64 || L.namaxII > 128) continue;
+          const int64_t b = S.levptr[l] + L.nI;
+          bool ok = true;
+          for (int64_t q = 0; q < L.nII; ++q) ok = ok && S.na(lev2[b + q]) > 0;
+          if (!ok) continue;
+          std::vector<int32_t> gptr(1, 0), glist;
+          std::vector<uint8_t> taken((size_t)L.nII, 0);
+          bool shared = false;
+          for (int64_t q = 0; q < L.nII; ++q) {
+            if (taken[(size_t)q]) continue;
+            const int32_t k = lev2[b + q];
+            taken[(size_t)q] = 1;
+            glist.push_back(k);
+            int size = 1;
+            const int64_t par = S.snpar[k];
+            if (par >= 0 && is_large[(size_t)par])
+              for (int64_t q2 = q + 1; q2 < L.nII && size < 8; ++q2) {
+                const int32_t k2 = lev2[b + q2];
+                if (taken[(size_t)q2] || S.snpar[k2] != par || S.na(k2) != S.na(k)) continue;
+                if (!std::equal(S.relidx.begin() + S.sepptr[k], S.relidx.begin() + S.sepptr[k + 1], S.relidx.begin() + S.sepptr[k2])) continue;
+                taken[(size_t)q2] = 1;
+                glist.push_back(k2);
+                ++size;
+              }
+            gptr.push_back((int32_t)glist.size());
+            if (size > 1) shared = true;
+          }
+          if (!shared) continue;
+          const int ng = (int)gptr.size() - 1;
+          for (int g = 0; g < ng; ++g) {
+            const int sz = gptr[(size_t)g + 1] - gptr[(size_t)g];
+            for (int q = 0; q < sz; ++q)
+              if (q != g % sz) skip[(size_t)glist[(size_t)gptr[(size_t)g] + q]] = 1;
+          }
+          csp_ctx::LfspGroups& G = c->lfsp_grp[(size_t)l];
+          if ((rc = dev_upload(&G.ptr, gptr, D.bytes))) return rc;
+          if ((rc = dev_upload(&G.list, glist, D.bytes))) return rc;
+          G.ngroups = ng;
+          c->lfsp_any_groups = true;
+        }
+        if (c->lfsp_any_groups && (rc = dev_upload(&D.lfsp_skip, skip, D.bytes))) return rc;
       }
       lev3.insert(lev3.end(), large.begin(), large.end());
       if ((rc = dev_upload(&D.lev3idx, lev3, D.bytes))) return rc;

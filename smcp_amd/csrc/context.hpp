@@ -129,6 +129,10 @@ struct DeviceCtx {
   // entry list of such a front, and the generations of fac / lk they were formed from
   double* sp_rt = nullptr; double* sp_mk = nullptr;
   int32_t* lfsp_list = nullptr; int64_t lfsp_cnt = 0; bool lfsp_exact = false;
+  // sibling groups of the sparse-input sweep (front_lfsp.hip): childless large fronts under one large parent whose
+  // separators are the same rows of it send ONE summed update per group.  Per clique: 1 = a group member whose slot in the
+  // exchange buffer stays unwritten (the parent's extend-add skips it)
+  uint8_t* lfsp_skip = nullptr;
   int64_t kc_maxlist_large = 0;
   int64_t fac_gen = 0, lk_gen = 0, sp_fac_gen = -1, sp_lk_gen = -1;
   bool part_valid = false;     // lk / yaa / fac hold the sharded factor prepared by kkt_prepare_part (sets 2 then 1)
@@ -196,6 +200,9 @@ struct csp_ctx {
   smcp::Profiler prof;
   std::vector<int64_t> h_tmpptr;
   std::vector<int> lev_namax;   // per level: largest separator (sizes the gather launches)
+  struct LfspGroups { int32_t* ptr = nullptr; int32_t* list = nullptr; int ngroups = 0; };
+  std::vector<LfspGroups> lfsp_grp;   // per level: the groups of its large-front class (device arrays; ngroups 0 = none)
+  bool lfsp_any_groups = false;
   std::vector<int64_t> fam;     // per clique: family role (CSP_Q_FAMILY)
   std::vector<uint8_t> is_diag_cache;
   // boundary exchange of the subtree partition: the subtree roots of all ranks (device: clique, owning rank, offset in

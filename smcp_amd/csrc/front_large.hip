@@ -353,8 +353,10 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
   int64_t* const sCr = sCu + tcap;
   int* const sCn = reinterpret_cast<int*>(sCr + tcap);
   for (int qi = tid; qi < nmine; qi += nthr) {
-    const CliqueDesc c = a.t.cl[a.t.chidx[d.chbeg + wz + qi * nz]];
-    sCu[qi] = c.updp; sCr[qi] = c.rel; sCn[qi] = c.na;
+    const int ck = a.t.chidx[d.chbeg + wz + qi * nz];
+    const CliqueDesc c = a.t.cl[ck];
+    // (a member of a sibling group that did not write its slot in this sweep -- its sum is in the leader's -- counts as empty)
+    sCu[qi] = c.updp; sCr[qi] = c.rel; sCn[qi] = (a.chskip && a.chskip[ck]) ? 0 : c.na;
   }
   for (int e = tid; e < ntot; e += nthr) T[e] = 0.0;
   __syncthreads();
@@ -371,6 +373,7 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
   const int part = parts > 1 ? wave / max(nmine, 1) : 0;
   for (int qi = parts > 1 ? wave % max(nmine, 1) : wave; qi < nmine && part < parts; qi += nw) {
     const int nac = sCn[qi];
+    if (nac == 0) continue;
     const int32_t* rel = a.t.relidx + sCr[qi];
     const double* Uc = ubase + sCu[qi];
     if (nac <= 64) lf_add_child<16, false>(T, nf, Uc, rel, nac, lane, part, parts);
@@ -492,6 +495,18 @@ __global__ void __launch_bounds__(256) k_lf_assemble_tiled(MfmaArgs a, double* u
     } else {
       U[(i - nn) + (int64_t)(j - nn) * na] = v;                    // full assignment: no prior clear needed
     }
+  }
+}
+// packed update slots of the children marked in MfmaArgs::chskip <- 0 (for the extend-add routes that read every slot)
+__global__ void k_lf_zero_skipped(MfmaArgs a) {
+  const CliqueDesc d = a.t.cl[a.t.lev[blockIdx.x]];
+  const int r = blockIdx.y;
+  for (int q = d.chbeg; q < d.chend; ++q) {
+    const int ck = a.t.chidx[q];
+    if (!a.chskip[ck]) continue;
+    const CliqueDesc c = a.t.cl[ck];
+    double* UP = a.t.updp + (int64_t)r * a.t.updplen + c.updp;
+    for (int e = threadIdx.x; e < c.na * (c.na + 1) / 2; e += blockDim.x) UP[e] = 0.0;
   }
 }
 __global__ void k_lf_clear_upd(MfmaArgs a) {

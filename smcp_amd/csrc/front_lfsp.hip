@@ -101,8 +101,14 @@ __device__ inline void lfsp_rank(d4 (&acc)[NL][NR], int t0, int t1, int kq, FL f
 }
 
 // na <= 16 NTA, nn <= 16 NTN; grid (right-hand-side groups, fronts), 256 threads
-template <int NTA, int NTN, int PH, int OCC, int KSQ, bool PIPE, bool EXACT>
+// GRP (the update phase only): blockIdx.y names a GROUP of sibling fronts whose separators are the same rows of their
+// parent (config 3: all 1999 leaves hang off the root's 128 columns) -- their updates add up element by element, so the
+// workgroup sweeps the members one after the other into the same accumulators and stores ONE packed update, into the
+// slot of the group's leader; the parent's extend-add skips the other members (MfmaArgs::chskip).  On config 3 the
+// per-front updates were 13 GB written and 13 GB read back per Schur complement.
+template <int NTA, int NTN, int PH, int OCC, int KSQ, bool PIPE, bool EXACT, bool GRP = false>
 __global__ void __launch_bounds__(256, OCC) k_lfsp_up(MfmaArgs a, double* u, int64_t ldu) {
+  static_assert(!GRP || PH == 2, "groups exist for the update phase only");
   constexpr int EC = LFSP_ECAP;
   __shared__ int s_ta[2 * EC + 4], s_tb[2 * EC + 4];     // NN terms: columns (ta, tb) and value tv
   __shared__ double s_tv[2 * EC + 4];
@@ -110,17 +116,24 @@ __global__ void __launch_bounds__(256, OCC) k_lfsp_up(MfmaArgs a, double* u, int
   __shared__ double s_av[EC + 4 * NTA + 4];
   __shared__ int s_bkt[NTA + 2];                         // start of the entries of row tile b in s_a*
   __shared__ int s_n[2];                                 // NN terms (padded to a multiple of 4), AN entries
-  const int k = a.t.lev[blockIdx.y];           // right-hand-side groups of one front are neighbours in the launch order:
-  const CliqueDesc d = a.t.cl[k];              // the fronts in flight at any time are few and their constants stay in L2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  const int g0 = GRP ? a.grp_ptr[blockIdx.y] : 0, nmem = GRP ? a.grp_ptr[blockIdx.y + 1] - g0 : 1;
+  // (the leader rotates with the group index: the parent's extend-add deals its children round-robin over several
+  // workgroups, and leaders at every eighth position would all land on the same few)
+  const int kleader = GRP ? a.grp_list[g0 + (int)(blockIdx.y % (unsigned)nmem)] : 0;
+  d4 uA[1][NTA], uB[1][NTA];                    // GRP: the two tile rows of this wave, summed over the members
+  for (int r = blockIdx.x; r < a.nrhs; r += gridDim.x)
+  for (int mi = 0; mi < nmem; ++mi) {
+  const int k = GRP ? a.grp_list[g0 + mi] : a.t.lev[blockIdx.y];   // right-hand-side groups of one front are neighbours in the launch
+  const CliqueDesc d = a.t.cl[k];              // order: the fronts in flight at any time are few and their constants stay in L2
   const int nn = d.nn, na = d.na;
   const int nf = nn + na;                       // panels of these fronts have < 2^31 / 8 elements: 32-bit element offsets
   const double* Li = a.LK + d.blk;
   const double* Kk = Li + nn;
   const double* MK = a.sp_mk + d.blk + nn;
   const double* Rt = a.sp_rt + d.upd;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
   const int32_t* kp = a.kc_ptr + (int64_t)k * a.kc_stride;
-  for (int r = blockIdx.x; r < a.nrhs; r += gridDim.x) {
+  {
     const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
     const int e0 = kp[j], e1 = kp[j + 1];
     __syncthreads();                                     // the tables of the previous right-hand side have been consumed
@@ -216,8 +229,9 @@ __global__ void __launch_bounds__(256, OCC) k_lfsp_up(MfmaArgs a, double* u, int
           [&](int t) { return s_av[t]; }, all, nold);
     }
     // ---- Upd = sum_NN v k_a k_b^T - sum_AN v (k_j e_r^T + e_r k_j^T), lower tiles; wave w owns the tile rows w and NTA-1-w
-    auto upd_row = [&](auto& ua, int tm) {
+    auto upd_row = [&](auto& ua, int tm, bool fresh) {
       constexpr int NR = sizeof(ua[0]) / sizeof(d4);
+      if (fresh)
 #pragma unroll
       for (int tn = 0; tn < NR; ++tn) ua[0][tn] = d4{0.0, 0.0, 0.0, 0.0};
       const int m = 16 * tm + l15, mc = EXACT ? m : min(m, na - 1);
@@ -269,7 +283,7 @@ __global__ void __launch_bounds__(256, OCC) k_lfsp_up(MfmaArgs a, double* u, int
           }
         }
     };
-    double* UP = a.t.updp + (int64_t)r * a.t.updplen + d.updp;
+    double* UP = a.t.updp + (int64_t)r * a.t.updplen + (GRP ? a.t.cl[kleader].updp : d.updp);
     auto put = [&](auto& ua, int tm) {
       constexpr int NR = sizeof(ua[0]) / sizeof(d4);
       const int m = 16 * tm + l15;
@@ -284,9 +298,18 @@ __global__ void __launch_bounds__(256, OCC) k_lfsp_up(MfmaArgs a, double* u, int
           }
         }
     };
-    if (PH & 2) {                                    // the shorter row first; its stores overlap the longer row's products
-      if (has0) { upd_row(u1, tm0); put(u1, tm0); }
-      if (has1) { upd_row(u1, tm1); put(u1, tm1); }
+    if (PH & 2) {
+      if constexpr (GRP) {
+        if (has0) upd_row(uA, tm0, mi == 0);
+        if (has1) upd_row(uB, tm1, mi == 0);
+        if (mi == nmem - 1) {
+          if (has0) put(uA, tm0);
+          if (has1) put(uB, tm1);
+        }
+      } else {                                       // the shorter row first; its stores overlap the longer row's products
+        if (has0) { upd_row(u1, tm0, true); put(u1, tm0); }
+        if (has1) { upd_row(u1, tm1, true); put(u1, tm1); }
+      }
     }
     // ---- G_NN = sum_NN v l_a l_b^T, lower tiles: wave w owns tile row w
     if ((PH & 4) && hasg) {
@@ -323,6 +346,7 @@ __global__ void __launch_bounds__(256, OCC) k_lfsp_up(MfmaArgs a, double* u, int
           }
         }
     }
+  }
   }
 }
 

@@ -100,6 +100,9 @@ struct MfmaArgs {
   // host-side only (level loop of hess_up_fast): level index and the family tail of the LDS class (LevelClass::nS ...)
   int level, nS, famna, fampan, fampk, famcna, famnn, famcnn;
   int nnmin;     // narrowest supernode of a large-front class
+  // sibling groups of the sparse-input sweep of childless large fronts (front_lfsp.hip): group g = the cliques
+  // grp_list[grp_ptr[g] .. grp_ptr[g + 1]); chskip[k] != 0: the packed update slot of child k is not written in this sweep
+  const int32_t* grp_ptr; const int32_t* grp_list; const uint8_t* chskip;
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }

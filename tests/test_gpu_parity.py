@@ -559,6 +559,48 @@ def test_kkt_wide_dense_clique_sparse_first_phase():
     assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
 
 
+@pytest.mark.parametrize("nleaf", [12, 9, 3])
+def test_kkt_sibling_groups_send_one_summed_update(nleaf, monkeypatch):
+    """Config-3 shape at test size: `nleaf` childless (64, 128) fronts under one (128, 0) root, all with the root's 128
+    columns as separator.  The sparse-input sweep sums the updates of up to eight siblings in one workgroup and stores ONE
+    packed update per group (k_lfsp_up<..., GRP>); the root's extend-add skips the other members.  12 leaves = groups of
+    8 + 4, 9 = 8 + 1 (a singleton group), 3 = one group of three.  H and the solve against the oracle, and H against the ungrouped route
+    (SMCP_LFSP_GROUP=0 at device_init) to rounding."""
+    pat = problems.block_arrow_pattern(nleaf, 64, 128)
+    m = 6
+    Hs = []
+    for grouped in (True, False):
+        if not grouped:
+            monkeypatch.setenv("SMCP_LFSP_GROUP", "0")
+        symb = Symbolic(pat)
+        symb.device_init(0, m)
+        S = orc.Sym(symb)
+        A = problems.random_factor_blkval(symb, 51)
+        orc.llt(S, A)
+        L = A.copy()
+        orc.cholesky(S, L)
+        Yh = L.copy()
+        orc.projected_inverse(S, Yh)
+        cptr, cidx, cval = problems.random_constraints(symb, m, density=0.004, seed=52)
+        sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+        Ld, Yd = dev(symb, L), dev(symb, Yh)
+        counts = _launch_counts(symb, lambda: sys_.factor(Ld, Yd))
+        assert counts.get("k_lfsp_up", 0) == 3, counts
+        Hs.append(np.tril(sys_.H.cpu().numpy().T))
+        if grouped:
+            K = orc.KKT(S, cptr, cidx, cval)
+            Href = K.schur_factor(L, Yh)
+            assert rel(Hs[0], np.tril(Href)) < 1e-9
+            rng = np.random.default_rng(53)
+            msk = lowmask(symb)
+            bx, by = rng.standard_normal(symb.blklen) * msk, rng.standard_normal(m)
+            xr, yr = K.solve(L, Yh, Href, bx, by, 1.0)
+            bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+            sys_.factor(Ld, Yd)(bxd, byd, 1.0)
+            assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+    assert rel(Hs[0], Hs[1]) < 1e-12
+
+
 def test_kkt_family_kernel_dense_constraints():
     """Family kernel with long entry lists: constraints dense on V give a (5,31) child 180 entries (more than the 64
     prefetched per wave) and a (15,64) parent 1185 (more than the 256 prefetched per group): the direct-load tails
