@@ -860,12 +860,14 @@ def test_kkt_qr_more_than_320_constraints():
     assert rel(byd.cpu().numpy(), yr) < 1e-8
 
 
-@pytest.mark.parametrize("eps,shifted", [(1e-9, False), (1e-13, True)])
-def test_kkt_qr_nearly_dependent_constraints(eps, shifted):
+@pytest.mark.parametrize("eps,shifted,lazy", [(1e-9, False, False), (1e-13, True, False), (1e-13, True, True)])
+def test_kkt_qr_nearly_dependent_constraints(eps, shifted, lazy):
     """Two constraints that differ by eps times a third, independent one: kappa(At) ~ 2 / eps.  At 1e-9 chol(At^T At)
     still goes through and a third pass is planned from the deviation of the second Gram matrix; at 1e-13 it breaks
     down and the first pass is repeated on the shifted Gram matrix (shifted CholeskyQR3).  Either way the QR path must
-    deliver the residuals of the reference's DEBUG check; the Householder restatement is the yardstick."""
+    deliver the residuals of the reference's DEBUG check; the Householder restatement is the yardstick.
+    lazy: with chordal.lazy_status on (what bench.py runs) the breakdown must still be SEEN by kkt_qr_factor -- the flag
+    reads that choose between the plain and the shifted route are eager whatever the mode."""
     m = 6
     symb, S, msk, L, Yh, cptr, cidx, cval = _kkt_qr_case("nested_mid", m + 1, 41, density=0.05)
     K0 = orc.KKT(S, cptr, cidx, cval)
@@ -880,7 +882,15 @@ def test_kkt_qr_nearly_dependent_constraints(eps, shifted):
     F = K.qr_factor(L, Yh)
     assert np.linalg.cond(F["R"]) > 1e8
     sys = KKTSystem(symb, cptr2, cidx2, cval2, max_rhs=4, tnzcols=0.0)
-    solve = sys.factor_qr(dev(symb, L), dev(symb, Yh))
+    if lazy:
+        chordal.lazy_status(symb, True)
+    try:
+        solve = sys.factor_qr(dev(symb, L), dev(symb, Yh))
+        if lazy:
+            chordal.check_status(symb)               # nothing latched: the shifted route succeeded
+    finally:
+        if lazy:
+            chordal.lazy_status(symb, False)
     Rt, G = sys.qr_inspect()
     assert np.abs(G.cpu().numpy() - np.eye(m)).max() < 1e-10
     rng = np.random.default_rng(42)
