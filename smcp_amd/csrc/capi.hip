@@ -437,6 +437,10 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
     int nz = 1;
     if (zenv > 0) nz = zenv;
     else if (a.nchmax >= 256) nz = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)a.nchmax / 16, (int64_t)64, (4 * (int64_t)c->D.ncu + pairs - 1) / pairs}));
+    // fewer (front, right-hand side) pairs than half the CUs, each with many children (one rank's share of an eight-rank job
+    // on synth50k: ONE front x 100 constraints, 112 children each -- 150 us with a workgroup per pair): deal the children
+    else if (nrhs >= 16 && 2 * pairs <= c->D.ncu && a.nchmax >= 32)
+      nz = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)a.nchmax / 16, (int64_t)8, (2 * (int64_t)c->D.ncu + pairs - 1) / pairs}));
     nz = std::max(1, std::min(nz, std::max(1, a.nchmax)));
     const size_t bytes = (size_t)(lf_alds_doubles(nfmax) + 3 * ((a.nchmax + nz - 1) / nz) + 2) * sizeof(double);   // front + child table
     if (alds && a.nchmax > 0 && pairs * nz >= 32 && nfmax <= LF_ALDS_MAXNF && bytes <= LDS_LIMIT) {   // enough workgroups to fill the chip

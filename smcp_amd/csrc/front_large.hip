@@ -1697,9 +1697,18 @@ __global__ void k_exchange_combine(const CliqueDesc* cl, const int32_t* roots, c
   const double* gq = g + owner[q] * gwidth + bptr[q] * nrhs;
   double* oq = out + owner[q] * owidth + bptr[q];
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < np; e += gridDim.x * blockDim.x) {
+    // twenty loads in flight per thread, summed in the order of the constraints (one at a time was a chain of nrhs memory
+    // round trips: 84 us for the 100 constraints of synth50k on rank 0 of 8)
     double s = 0.0;
-    for (int i = 0; i < nrhs; ++i) s += y[i] * gq[(int64_t)i * np + e];
-    oq[e] = mode ? oq[e] + s : s - oq[e];
+    const double o0 = oq[e];
+    for (int i0 = 0; i0 < nrhs; i0 += 20) {
+      double v[20];
+#pragma unroll
+      for (int u = 0; u < 20; ++u) v[u] = gq[(int64_t)min(i0 + u, nrhs - 1) * np + e];
+#pragma unroll
+      for (int u = 0; u < 20; ++u) s += (i0 + u < nrhs) ? y[min(i0 + u, nrhs - 1)] * v[u] : 0.0;
+    }
+    oq[e] = mode ? o0 + s : s - o0;
   }
 }
 
