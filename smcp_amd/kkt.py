@@ -4,6 +4,7 @@ Python-side mirror of the closures at src/python/solvers.py:369-386 and 477-541;
 arithmetic is done by the C-ABI entry points ``kkt_*`` (include/smcp_amd.h).
 """
 import ctypes
+import os
 import weakref
 
 import numpy as np
@@ -194,7 +195,8 @@ class ShardedSchur:
         # the gathered root blocks of every chunk are kept (if they fit KEEP_LIMIT doubles): solve_'s second Hessian
         # forms its own boundary blocks from them instead of a third exchange
         _, sizes_m, width_m = self._exchange_plan(group, min(step, self.m))
-        keep = width_m * world * ((self.m + step - 1) // step) <= self.KEEP_LIMIT
+        keep = (width_m * world * ((self.m + step - 1) // step) <= self.KEEP_LIMIT
+                and os.environ.get("SMCP_SHARD_KEEP", "1") != "0")       # 0: the second Hessian of solve_ exchanges like the first
         self._kept = []
         for n, j0 in enumerate(range(0, self.m, step)):
             j1 = min(self.m, j0 + step)
