@@ -1170,6 +1170,19 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
       int g = rhs_groups(cnt, nrhs, lds ? 2048 : 1024);
       if (lds) {
         // (fewer threads per workgroup do NOT help this kernel on the leaves: 0.302 ms per step with 256, 0.330 with 128)
+        // small fronts without scaling operand: one wave per (clique, right-hand side), operands in registers (front_n16.hip)
+        static int dw = -1;
+        if (dw < 0) { const char* e = getenv("SMCP_DOWN_W"); dw = (e && e[0] == '0') ? 0 : 1; }
+        if (dw && ymode == 0 && a.nnmax <= 16 && a.namax <= 64 && a.nnmax >= 1) {
+          const int gw = rhs_groups((cnt + 3) / 4, nrhs, 4096);
+          const dim3 grid((cnt + 3) / 4, gw), blk(256);
+          switch ((std::max(a.namax, 1) + 15) / 16) {
+            case 1: launch(c, KID_hess_down_mfma, k_hess_down_w<1>, grid, blk, st, a, U, ldu, cnt); break;
+            case 2: launch(c, KID_hess_down_mfma, k_hess_down_w<2>, grid, blk, st, a, U, ldu, cnt); break;
+            case 3: launch(c, KID_hess_down_mfma, k_hess_down_w<3>, grid, blk, st, a, U, ldu, cnt); break;
+            default: launch(c, KID_hess_down_mfma, k_hess_down_w<4>, grid, blk, st, a, U, ldu, cnt); break;
+          }
+        } else
         if (ymode == 0) {     // no scaling operand: compact layout (the Y block is the largest buffer of the general one)
           const size_t b0 = (size_t)mfma_lds_doubles_for(WK_DOWN0, a.nnmax, a.namax) * sizeof(double);
           launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true, WK_DOWN0>, dim3(cnt, g), dim3(b0 > 48 * 1024 ? 512 : 256), b0, st, a, U, ldu);

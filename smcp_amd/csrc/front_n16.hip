@@ -396,6 +396,129 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k
 #undef STAMP
 }
 
+// Root -> leaves Hessian sweep (no scaling operand: the second half of hessian(adj=None), solvers.py:524, 531) of fronts with
+// nn <= 16 and na <= 16 NAT <= 64 by ONE WAVE per (clique, right-hand side), four cliques per workgroup, no LDS and no
+// barrier: every operand is loaded straight into the lane that needs it as an MFMA operand, and the products are arranged so
+// that each loaded register serves as a left operand in one product and as a right operand in another and every
+// intermediate is consumed in the accumulator layout it was produced in (the transposed D^T = Li^T Q^T - K^T Z_AA / 2 is
+// formed instead of D; register rr of a result tile is the operand of k-step rr of the next product):
+//     Tt = Li^T G_NN,  Z1 = Tt Li,  D^T = Li^T Q^T - K^T Z_AA / 2,  Z_AN^T = Li^T Q^T - K^T Z_AA,
+//     Z_NN = Z1 - K^T D - D^T K      (= Li^T G_NN Li - K^T D - D^T K, front_mfma.hip k_hess_down_mfma)
+// k_hess_down_mfma stages the same products through LDS with five workgroup barriers per clique: 65 us for the 7168 leaves
+// of synth50k and 47 us for their 896 parents per right-hand side, against the ~30 us their traffic takes.
+// fmma(acc, left, right): left = Left[row l15][k = kq + 4 s], right = Right[k = kq + 4 s][col l15], acc[rr] = (row l15, col kq + 4 rr).
+template <int NAT>
+__global__ void __launch_bounds__(256, NAT <= 2 ? 3 : 1) k_hess_down_w(MfmaArgs a, double* u, int64_t ldu, int cnt) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  const int idx = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (idx >= cnt) return;
+  const int k = a.t.lev[idx];
+  const CliqueDesc d = a.t.cl[k];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  const bool haspar = d.parent >= 0 && na > 0;
+  const CliqueDesc par = a.t.cl[haspar ? d.parent : k];
+  const int nnp = par.nn, nfp = par.nn + par.na, nap = par.na;
+  const bool mirror = d.chend > d.chbeg;               // the children gather Z_AA from the copy in global memory
+  const double* LK = a.LK + d.blk;
+  double li[4], kk[4 * NAT];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int r = kq + 4 * s;
+    const double v = LK[min(r, nn - 1) + (int64_t)min(l15, nn - 1) * nf];
+    li[s] = (r < nn && l15 < nn && r >= l15) ? v : 0.0;                       // Li[r][l15], lower triangular
+  }
+#pragma unroll
+  for (int s = 0; s < 4 * NAT; ++s) {
+    const int j = kq + 4 * s;
+    const double v = LK[nn + min(j, max(na, 1) - 1) + (int64_t)min(l15, nn - 1) * nf];
+    kk[s] = (j < na && l15 < nn) ? v : 0.0;                                    // K[j][l15]
+  }
+  int ri[NAT], rj[4 * NAT];
+  const int32_t* rel = a.t.relidx + d.rel;
+#pragma unroll
+  for (int t = 0; t < NAT; ++t) ri[t] = haspar ? rel[min(16 * t + l15, na - 1)] : 0;
+#pragma unroll
+  for (int s = 0; s < 4 * NAT; ++s) rj[s] = haspar ? rel[min(kq + 4 * s, na - 1)] : 0;
+  const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  for (int r = blockIdx.y; r < a.nrhs; r += gridDim.y) {
+    double* P = u + (int64_t)r * ldu + d.blk;
+    const double* Pp = u + (int64_t)r * ldu + par.blk;
+    const double* Up = a.t.upd + (int64_t)r * a.t.updlen + par.upd;
+    double g[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = kq + 4 * s;
+      const int hi = min(max(l15, c), nn - 1), lo = min(min(l15, c), nn - 1);
+      const double v = P[hi + lo * nf];
+      g[s] = (l15 < nn && c < nn) ? v : 0.0;                                  // G_NN[c][l15] (symmetric, lower stored)
+    }
+    // Tt = Li^T G_NN, Z1 = Tt Li
+    d4 tt = zero4, z1 = zero4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(g[s], li[s], tt, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) z1 = __builtin_amdgcn_mfma_f64_16x16x4f64(li[s], tt[s], z1, 0, 0, 0);
+    d4 w = zero4;
+    double* UkG = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+#pragma unroll
+    for (int t = 0; t < NAT; ++t) {
+      if (16 * t < na) {
+        // the operands of ONE row tile at a time (a separator of 64 rows would otherwise keep 100 loads and their
+        // addresses live: 512 registers and spills); the scheduling barrier keeps the next tile's loads behind this tile
+        double q[4], z[4 * NAT];
+        const int m = 16 * t + l15;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int c = kq + 4 * s;
+          const double v = P[nn + min(m, na - 1) + min(c, nn - 1) * nf];
+          q[s] = (m < na && c < nn) ? v : 0.0;                                  // Q[m][c]
+        }
+#pragma unroll
+        for (int s = 0; s < 4 * NAT; ++s) {
+          const int j = kq + 4 * s;
+          int i1 = ri[t], j1 = rj[s];
+          asm volatile("" : "+v"(i1), "+v"(j1));       // (keeps the 16 NAT^2 right-hand-side-invariant offsets from being hoisted out of the loop: registers)
+          const int hi = max(i1, j1), lo = min(i1, j1);
+          // parent's Z: columns of its supernode in its panel, the rest in its separator block (both lower)
+          const double* src = lo < nnp ? Pp + (hi + lo * nfp) : Up + ((hi - nnp) + (lo - nnp) * nap);
+          const double v = haspar ? *src : 0.0;
+          z[s] = (m < na && j < na) ? v : 0.0;                                  // Z_AA[m][j]
+        }
+        d4 qlt = zero4, zkt = zero4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qlt = __builtin_amdgcn_mfma_f64_16x16x4f64(q[s], li[s], qlt, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4 * NAT; ++s) zkt = __builtin_amdgcn_mfma_f64_16x16x4f64(z[s], kk[s], zkt, 0, 0, 0);
+        d4 dt;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          dt[rr] = qlt[rr] - 0.5 * zkt[rr];                                     // D^T[l15][16 t + kq + 4 rr]
+          const int mm = 16 * t + kq + 4 * rr;
+          if (mm < na && l15 < nn) P[nn + mm + l15 * nf] = qlt[rr] - zkt[rr];              // Z_AN[mm][l15]
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          w = __builtin_amdgcn_mfma_f64_16x16x4f64(dt[s], kk[4 * t + s], w, 0, 0, 0);       // K^T D
+          w = __builtin_amdgcn_mfma_f64_16x16x4f64(kk[4 * t + s], dt[s], w, 0, 0, 0);       // D^T K
+        }
+        if (mirror) {
+#pragma unroll
+          for (int s = 0; s < 4 * NAT; ++s) {
+            const int j = kq + 4 * s;
+            if (m < na && j <= m) UkG[m + j * na] = z[s];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int c = kq + 4 * rr;
+      if (l15 < nn && c <= l15) P[l15 + (int64_t)c * nf] = z1[rr] - w[rr];               // Z_NN, lower
+    }
+  }
+}
+
 // Dense input panels for the cliques of one launch whose sweep kernel reads its input from u: panel of (clique,
 // rhs r) <- A_j restricted to the clique (zeros + the constraint's entries), j as in MfmaArgs::kc_*.
 __global__ void k_panel_fill(MfmaArgs a, double* u, int64_t ldu) {
