@@ -502,6 +502,14 @@ static bool pd_deep() {
     else launch(c, kid, kern<1>, g_, blk, __VA_ARGS__);                                                \
   } while (0)
 
+// (two products with the dense Y_NN cost 3 nn^3 flops against 2 nn^3 of the four phases that exploit the triangular Li:
+// the fusion is for roots whose sweeps are launch-bound, not for config 2's 4096 clique)
+constexpr int ROOT_FUSED_MAXNN = 512;
+static bool root_fused() {      // SMCP_ROOT_FUSED=0: the four phase launches for fronts without separator too
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMCP_ROOT_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
 void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
@@ -1014,8 +1022,11 @@ bool lfsp_dynamic_ok(csp_ctx* c, const MfmaArgs& a) {
 
 // sparse_j0 >= 0: the right-hand sides are the constraints sparse_j0 .. (through `ids` if given) and are taken from
 // their per-clique entry lists (MfmaArgs::kc_*) -- U is output only and need not be cleared or scattered into
+// yroot: the projected inverse Y (blkval) when the caller runs the down sweep right after this one (hessian(adj = None)):
+// fronts without separator then take Z_NN = Y_NN F_NN Y_NN in two products (k_lf_root1 here, k_lf_root2 in hess_down_fast)
 void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0,
-                  int64_t sparse_j0 = -1, const int32_t* ids = nullptr, int64_t lev_lo = 0, int64_t lev_hi = -1) {
+                  int64_t sparse_j0 = -1, const int32_t* ids = nullptr, int64_t lev_lo = 0, int64_t lev_hi = -1,
+                  const double* yroot = nullptr) {
   MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
   const bool sparse = sparse_j0 >= 0 && c->D.kc_ptr;
   if (sparse) {
@@ -1146,6 +1157,12 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
           return;
         }
         dense_input(a, cnt);
+        if (yroot && a.namax == 0 && a.nnmax <= ROOT_FUSED_MAXNN && root_fused()) {
+          if (a.nchmax > 0) lf_assemble(c, a, cnt, nrhs, U, ldu, 0, st, true);
+          const int ntN = tiles64(a.nnmax);
+          LAUNCH_PD(c, KID_lf_up1, k_lf_root1, dim3(umax1(ntN * ntN), cnt, nrhs), dim3(256), st, a, U, ldu, yroot);
+          return;
+        }
         lf_up(c, a, cnt, nrhs, U, ldu, st);
       }
       else { dense_input(a, cnt); launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu); }
@@ -1163,7 +1180,8 @@ void gather_set(csp_ctx* c, int set, const double* x, int64_t ldx, int nrhs, dou
     launch(c, KID_gather_level, k_gather_level, dim3(cnt, nrhs, gather_parts(std::max(L.namaxI, L.namaxII), (int64_t)cnt * nrhs, c->D.ncu)), dim3(NT), st, a, x, ldx, updbase);
   }
 }
-void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0) {
+void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ysc, int ymode, hipStream_t st, int set = 0,
+                    const double* yroot = nullptr) {
   MfmaArgs a0 = mfma_args(c, ysc, ymode, nrhs);
   for (int64_t l = c->S.nlev - 1; l >= 0; --l)
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
@@ -1188,6 +1206,10 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
           launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true, WK_DOWN0>, dim3(cnt, g), dim3(b0 > 48 * 1024 ? 512 : 256), b0, st, a, U, ldu);
         } else
         launch_lds(c, KID_hess_down_mfma, k_hess_down_mfma<true>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
+      }
+      else if (use_large() && yroot && a.namax == 0 && a.nnmax <= ROOT_FUSED_MAXNN && root_fused() && c->D.gp_tptr) {
+        const int ntN = tiles64(a.nnmax);
+        LAUNCH_PD(c, KID_lf_down3, k_lf_root2, dim3(umax1(ntN * (ntN + 1) / 2), cnt, nrhs), dim3(256), st, a, U, ldu, yroot);
       }
       else if (use_large() && (ymode == 0 || ymode == 3 || ymode == 2)) {
         if (ymode && a.namax) {   // Q = R Ghat_AN (ymode 3) / R^T Ghat_AN (ymode 2) first, then the unscaled sweep
@@ -1367,7 +1389,13 @@ int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t l
     // LK must have been prepared for this L (prep_lk) by the caller
     if (adj == 0) hess_up_fast(c, U, (int)nrhs, ldu, c->D.fac, 2, st);
     else if (adj == 1) hess_down_fast(c, U, (int)nrhs, ldu, c->D.fac, 3, st);
-    else { hess_up_fast(c, U, (int)nrhs, ldu, c->D.yaa, 1, st); hess_down_fast(c, U, (int)nrhs, ldu, nullptr, 0, st); }
+    else {
+      // (Y: the matrix the cached Y_AA blocks were gathered from -- the pair (L, Y) of this call; its root blocks serve the
+      // fronts without separator directly)
+      const double* yroot = (const double*)c->D.yaa_tag;
+      hess_up_fast(c, U, (int)nrhs, ldu, c->D.yaa, 1, st, 0, -1, nullptr, 0, -1, yroot);
+      hess_down_fast(c, U, (int)nrhs, ldu, nullptr, 0, st, 0, yroot);
+    }
   } else if (!inv) {
     if (adj == 0) { up(); scale(0); }
     else if (adj == 1) { scale(1); down(); }

@@ -118,6 +118,7 @@ struct DeviceCtx {
   double* lg_tab = nullptr; int lg_rec = 0;                           // per-step tables (Psi, Omega), lg_rec doubles per child
   int lg_nf = 0, lg_nn = 0, lg_na = 0;                                // sizing over that list
   int64_t lg_children = 0, lg_maxent = 0, lg_pairs = 0, lg_rows = 0;  // over all family children (kkt_set_constraints)
+  const double* part_Y = nullptr;   // the Y of the last kkt_prepare_part (sharded step): valid while part_valid
   bool kc_sorted = false;    // every per-(clique, constraint) entry list ascends in panel position (columns are contiguous runs)
   bool lg_request = false;   // the running Schur sweep may leave the panels of the family children out
   bool lg_nochild = false;   // ... and did: the stack lacks them, their Gram block comes from k_leaf_gram

@@ -805,6 +805,47 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down3(MfmaArgs a, d
   tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
 }
 
+// ---- fronts WITHOUT separator (the roots of the forest) in hessian(adj = None): both sweeps together are
+//     Z_NN = Li^T (Li F_NN Li^T) Li = Y_NN F_NN Y_NN,   Y_NN = Li^T Li = the root block of the projected inverse Y itself,
+// i.e. two products with a matrix the caller already holds, in place of the four phase launches up1 / up2 / down1 / down3
+// (the root of synth50k, one right-hand side: 58 us of the 345 us of a Hessian).  Phase 1 (end of the up sweep, after the
+// extend-add): T = F_NN Y_NN; phase 2 (start of the down sweep): Z_NN = Y_NN T, lower, into the panel.
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_root1(MfmaArgs a, double* u, int64_t ldu, const double* Yb) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, nf = c.nf, ntN = tiles64(nn);
+  const int t = blockIdx.x;
+  if (t >= ntN * ntN) return;
+  const int m0 = (t % ntN) * LT, n0 = (t / ntN) * LT;
+  const double* P = c.P;
+  const double* Y = Yb + a.t.cl[c.k].blk;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return P[max(m, kk) + (int64_t)min(m, kk) * nf]; },
+                  [=](int kk, int n) { return Y[max(kk, n) + (int64_t)min(kk, n) * nf]; }, sA, sB);
+  double* T = c.T;
+  tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
+}
+template <int PD>
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_root2(MfmaArgs a, double* u, int64_t ldu, const double* Yb) {
+  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  const LfCtx c = lf_ctx(a, u, ldu);
+  const int nn = c.nn, nf = c.nf, ntN = tiles64(nn);
+  if ((int)blockIdx.x >= ntN * (ntN + 1) / 2) return;
+  int tm, tn;
+  lower_pair(blockIdx.x, tm, tn);
+  const int m0 = tm * LT, n0 = tn * LT;
+  const double* T = c.T;
+  const double* Y = Yb + a.t.cl[c.k].blk;
+  d4 acc[2][2];
+  tile64_zero(acc);
+  gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Y[max(m, kk) + (int64_t)min(m, kk) * nf]; },
+                  [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB);
+  double* Pw = c.P;
+  tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
+}
+
 // ---- supernodal triangular solves with a dense n x nrhs right-hand side (chompack.trsm; the S^-1[:, K_j] columns of the
 // SCMcolumn2 route, solvers.py:490-492) as tile products with the inverse-form factor LK = [Li; K]:
 //   forward  (B <- L^-1 B), per clique:  x_N = Li b_N,  B[rows_A] -= K b_N        (L_AN x_N = K b_N)

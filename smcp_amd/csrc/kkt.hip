@@ -1186,6 +1186,7 @@ int kkt_prepare_part(csp_ctx* c, const double* L, const double* Y, int set, int 
   D.yaa_tag = D.fac_tag = D.faci_tag = nullptr;        // partial content: nothing to claim for the caches
   D.lk_tag_L = D.lk_tag_Y = nullptr;
   D.part_valid = false;
+  D.part_Y = nullptr;
   D.fac_gen++;
   if (set == 2) HIPCHK(zero_flag(c, st));
   if (with_lk) prep_lk_set(c, set, L, st);
@@ -1219,6 +1220,7 @@ int kkt_prepare_part(csp_ctx* c, const double* L, const double* Y, int set, int 
   if (set == 2) return 0;
   if (int rc = fetch_info(c, st)) return rc;
   D.part_valid = true;
+  D.part_Y = Y;          // (the root blocks of Y serve the fronts without separator in csp_hessian_sweep_part: Z_NN = Y_NN F_NN Y_NN)
   return 0;
 }
 // one half of the Hessian hessian(L, Y, U, adj=None) over the cliques of a set: dir 0 = leaves->root (with the Y_AA
@@ -1229,8 +1231,10 @@ int csp_hessian_sweep_part(csp_ctx* c, double* U, int64_t nrhs, int64_t ldu, int
   if (set < 1 || set > 2 || !c->sets[set].lev2 || use_generic(c) || nrhs < 1 || nrhs > c->D.max_rhs) return SMCP_EINVAL;
   if (!c->D.part_valid) return SMCP_ESTALE;
   hipStream_t st = (hipStream_t)stream;
-  if (dir == 0) hess_up_fast(c, U, (int)nrhs, ldu, c->D.yaa, 1, st, set);
-  else hess_down_fast(c, U, (int)nrhs, ldu, nullptr, 0, st, set);
+  // (the two halves of a set always come as a pair -- the caller runs dir 1 of every set after dir 0 of every set -- so the
+  // fronts without separator take both together, as in hessian_impl)
+  if (dir == 0) hess_up_fast(c, U, (int)nrhs, ldu, c->D.yaa, 1, st, set, -1, nullptr, 0, -1, c->D.part_Y);
+  else hess_down_fast(c, U, (int)nrhs, ldu, nullptr, 0, st, set, c->D.part_Y);
   HIPCHK(end_call(c));
   return 0;
 }
