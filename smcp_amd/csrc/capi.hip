@@ -505,9 +505,15 @@ static bool pd_deep() {
 // (two products with the dense Y_NN cost 3 nn^3 flops against 2 nn^3 of the four phases that exploit the triangular Li:
 // the fusion is for roots whose sweeps are launch-bound, not for config 2's 4096 clique)
 constexpr int ROOT_FUSED_MAXNN = 512;
-static bool root_fused() {      // SMCP_ROOT_FUSED=0: the four phase launches for fronts without separator too
+// OFF unless SMCP_ROOT_FUSED=1.  The explicit Y_NN = Li^T Li carries the SQUARE of the factor's condition number into every
+// entry it touches, the nested congruences Li^T (Li F Li^T) Li do not, and solve_ must apply the operator the Schur
+// complement was built from (H = <G(A_i), G(A_j)>) to rounding x cond(Li), not x cond(Li)^2: over 288 interior-point runs
+// of scratch/fuzz_ipm.py (48 random problems x 6 driver / solver combinations) the fused route ended three runs with
+// status "unknown" in the last, ill-conditioned iterations where the nested route (and round 2) end optimal; it saves
+// 27 us per Hessian on synth50k (solve_ 0.79 -> 0.74 ms) and is kept for studies only.
+static bool root_fused() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMCP_ROOT_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = getenv("SMCP_ROOT_FUSED"); on = (e && e[0] == '1') ? 1 : 0; }
   return on == 1;
 }
 void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
