@@ -521,6 +521,13 @@ void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t 
   dim3 blk(256);
   if (a.nchmax > 0) {     // a level of childless large fronts has nothing to assemble (k_lf_up2 does not read their update blocks)
     lf_assemble(c, a, cnt, nrhs, U, ldu, 0, st, true);
+    if (c->side_work) {   // independent work of the caller: beside the phase kernels from here on (csp_ctx::side_work)
+      std::function<void(hipStream_t)> w = std::move(c->side_work);
+      c->side_work = nullptr;
+      Fork* f = new Fork(c, st, 0);
+      c->side_fork = f;
+      w(f->s);
+    }
   }
   LAUNCH_PD(c, KID_lf_up1, k_lf_up1, dim3(umax1(mtA * ntN + ntN * ntN), cnt, nrhs), blk, st, a, U, ldu);
   LAUNCH_PD(c, KID_lf_up2, k_lf_up2, dim3(umax1(mtA * (mtA + 1) / 2 + mtA * ntN + ntN * (ntN + 1) / 2), cnt, nrhs), blk, st, a, U, ldu);
@@ -1640,6 +1647,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
     void* ptrs[] = {D.lfsp_skip, D.trsm_x, D.fp, D.fp_bad, D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
+    if (c->side_fork) { Fork* f = (Fork*)c->side_fork; c->side_fork = nullptr; f->join(); delete f; }
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& G : c->lfsp_grp) { if (G.ptr) hipFree(G.ptr); if (G.list) hipFree(G.list); }
     for (int q = 0; q < 2; ++q) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "symbolic.hpp"
@@ -201,6 +202,13 @@ struct csp_ctx {
   smcp::Profiler prof;
   std::vector<int64_t> h_tmpptr;
   std::vector<int> lev_namax;   // per level: largest separator (sizes the gather launches)
+  // Work that does not depend on the running leaves->root sweep and may run beside its large-front stage (the closed-form
+  // Gram blocks of the family children beside the phase kernels of the top fronts): set by the caller of the sweep, taken
+  // (once) by lf_up right after the first extend-add launch and started on a side stream; side_fork = that branch (a Fork,
+  // capi.hip), joined by whoever consumes the results.  gpre: what the side work planned for gram_accumulate.
+  std::function<void(hipStream_t)> side_work;
+  void* side_fork = nullptr;
+  struct GramPre { bool valid = false; int ngram = 0, nchunk = 0, spw = 0, nl = 0; } gpre;
   struct LfspGroups { int32_t* ptr = nullptr; int32_t* list = nullptr; int ngroups = 0; };
   std::vector<LfspGroups> lfsp_grp;   // per level: the groups of its large-front class (device arrays; ngroups 0 = none)
   bool lfsp_any_groups = false;

@@ -904,14 +904,22 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
   const int nb = (int)((m + GRAM_BLK - 1) / GRAM_BLK);
   const int nblk = nb * (nb + 1) / 2;
   if (nblk == 1) {
-    if (int rc = gram_tables(c, rs, leaf, st)) return rc;
-    const int64_t chunk = gram_chunk_rows((int64_t)D.gsl_n * GRAM_KS);
-    const int spw = (int)(chunk / GRAM_KS);
-    const int nchunk = std::max(1, (D.gsl_n + spw - 1) / spw);
-    const int ngram = D.gsl_n > 0 ? nchunk : 0;
-    if (int rc = gram_reserve(c, m, nchunk + (leaf ? leafgram_slots(c) : 0))) return rc;
-    int nl = 0;
-    if (leaf) { if (int rc = leafgram_partials(c, m, ids, st, D.gpart + (int64_t)ngram * (64 * 256), &nl)) return rc; }
+    int spw, nchunk, ngram, nl = 0;
+    Fork* side = (Fork*)c->side_fork;
+    c->side_fork = nullptr;
+    if (c->gpre.valid && leaf) {        // planned, and the leaf partials started, beside the large-front stage of the sweep (schur_gram)
+      spw = c->gpre.spw; nchunk = c->gpre.nchunk; ngram = c->gpre.ngram; nl = c->gpre.nl;
+    } else {
+      if (side) { side->join(); delete side; side = nullptr; }
+      if (int rc = gram_tables(c, rs, leaf, st)) return rc;
+      const int64_t chunk = gram_chunk_rows((int64_t)D.gsl_n * GRAM_KS);
+      spw = (int)(chunk / GRAM_KS);
+      nchunk = std::max(1, (D.gsl_n + spw - 1) / spw);
+      ngram = D.gsl_n > 0 ? nchunk : 0;
+      if (int rc = gram_reserve(c, m, nchunk + (leaf ? leafgram_slots(c) : 0))) return rc;
+      if (leaf) { if (int rc = leafgram_partials(c, m, ids, st, D.gpart + (int64_t)ngram * (64 * 256), &nl)) return rc; }
+    }
+    c->gpre.valid = false;
     // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
     // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
     static int nw = -1;
@@ -933,10 +941,13 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
       }
 #undef SMCP_GRAM_CASE
     }
+    if (side) { side->join(); delete side; }      // the leaf partials of the side branch
     launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(256), st, (const double*)D.gpart, ngram + nl, (int)m, H, ldh);
     HIPCHK(end_call(c));
     return 0;
   }
+  if (c->side_fork) { Fork* f = (Fork*)c->side_fork; c->side_fork = nullptr; f->join(); delete f; }
+  c->gpre.valid = false;
   if (leaf) return SMCP_EINVAL;                 // leafgram_ok admits one block only
   const int64_t chunk = gram_chunk_rows(total);
   const int nchunk = gram_count_chunks(rs, chunk);
@@ -971,10 +982,35 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     // (Accumulating the Gram tiles of the lower levels on a side stream while the large fronts are still swept was
     // measured in round 2 and dropped: 5.92 against 5.61 ms per step -- the two stages only take CUs from each other.)
     D.lg_request = leafgram_ok(c, m);
+    // The closed-form Gram blocks of the family children depend on the factors only, not on the sweep: with one chunk of
+    // right-hand sides they start on a side stream as soon as the extend-add of the first large level has been launched and
+    // run beside the phase kernels of the top fronts (MFMA at a few workgroups per CU against VALU / LDS work: they share
+    // the CUs instead of taking them from each other).  SMCP_LG_SIDE=0: after the sweep, on the caller's stream.
+    static int lgside = -1;
+    if (lgside < 0) { const char* e = getenv("SMCP_LG_SIDE"); lgside = (e && e[0] == '0') ? 0 : 1; }
+    c->gpre.valid = false;
+    if (lgside && D.lg_request && m <= D.max_rhs && Fork::enabled() && (m + GRAM_BLK - 1) / GRAM_BLK == 1) {
+      c->side_work = [c, m, bl](hipStream_t side) {
+        DeviceCtx& D = c->D;
+        if (!D.lg_nochild) return;                   // the family launch kept the children's panels: the Gram kernel takes them
+        const int64_t range[2] = {0, bl};
+        const std::vector<std::pair<int64_t, int64_t>> rs = gram_merge_ranges(1, range);
+        if (gram_tables(c, rs, true, side)) return;
+        const int64_t chunk = gram_chunk_rows((int64_t)D.gsl_n * GRAM_KS);
+        const int spw = (int)(chunk / GRAM_KS);
+        const int nchunk = std::max(1, (D.gsl_n + spw - 1) / spw);
+        const int ngram = D.gsl_n > 0 ? nchunk : 0;
+        if (gram_reserve(c, m, nchunk + leafgram_slots(c))) return;
+        int nl = 0;
+        if (leafgram_partials(c, m, nullptr, side, D.gpart + (int64_t)ngram * (64 * 256), &nl)) return;
+        c->gpre.valid = true; c->gpre.ngram = ngram; c->gpre.nchunk = nchunk; c->gpre.spw = spw; c->gpre.nl = nl;
+      };
+    }
     for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
       int nr = (int)std::min(D.max_rhs, m - jb);
       hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st, 0, D.kc_ptr ? jb : -1);     // G(A_j) = (G_NN, R^T G_AN)
     }
+    c->side_work = nullptr;
     D.lg_request = false;
     const int64_t range[2] = {0, bl};
     if (int rc = gram_accumulate(c, 1, range, H, ldh, st, -1, D.lg_nochild)) return rc;
