@@ -420,33 +420,48 @@ static int fact_threads(const MfmaArgs& am, int thr, int kind) {
 // clear_first (sgn 0 callers): the update blocks must read as zero where no child contributes -- the gather plan and the
 // tiled kernel store only what they receive, so the blocks are cleared before them; k_lf_assemble_lds assigns the whole
 // lower triangle (zeros included) and needs no clear pass (26 us per Schur sweep on synth50k: 105 MB of stores)
+// does the streaming extend-add (k_lf_assemble_lds) take this launch, and with how many workgroups per (front, rhs) pair
+static bool alds_route(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, int& nz, size_t& bytes) {
+  // fronts whose packed lower triangle fits LDS: stream the children through it (k_lf_assemble_lds)
+  static int alds = -1;
+  if (alds < 0) { const char* e = getenv("SMCP_ALDS"); alds = (e && e[0] == '0') ? 0 : 1; }
+  const int nfmax = a.nnmax + a.namax;
+  // workgroups per (front, right-hand side): one, unless a front has so many children that one CU would stream them
+  // for long (config 3: 1999 children of the root, 100 pairs) -- then the children are dealt over nz workgroups whose
+  // partial fronts meet in global memory (atomics; the update blocks are cleared first).  SMCP_ALDS_Z overrides.
+  static int zenv = -1;
+  if (zenv < 0) { const char* e = getenv("SMCP_ALDS_Z"); zenv = e ? atoi(e) : 0; }
+  const int64_t pairs = std::max<int64_t>(1, (int64_t)cnt * nrhs);
+  nz = 1;
+  if (zenv > 0) nz = zenv;
+  else if (a.nchmax >= 256) nz = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)a.nchmax / 16, (int64_t)64, (4 * (int64_t)c->D.ncu + pairs - 1) / pairs}));
+  // fewer (front, right-hand side) pairs than half the CUs, each with many children (one rank's share of an eight-rank job
+  // on synth50k: ONE front x 100 constraints, 112 children each -- 150 us with a workgroup per pair): deal the children
+  else if (nrhs >= 16 && 2 * pairs <= c->D.ncu && a.nchmax >= 32)
+    nz = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)a.nchmax / 16, (int64_t)8, (2 * (int64_t)c->D.ncu + pairs - 1) / pairs}));
+  nz = std::max(1, std::min(nz, std::max(1, a.nchmax)));
+  bytes = (size_t)(lf_alds_doubles(nfmax) + 3 * ((a.nchmax + nz - 1) / nz) + 2) * sizeof(double);   // front + child table
+  if (!(alds && a.nchmax > 0 && pairs * nz >= 32 && nfmax <= LF_ALDS_MAXNF && bytes <= LDS_LIMIT)) return false;   // enough workgroups to fill the chip
+  static bool attr = false;
+  if (!attr) { attr = hipFuncSetAttribute((const void*)k_lf_assemble_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess; }
+  return attr;
+}
+// (sparse right-hand sides) would lf_assemble build the input panels itself -- sgn 3 of lf_alds_task -- so that the caller
+// can skip k_panel_fill?  SMCP_ALDS_FILL=0: never.
+static bool lf_assemble_fills(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMCP_ALDS_FILL"); on = (e && e[0] == '0') ? 0 : 1; }
+  int nz; size_t bytes;
+  return on && a.kc_ptr && alds_route(c, a, cnt, nrhs, nz, bytes) && nz == 1;
+}
 void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, int sgn, hipStream_t st, bool clear_first = false) {
   static int plan = -1;
   if (plan < 0) { const char* e = getenv("SMCP_ASM"); plan = (e && e[0] == 't') ? 0 : 1; }
   {
-    // fronts whose packed lower triangle fits LDS: stream the children through it (k_lf_assemble_lds)
-    static int alds = -1;
-    if (alds < 0) { const char* e = getenv("SMCP_ALDS"); alds = (e && e[0] == '0') ? 0 : 1; }
-    const int nfmax = a.nnmax + a.namax;
-    // workgroups per (front, right-hand side): one, unless a front has so many children that one CU would stream them
-    // for long (config 3: 1999 children of the root, 100 pairs) -- then the children are dealt over nz workgroups whose
-    // partial fronts meet in global memory (atomics; the update blocks are cleared first).  SMCP_ALDS_Z overrides.
-    static int zenv = -1;
-    if (zenv < 0) { const char* e = getenv("SMCP_ALDS_Z"); zenv = e ? atoi(e) : 0; }
-    const int64_t pairs = std::max<int64_t>(1, (int64_t)cnt * nrhs);
-    int nz = 1;
-    if (zenv > 0) nz = zenv;
-    else if (a.nchmax >= 256) nz = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)a.nchmax / 16, (int64_t)64, (4 * (int64_t)c->D.ncu + pairs - 1) / pairs}));
-    // fewer (front, right-hand side) pairs than half the CUs, each with many children (one rank's share of an eight-rank job
-    // on synth50k: ONE front x 100 constraints, 112 children each -- 150 us with a workgroup per pair): deal the children
-    else if (nrhs >= 16 && 2 * pairs <= c->D.ncu && a.nchmax >= 32)
-      nz = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)a.nchmax / 16, (int64_t)8, (2 * (int64_t)c->D.ncu + pairs - 1) / pairs}));
-    nz = std::max(1, std::min(nz, std::max(1, a.nchmax)));
-    const size_t bytes = (size_t)(lf_alds_doubles(nfmax) + 3 * ((a.nchmax + nz - 1) / nz) + 2) * sizeof(double);   // front + child table
-    if (alds && a.nchmax > 0 && pairs * nz >= 32 && nfmax <= LF_ALDS_MAXNF && bytes <= LDS_LIMIT) {   // enough workgroups to fill the chip
-      static bool attr = false;
-      if (!attr) { attr = hipFuncSetAttribute((const void*)k_lf_assemble_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess; }
-      if (attr) {
+    int nz; size_t bytes;
+    if (alds_route(c, a, cnt, nrhs, nz, bytes)) {
+      const int64_t pairs = std::max<int64_t>(1, (int64_t)cnt * nrhs);
+      {
         if (nz > 1 && sgn == 0)
           launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), dim3(256), st, a);
         // more tasks than CUs (one workgroup per CU: the front fills LDS): a persistent grid draws them from a counter, so
@@ -516,11 +531,12 @@ static bool root_fused() {
   if (on < 0) { const char* e = getenv("SMCP_ROOT_FUSED"); on = (e && e[0] == '1') ? 1 : 0; }
   return on == 1;
 }
-void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+// fill: the input panels have not been built (sparse right-hand sides, lf_assemble_fills): the extend-add builds them
+void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st, bool fill = false) {
   const int mtA = tiles64(a.namax), ntN = tiles64(a.nnmax);
   dim3 blk(256);
   if (a.nchmax > 0) {     // a level of childless large fronts has nothing to assemble (k_lf_up2 does not read their update blocks)
-    lf_assemble(c, a, cnt, nrhs, U, ldu, 0, st, true);
+    lf_assemble(c, a, cnt, nrhs, U, ldu, fill ? 3 : 0, st, true);
     if (c->side_work) {   // independent work of the caller: beside the phase kernels from here on (csp_ctx::side_work)
       std::function<void(hipStream_t)> w = std::move(c->side_work);
       c->side_work = nullptr;
@@ -1167,6 +1183,10 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
           const int ntN = tiles64(a.nnmax);
           launch_lds(c, KID_lf_zsp, k_lf_zsp, dim3(a.nnmax, cnt, nrhs), dim3(256), (size_t)a.nnmax * sizeof(double), st, a, U, ldu);
           LAUNCH_PD(c, KID_lf_up2, k_lf_up2, dim3(umax1(ntN * (ntN + 1) / 2), cnt, nrhs), dim3(256), st, a, U, ldu);
+          return;
+        }
+        if (sparse && a.nchmax > 0 && lf_assemble_fills(c, a, cnt, nrhs)) {     // no k_panel_fill: the extend-add builds the panels
+          lf_up(c, a, cnt, nrhs, U, ldu, st, true);
           return;
         }
         dense_input(a, cnt);

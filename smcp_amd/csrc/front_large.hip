@@ -326,10 +326,15 @@ __device__ inline void lf_add_child(double* T, int nf, const double* Uc, const i
 }
 // (body of one (front, right-hand side, share of the children) task; bx / by / bz and nz: block index and z-extent of the grid
 // in the plain launch)
+// sgn 3 (nz = 1 only): sgn 0 for a sparse right-hand side whose dense input panel has NOT been built -- the constraint's
+// entries of the front (MfmaArgs::kc_*) are added to the front in LDS and the panel is stored whole (no k_panel_fill pass
+// over the panels before, no read of them here: 2 x 79 MB per Schur sweep on synth50k)
 __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, int sgn, int bx, int by, int bz, int nz, double* T) {
+  const bool fill = sgn == 3;
+  if (fill) sgn = 0;
   const int k = a.t.lev[bx];
   const CliqueDesc d = a.t.cl[k];
-  if (d.chend == d.chbeg) {
+  if (d.chend == d.chbeg && !fill) {
     if (!sgn) {      // a childless front among fronts with children: its update block is assigned too (zero)
       double* U0 = a.t.upd + (int64_t)by * a.t.updlen + d.upd;
       for (int e = threadIdx.x; e < d.na * d.na; e += blockDim.x) U0[e] = 0.0;
@@ -382,6 +387,24 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
   __syncthreads();
   double* P = u + (int64_t)r * ldu + d.blk;
   double* U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+  if (fill) {
+    const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
+    const int32_t* kp = a.kc_ptr + (int64_t)k * a.kc_stride;
+    for (int p = kp[j] + tid; p < kp[j + 1]; p += nthr) {
+      const int off = a.kc_off[p], i = off % nf, jc = off / nf;
+      if (i >= jc) unsafeAtomicAdd(&T[cb(jc) + i], a.kc_val[p]);
+    }
+    __syncthreads();
+    for (int e = tid; e < nf * nn; e += nthr) {
+      const int i = e % nf, jc = e / nf;
+      if (i >= jc) P[e] = T[cb(jc) + i];
+    }
+    for (int e = tid; e < na * na; e += nthr) {
+      const int i = e % na, jc = e / na;
+      if (i >= jc) U[e] = T[cb(nn + jc) + nn + i];
+    }
+    return;
+  }
   if (nz > 1) {        // partial front: atomics into the panel and the (pre-cleared or accumulating) update block
     const double spz = (sgn == 1) ? -1.0 : 1.0;
     for (int e = tid; e < nf * nn; e += nthr) {
