@@ -987,7 +987,13 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     // run beside the phase kernels of the top fronts (MFMA at a few workgroups per CU against VALU / LDS work: they share
     // the CUs instead of taking them from each other).  SMCP_LG_SIDE=0: after the sweep, on the caller's stream.
     static int lgside = -1;
-    if (lgside < 0) { const char* e = getenv("SMCP_LG_SIDE"); lgside = (e && e[0] == '0') ? 0 : 1; }
+    if (lgside < 0) {
+      const char* e = getenv("SMCP_LG_SIDE");
+      const char* d0 = getenv("SMCP_ALDS_DYN");
+      const char* d1 = getenv("SMCP_RHS_SPLIT_DYN");
+      // (the two-stream split of the right-hand sides -- the plain extend-add launch, hess_up_fast -- uses the same side streams)
+      lgside = ((e && e[0] == '0') || (d0 && d0[0] == '0') || (d1 && d1[0] == '1')) ? 0 : 1;
+    }
     c->gpre.valid = false;
     if (lgside && D.lg_request && m <= D.max_rhs && Fork::enabled() && (m + GRAM_BLK - 1) / GRAM_BLK == 1) {
       c->side_work = [c, m, bl](hipStream_t side) {
