@@ -276,7 +276,10 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
     # than n / 10 columns and is swept; the max-cut constraints are column-sparse
     kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs, tnzcols=0.0 if args.kktsolver == "qr" else None)
     part = None
-    if (world > 1 or force_sharded) and args.shard == "subtree":
+    # max-cut: every constraint is column-sparse (SCMcolumn2 route) -- with N > 1 the factors are replicated (n = 1000: the
+    # factorisation is not what costs) and the constraints sharded over the ranks (kkt_schur_gram_part), one all-reduce of H
+    shard = "columns" if workload == "maxcut" else args.shard
+    if (world > 1 or force_sharded) and shard == "subtree":
         kkt.force_sharded = force_sharded
         part = kkt.set_partition(dist.group.WORLD)   # subtrees -> ranks, replicated top, boundary exchange lists
     Lh = problems.random_factor_blkval(symb, seed=0)
@@ -507,7 +510,8 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
                        "update_doubles": int(U), "rhs_per_sweep": max_rhs,
                        "parallelism": ("single" if world == 1 else
                                        ("subtree-sharded Gram + boundary exchange/%d" % world if part is not None
-                                        else "schur-columns/%d" % world))},
+                                        else ("column-sparse constraints by rank (SCMcolumn2)/%d" % world if workload == "maxcut"
+                                              else "schur-columns/%d" % world)))},
             "roofline": roofline, "cpu_baseline": cpu, "back_solve": back_solve,
             "symbolic_s": round(t_sym, 3),
             # per-kernel HIP-event times: the dominant kernel from the timed steps, the others from the untimed

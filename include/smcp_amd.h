@@ -143,6 +143,16 @@ int kkt_schur_factor(csp_ctx* ctx, const double* L, const double* Y, double* H, 
  * GPUs (each rank builds its column range, then one RCCL all-gather of H). */
 int kkt_schur_columns(csp_ctx* ctx, const double* L, const double* Y, double* H, int64_t ldh,
                       int64_t j0, int64_t j1, void* stream);
+/* N > 1 GPUs with REPLICATED factors (L, Y valid on every rank) and column-sparse constraints (the SCMcolumn2 route,
+ * solvers.py:489-497, misc.c:620-663): caller `part` of `nparts` computes the columns of its contiguous share of the
+ * column-sparse constraints (trsm x 2 + SCMcolumn2 per chunk) and, as part 0, the Gram block of the swept ones, into a
+ * CLEARED H; one all-reduce (sum) of H over the callers completes the Schur complement (both triangles; a pair of sparse
+ * constraints owned by two callers is written by the owner of the smaller index only).  Then dense_potrf on every rank. */
+int kkt_schur_gram_part(csp_ctx* ctx, const double* L, const double* Y, double* H, int64_t ldh, int64_t part,
+                        int64_t nparts, void* stream);
+/* counts[0] = constraints swept through the Hessian, counts[1] = column-sparse ones (misc.nzcolumns / matperm,
+ * misc.c:682-773; as classified by the last kkt_set_constraints under the current kkt_set_tnzcols). */
+int kkt_constraint_classes(csp_ctx* ctx, int64_t* counts);
 /* lapack.potrf / potrs on a dense device matrix (solvers.py:501,526). */
 int dense_potrf(csp_ctx* ctx, double* A, int64_t n, int64_t lda, void* stream);
 int dense_potrs(csp_ctx* ctx, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs,

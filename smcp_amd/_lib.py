@@ -42,6 +42,8 @@ SIGNATURES = {
     "kkt_aadj": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "kkt_schur_factor": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kkt_schur_columns": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "kkt_schur_gram_part": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "kkt_constraint_classes": (ctypes.c_int, [c_vp, c_vp]),
     "csp_cache_reset": (ctypes.c_int, [c_vp]),
     "csp_touch": (ctypes.c_int, [c_vp, c_vp]),
     "csp_tune": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64]),

@@ -1666,7 +1666,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
     hipSetDevice(D.device);
     void* ptrs[] = {D.lfsp_skip, D.trsm_x, D.fp, D.fp_bad, D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
-                    D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc};
+                    D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc, D.scm_owner};
     if (c->side_fork) { Fork* f = (Fork*)c->side_fork; c->side_fork = nullptr; f->join(); delete f; }
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& G : c->lfsp_grp) { if (G.ptr) hipFree(G.ptr); if (G.list) hipFree(G.list); }

@@ -83,12 +83,16 @@ __global__ void k_unit_columns(const int32_t* kidx, int64_t ncols, double* V, in
 // misc.SCMcolumn2 (misc.c:620-663): H[i, s] = tr(A_i S^-1 A_s S^-1) from V_s = S^-1[:, K_s], for every
 // constraint i and the column-sparse constraints s of this chunk (one wave per pair; H is symmetric, both
 // triangles are written).  voff[q]: first column of V_s inside V for the q-th sparse constraint of the chunk.
+// owner / me (sharded over ranks by sparse constraint, kkt_schur_gram_part): owner[i] = the rank that computes the columns of
+// constraint i, -1 for the swept (dense-class) constraints.  The partial matrices of the ranks are SUMMED, so a pair of
+// sparse constraints owned by two different ranks must be written by one of them only: the owner of the smaller index.
 __global__ void k_scm_columns(int64_t m, const int64_t* cptr, const int32_t* a_r, const int32_t* a_c, const double* cval,
                               const int32_t* slist, const int64_t* voff, const int32_t* rloc, const int32_t* cloc,
-                              const double* V, int64_t n, double* H, int64_t ldh) {
+                              const double* V, int64_t n, double* H, int64_t ldh, const int32_t* owner = nullptr, int me = 0) {
   const int lane = threadIdx.x & 63;
   const int64_t i = blockIdx.x;
   const int64_t s = slist[blockIdx.y];
+  if (owner && owner[i] >= 0 && owner[i] != me && i < s) return;
   const double* Vs = V + voff[blockIdx.y] * n;
   double acc = 0.0;
   for (int64_t q = cptr[i] + lane; q < cptr[i + 1]; q += 64) {
@@ -307,11 +311,12 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   const Symbolic& S = c->S;
   HIPCHK(hipSetDevice(D.device));
   void* old[] = {D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack,
-                 D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.kc_ij};
+                 D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.kc_ij, D.scm_owner};
   for (void* p : old) if (p) hipFree(p);
   D.cptr = nullptr; D.cidx = nullptr; D.cval = nullptr; D.cwval = nullptr; D.rpos = nullptr;
   D.rptr = nullptr; D.rcon = nullptr; D.rval = nullptr; D.ustack = nullptr;
   D.a_r = D.a_c = D.s_rloc = D.s_cloc = D.dlist = D.slist = D.kidx = nullptr;
+  D.scm_owner = nullptr;
   D.vbuf = D.hd = nullptr;
   D.kc_ptr = D.kc_off = nullptr; D.kc_val = nullptr; D.kc_ij = nullptr;
   D.md = D.ns = D.vcols = 0;
@@ -974,10 +979,14 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
 
 // Gram formulation of the whole Schur complement (what kkt_qr implies, solvers.py:414-420):
 // H = G(A)^T G(A) with ONE leaves->root sweep per constraint, then one tall-skinny SYRK.
-static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, hipStream_t st) {
+// part / nparts (kkt_schur_gram_part): this caller's share of the column-sparse constraints -- a contiguous range of the
+// sparse list -- and, for part 0, the Gram block of the swept ones; H must have been cleared, the parts are summed
+static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, hipStream_t st, int64_t part = 0,
+                      int64_t nparts = 1) {
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
   if (!D.ns) {
+    if (part) return 0;
     if (int rc = gram_prepare(c, L, Y, st)) return rc;
     // (Accumulating the Gram tiles of the lower levels on a side stream while the large fronts are still swept was
     // measured in round 2 and dropped: 5.92 against 5.61 ms per step -- the two stages only take CUs from each other.)
@@ -1024,7 +1033,18 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     return 0;
   }
   // ---- hybrid (solvers.py:479-497): Gram block of the swept constraints + SCMcolumn2 columns of the sparse ones
-  const int64_t md = D.md, n = c->S.n;
+  const int64_t md = part == 0 ? D.md : 0, n = c->S.n;
+  const int64_t qlo = D.ns * part / nparts, qhi = D.ns * (part + 1) / nparts;
+  const int32_t* owner = nullptr;
+  if (nparts > 1) {
+    std::vector<int32_t> ow((size_t)m, -1);
+    for (int64_t p = 0; p < nparts; ++p)
+      for (int64_t q = D.ns * p / nparts; q < D.ns * (p + 1) / nparts; ++q) ow[(size_t)c->h_slist[(size_t)q]] = (int32_t)p;
+    if (!D.scm_owner) { if (int rc = dev_alloc(&D.scm_owner, m, D.bytes)) return rc; }
+    HIPCHK(hipMemcpyAsync(D.scm_owner, ow.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));      // ow is a local
+    owner = D.scm_owner;
+  }
   if (md) {
     prepare_yaa(c, Y, true, st);
     if (int rc = prep_lk_cached(c, L, Y, st)) return rc;
@@ -1048,10 +1068,10 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
   }
   // sparse constraints in chunks of at most vcols columns of S^-1
   std::vector<int64_t> voff;
-  for (int64_t q0 = 0; q0 < D.ns;) {
+  for (int64_t q0 = qlo; q0 < qhi;) {
     int64_t q1 = q0, cols = 0;
     voff.clear();
-    while (q1 < D.ns && cols + (c->h_kptr[q1 + 1] - c->h_kptr[q1]) <= D.vcols && q1 - q0 < 65535) {
+    while (q1 < qhi && cols + (c->h_kptr[q1 + 1] - c->h_kptr[q1]) <= D.vcols && q1 - q0 < 65535) {
       voff.push_back(cols);
       cols += c->h_kptr[q1 + 1] - c->h_kptr[q1];
       ++q1;
@@ -1068,7 +1088,7 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     HIPCHK(hipStreamSynchronize(st));    // voff is reused by the next chunk
     launch(c, KID_scatter_constraints, k_scm_columns, dim3((unsigned)m, (unsigned)(q1 - q0)), dim3(64), st, m, D.cptr,
            (const int32_t*)D.a_r, (const int32_t*)D.a_c, (const double*)D.cval, (const int32_t*)D.slist + q0,
-           (const int64_t*)dvoff, (const int32_t*)D.s_rloc, (const int32_t*)D.s_cloc, (const double*)D.vbuf, n, H, ldh);
+           (const int64_t*)dvoff, (const int32_t*)D.s_rloc, (const int32_t*)D.s_cloc, (const double*)D.vbuf, n, H, ldh, owner, (int)part);
     q0 = q1;
   }
   HIPCHK(end_call(c));
@@ -1101,6 +1121,28 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
   return 0;
 }
 
+// The hybrid Schur complement (Gram block of the swept constraints + SCMcolumn2 columns of the column-sparse ones,
+// solvers.py:479-497, misc.c:620-663) sharded over `nparts` callers by sparse constraint: this one computes the columns of
+// its contiguous share of the sparse list (trsm x 2 + k_scm_columns per chunk) and, as part 0, the Gram block.  H (cleared
+// by the caller) receives this part only; the sum of the parts over all callers is the Schur complement (both triangles).
+int kkt_schur_gram_part(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, int64_t part, int64_t nparts,
+                        void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  if (!D.m || ldh < D.m || nparts < 1 || part < 0 || part >= nparts || !use_gram(c)) return SMCP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  D.qr_valid = false;
+  HIPCHK(zero_flag(c, st));
+  return schur_gram(c, L, Y, H, ldh, st, part, nparts);
+}
+// how kkt_set_constraints classified the constraints (misc.nzcolumns / matperm, misc.c:682-773): counts[0] = swept through the
+// Hessian (dense class), counts[1] = column-sparse (SCMcolumn2 route)
+int kkt_constraint_classes(csp_ctx* c, int64_t* counts) {
+  if (!c || !counts) return SMCP_EINVAL;
+  counts[0] = c->D.ns ? c->D.md : c->D.m;
+  counts[1] = c->D.ns;
+  return 0;
+}
 int kkt_schur_factor(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, void* stream) {
   if (int rc = kkt_schur_columns(c, L, Y, H, ldh, 0, c ? c->D.m : 0, stream)) return rc;
   return dense_potrf(c, H, c->D.m, ldh, stream);

@@ -166,10 +166,15 @@ class ShardedSchur:
             return
         P = self.partition
         if P is None:
-            j0, j1 = column_range(self.m, rank, world)
             self.H.zero_()
-            if j1 > j0:
-                self._columns(L, Y, j0, j1)
+            if self._sparse_count() > 0:
+                # column-sparse constraints (misc.SCMcolumn2, solvers.py:489-497): every rank takes a contiguous share of them
+                # (trsm x 2 + SCMcolumn2 per chunk), rank 0 the Gram block of the swept ones as well; factors replicated
+                self._scm_part(L, Y, rank, world)
+            else:
+                j0, j1 = column_range(self.m, rank, world)
+                if j1 > j0:
+                    self._columns(L, Y, j0, j1)
             _all_reduce(self.H, group)
             self.collectives += 1
             return
@@ -401,6 +406,17 @@ class KKTSystem(ShardedSchur):
         sync_cache(self.symb, L, Y)
         _chk(_lib.lib().kkt_schur_columns(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(),
                                           self.H.data_ptr(), self.m, int(j0), int(j1), _stream()), "kkt_schur_columns")
+
+    def _sparse_count(self):
+        cnt = (ctypes.c_int64 * 2)()
+        _chk(_lib.lib().kkt_constraint_classes(self.symb.handle, cnt), "kkt_constraint_classes")
+        return int(cnt[1])
+
+    def _scm_part(self, L, Y, part, nparts):
+        self._own()
+        sync_cache(self.symb, L, Y)
+        _chk(_lib.lib().kkt_schur_gram_part(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), self.H.data_ptr(), self.m,
+                                            int(part), int(nparts), _stream()), "kkt_schur_gram_part")
 
     def _potrf(self):
         _chk(_lib.lib().dense_potrf(self.symb.handle, self.H.data_ptr(), self.m, self.m, _stream()), "dense_potrf")

@@ -43,6 +43,29 @@ class OracleKKT(kkt.ShardedSchur):
             orc.hessian(self.K.S, _np(L), _np(Y), u, adj=None, inv=False)
             self.H[j, :] = torch.from_numpy(self.K.amap(u))
 
+    # ---- column-sparse constraints sharded by constraint (kkt_schur_gram_part): emulated with every constraint treated
+    # as column-sparse when emulate_sparse is set -- the columns come from the oracle's Hessian, the ownership rule (a pair
+    # owned by two ranks is written by the owner of the smaller index) is the product's (k_scm_columns)
+    emulate_sparse = False
+
+    def _sparse_count(self):
+        return self.m if self.emulate_sparse else 0
+
+    def _scm_part(self, L, Y, part, nparts):
+        m = self.m
+        owner = np.empty(m, dtype=int)
+        for p in range(nparts):
+            owner[m * p // nparts: m * (p + 1) // nparts] = p
+        for s_ in range(m * part // nparts, m * (part + 1) // nparts):
+            u = self.K.constraint(s_)
+            orc.hessian(self.K.S, _np(L), _np(Y), u, adj=None, inv=False)
+            col = self.K.amap(u)
+            for i in range(m):
+                if owner[i] != part and i < s_:
+                    continue
+                self.H[s_, i] = col[i]
+                self.H[i, s_] = col[i]
+
     # ---- subtree-sharded Gram path, emulated with the oracle's masked G sweep
     def _apply_partition(self, P, rank):
         self._mask = {1: (P.owner == rank).astype(np.uint8), 2: (P.owner == -1).astype(np.uint8)}

@@ -44,6 +44,8 @@ def _worker(rank, world, port, out, mode):
         cptr, cidx, cval = problems.random_constraints(symb, m, density=0.1, seed=3)
         L, Y = cspmatrix(symb, torch.from_numpy(Lh)), cspmatrix(symb, torch.from_numpy(Yh))
         sharded = OracleKKT(symb, cptr, cidx, cval)
+        if mode == "sparse":        # the constraint-sharded SCMcolumn2 route of the product's host logic (kkt_schur_gram_part)
+            sharded.emulate_sparse = True
         if mode == "factor":
             _factor_mode(rank, world, out, symb, sharded, OracleKKT(symb, cptr, cidx, cval), A, Lh, Yh, m)
             return
@@ -200,7 +202,14 @@ def _run_two(mode, world=2):
     return out.get()
 
 
-@pytest.mark.parametrize("mode", ["columns", "subtree"])
+@pytest.mark.parametrize("mode", ["columns", "subtree", "sparse"])
 def test_sharded_schur_two_ranks_gloo(mode):
     err, spread = _run_two(mode)
+    assert err < 1e-12 and spread == 0.0
+
+
+def test_sharded_sparse_columns_three_ranks_gloo():
+    """Column-sparse constraints sharded by constraint over three ranks (7 constraints: shares of 2, 2 and 3): every pair of
+    constraints owned by two different ranks must enter the summed H exactly once."""
+    err, spread = _run_two("sparse", world=3)
     assert err < 1e-12 and spread == 0.0

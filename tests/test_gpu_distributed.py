@@ -166,6 +166,78 @@ def _run_two(mode):
     return out.get()
 
 
+def _scm_worker(rank, world, port, out):
+    """Column-sparse constraints (the SCMcolumn2 route, solvers.py:489-497) sharded by constraint over the ranks with replicated
+    factors (kkt_schur_gram_part): a mix of constraints of few columns (sparse class) and dense-on-V ones (Gram block, rank 0)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from smcp_amd import chordal, problems
+        from smcp_amd.cspmatrix import cspmatrix
+        from smcp_amd.kkt import KKTSystem
+        from smcp_amd.symbolic import Symbolic
+        symb = Symbolic(problems.nested_block_arrow_pattern(nsub=2, nmid=5, nleaf_per_mid=6, seed=4))
+        symb.device_init(0, 6)
+        S = cspmatrix(symb, torch.from_numpy(problems.random_factor_blkval(symb, 1)).cuda())
+        chordal.llt(S)
+        L = S.copy()
+        chordal.cholesky(L)
+        Y = L.copy()
+        chordal.projected_inverse(Y)
+        # 11 constraints: e_i e_i^T-like ones on a few columns (max-cut style) and three spread over the whole pattern
+        rng = np.random.default_rng(9)
+        low = np.asarray(problems.lower_positions(symb))
+        cptr, cidx, cval = [0], [], []
+        for j in range(11):
+            if j % 4 == 3:
+                pos = np.sort(rng.choice(low, size=max(3, len(low) // 20), replace=False))
+            else:
+                pos = np.sort(rng.choice(low[: max(8, len(low) // 30)] if j % 2 else low[-max(8, len(low) // 30):], size=3, replace=False))
+            cidx.extend(pos.tolist()); cval.extend(rng.standard_normal(len(pos)).tolist()); cptr.append(len(cidx))
+        cptr, cidx, cval = np.array(cptr), np.array(cidx), np.array(cval)
+        single = KKTSystem(symb, cptr, cidx, cval, max_rhs=6)           # default tnzcols = 0.1: hybrid route on one rank
+        single.factor(L, Y)
+        Href = single.H.clone()
+        nsp = single._sparse_count()
+        sharded = KKTSystem(symb, cptr, cidx, cval, max_rhs=6)
+        solve = sharded.factor(L, Y, group=dist.group.WORLD)          # no partition: replicated factors, constraints sharded
+        err = float((torch.tril(sharded.H) - torch.tril(Href)).abs().max() / Href.abs().max())
+        msk = np.zeros(symb.blklen, dtype=bool)
+        msk[symb.ccs_to_blk()] = True
+        bx = cspmatrix(symb, torch.from_numpy(rng.standard_normal(symb.blklen) * msk).cuda())
+        by = torch.from_numpy(rng.standard_normal(11)).cuda()
+        cx, cy = bx.copy(), by.clone()
+        solve(bx, by, 0.5)
+        single.factor(L, Y)(cx, cy, 0.5)
+        errx = float((bx.blkval - cx.blkval).abs().max() / cx.blkval.abs().max())
+        if rank == 0:
+            out.put((err, errx, nsp, sharded.collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_column_sparse_constraints_sharded_by_constraint(world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_scm_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    err, errx, nsp, ncoll = out.get()
+    assert nsp >= 4, nsp                       # the sparse class is populated (and so is the dense one: 11 - nsp >= 2)
+    assert 11 - nsp >= 2, nsp
+    assert err < 1e-11 and errx < 1e-10, (err, errx)
+    assert ncoll == 1                          # ONE all-reduce of H
+
+
 @pytest.mark.parametrize("world,seed0,ncases", [(2, 5000, 14), (3, 6000, 8)])
 def test_sharded_step_on_random_trees(world, seed0, ncases):
     """Random clique trees of all the pattern families of the parity sweep (tests/fuzz_sharded.py): tops of several cliques
