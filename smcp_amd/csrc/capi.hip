@@ -105,7 +105,20 @@ struct Fork {
   Fork(csp_ctx* c_, hipStream_t st, int which_) : c(c_), main(st), s(st), which(which_), on(false) {
     if (!enabled()) return;
     if (!c->aux_fork && hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming) != hipSuccess) { c->aux_fork = nullptr; return; }
-    if (!c->aux_stream[which] && hipStreamCreateWithFlags(&c->aux_stream[which], hipStreamNonBlocking) != hipSuccess) { c->aux_stream[which] = nullptr; return; }
+    if (!c->aux_stream[which]) {
+      // side stream 0 carries the LONG POLE of every forked stage -- a handful of workgroups factoring or inverting the large
+      // fronts beside launches of thousands of small-clique workgroups (k_mid_chol on the Y_AA blocks of the eight mid fronts
+      // of synth50k: 55 us alone, 140 us beside k_factor_yaa_lds) -- so it is created with the highest priority the device
+      // offers: its few workgroups get their CUs first.  SMCP_AUX_PRIO=0: default priority.
+      static int prio = -2;
+      if (prio == -2) { const char* e = getenv("SMCP_AUX_PRIO"); prio = (e && e[0] == '0') ? 0 : 1; }
+      int lo = 0, hi = 0;
+      hipError_t rc = hipErrorUnknown;
+      if (which == 0 && prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+        rc = hipStreamCreateWithPriority(&c->aux_stream[which], hipStreamNonBlocking, hi);
+      if (rc != hipSuccess) rc = hipStreamCreateWithFlags(&c->aux_stream[which], hipStreamNonBlocking);
+      if (rc != hipSuccess) { c->aux_stream[which] = nullptr; return; }
+    }
     if (!c->aux_join[which] && hipEventCreateWithFlags(&c->aux_join[which], hipEventDisableTiming) != hipSuccess) { c->aux_join[which] = nullptr; return; }
     if (hipEventRecord(c->aux_fork, main) != hipSuccess) return;
     if (hipStreamWaitEvent(c->aux_stream[which], c->aux_fork, 0) != hipSuccess) return;
@@ -540,7 +553,7 @@ void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t 
     if (c->side_work) {   // independent work of the caller: beside the phase kernels from here on (csp_ctx::side_work)
       std::function<void(hipStream_t)> w = std::move(c->side_work);
       c->side_work = nullptr;
-      Fork* f = new Fork(c, st, 0);
+      Fork* f = new Fork(c, st, 1);           // (normal priority: the phase kernels on the caller's stream are the long pole here)
       c->side_fork = f;
       w(f->s);
     }
