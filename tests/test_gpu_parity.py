@@ -601,6 +601,39 @@ def test_kkt_sibling_groups_send_one_summed_update(nleaf, monkeypatch):
     assert rel(Hs[0], Hs[1]) < 1e-12
 
 
+def test_kkt_few_fronts_many_children_deal_children_over_workgroups():
+    """One (64, 128) front with 40 children and 20 constraints in one chunk: fewer (front, right-hand side) pairs than half
+    the CUs, so the streaming extend-add deals the children of a pair over several workgroups whose partial fronts meet in
+    global memory by atomics (the share of ONE rank of an eight-rank job on synth50k; lf_assemble's second nz rule).  H and
+    the solve against the oracle."""
+    symb = Symbolic(problems.nested_block_arrow_pattern(nsub=1, nmid=40, nleaf_per_mid=2, seed=11))
+    m = 20
+    symb.device_init(0, m)
+    S = orc.Sym(symb)
+    A = problems.random_factor_blkval(symb, 61)
+    orc.llt(S, A)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.01, seed=62)
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    counts = _launch_counts(symb, lambda: sys_.factor(Ld, Yd))
+    assert counts.get("k_lf_assemble_lds", 0) + counts.get("k_lf_assemble_lds_dyn", 0) >= 1, counts
+    assert counts.get("k_lf_clear_upd", 0) >= 1, counts          # the partial fronts are added into cleared blocks
+    assert rel(np.tril(sys_.H.cpu().numpy().T), np.tril(Href)) < 1e-9
+    rng = np.random.default_rng(63)
+    msk = lowmask(symb)
+    bx, by = rng.standard_normal(symb.blklen) * msk, rng.standard_normal(m)
+    xr, yr = K.solve(L, Yh, Href, bx, by, 1.0)
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    sys_.factor(Ld, Yd)(bxd, byd, 1.0)
+    assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+
+
 def test_kkt_family_kernel_dense_constraints():
     """Family kernel with long entry lists: constraints dense on V give a (5,31) child 180 entries (more than the 64
     prefetched per wave) and a (15,64) parent 1185 (more than the 256 prefetched per group): the direct-load tails
