@@ -179,28 +179,41 @@ __device__ inline double wave_trsv16(const double* A, int64_t lda, int jb, int b
   double dii = 1.0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) if (j == i) dii = Lr[j];
+  // one division per lane and call: a division inside each of the sixteen dependent steps was most of the chain
+  // (k_dense_potrs_small: 41 us at m = 100 whether the factor came from LDS or from global memory)
+  const double rdii = 1.0 / dii;
   double xi = 0.0;
   if (!trans) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const double xj = __shfl(ti / dii, j, 64);
+      const double xj = __shfl(ti * rdii, j, 64);
       if (i == j) xi = xj;
       if (i > j) ti -= Lr[j] * xj;
     }
   } else {
 #pragma unroll
     for (int j = 15; j >= 0; --j) {
-      const double xj = __shfl(ti / dii, j, 64);
+      const double xj = __shfl(ti * rdii, j, 64);
       if (i == j) xi = xj;
       if (i < j) ti -= Lr[j] * xj;
     }
   }
   return xi;
 }
-// A x = b with the factor of k_dense_potrf_small (one right-hand side, one workgroup, n <= 128)
-__global__ void __launch_bounds__(256) k_dense_potrs_small(const double* A, int n, int64_t lda, const double* dinv, double* b) {
+// A x = b with the factor of k_dense_potrf_small (one right-hand side, one workgroup, n <= 128).  The factor is copied to
+// LDS first (dynamic: n (n | 1) doubles): the 2 ceil(n / 16) block steps each read their diagonal block and the columns
+// below / beside it, and from global memory every step was two dependent round trips (41 us at m = 100, twice per solve_
+// of the interior-point iteration ... once per solve_); from LDS the steps are the substitution chains alone.
+__global__ void __launch_bounds__(256) k_dense_potrs_small(const double* Ag, int n, int64_t ldag, const double* dinv, double* b) {
+  extern __shared__ __attribute__((aligned(16))) double sAf[];
   __shared__ double x[128], t[16];
   const int tid = threadIdx.x;
+  const int lda = n | 1;
+  double* const A = sAf;
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e % n, j = e / n;
+    if (i >= j) A[i + j * lda] = Ag[i + (int64_t)j * ldag];
+  }
   if (tid < n) x[tid] = b[tid];
   __syncthreads();
   for (int jb = 0; jb < n; jb += 16) {            // L y = b
@@ -672,7 +685,10 @@ static int potrs_impl(csp_ctx* c, const double* A, int64_t n, int64_t lda, doubl
     return 0;
   }
   if (nrhs == 1 && D.hinv_tag == A && D.hinv_n == n && n <= 2 * LB) {
-    launch(c, KID_dense_potrs, k_dense_potrs_small, dim3(1), dim3(256), st, A, (int)n, lda, (const double*)D.hinv, B);
+    static bool attr = false;
+    if (!attr) attr = hipFuncSetAttribute((const void*)k_dense_potrs_small, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) == hipSuccess;
+    launch_lds(c, KID_dense_potrs, k_dense_potrs_small, dim3(1), dim3(256), (size_t)n * (n | 1) * sizeof(double), st, A, (int)n, lda,
+               (const double*)D.hinv, B);
     return 0;
   }
   if (nrhs == 1 && D.hinv_tag == A && D.hinv_n == n && n > 2 * LB) {
