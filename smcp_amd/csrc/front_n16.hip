@@ -430,7 +430,9 @@ __global__ void __launch_bounds__(256, NAT <= 2 ? 3 : 1) k_hess_down_w(MfmaArgs 
 #pragma unroll
   for (int s = 0; s < 4 * NAT; ++s) {
     const int j = kq + 4 * s;
-    const double v = LK[nn + min(j, max(na, 1) - 1) + (int64_t)min(l15, nn - 1) * nf];
+    // (a front without separator has no K rows: the clamped row index falls back into the supernode block -- element 0 of
+    // the column -- instead of one row past the panel, which for the last clique is one element past the array)
+    const double v = LK[(na > 0 ? nn + min(j, na - 1) : 0) + (int64_t)min(l15, nn - 1) * nf];
     kk[s] = (j < na && l15 < nn) ? v : 0.0;                                    // K[j][l15]
   }
   int ri[NAT], rj[4 * NAT];
