@@ -2,6 +2,7 @@
 // level by level and launch the HIP kernels.  No CPU compute fallback exists here.
 #include <hip/hip_runtime.h>
 #include <memory>
+#include <unordered_map>
 
 #include <algorithm>
 #include <chrono>
@@ -1850,6 +1851,9 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
           std::vector<int32_t> gptr(1, 0), glist;
           std::vector<uint8_t> taken((size_t)L.nII, 0);
           bool shared = false;
+          // the members of the class by parent, in list order: a front is only ever compared with its own siblings
+          std::unordered_map<int64_t, std::vector<int64_t>> sibs;
+          for (int64_t q = 0; q < L.nII; ++q) sibs[S.snpar[lev2[b + q]]].push_back(q);
           for (int64_t q = 0; q < L.nII; ++q) {
             if (taken[(size_t)q]) continue;
             const int32_t k = lev2[b + q];
@@ -1857,15 +1861,18 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
             glist.push_back(k);
             int size = 1;
             const int64_t par = S.snpar[k];
-            if (par >= 0 && is_large[(size_t)par])
-              for (int64_t q2 = q + 1; q2 < L.nII && size < 8; ++q2) {
+            if (par >= 0 && is_large[(size_t)par]) {
+              const std::vector<int64_t>& sb = sibs[par];
+              for (auto it = std::upper_bound(sb.begin(), sb.end(), q); it != sb.end() && size < 8; ++it) {
+                const int64_t q2 = *it;
                 const int32_t k2 = lev2[b + q2];
-                if (taken[(size_t)q2] || S.snpar[k2] != par || S.na(k2) != S.na(k)) continue;
+                if (taken[(size_t)q2] || S.na(k2) != S.na(k)) continue;
                 if (!std::equal(S.relidx.begin() + S.sepptr[k], S.relidx.begin() + S.sepptr[k + 1], S.relidx.begin() + S.sepptr[k2])) continue;
                 taken[(size_t)q2] = 1;
                 glist.push_back(k2);
                 ++size;
               }
+            }
             gptr.push_back((int32_t)glist.size());
             if (size > 1) shared = true;
           }
