@@ -266,7 +266,9 @@ int fetch_info(csp_ctx* c, hipStream_t st) {
   if (c->launch_err) { c->launch_err = 0; return SMCP_EHIP; }
   if (c->lazy_status) {
     hipLaunchKernelGGL(k_latch_status, dim3(1), dim3(64), 0, st, c->D.info, (int)c->ntrial, c->D.info + 16);
-    return hipGetLastError() == hipSuccess ? 0 : SMCP_EHIP;
+    if (hipGetLastError() != hipSuccess) return SMCP_EHIP;
+    c->flags_clean = true;
+    return 0;
   }
   HIPCHK(hipMemcpyAsync(c->D.info_host, c->D.info, sizeof(int) * c->ntrial, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1282,7 +1284,13 @@ void lf_factor_inverse(csp_ctx* c, const MfmaArgs& a, int cnt, hipStream_t st) {
   }
 }
 
-inline hipError_t zero_flag(csp_ctx* c, hipStream_t st) { return hipMemsetAsync(c->D.info, 0, sizeof(int) * c->ntrial, st); }
+// (with deferred status reports every call ends with k_latch_status, which moves a set flag to the latch and leaves the
+// flags zero: the clear at the next entry point -- a 5 us launch in the chain, five or six per KKT solve -- is then skipped)
+inline hipError_t zero_flag(csp_ctx* c, hipStream_t st) {
+  const bool skip = c->lazy_status && c->flags_clean;
+  c->flags_clean = false;
+  return skip ? hipSuccess : hipMemsetAsync(c->D.info, 0, sizeof(int) * c->ntrial, st);
+}
 // yaa <- separator blocks of Y; fac <- their Cholesky factors (need_fac); faci <- inverses of those (need_inv).
 // Each stage is skipped when the cache already holds it for the matrix at this address (see invalidate_tags).
 int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool need_inv) {
