@@ -204,6 +204,8 @@ int dev_alloc(T** dst, int64_t count, int64_t& bytes) {
   size_t n = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
   if (hipMalloc((void**)dst, n) != hipSuccess) return SMCP_ENOMEM;
   bytes += (int64_t)n;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SMCP_DEBUG_ADDR"); dbg = (e && e[0] == '1') ? 1 : 0; }      // placement studies
+    if (dbg && n >= ((size_t)1 << 24)) fprintf(stderr, "smcp_amd: alloc %zu MB at %p\n", n >> 20, (void*)*dst); }
   return 0;
 }
 
@@ -218,7 +220,7 @@ TreeArgs tree_args(csp_ctx* c) {
   a.tmpptr = c->D.tmpptr;
   a.upd = c->D.upd;
   a.updp = c->D.updp;
-  a.updplen = c->S.updplen();
+  a.updplen = c->D.updp_stride ? c->D.updp_stride : c->S.updplen();
   a.tmp = c->D.tmp;
   a.info = c->D.info;
   a.nsn1 = (int)(c->S.nsn / c->ntrial);
@@ -2076,12 +2078,13 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
     D.device = device;
   } else {
     if (D.upd) { hipFree(D.upd); D.bytes -= D.max_rhs * S.updlen() * 8; D.upd = nullptr; }
-    if (D.updp) { hipFree(D.updp); D.bytes -= D.max_rhs * S.updplen() * 8; D.updp = nullptr; }
+    if (D.updp) { hipFree(D.updp); D.bytes -= D.max_rhs * D.updp_stride * 8; D.updp = nullptr; }
     if (D.tmp) { hipFree(D.tmp); D.bytes -= D.max_rhs * D.tmplen * 8; D.tmp = nullptr; }
   }
   int rc = 0;
   if ((rc = dev_alloc(&D.upd, max_rhs * S.updlen(), D.bytes))) return rc;
-  if ((rc = dev_alloc(&D.updp, max_rhs * S.updplen(), D.bytes))) return rc;
+  { const char* e = getenv("SMCP_UPDP_PAD"); D.updp_stride = S.updplen() + (e ? std::max(0, atoi(e)) : 0); }
+  if ((rc = dev_alloc(&D.updp, max_rhs * D.updp_stride, D.bytes))) return rc;
   if ((rc = dev_alloc(&D.tmp, max_rhs * D.tmplen, D.bytes))) return rc;
   D.max_rhs = max_rhs;
   clk.mark("per-rhs workspaces");
@@ -2437,6 +2440,48 @@ int64_t csp_profile_read(csp_ctx* c, double* ms, int64_t* count) {
   return KID_COUNT;
 }
 
+// placement studies (scratch/famt_realloc2.py): move one of the big work buffers to a fresh allocation -- 0 the packed
+// exchange buffer (updp), 1 the constraint stack (ustack); `shift` bytes are allocated first and freed afterwards so that
+// the new buffer lands elsewhere.  Not part of the documented boundary.
+int csp_debug_realloc(csp_ctx* c, int which, int64_t shift) {
+  if (int rc = ready(c)) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  DeviceCtx& D = c->D;
+  if (which >= 10) {      // probe: milliseconds of a linear fill of the buffer (which - 10), printed
+    double* p = which == 10 ? D.updp : D.ustack;
+    const size_t bytes = sizeof(double) * (size_t)(which == 10 ? D.max_rhs * D.updp_stride : D.ustack_cols * c->S.blklen());
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemsetAsync(p, 0, bytes, 0));
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < 3; ++r) HIPCHK(hipMemsetAsync(p, 0, bytes, 0));
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    fprintf(stderr, "smcp_amd: fill of %s: %.3f ms per pass, %.2f TB/s\n", which == 10 ? "updp" : "ustack", ms / 3, bytes / (ms / 3 * 1e-3) / 1e12);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+  }
+  void* dummy = nullptr;
+  if (shift > 0 && hipMalloc(&dummy, (size_t)shift) != hipSuccess) return SMCP_ENOMEM;
+  int64_t junk = 0;
+  if (which == 0) {
+    double* nu = nullptr;
+    if (dev_alloc(&nu, D.max_rhs * D.updp_stride, junk)) return SMCP_ENOMEM;
+    HIPCHK(hipFree(D.updp));
+    D.updp = nu;
+  } else {
+    double* nu = nullptr;
+    const int64_t len = D.ustack_cols * c->S.blklen();
+    if (dev_alloc(&nu, len, junk)) return SMCP_ENOMEM;
+    HIPCHK(hipMemset(nu, 0, sizeof(double) * len));
+    HIPCHK(hipFree(D.ustack));
+    D.ustack = nu;
+  }
+  if (dummy) HIPCHK(hipFree(dummy));
+  return 0;
+}
 int csp_debug_stamps(csp_ctx* c, unsigned long long* out, int reset) {
   if (int rc = ready(c)) return rc;
   HIPCHK(hipDeviceSynchronize());

@@ -120,6 +120,7 @@ struct DeviceCtx {
   int lg_nf = 0, lg_nn = 0, lg_na = 0;                                // sizing over that list
   int64_t lg_children = 0, lg_maxent = 0, lg_pairs = 0, lg_rows = 0;  // over all family children (kkt_set_constraints)
   const double* part_Y = nullptr;   // the Y of the last kkt_prepare_part (sharded step): valid while part_valid
+  int64_t updp_stride = 0;          // doubles between the packed exchange buffers of consecutive right-hand sides (>= updplen)
   int32_t* scm_owner = nullptr;     // per constraint: the part that computes its SCMcolumn2 columns (kkt_schur_gram_part), -1 = swept
   bool kc_sorted = false;    // every per-(clique, constraint) entry list ascends in panel position (columns are contiguous runs)
   bool lg_request = false;   // the running Schur sweep may leave the panels of the family children out

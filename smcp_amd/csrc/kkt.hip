@@ -1352,7 +1352,7 @@ static int exchange_roots(csp_ctx* c, int64_t nrhs, double* buf, int64_t width, 
   if (!c->xr_n) return 0;
   launch(c, KID_axpby, k_exchange_roots, dim3((unsigned)std::min<int64_t>(32, (c->xr_npmax + 255) / 256), (unsigned)c->xr_n, (unsigned)nrhs),
          dim3(256), (hipStream_t)stream, (const CliqueDesc*)c->D.cl, (const int32_t*)c->xr_roots, (const int32_t*)c->xr_owner,
-         (const int64_t*)c->xr_bptr, c->xr_me, (int)nrhs, c->D.updp, c->S.updplen(), buf, width, unpack);
+         (const int64_t*)c->xr_bptr, c->xr_me, (int)nrhs, c->D.updp, c->D.updp_stride ? c->D.updp_stride : c->S.updplen(), buf, width, unpack);
   HIPCHK(end_call(c));
   return 0;
 }
