@@ -275,6 +275,15 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
     # the reference's default classification (tnzcols = 0.1): on the synthetic patterns every constraint touches more
     # than n / 10 columns and is swept; the max-cut constraints are column-sparse
     kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs, tnzcols=0.0 if args.kktsolver == "qr" else None)
+    placement = None
+    if getattr(args, "tune_placement", 0) > 0 and world == 1 and workload == "synth50k":
+        # csp_tune(CSP_TUNE_PLACEMENT), part of the (untimed) set-up like the symbolic analysis: the packed exchange buffer goes
+        # to the fastest of up to N fresh allocations for the store pattern of the family sweep (the
+        # same kernel takes 0.80 or 0.98 ms depending on where its two output buffers lie).  --tune-placement 0: as allocated.
+        chordal.tune(symb, chordal.TUNE_PLACEMENT, int(args.tune_placement))
+        rep = (ctypes.c_double * 2)()
+        lib.csp_tune_report(symb.handle, rep)
+        placement = {"tries": int(args.tune_placement), "probe_ms_before": round(rep[0], 4), "probe_ms_after": round(rep[1], 4)}
     part = None
     # max-cut: every constraint is column-sparse (SCMcolumn2 route) -- with N > 1 the factors are replicated (n = 1000: the
     # factorisation is not what costs) and the constraints sharded over the ranks (kkt_schur_gram_part), one all-reduce of H
@@ -507,7 +516,7 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": label, "kktsolver": args.kktsolver, "n": symb.n, "cliques": symb.Nsn, "m": m, "blkval_doubles": int(B),
-                       "update_doubles": int(U), "rhs_per_sweep": max_rhs,
+                       "update_doubles": int(U), "rhs_per_sweep": max_rhs, "placement_tuning": placement,
                        "parallelism": ("single" if world == 1 else
                                        ("subtree-sharded Gram + boundary exchange/%d" % world if part is not None
                                         else ("column-sparse constraints by rank (SCMcolumn2)/%d" % world if workload == "maxcut"
@@ -541,6 +550,9 @@ def main():
     ap.add_argument("--max-rhs", type=int, default=None)
     ap.add_argument("--cpu-cols", type=int, default=10 ** 9, help="Schur columns timed on the CPU oracle (default: all; at least one per thread)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (a 1-GPU box has a 16-core share)")
+    ap.add_argument("--tune-placement", type=int, default=6,
+                    help="tries of csp_tune(CSP_TUNE_PLACEMENT) during set-up (0 = off; N = 1, synth50k only): the packed exchange buffer is "
+                         "moved to the fastest of that many fresh allocations for the store pattern of the family sweep")
     ap.add_argument("--shard", default="subtree", choices=["subtree", "columns"],
                     help="N > 1: subtree sharding + boundary exchange (default) or column sharding of H")
     ap.add_argument("--no-cpu", action="store_true")

@@ -248,7 +248,16 @@ int csp_touch(csp_ctx* ctx, const void* ptr);
                                      caller that forgot csp_touch gets SMCP_ESTALE instead of stale factors */
 #define CSP_TUNE_DETERMINISTIC 3  /* 1: every sum in a fixed order (no floating-point atomics): results are bit-identical
                                      from run to run; slower */
+#define CSP_TUNE_PLACEMENT 4      /* value = tries (1..16): an ACTION, not a setting -- call it after kkt_set_constraints.  The
+                                     family sweep of the Schur complement streams into two multi-GB buffers at once, and how fast
+                                     the memory system takes that depends on where the buffers physically lie (+-20 % on that
+                                     kernel from one allocation to the next).  A store-only probe of the pattern is timed, the
+                                     packed exchange buffer is moved to up to `tries` fresh allocations and the fastest placement
+                                     kept (a few ms per try, 4 GB of transient memory on the headline problem).  Worth it for runs
+                                     of many Newton steps on one problem; off unless called */
 int csp_tune(csp_ctx* ctx, int what, int64_t value);
+/* out[0], out[1]: milliseconds of the store-pattern probe of the last CSP_TUNE_PLACEMENT before / after (zeros: not run) */
+int csp_tune_report(csp_ctx* ctx, double* out);
 
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on its own stream. */

@@ -30,10 +30,11 @@ def measure():
     i = names.index("k_fam_terms"); j = names.index("k_lf_assemble_lds_dyn")
     return ms[i] / max(1, cnt[i]), ms[j] / max(1, cnt[j])
 print("start: k_fam_terms %.3f ms  assemble %.3f" % measure(), flush=True)
-L_.csp_debug_realloc(h, 10, 0); L_.csp_debug_realloc(h, 11, 0)
+L_.csp_debug_realloc(h, 20, 0)
 for which, tag in ((0, "updp"), (1, "ustack")):
-    for t in range(3):
-        rc = L_.csp_debug_realloc(h, which, (t * 2 + 1) * (64 << 20) + (t % 3) * (2 << 20))
+    for t in range(10):
+        rc = L_.csp_debug_realloc(h, which, ((t * 7 + 3) % 23) * (32 << 20) + (t % 5) * (2 << 20))
         assert rc == 0, rc
-        print("moved %-6s #%d: k_fam_terms %.3f ms  assemble %.3f" % ((tag, t) + measure()), flush=True)
-        L_.csp_debug_realloc(h, 10 + which, 0)
+        if os.environ.get("FAST"): print("moved %-6s #%d" % (tag, t), flush=True)
+        else: print("moved %-6s #%d: k_fam_terms %.3f ms  assemble %.3f" % ((tag, t) + measure()), flush=True)
+        L_.csp_debug_realloc(h, 20, 0)

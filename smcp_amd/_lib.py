@@ -47,6 +47,7 @@ SIGNATURES = {
     "csp_cache_reset": (ctypes.c_int, [c_vp]),
     "csp_touch": (ctypes.c_int, [c_vp, c_vp]),
     "csp_tune": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64]),
+    "csp_tune_report": (ctypes.c_int, [c_vp, c_vp]),
     "csp_profile_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "csp_profile_kinds": (c_i64, []),
     "csp_profile_filter": (ctypes.c_int, [c_vp, ctypes.c_int]),

@@ -40,14 +40,16 @@ def lazy_status(symb, on=True):
     symb.__dict__["_lazy_status"] = bool(on)
 
 
-TUNE_LEAFGRAM, TUNE_VERIFY_CACHE, TUNE_DETERMINISTIC = 1, 2, 3
+TUNE_LEAFGRAM, TUNE_VERIFY_CACHE, TUNE_DETERMINISTIC, TUNE_PLACEMENT = 1, 2, 3, 4
 
 
 def tune(symb, what, value):
     """include/smcp_amd.h: csp_tune -- TUNE_LEAFGRAM (0 never / 1 when cheaper / 2 whenever possible: closed-form Gram
     blocks of childless small cliques), TUNE_VERIFY_CACHE (1: every reuse of a cached derived quantity checks a
     fingerprint of the matrix it came from; a forgotten ``touch`` raises instead of serving stale factors),
-    TUNE_DETERMINISTIC (1: fixed-order summation, bit-identical results from run to run)."""
+    TUNE_DETERMINISTIC (1: fixed-order summation, bit-identical results from run to run), TUNE_PLACEMENT (an action: value =
+    tries; after the constraints are set, moves the packed exchange buffer to the fastest of up to `tries` fresh allocations
+    for the store pattern of the family sweep -- for runs of many Newton steps on one problem)."""
     _ensure(symb)
     _chk(_lib.lib().csp_tune(symb.handle, int(what), int(value)), "csp_tune")
 

@@ -202,7 +202,13 @@ int dev_upload(T** dst, const std::vector<T>& src, int64_t& bytes) {
 template <class T>
 int dev_alloc(T** dst, int64_t count, int64_t& bytes) {
   size_t n = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
-  if (hipMalloc((void**)dst, n) != hipSuccess) return SMCP_ENOMEM;
+  // SMCP_CONTIG=1 (placement studies): large buffers from physically contiguous memory (hipDeviceMallocContiguous)
+  static int contig = -1;
+  if (contig < 0) { const char* e = getenv("SMCP_CONTIG"); contig = (e && e[0] == '1') ? 1 : 0; }
+  hipError_t arc = hipErrorUnknown;
+  if (contig && n >= ((size_t)1 << 24)) arc = hipExtMallocWithFlags((void**)dst, n, hipDeviceMallocContiguous);
+  if (arc != hipSuccess) { (void)hipGetLastError(); arc = hipMalloc((void**)dst, n); }
+  if (arc != hipSuccess) return SMCP_ENOMEM;
   bytes += (int64_t)n;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SMCP_DEBUG_ADDR"); dbg = (e && e[0] == '1') ? 1 : 0; }      // placement studies
     if (dbg && n >= ((size_t)1 << 24)) fprintf(stderr, "smcp_amd: alloc %zu MB at %p\n", n >> 20, (void*)*dst); }
@@ -2384,9 +2390,87 @@ int csp_touch(csp_ctx* c, const void* p) {
   return 0;
 }
 
+// ---- placement of the packed exchange buffer (CSP_TUNE_PLACEMENT) ------------------------------------------------
+// The family sweep of the Schur complement (k_fam_terms) writes, per (family parent, constraint), the parent's panel into the
+// constraint stack and its packed update into the exchange buffer -- ~2000 concurrent store streams over two multi-GB
+// buffers.  How fast the memory system takes that pattern depends on where the two buffers physically lie: 0.80 to 0.99 ms for
+// the same kernel on the same data from one pair of allocations to the next, and a kernel that issues
+// only the stores, without the arithmetic, shows the same spread (0.37 to 0.49 ms).  That kernel is the probe here: the
+// exchange buffer is moved to fresh allocations, up to `tries` times, and the fastest placement is kept.
+__global__ void __launch_bounds__(512) k_probe_family_stores(TreeArgs t, const int32_t* parents, int nrhs, double* ustack, int64_t bl) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const CliqueDesc d = t.cl[parents[blockIdx.x]];
+  const int npan = (d.nn + d.na) * d.nn, npk = d.na * (d.na + 1) / 2;
+  for (int r = blockIdx.y + gridDim.y * wave; r < nrhs; r += gridDim.y * 8) {
+    double* P = ustack + (int64_t)r * bl + d.blk;
+    double* U = t.updp + (int64_t)r * t.updplen + d.updp;
+    for (int e = lane; e < npan; e += 64) P[e] = 0.0;           // (zeros: the stack's never-written entries must stay finite)
+    for (int e = lane; e < npk; e += 64) U[e] = 0.0;
+  }
+}
+static int tune_placement(csp_ctx* c, int tries) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  if (!D.ustack || !D.updp || tries < 1) return SMCP_EINVAL;
+  std::vector<int32_t> par;
+  for (int64_t k = 0; k < c->S.nsn; ++k)
+    if (k < (int64_t)c->fam.size() && c->fam[(size_t)k] == 2) par.push_back((int32_t)k);
+  if (par.size() < 64) return 0;               // no family sweep worth tuning for
+  int32_t* dpar = nullptr;
+  int64_t junk = 0;
+  if (int rc = dev_upload(&dpar, par, junk)) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  const int nrhs = (int)std::min<int64_t>(D.max_rhs, D.ustack_cols);
+  auto probe = [&](float& ms) -> int {
+    TreeArgs t = tree_args(c);
+    const dim3 grid((unsigned)par.size(), 2);
+    hipLaunchKernelGGL(k_probe_family_stores, grid, dim3(512), 0, 0, t, (const int32_t*)dpar, nrhs, D.ustack, c->S.blklen());
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_probe_family_stores, grid, dim3(512), 0, 0, t, (const int32_t*)dpar, nrhs, D.ustack, c->S.blklen());
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 3;
+    return 0;
+  };
+  float best = 0.f;
+  int rc = probe(best);
+  const float first = best;
+  std::vector<void*> rejected;                 // kept until the end: a freed buffer would be handed out again at once
+  for (int q = 0; q < tries && !rc; ++q) {
+    double* old = D.updp;
+    double* nu = nullptr;
+    if (hipMalloc((void**)&nu, sizeof(double) * (size_t)(D.max_rhs * D.updp_stride)) != hipSuccess) break;   // out of memory: keep what we have
+    D.updp = nu;
+    float ms = 0.f;
+    rc = probe(ms);
+    if (!rc && ms < best) { best = ms; rejected.push_back(old); }
+    else { D.updp = old; rejected.push_back(nu); }
+    if (best <= 0.82f * first) break;          // from the slow end of the spread to the fast one: good enough
+  }
+  for (void* p : rejected) (void)hipFree(p);
+  (void)hipFree(dpar);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  static int verbose = -1;
+  if (verbose < 0) { const char* e = getenv("SMCP_TIMING"); verbose = (e && e[0] == '1') ? 1 : 0; }
+  if (verbose) fprintf(stderr, "smcp_amd: placement of the exchange buffer: store-pattern probe %.3f -> %.3f ms\n", first, best);
+  c->placement_probe[0] = first; c->placement_probe[1] = best;
+  return rc;
+}
+// milliseconds of the store-pattern probe before / after the last CSP_TUNE_PLACEMENT (zeros: never run, or nothing to tune)
+int csp_tune_report(csp_ctx* c, double* out) {
+  if (!c || !out) return SMCP_EINVAL;
+  out[0] = c->placement_probe[0]; out[1] = c->placement_probe[1];
+  return 0;
+}
+
 int csp_tune(csp_ctx* c, int what, int64_t value) {
   if (!c) return SMCP_EINVAL;
   switch (what) {
+    case CSP_TUNE_PLACEMENT:
+      return tune_placement(c, (int)std::min<int64_t>(value, 16));
     case CSP_TUNE_LEAFGRAM:
       if (value < 0 || value > 2) return SMCP_EINVAL;
       c->leafgram_policy = (int)value;
@@ -2443,10 +2527,41 @@ int64_t csp_profile_read(csp_ctx* c, double* ms, int64_t* count) {
 // placement studies (scratch/famt_realloc2.py): move one of the big work buffers to a fresh allocation -- 0 the packed
 // exchange buffer (updp), 1 the constraint stack (ustack); `shift` bytes are allocated first and freed afterwards so that
 // the new buffer lands elsewhere.  Not part of the documented boundary.
+// store pattern of the family sweep without its arithmetic: one wave per (slot, right-hand side), eight right-hand sides in
+// flight per workgroup, a 9.5 KB run into the stack and a 16.6 KB run into the exchange buffer per pair
+__global__ void __launch_bounds__(512) k_probe_streams(double* ustack, int64_t bl, double* updp, int64_t ustride, int nslots, int nrhs,
+                                                        int64_t blk0, int64_t upd0) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = blockIdx.x;
+  for (int r = blockIdx.y + gridDim.y * wave; r < nrhs; r += gridDim.y * 8) {
+    double* P = ustack + (int64_t)r * bl + blk0 + (int64_t)p * 1185;
+    double* U = updp + (int64_t)r * ustride + upd0 + (int64_t)p * 2080;
+    for (int e = lane; e < 1185; e += 64) P[e] = 1.0;
+    for (int e = lane; e < 2080; e += 64) U[e] = 1.0;
+  }
+}
 int csp_debug_realloc(csp_ctx* c, int which, int64_t shift) {
   if (int rc = ready(c)) return rc;
   HIPCHK(hipDeviceSynchronize());
   DeviceCtx& D = c->D;
+  if (which == 20) {      // probe: the store pattern of the family sweep on the buffers as they lie (synth50k geometry)
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const int nrhs = (int)std::min<int64_t>(D.max_rhs, D.ustack_cols);
+    const int64_t blk0 = 7168 * 180, upd0 = (int64_t)7168 * 496;
+    if ((int64_t)896 * 1185 + blk0 > c->S.blklen() || (int64_t)896 * 2080 + upd0 > c->S.updplen()) return SMCP_EINVAL;
+    hipLaunchKernelGGL(k_probe_streams, dim3(896, 2), dim3(512), 0, 0, D.ustack, c->S.blklen(), D.updp, D.updp_stride, 896, nrhs, blk0, upd0);
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < 3; ++r)
+      hipLaunchKernelGGL(k_probe_streams, dim3(896, 2), dim3(512), 0, 0, D.ustack, c->S.blklen(), D.updp, D.updp_stride, 896, nrhs, blk0, upd0);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    fprintf(stderr, "smcp_amd: store-pattern probe: %.3f ms per pass  ustack %p updp %p\n", ms / 3, (void*)D.ustack, (void*)D.updp);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+  }
   if (which >= 10) {      // probe: milliseconds of a linear fill of the buffer (which - 10), printed
     double* p = which == 10 ? D.updp : D.ustack;
     const size_t bytes = sizeof(double) * (size_t)(which == 10 ? D.max_rhs * D.updp_stride : D.ustack_cols * c->S.blklen());

@@ -226,6 +226,7 @@ struct csp_ctx {
   hipStream_t aux_stream[2] = {nullptr, nullptr};
   hipEvent_t aux_fork = nullptr, aux_join[2] = {nullptr, nullptr};
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status
+  double placement_probe[2] = {0.0, 0.0};   // CSP_TUNE_PLACEMENT: probe time before / after, ms
   bool flags_clean = false;             // lazy mode: the last thing done to the flags was k_latch_status (which leaves them zero)
   int launch_err = 0;                   // first failed kernel launch of the running call (launch helpers); read by end_call
   double tnzcols = 0.1;                 // options['tnzcols'] (solvers.py:31,210-216)

@@ -634,6 +634,43 @@ def test_kkt_few_fronts_many_children_deal_children_over_workgroups():
     assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
 
 
+def test_placement_tuning_moves_the_exchange_buffer_and_changes_nothing_else():
+    """csp_tune(CSP_TUNE_PLACEMENT): the packed exchange buffer is re-allocated a few times for the store-pattern probe; the
+    Schur complement and the solve after it are what they were before (every kernel takes the buffer from the context)."""
+    import ctypes
+    from smcp_amd import _lib
+    symb = Symbolic(problems.nested_block_arrow_pattern(nsub=2, nmid=40, nleaf_per_mid=3, seed=12))      # 80 family parents
+    m = 12
+    symb.device_init(0, m)
+    S = orc.Sym(symb)
+    A = problems.random_factor_blkval(symb, 71)
+    orc.llt(S, A)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.01, seed=72)
+    sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+    Ld, Yd = dev(symb, L), dev(symb, Yh)
+    sys_.factor(Ld, Yd)
+    H0 = sys_.H.clone()
+    chordal.tune(symb, chordal.TUNE_PLACEMENT, 3)
+    rep = (ctypes.c_double * 2)()
+    assert _lib.lib().csp_tune_report(symb.handle, rep) == 0
+    assert rep[0] > 0.0 and 0.0 < rep[1] <= rep[0]
+    solve = sys_.factor(Ld, Yd)
+    assert rel(np.tril(sys_.H.cpu().numpy().T), np.tril(H0.cpu().numpy().T)) < 1e-13
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    rng = np.random.default_rng(73)
+    msk = lowmask(symb)
+    bx, by = rng.standard_normal(symb.blklen) * msk, rng.standard_normal(m)
+    xr, yr = K.solve(L, Yh, Href, bx, by, 1.0)
+    bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+    solve(bxd, byd, 1.0)
+    assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+
+
 def test_kkt_family_kernel_dense_constraints():
     """Family kernel with long entry lists: constraints dense on V give a (5,31) child 180 entries (more than the 64
     prefetched per wave) and a (15,64) parent 1185 (more than the 256 prefetched per group): the direct-load tails
