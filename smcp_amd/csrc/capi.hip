@@ -54,7 +54,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn, KID_lf_zsp,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn, KID_lf_zsp, KID_fam_terms_grp,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -72,7 +72,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn", "k_lf_zsp"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn", "k_lf_zsp", "k_fam_terms_grp"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -371,7 +371,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.sp_rt = c->D.sp_rt; a.sp_mk = c->D.sp_mk;
   a.kc_stride = 0; a.kc_j0 = 0;
   a.nnmin = 0;
-  a.grp_ptr = nullptr; a.grp_list = nullptr; a.chskip = nullptr;
+  a.grp_ptr = nullptr; a.grp_list = nullptr; a.chskip = nullptr; a.famt_ngrp = 0;
   a.level = 0; a.nS = 0; a.famna = a.fampan = a.fampk = a.famcna = a.famnn = a.famcnn = 0;
   return a;
 }
@@ -939,12 +939,67 @@ bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
 }
 // Entry-driven family sweep (front_famt.hip) for sweeps that leave the children's panels to k_leaf_gram: false = not
 // applicable (the caller falls back to k_fam_sparse).  SMCP_FAMT=0 disables.
+inline bool famt_disabled() {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("SMCP_FAMT"); off = (e && e[0] == '0') ? 1 : 0; }
+  return off != 0;
+}
+// LDS of the grouped kernel: entries it can stage (< 0: the fixed part does not fit); one pass of a group needs at most
+// FAMT_GMAX x FAMT_TCAP / 2 of them
+template <int NAT>
+int famt_grp_ecap(int cnn) {
+  const int64_t lim = (160 * 1024 - 1024) / 8;
+  const int64_t fixed = famt_layout<NAT>(8 * cnn).total + 8 * famt_desc_doubles() + famt_grp_misc_doubles();
+  const int64_t left = lim - fixed - 4;
+  if (left <= 0 || famt_prep_doubles<NAT>(cnn) > lim) return -1;
+  return (int)std::max<int64_t>(0, (left * 2) / 3 - 2);
+}
+inline bool famt_grp_fits(int nat, int cnn) {
+  int ecap = -1;
+  switch (nat) {
+    case 1: ecap = famt_grp_ecap<1>(cnn); break;
+    case 2: ecap = famt_grp_ecap<2>(cnn); break;
+    case 3: ecap = famt_grp_ecap<3>(cnn); break;
+    case 4: ecap = famt_grp_ecap<4>(cnn); break;
+  }
+  return ecap >= FAMT_GMAX * (FAMT_TCAP / 2);
+}
 template <int NAT>
 bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   DeviceCtx& D = c->D;
-  static int off = -1;
-  if (off < 0) { const char* e = getenv("SMCP_FAMT"); off = (e && e[0] == '0') ? 1 : 0; }
-  if (off || !D.lg_request) return false;
+  if (a.famt_ngrp > 0) {
+    // sibling groups: the levels above have been told that the non-leaders' slots stay unwritten -- no other kernel may
+    // take this launch, so everything that could refuse it fails the call instead (end_call returns SMCP_EHIP)
+    const int cnn = std::max(1, a.famcnn);
+    const FamtL L = famt_layout<NAT>(8 * cnn);
+    const int ecap = famt_grp_ecap<NAT>(cnn);
+    static bool attrg = false;
+    bool ok = !famt_disabled() && D.lg_request && D.fam_maxterms <= FAMT_TCAP / 2 && ecap >= FAMT_GMAX * (FAMT_TCAP / 2);
+    if (ok && !attrg) {
+      ok = hipFuncSetAttribute((const void*)k_fam_terms_grp<NAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess &&
+           hipFuncSetAttribute((const void*)k_famt_prep<NAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
+      attrg = ok;
+    }
+    const int64_t need = (int64_t)cnt * (FAMT_HDR + L.total);
+    if (ok && D.famc_len < need) {
+      if (D.famc) { if (hipFree(D.famc) != hipSuccess) ok = false; D.bytes -= D.famc_len * 8; }
+      D.famc = nullptr; D.famc_len = 0;
+      if (ok && dev_alloc(&D.famc, need, D.bytes)) ok = false;
+      if (ok) D.famc_len = need;
+    }
+    if (!ok) {
+      fprintf(stderr, "smcp_amd: grouped family sweep not launchable\n");
+      if (!c->launch_err) c->launch_err = -1;
+      return true;
+    }
+    const int gy = std::min(65535, (nrhs + 7) / 8);
+    launch_lds(c, KID_famt_prep, k_famt_prep<NAT>, dim3(cnt), dim3(512), (size_t)famt_prep_doubles<NAT>(cnn) * sizeof(double), st, a, D.famc, cnn);
+    launch_lds(c, KID_fam_terms_grp, k_fam_terms_grp<NAT>, dim3(a.famt_ngrp, gy), dim3(512), (size_t)(160 * 1024 - 1024), st, a, U, ldu,
+               (const double*)D.famc, cnn, (const int32_t*)D.kc_ij, ecap);
+    D.lg_nochild = true;
+    return true;
+  }
+  if (famt_disabled() || !D.lg_request) return false;
   const int cnn = std::max(1, a.famcnn);
   const FamtL L = famt_layout<NAT>(8 * cnn);
   const int64_t lim = (160 * 1024 - 1024) / 8;                          // doubles of LDS a workgroup may use
@@ -1089,7 +1144,12 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
   // sibling groups of the sparse-input sweep of childless large fronts: when they are in use the non-leaders' slots of the
   // exchange buffer stay unwritten, and every extend-add above must know (MfmaArgs::chskip)
   const bool groups_on = sparse && set == 0 && c->lfsp_any_groups && c->D.lfsp_skip && lfsp_dynamic_ok(c, a0);
-  if (groups_on) a0.chskip = c->D.lfsp_skip;
+  // the same for the sibling groups of family parents (k_fam_terms_grp): on exactly when try_fam2 / launch_famt will take the
+  // family launches of this sweep (their conditions, repeated here: the decision must hold for every level of the sweep)
+  const bool fgroups_on = sparse && set == 0 && c->famt_any_groups && c->D.famt_skip && !famt_disabled() && c->D.lg_request &&
+                          c->D.kc_ij && a0.ymode == 2 && a0.ysc && c->D.fam_maxterms <= FAMT_TCAP / 2 &&
+                          c->D.cnnz <= (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m);
+  if (groups_on || fgroups_on) a0.chskip = groups_on && fgroups_on ? c->D.both_skip : (groups_on ? c->D.lfsp_skip : c->D.famt_skip);
   // kernels that read their input from U get dense panels built first (zeros + the constraint's entries)
   auto dense_input_on = [&](MfmaArgs& a, int cnt, double* Ub, int nr, hipStream_t s) {
     if (!sparse) return;
@@ -1120,6 +1180,9 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         if (a.level > 0) {
           MfmaArgs af = a;
           af.t.lev = a.t.lev + (cnt - nS);
+          if (fgroups_on && (size_t)l < c->famt_grp.size() && c->famt_grp[(size_t)l].ngroups > 0) {
+            af.grp_ptr = c->famt_grp[(size_t)l].ptr; af.grp_list = c->famt_grp[(size_t)l].list; af.famt_ngrp = c->famt_grp[(size_t)l].ngroups;
+          }
           if (!try_fam(c, af, nS, nrhs, U, ldu, st)) {
             // the level-0 members were skipped for this kernel: without it their panels and the parents' updates
             // would be missing, so the call must fail (end_call returns SMCP_EHIP)
@@ -1694,12 +1757,13 @@ void csp_symbolic_destroy(csp_ctx* c) {
   DeviceCtx& D = c->D;
   if (D.device >= 0) {
     hipSetDevice(D.device);
-    void* ptrs[] = {D.lfsp_skip, D.trsm_x, D.fp, D.fp_bad, D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
+    void* ptrs[] = {D.lfsp_skip, D.famt_skip, D.both_skip, D.trsm_x, D.fp, D.fp_bad, D.gsl_start, D.gsl_len, D.lg_list, D.lg_slot, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.sp_rt, D.sp_mk, D.lfsp_list, D.faci, D.lfd, D.lev3idx, D.updp, D.gp_tptr, D.gp_tgt, D.gp_cptr, D.gp_src, D.sw, D.gpart, D.lev2idx, D.lk, D.cl, D.rowidx, D.relidx, D.chidx, D.levidx, D.upd, D.yaa, D.fac, D.tmp, D.tmpptr,
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc, D.scm_owner};
     if (c->side_fork) { Fork* f = (Fork*)c->side_fork; c->side_fork = nullptr; f->join(); delete f; }
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& G : c->lfsp_grp) { if (G.ptr) hipFree(G.ptr); if (G.list) hipFree(G.list); }
+    for (auto& G : c->famt_grp) { if (G.ptr) hipFree(G.ptr); if (G.list) hipFree(G.list); }
     for (int q = 0; q < 2; ++q) {
       if (c->aux_stream[q]) { (void)hipStreamSynchronize(c->aux_stream[q]); (void)hipStreamDestroy(c->aux_stream[q]); }
       if (c->aux_join[q]) (void)hipEventDestroy(c->aux_join[q]);
@@ -1906,6 +1970,65 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
           c->lfsp_any_groups = true;
         }
         if (c->lfsp_any_groups && (rc = dev_upload(&D.lfsp_skip, skip, D.bytes))) return rc;
+        // sibling groups of FAMILY PARENTS for the entry-driven family sweep (front_famt.hip, k_fam_terms_grp): family parents of a
+        // level under one LARGE front with identical relative indices, at most FAMT_GMAX per group, in list order; the lists
+        // hold positions in the level's family list (= record indices of k_famt_prep).  Every family parent of the level is in
+        // exactly one group (singletons included).  SMCP_FAMT_GROUP=0: none.
+        const char* fe = getenv("SMCP_FAMT_GROUP");
+        const bool fon = !(fe && fe[0] == '0');
+        std::vector<uint8_t> fskip((size_t)S.nsn, 0);
+        c->famt_grp.assign((size_t)S.nlev, csp_ctx::LfspGroups());
+        c->famt_any_groups = false;
+        for (int64_t l = 1; l < S.nlev && fon; ++l) {
+          const LevelClass& L = c->lvl[l];
+          if (!L.nS) continue;
+          const int nat = std::max(1, (L.famna + 15) / 16);
+          if (nat > 4 || !famt_grp_fits(nat, std::max(1, L.famcnn))) continue;
+          const int64_t b = S.levptr[l] + (L.nI - L.nS);
+          std::vector<int32_t> gptr(1, 0), glist;
+          std::vector<uint8_t> taken((size_t)L.nS, 0);
+          bool shared = false;
+          std::unordered_map<int64_t, std::vector<int64_t>> sibs;
+          for (int64_t q = 0; q < L.nS; ++q) sibs[S.snpar[lev2[b + q]]].push_back(q);
+          for (int64_t q = 0; q < L.nS; ++q) {
+            if (taken[(size_t)q]) continue;
+            const int32_t k = lev2[b + q];
+            taken[(size_t)q] = 1;
+            glist.push_back((int32_t)q);
+            int size = 1;
+            const int64_t par = S.snpar[k];
+            if (par >= 0 && is_large[(size_t)par]) {
+              const std::vector<int64_t>& sb = sibs[par];
+              for (auto it = std::upper_bound(sb.begin(), sb.end(), q); it != sb.end() && size < FAMT_GMAX; ++it) {
+                const int64_t q2 = *it;
+                const int32_t k2 = lev2[b + q2];
+                if (taken[(size_t)q2] || S.na(k2) != S.na(k)) continue;
+                if (!std::equal(S.relidx.begin() + S.sepptr[k], S.relidx.begin() + S.sepptr[k + 1], S.relidx.begin() + S.sepptr[k2])) continue;
+                taken[(size_t)q2] = 1;
+                glist.push_back((int32_t)q2);
+                fskip[(size_t)k2] = 1;
+                ++size;
+              }
+            }
+            gptr.push_back((int32_t)glist.size());
+            if (size > 1) shared = true;
+          }
+          if (!shared) {
+            for (int64_t q = 0; q < L.nS; ++q) fskip[(size_t)lev2[b + q]] = 0;
+            continue;
+          }
+          csp_ctx::LfspGroups& G = c->famt_grp[(size_t)l];
+          if ((rc = dev_upload(&G.ptr, gptr, D.bytes))) return rc;
+          if ((rc = dev_upload(&G.list, glist, D.bytes))) return rc;
+          G.ngroups = (int)gptr.size() - 1;
+          c->famt_any_groups = true;
+        }
+        if (c->famt_any_groups) {
+          if ((rc = dev_upload(&D.famt_skip, fskip, D.bytes))) return rc;
+          std::vector<uint8_t> both(fskip);
+          if (c->lfsp_any_groups) for (size_t i = 0; i < both.size(); ++i) both[i] |= skip[i];
+          if ((rc = dev_upload(&D.both_skip, both, D.bytes))) return rc;
+        }
       }
       lev3.insert(lev3.end(), large.begin(), large.end());
       if ((rc = dev_upload(&D.lev3idx, lev3, D.bytes))) return rc;

@@ -137,6 +137,8 @@ struct DeviceCtx {
   // separators are the same rows of it send ONE summed update per group.  Per clique: 1 = a group member whose slot in the
   // exchange buffer stays unwritten (the parent's extend-add skips it)
   uint8_t* lfsp_skip = nullptr;
+  uint8_t* famt_skip = nullptr;   // family parents whose update is summed into their group leader's (k_fam_terms_grp)
+  uint8_t* both_skip = nullptr;   // lfsp_skip | famt_skip
   int64_t kc_maxlist_large = 0;
   int64_t fac_gen = 0, lk_gen = 0, sp_fac_gen = -1, sp_lk_gen = -1;
   bool part_valid = false;     // lk / yaa / fac hold the sharded factor prepared by kkt_prepare_part (sets 2 then 1)
@@ -214,6 +216,8 @@ struct csp_ctx {
   struct LfspGroups { int32_t* ptr = nullptr; int32_t* list = nullptr; int ngroups = 0; };
   std::vector<LfspGroups> lfsp_grp;   // per level: the groups of its large-front class (device arrays; ngroups 0 = none)
   bool lfsp_any_groups = false;
+  std::vector<LfspGroups> famt_grp;   // per level: sibling groups of its family parents (lists hold positions in the family list)
+  bool famt_any_groups = false;
   std::vector<int64_t> fam;     // per clique: family role (CSP_Q_FAMILY)
   std::vector<uint8_t> is_diag_cache;
   // boundary exchange of the subtree partition: the subtree roots of all ranks (device: clique, owning rank, offset in

@@ -435,4 +435,268 @@ __global__ void __launch_bounds__(512) k_fam_terms(MfmaArgs a, double* u, int64_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same sweep by SIBLING GROUPS: family parents under one large front whose separators are the same rows of that front
+// (identical relative indices, hence equal na) hand it update matrices that the extend-add only ever uses as their SUM.
+// One workgroup takes a group of up to FAMT_GMAX such families and eight right-hand sides (one per wave): the members'
+// tables pass through LDS one after the other, every wave adds the update tiles of (member, its right-hand side) to the
+// SAME accumulators, the members' panels (Q, G_NN) are stored as before and the summed update is stored ONCE, into the slot
+// of the group's first member -- the other members' slots of the exchange buffer are not written, and every extend-add
+// above is told so (MfmaArgs::chskip).  synth50k: 112 parents under each of the 8 top fronts, 14 groups of 8 per front: the
+// exchange shrinks from 1.49 GB written here and read again by k_lf_assemble_lds to 0.19 GB each way per Schur sweep.
+// The entry lists of all members for the round's right-hand sides are staged in one set-up (three dependent global round
+// trips per round instead of per member); what a member switch costs is the copy of its tables (L.total doubles).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int FAMT_GMAX = 8;
+constexpr int FAMT_GTAB = 2 * 8 * FAMT_GMAX * 9;      // ints of the (pass, member, list) table
+__host__ __device__ inline int famt_grp_misc_doubles() { return (12 + FAMT_GTAB) / 2; }
+
+template <int NAT>
+__global__ void __launch_bounds__(512) k_fam_terms_grp(MfmaArgs a, double* u, int64_t ldu, const double* famt, int cnn,
+                                                       const int32_t* kc_ij, int ecap) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NA = 16 * NAT, NW = 8, NMEM = 9, NTU = NAT * (NAT + 1) / 2;
+  const int ncol = 8 * cnn;
+  const FamtL L = famt_layout<NAT>(ncol);
+  const int64_t recl = FAMT_HDR + L.total;
+  const int g0 = a.grp_ptr[blockIdx.x];
+  const int M = min(a.grp_ptr[blockIdx.x + 1] - g0, FAMT_GMAX);
+  const int32_t* const glist = a.grp_list + g0;              // record indices of the members
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gy = (int)gridDim.y;
+  const int npass = ((int)a.nrhs - (int)blockIdx.y + gy - 1) / gy;
+  double* const dS = smem + L.total + wave * famt_desc_doubles();
+  int* const dI = reinterpret_cast<int*>(dS + FAMT_TCAP);
+  int* const misc = reinterpret_cast<int*>(smem + L.total + NW * famt_desc_doubles());
+  int* const epfit = misc;
+  int* const cdim = misc + 2;
+  int* const tab = misc + 12;                                // [pass][member][list] -> (count, where)
+  double* const lval = reinterpret_cast<double*>(tab + FAMT_GTAB);
+  int* const lpk = reinterpret_cast<int*>(lval + ecap);
+  const int32_t* const hlead = reinterpret_cast<const int32_t*>(famt + (int64_t)glist[0] * recl);
+  const int na = hlead[2];                                   // the same for every member
+  const int64_t lupdp = (int64_t)(uint32_t)hlead[8] | ((int64_t)hlead[9] << 32);
+  const int stride = M * NMEM;
+
+  for (int q0 = 0; q0 < npass;) {
+    // ------------------------------------------------------------------------------------------------- set-up of a round
+    const int epmax = min(NW, npass - q0), npairs = epmax * stride;
+    __syncthreads();
+    if (tid == 0) *epfit = epmax;
+    int myp0[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int idx = tid + 512 * h;
+      if (idx < npairs) {
+        const int qq = idx / stride, rem = idx - qq * stride, mf = rem / NMEM, mem = rem - mf * NMEM;
+        const int r = (int)blockIdx.y + (q0 + qq) * gy;
+        const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
+        const int32_t* const hm = reinterpret_cast<const int32_t*>(famt + (int64_t)glist[mf] * recl);
+        const int ck = mem ? hm[16 + 6 * (mem - 1)] : hm[0];
+        int cnt = 0;
+        if (ck >= 0) {
+          const int32_t* kp = a.kc_ptr + (int64_t)ck * a.kc_stride;
+          myp0[h] = kp[j];
+          cnt = kp[j + 1] - myp0[h];
+        }
+        tab[2 * idx] = cnt;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int per = (npairs + 63) / 64, b = lane * per;
+      int sum = 0;
+      for (int x = 0; x < per; ++x) sum += (b + x < npairs) ? tab[2 * (b + x)] : 0;
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+      int run = incl - sum;
+      for (int x = 0; x < per; ++x)
+        if (b + x < npairs) {
+          const int c = tab[2 * (b + x)];
+          tab[2 * (b + x) + 1] = run;
+          run += c;
+          if (run > ecap) atomicMin(epfit, (b + x) / stride);
+        }
+    }
+    __syncthreads();
+    const int ep = max(1, *epfit);                           // (one pass always fits: host-checked)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int idx = tid + 512 * h;
+      if (idx < ep * stride) {
+        const int c = tab[2 * idx], p0 = myp0[h], off = tab[2 * idx + 1];
+        const int qq = idx / stride, rem = idx - qq * stride, mf = rem / NMEM, mem = rem - mf * NMEM;
+        if (c > 0) {
+          const int32_t* const hm = reinterpret_cast<const int32_t*>(famt + (int64_t)glist[mf] * recl);
+          const int mnn = mem ? hm[16 + 6 * (mem - 1) + 1] : 0;
+          const int mck = mem ? hm[16 + 6 * (mem - 1)] : hm[0];
+          const int32_t* const mrel = a.t.relidx + a.t.cl[mck].rel;
+          for (int t = 0; t < c && off + t < ecap; ++t) {
+            const int ij = kc_ij[p0 + t];
+            const int i = ij & 0xffff, jc = ij >> 16;
+            int pk = i | (jc << 8);
+            if (mem && i >= mnn) pk |= mrel[i - mnn] << 16;
+            lpk[off + t] = pk;
+            lval[off + t] = a.kc_val[p0 + t];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // ------------------------------------------------------------------------------------------------- the members in turn
+    const int qq = wave;
+    const bool active = qq < ep;
+    const int r = (int)blockIdx.y + (q0 + min(qq, ep - 1)) * gy;
+    d4 accU[NTU];
+#pragma unroll
+    for (int x = 0; x < NTU; ++x) accU[x] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int mf = 0; mf < M; ++mf) {
+      const double* const fcm = famt + (int64_t)glist[mf] * recl;
+      const int32_t* const hm = reinterpret_cast<const int32_t*>(fcm);
+      const int nn = hm[1], nch = hm[3], nf = nn + na;
+      const int64_t pblk = (int64_t)(uint32_t)hm[4] | ((int64_t)hm[5] << 32);
+      __syncthreads();                                       // the staged entries are in place / the previous tables are consumed
+      {
+        const double2* const src = reinterpret_cast<const double2*>(fcm + FAMT_HDR);
+        double2* const dst = reinterpret_cast<double2*>(smem);
+        for (int e = tid; e < L.total / 2; e += 512) dst[e] = src[e];
+      }
+      if (tid < 8) cdim[tid] = tid < nch ? (hm[16 + 6 * tid + 1] | (hm[16 + 6 * tid + 3] << 8)) : 1;
+      __syncthreads();
+      if (!active) continue;
+      const int* const trow = tab + 2 * ((qq * M + mf) * NMEM);
+      int cntm = lane < NMEM ? trow[2 * lane] : 0;
+      int incl = cntm;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+      const int T = min(__builtin_amdgcn_readlane(incl, 15), FAMT_TCAP / 2);
+      {
+        int mem = 0, base = 0;
+#pragma unroll
+        for (int mm = 0; mm < 8; ++mm) {
+          const int up = __builtin_amdgcn_readlane(incl, mm);
+          if (lane >= up) { mem = mm + 1; base = up; }
+        }
+        if (lane < T) {
+          const int where = trow[2 * mem + 1];
+          const int pk = lpk[where + (lane - base)];
+          const double v = lval[where + (lane - base)];
+          const int i = pk & 0xff, jc = (pk >> 8) & 0xff, rl = (pk >> 16) & 0xff;
+          int vx, vy;
+          double s;
+          if (mem == 0) { vx = i; vy = jc; s = i == jc ? 0.5 * v : v; }
+          else {
+            const int cd = cdim[mem - 1], nnc = cd & 0xff, cb = cd >> 8;
+            if (i >= nnc) { vx = FAMT_CHILD + cb + jc; vy = rl; s = -v; }
+            else { vx = FAMT_CHILD + cb + i; vy = FAMT_CHILD + cb + jc; s = i == jc ? 0.5 * v : v; }
+          }
+          auto img = [&](int vid, int& on, int& oa, int& om, int& ui) {
+            if (vid >= FAMT_CHILD) { const int g = vid - FAMT_CHILD; on = L.oCN + 16 * g; oa = L.oCA + NA * g; om = L.oCM + NA * g; ui = 255; }
+            else if (vid < nn) { on = L.oLi + 16 * vid; oa = L.onK + NA * vid; om = L.onMK + NA * vid; ui = 255; }
+            else { on = L.oZero; oa = L.oZero; om = L.oRt + NA * (vid - nn); ui = vid - nn; }
+          };
+          int nx, ax, mx, ux, ny, ay, my, uy;
+          img(vx, nx, ax, mx, ux);
+          img(vy, ny, ay, my, uy);
+          dS[2 * lane] = s; dS[2 * lane + 1] = s;
+          int4 w0 = {nx | (ax << 16), mx | (ux << 16), ny | (ay << 16), uy};
+          int4 w1 = {ny | (ay << 16), my | (uy << 16), nx | (ax << 16), ux};
+          reinterpret_cast<int4*>(dI)[2 * lane] = w0;
+          reinterpret_cast<int4*>(dI)[2 * lane + 1] = w1;
+        }
+        if (lane < 4 && 2 * T + lane < ((2 * T + 3) & ~3)) {
+          dS[2 * T + lane] = 0.0;
+          int4 z = {L.oZero | (L.oZero << 16), L.oZero | (255 << 16), L.oZero | (L.oZero << 16), 255};
+          reinterpret_cast<int4*>(dI)[2 * T + lane] = z;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int ks = (2 * T + 3) >> 2;
+      const __amdgpu_buffer_rsrc_t rP = famt_rsrc(u + (int64_t)r * ldu + pblk, nf * nn);
+      auto pass = [&](auto LOc, auto HIc, auto Gc) {
+        constexpr int LO = decltype(LOc)::value, HI = decltype(HIc)::value;
+        constexpr bool WITHG = decltype(Gc)::value;
+        d4 accQ[HI - LO], accG = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < HI - LO; ++x) accQ[x] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < ks; ++s) {
+          const int tp = kq + 4 * s;
+          const double sc = dS[tp];
+          const int4 w = reinterpret_cast<const int4*>(dI)[tp];
+          const int nx = w.x & 0xffff, ax = w.x >> 16, mx = w.y & 0xffff, ux = w.y >> 16;
+          const int ny = w.z & 0xffff, ay = w.z >> 16, uy = w.w;
+          double bA[HI - LO], bM[HI - LO], aA[HI];
+#pragma unroll
+          for (int t = 0; t < HI; ++t) {
+            const int row = 16 * t + l15;
+            aA[t] = sc * (smem[ay + row] + (row == uy ? 1.0 : 0.0));
+            if (t >= LO) {
+              bA[t - LO] = smem[ax + row] + (row == ux ? 1.0 : 0.0);
+              bM[t - LO] = smem[mx + row];
+            }
+          }
+          const double aN = sc * smem[ny + l15];
+#pragma unroll
+          for (int rt = LO; rt < HI; ++rt) {
+#pragma unroll
+            for (int ct = 0; ct <= rt; ++ct) {
+              const int x = rt * (rt + 1) / 2 + ct;
+              accU[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[ct], bA[rt - LO], accU[x], 0, 0, 0);
+            }
+            accQ[rt - LO] = __builtin_amdgcn_mfma_f64_16x16x4f64(aN, bM[rt - LO], accQ[rt - LO], 0, 0, 0);
+          }
+          if constexpr (WITHG) {
+            const double bN = smem[nx + l15];
+            accG = __builtin_amdgcn_mfma_f64_16x16x4f64(aN, bN, accG, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int rt = LO; rt < HI; ++rt) {
+          const int m = 16 * rt + l15;
+          const bool mok = m < na;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int n = kq + 4 * x;
+            famt_store(rP, mok && n < nn, (nn + m) + n * nf, accQ[rt - LO][x]);
+          }
+        }
+        if constexpr (WITHG) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int jn = kq + 4 * x;
+            famt_store(rP, l15 < nn && jn <= l15, l15 + jn * nf, accG[x]);
+          }
+        }
+      };
+      if constexpr (NAT == 4) {
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, std::false_type{});
+        pass(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::true_type{});
+      } else {
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NAT>{}, std::true_type{});
+      }
+    }
+    // the summed update of the group -> the first member's slot (packed, column-major lower)
+    if (active) {
+      const __amdgpu_buffer_rsrc_t rU = famt_rsrc(a.t.updp + (int64_t)r * a.t.updplen + lupdp, (na * (na + 1)) >> 1);
+#pragma unroll
+      for (int rt = 0; rt < NAT; ++rt) {
+        const int m = 16 * rt + l15;
+        const bool mok = m < na;
+#pragma unroll
+        for (int ct = 0; ct <= rt; ++ct)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int n = 16 * ct + kq + 4 * x;
+            const int cb = (n * (2 * na - 1 - n)) >> 1;
+            famt_store(rU, ct < rt ? mok : (mok && m >= n), cb + m, accU[rt * (rt + 1) / 2 + ct][x]);
+          }
+      }
+    }
+    q0 += ep;
+  }
+}
+
 }  // namespace smcp

@@ -324,6 +324,100 @@ __device__ inline void lf_add_child(double* T, int nf, const double* Uc, const i
       for (int h = 0; h < NR; ++h) cur[x][h] = nxt[x][h];
   }
 }
+// The children of one wave as ONE stream of column batches (second version of the loop above; -DSMCP_ALDS_V1 keeps the
+// first).  A batch is sixteen wave loads -- sixteen columns of a child with at most 64 rows, eight columns x two row halves
+// of a taller one -- plus the two loads of the child's relative indices.  Every load is unconditional (column and row
+// clamped into the child's packed matrix; masked at the add), so the compiler counts them (s_waitcnt vmcnt(N)) instead of
+// draining the queue before the first add as it does for loads under branches: with two batch buffers used in turn the
+// NEXT batch -- of this child or of the wave's next child -- is in flight while the current one goes into the front.
+// (Rows and columns beyond 128 are left to lf_add_child_tail.)
+struct AldsBatch { double v[16]; int rA, rB; };
+struct AldsItem { int q, nac, j0; };
+__device__ inline int alds_cols(int nac) { return nac <= 64 ? 16 : 8; }
+__device__ inline void lf_add_children_stream(double* T, int nf, const double* ubase, const int32_t* relidx, const int64_t* sCu,
+                                              const int64_t* sCr, const int* sCn, int nmine, int q0, int qstep, int part, int parts,
+                                              int lane) {
+  auto cb = [nf](int j) { return j * nf - ((j * (j - 1)) >> 1) - j; };
+  auto seek = [&](int q) {                              // first child at or after q with a batch for this wave
+    AldsItem it{nmine, 0, 0};
+    for (; q < nmine; q += qstep) {
+      const int nac = sCn[q];
+      if (nac > alds_cols(nac) * part) { it.q = q; it.nac = nac; it.j0 = alds_cols(nac) * part; break; }
+    }
+    it.q = __builtin_amdgcn_readfirstlane(it.q); it.nac = __builtin_amdgcn_readfirstlane(it.nac);
+    it.j0 = __builtin_amdgcn_readfirstlane(it.j0);
+    return it;
+  };
+  auto next = [&](const AldsItem& it) {
+    AldsItem n = it;
+    n.j0 += alds_cols(it.nac) * parts;
+    if (n.j0 >= min(it.nac, 128)) n = seek(it.q + qstep);
+    return n;
+  };
+  auto issue = [&](AldsBatch& b, const AldsItem& it) {
+    const double* Uc = ubase + sCu[it.q];
+    const int32_t* rel = relidx + sCr[it.q];
+    const int nac = it.nac, last = nac - 1;
+    const bool two = nac > 64;
+    b.rA = rel[min(lane, last)];
+    b.rB = rel[min(lane + 64, last)];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int j = min(it.j0 + (two ? x >> 1 : x), last);
+      const int i = min(max(lane + ((two && (x & 1)) ? 64 : 0), j), last);
+      b.v[x] = Uc[pk_col(j, nac) - j + i];
+    }
+  };
+#ifdef SMCP_ALDS_NOADD
+  double sink = 0.0;
+#endif
+  auto process = [&](const AldsBatch& b, const AldsItem& it) {
+    const int nac = it.nac, nh = min(nac, 128);
+    const bool two = nac > 64;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int j = it.j0 + (two ? x >> 1 : x);
+      const bool hi = two && (x & 1);
+      const int i = lane + (hi ? 64 : 0);
+      const int jc = min(j, nh - 1);
+      const int cj = jc < 64 ? __builtin_amdgcn_readlane(b.rA, jc & 63) : __builtin_amdgcn_readlane(b.rB, jc & 63);
+#ifdef SMCP_ALDS_NOADD        // experiment: the stream without the LDS atomics
+      if (j < nh && i >= j && i < nac) sink += b.v[x] * (double)(cb(cj) + (hi ? b.rB : b.rA));
+#else
+      if (j < nh && i >= j && i < nac) unsafeAtomicAdd(&T[cb(cj) + (hi ? b.rB : b.rA)], b.v[x]);
+#endif
+    }
+  };
+  AldsItem it = seek(q0);
+  if (it.q >= nmine) return;
+  AldsBatch A, B;
+  issue(A, it);
+  for (;;) {
+    const AldsItem n1 = next(it);
+    const bool v1 = n1.q < nmine;
+    issue(B, v1 ? n1 : it);
+    process(A, it);
+    if (!v1) break;
+    const AldsItem n2 = next(n1);
+    const bool v2 = n2.q < nmine;
+    issue(A, v2 ? n2 : n1);
+    process(B, n1);
+    if (!v2) break;
+    it = n2;
+  }
+#ifdef SMCP_ALDS_NOADD
+  if (sink == 123.456) T[0] = sink;
+#endif
+}
+// rows (and with them columns) beyond 128 of a child: plain loop, one wave per child
+__device__ inline void lf_add_child_tail(double* T, int nf, const double* Uc, const int32_t* rel, int nac, int lane) {
+  auto cb = [nf](int j) { return j * nf - ((j * (j - 1)) >> 1) - j; };
+  for (int j = 0; j < nac; ++j) {
+    const int cbj = cb(rel[j]);
+    for (int i = 128 + lane; i < nac; i += 64)
+      if (i >= j) unsafeAtomicAdd(&T[cbj + rel[i]], col_at(Uc, nac, i, j));
+  }
+}
 // (body of one (front, right-hand side, share of the children) task; bx / by / bz and nz: block index and z-extent of the grid
 // in the plain launch)
 // sgn 3 (nz = 1 only): sgn 0 for a sparse right-hand side whose dense input panel has NOT been built -- the constraint's
@@ -376,6 +470,7 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
   // launch whose workgroup count leaves a poor last round is spread finer this way
   const int parts = nmine < nw ? max(1, nw / max(nmine, 1)) : 1;
   const int part = parts > 1 ? wave / max(nmine, 1) : 0;
+#ifdef SMCP_ALDS_V1
   for (int qi = parts > 1 ? wave % max(nmine, 1) : wave; qi < nmine && part < parts; qi += nw) {
     const int nac = sCn[qi];
     if (nac == 0) continue;
@@ -384,6 +479,15 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
     if (nac <= 64) lf_add_child<16, false>(T, nf, Uc, rel, nac, lane, part, parts);
     else lf_add_child<8, true>(T, nf, Uc, rel, nac, lane, part, parts);
   }
+#else
+  if (part < parts) {
+    const int q0 = parts > 1 ? wave % max(nmine, 1) : wave;
+    lf_add_children_stream(T, nf, ubase, a.t.relidx, sCu, sCr, sCn, nmine, q0, nw, part, parts, lane);
+    if (part == 0)
+      for (int qi = q0; qi < nmine; qi += nw)
+        if (sCn[qi] > 128) lf_add_child_tail(T, nf, ubase + sCu[qi], a.t.relidx + sCr[qi], sCn[qi], lane);
+  }
+#endif
   __syncthreads();
   double* P = u + (int64_t)r * ldu + d.blk;
   double* U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;

@@ -103,6 +103,7 @@ struct MfmaArgs {
   // sibling groups of the sparse-input sweep of childless large fronts (front_lfsp.hip): group g = the cliques
   // grp_list[grp_ptr[g] .. grp_ptr[g + 1]); chskip[k] != 0: the packed update slot of child k is not written in this sweep
   const int32_t* grp_ptr; const int32_t* grp_list; const uint8_t* chskip;
+  int famt_ngrp;   // host-side: sibling groups of the family parents of this launch (k_fam_terms_grp), 0 = none
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }

@@ -59,10 +59,12 @@ def block_arrow_pattern(nblocks, bs, arrow):
 
 
 def nested_block_arrow_pattern(nsub=8, nmid=112, nleaf_per_mid=8, leaf=(5, 31), mid=(15, 64), top=(64, 128),
-                               root=208, seed=0):
+                               root=208, seed=0, shared_mid_sep=False):
     """Three-level nested block-arrow pattern ("synth50k", config 5 with the defaults: n = 50000,
     8073 cliques): nsub subtrees x [1 x top + nmid x mid + nmid*nleaf_per_mid x leaf] + one root.
-    A clique (nn, na) owns nn new columns and is coupled to na rows of its parent's clique."""
+    A clique (nn, na) owns nn new columns and is coupled to na rows of its parent's clique -- a random subset of them, or,
+    shared_mid_sep, for the mid cliques the FIRST na rows of the top clique (siblings with one separator: a block-arrow
+    inside every subtree)."""
     rng = np.random.default_rng(seed)
     ln, la = leaf
     mn, ma = mid
@@ -83,6 +85,8 @@ def nested_block_arrow_pattern(nsub=8, nmid=112, nleaf_per_mid=8, leaf=(5, 31), 
         for mi in range(nmid):
             mid_own = np.arange(pos + nleaf_per_mid * ln, pos + nleaf_per_mid * ln + mn)
             mid_sep = np.sort(rng.choice(top_clique, size=ma, replace=False))
+            if shared_mid_sep:
+                mid_sep = np.sort(top_clique[:ma])
             mid_clique = np.concatenate([mid_own, mid_sep])
             for li in range(nleaf_per_mid):
                 leaf_own = np.arange(pos, pos + ln)

@@ -601,6 +601,53 @@ def test_kkt_sibling_groups_send_one_summed_update(nleaf, monkeypatch):
     assert rel(Hs[0], Hs[1]) < 1e-12
 
 
+@pytest.mark.parametrize("nmid,nleaf,m", [(19, 3, 12), (9, 3, 13), (8, 8, 21)])
+def test_kkt_family_sibling_groups_send_one_summed_update(nmid, nleaf, m, monkeypatch):
+    """synth50k's shape with ONE separator per subtree: `nmid` family parents (each with `nleaf` childless children) under one
+    large front, all with that front's own 64 columns as separator (synth50k itself draws every separator at random: no two
+    siblings share one, and its family sweep stays k_fam_terms).  The entry-driven family sweep takes the parents by sibling groups of up to
+    eight (k_fam_terms_grp): the members' tables pass through LDS in turn, the update tiles of a right-hand side are summed in
+    the accumulators and ONE packed update per group reaches the exchange buffer; the extend-add above skips the other
+    members.  19 parents = groups of 8 + 8 + 3, 9 = 8 + a singleton, 8 = one full group; 12 / 13 / 21 constraints = one full
+    and one ragged round of right-hand sides per workgroup column.  H and the solve against the oracle, and H against the
+    ungrouped route (SMCP_FAMT_GROUP=0 at device_init) to rounding."""
+    pat = problems.nested_block_arrow_pattern(nsub=1, nmid=nmid, nleaf_per_mid=nleaf, seed=71, shared_mid_sep=True)
+    Hs = []
+    for grouped in (True, False):
+        if not grouped:
+            monkeypatch.setenv("SMCP_FAMT_GROUP", "0")
+        symb = Symbolic(pat)
+        symb.device_init(0, m)
+        S = orc.Sym(symb)
+        A = problems.random_factor_blkval(symb, 72)
+        orc.llt(S, A)
+        L = A.copy()
+        orc.cholesky(S, L)
+        Yh = L.copy()
+        orc.projected_inverse(S, Yh)
+        cptr, cidx, cval = problems.random_constraints(symb, m, density=0.003, seed=73)
+        sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+        Ld, Yd = dev(symb, L), dev(symb, Yh)
+        counts = _launch_counts(symb, lambda: sys_.factor(Ld, Yd))
+        if grouped:
+            assert counts.get("k_fam_terms_grp", 0) >= 1 and counts.get("k_fam_terms", 0) == 0, counts
+        else:
+            assert counts.get("k_fam_terms_grp", 0) == 0 and counts.get("k_fam_terms", 0) >= 1, counts
+        Hs.append(np.tril(sys_.H.cpu().numpy().T))
+        if grouped:
+            K = orc.KKT(S, cptr, cidx, cval)
+            Href = K.schur_factor(L, Yh)
+            assert rel(Hs[0], np.tril(Href)) < 1e-9
+            rng = np.random.default_rng(74)
+            msk = lowmask(symb)
+            bx, by = rng.standard_normal(symb.blklen) * msk, rng.standard_normal(m)
+            xr, yr = K.solve(L, Yh, Href, bx, by, 1.0)
+            bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+            sys_.factor(Ld, Yd)(bxd, byd, 1.0)
+            assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+    assert rel(Hs[0], Hs[1]) < 1e-12
+
+
 def test_kkt_few_fronts_many_children_deal_children_over_workgroups():
     """One (64, 128) front with 40 children and 20 constraints in one chunk: fewer (front, right-hand side) pairs than half
     the CUs, so the streaming extend-add deals the children of a pair over several workgroups whose partial fronts meet in
