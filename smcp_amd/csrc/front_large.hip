@@ -332,28 +332,45 @@ __device__ inline void lf_add_child(double* T, int nf, const double* Uc, const i
 // NEXT batch -- of this child or of the wave's next child -- is in flight while the current one goes into the front.
 // (Rows and columns beyond 128 are left to lf_add_child_tail.)
 struct AldsBatch { double v[16]; int rA, rB; };
-struct AldsItem { int q, nac, j0; };
+struct AldsItem { int q, nac, j0, b; };
 __device__ inline int alds_cols(int nac) { return nac <= 64 ? 16 : 8; }
+__device__ inline int alds_batches(int nac) { return nac > 0 ? (min(nac, 128) + alds_cols(nac) - 1) / alds_cols(nac) : 0; }
+// The batches of ALL children of the task, in child order, are dealt round-robin to the nw waves (batch g to wave g mod nw):
+// the children of a front lie one after the other in the exchange buffer, so the workgroup reads ONE sequential stream with
+// its waves a few KB apart, instead of sixteen streams 16 KB apart that each stop and start (what the DRAM pages see: 256
+// streams on the chip instead of 4096) -- and a front with fewer children than waves keeps every wave busy without a
+// special case.
 __device__ inline void lf_add_children_stream(double* T, int nf, const double* ubase, const int32_t* relidx, const int64_t* sCu,
-                                              const int64_t* sCr, const int* sCn, int nmine, int q0, int qstep, int part, int parts,
-                                              int lane) {
+                                              const int64_t* sCr, const int* sCn, int nmine, int wave, int nw, int lane) {
   auto cb = [nf](int j) { return j * nf - ((j * (j - 1)) >> 1) - j; };
-  auto seek = [&](int q) {                              // first child at or after q with a batch for this wave
-    AldsItem it{nmine, 0, 0};
-    for (; q < nmine; q += qstep) {
-      const int nac = sCn[q];
-      if (nac > alds_cols(nac) * part) { it.q = q; it.nac = nac; it.j0 = alds_cols(nac) * part; break; }
+  auto norm = [&](int q, int b) {                       // (child q, batch b of it or of a later child) -> item
+    AldsItem it{nmine, 0, 0, 0};
+    for (; q < nmine; ++q) {
+      const int nac = sCn[q], nb = alds_batches(nac);
+      if (b < nb) { it.q = q; it.nac = nac; it.j0 = b * alds_cols(nac); it.b = b; break; }
+      b -= nb;
     }
     it.q = __builtin_amdgcn_readfirstlane(it.q); it.nac = __builtin_amdgcn_readfirstlane(it.nac);
-    it.j0 = __builtin_amdgcn_readfirstlane(it.j0);
+    it.j0 = __builtin_amdgcn_readfirstlane(it.j0); it.b = __builtin_amdgcn_readfirstlane(it.b);
     return it;
   };
-  auto next = [&](const AldsItem& it) {
-    AldsItem n = it;
-    n.j0 += alds_cols(it.nac) * parts;
-    if (n.j0 >= min(it.nac, 128)) n = seek(it.q + qstep);
-    return n;
+  // (children of at most 64 rows -- four batches each -- are dealt whole instead, child q to wave q mod nw, when there are
+  // at least nw of them: measured on synth50k, 112 children of 64 rows per front, 0.58 against 0.62 ms per sweep; on config 3,
+  // 250 summed updates of 128 rows under the root, the sequential deal wins, 0.81 against 1.13 ms)
+  auto normc = [&](int q, int b) {
+    AldsItem it{nmine, 0, 0, 0};
+    for (; q < nmine; q += nw, b = 0) {
+      const int nac = sCn[q], nb = alds_batches(nac);
+      if (b < nb) { it.q = q; it.nac = nac; it.j0 = b * alds_cols(nac); it.b = b; break; }
+    }
+    it.q = __builtin_amdgcn_readfirstlane(it.q); it.nac = __builtin_amdgcn_readfirstlane(it.nac);
+    it.j0 = __builtin_amdgcn_readfirstlane(it.j0); it.b = __builtin_amdgcn_readfirstlane(it.b);
+    return it;
   };
+  bool tall = false;                                    // any child of more than 64 rows (skipped group members count as empty)
+  for (int q = lane; q < nmine; q += 64) tall = tall || sCn[q] > 64;
+  const bool seq = nmine < nw || __builtin_amdgcn_ballot_w64(tall) != 0;
+  auto next = [&](const AldsItem& it) { return seq ? norm(it.q, it.b + nw) : normc(it.q, it.b + 1); };
   auto issue = [&](AldsBatch& b, const AldsItem& it) {
     const double* Uc = ubase + sCu[it.q];
     const int32_t* rel = relidx + sCr[it.q];
@@ -388,7 +405,7 @@ __device__ inline void lf_add_children_stream(double* T, int nf, const double* u
 #endif
     }
   };
-  AldsItem it = seek(q0);
+  AldsItem it = seq ? norm(0, wave) : normc(wave, 0);
   if (it.q >= nmine) return;
   AldsBatch A, B;
   issue(A, it);
@@ -468,9 +485,9 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
   // q mod gridDim.z) and add their partial fronts into the panel / the cleared update block with global atomics: a
   // front with very many children (config 3: 1999 under the root, i.e. 100 workgroups for 13 GB of child blocks) or a
   // launch whose workgroup count leaves a poor last round is spread finer this way
+#ifdef SMCP_ALDS_V1
   const int parts = nmine < nw ? max(1, nw / max(nmine, 1)) : 1;
   const int part = parts > 1 ? wave / max(nmine, 1) : 0;
-#ifdef SMCP_ALDS_V1
   for (int qi = parts > 1 ? wave % max(nmine, 1) : wave; qi < nmine && part < parts; qi += nw) {
     const int nac = sCn[qi];
     if (nac == 0) continue;
@@ -480,13 +497,9 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
     else lf_add_child<8, true>(T, nf, Uc, rel, nac, lane, part, parts);
   }
 #else
-  if (part < parts) {
-    const int q0 = parts > 1 ? wave % max(nmine, 1) : wave;
-    lf_add_children_stream(T, nf, ubase, a.t.relidx, sCu, sCr, sCn, nmine, q0, nw, part, parts, lane);
-    if (part == 0)
-      for (int qi = q0; qi < nmine; qi += nw)
-        if (sCn[qi] > 128) lf_add_child_tail(T, nf, ubase + sCu[qi], a.t.relidx + sCr[qi], sCn[qi], lane);
-  }
+  lf_add_children_stream(T, nf, ubase, a.t.relidx, sCu, sCr, sCn, nmine, wave, nw, lane);
+  for (int qi = wave; qi < nmine; qi += nw)
+    if (sCn[qi] > 128) lf_add_child_tail(T, nf, ubase + sCu[qi], a.t.relidx + sCr[qi], sCn[qi], lane);
 #endif
   __syncthreads();
   double* P = u + (int64_t)r * ldu + d.blk;
