@@ -1003,7 +1003,7 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   const int cnn = std::max(1, a.famcnn);
   const FamtL L = famt_layout<NAT>(8 * cnn);
   const int64_t lim = (160 * 1024 - 1024) / 8;                          // doubles of LDS a workgroup may use
-  const int64_t fixed = L.total + 8 * famt_desc_doubles() + 6;
+  const int64_t fixed = L.total + FAMT_NW * famt_desc_doubles() + 6;
   if (D.fam_maxterms > FAMT_TCAP / 2) return false;                      // pairs of one right-hand side: the descriptor area
   if (fixed + 9 * 4 + 64 > lim) return false;
   const int64_t prep_doubles = famt_prep_doubles<NAT>(cnn);
@@ -1029,7 +1029,7 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   for (int gc = 1; gc <= std::min(nrhs, 32); ++gc) {
     const int64_t rounds = ((int64_t)cnt * gc + ncu - 1) / ncu;
     const int64_t passes = (nrhs + gc - 1) / gc;
-    const int64_t cost = rounds * ((passes + 7) / 8 + 2);
+    const int64_t cost = rounds * ((passes + FAMT_NW - 1) / FAMT_NW + 2);
     if (best < 0 || cost < best) { best = cost; g = gc; }
   }
   static int genv = -1;
@@ -1044,7 +1044,7 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   const int ecap = (int)std::max<int64_t>(0, (left * 2) / 3 - 2);
   if (9 * D.kc_maxlist > ecap) return false;
   launch_lds(c, KID_famt_prep, k_famt_prep<NAT>, dim3(cnt), dim3(512), (size_t)prep_doubles * sizeof(double), st, a, D.famc, cnn);
-  launch_lds(c, KID_fam_terms, k_fam_terms<NAT>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a, U, ldu,
+  launch_lds(c, KID_fam_terms, k_fam_terms<NAT>, dim3(cnt, g), dim3(64 * FAMT_NW), (size_t)lim * 8, st, a, U, ldu,
              (const double*)D.famc, cnn, (const int32_t*)D.kc_ij, tabpasses, ecap);
   D.lg_nochild = true;
   return true;

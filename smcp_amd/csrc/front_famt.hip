@@ -60,6 +60,10 @@ __device__ inline __amdgpu_buffer_rsrc_t famt_rsrc(double* base, int doubles) {
 __device__ inline void famt_store(__amdgpu_buffer_rsrc_t r, bool ok, int pos, double v) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(famt_u2, v), r, ok ? pos * 8 : -1, 0, SMCP_FAMT_AUX);
 }
+#ifndef SMCP_FAMT_NW
+#define SMCP_FAMT_NW 12
+#endif
+constexpr int FAMT_NW = SMCP_FAMT_NW;   // waves of a k_fam_terms workgroup (12: three per SIMD, 168 registers each; 8: two, 256)
 constexpr int FAMT_HDR = 32;        // doubles: the header of a record (ints, as FAM2: [0] clique, [1] nn, [2] na, [3] children,
                                     // [4,5] panel offset, [8,9] packed-update offset; child c at 16 + 6 c: clique, nn, na,
                                     // first column in the child tables, -, -)
@@ -199,10 +203,10 @@ __global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int
 __host__ __device__ inline int famt_desc_doubles() { return FAMT_TCAP * 3; }
 
 template <int NAT>
-__global__ void __launch_bounds__(512) k_fam_terms(MfmaArgs a, double* u, int64_t ldu, const double* famt, int cnn,
+__global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* u, int64_t ldu, const double* famt, int cnn,
                                                    const int32_t* kc_ij, int tabpasses, int ecap) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int NA = 16 * NAT, NW = 8;
+  constexpr int NA = 16 * NAT, NW = FAMT_NW, NTH = 64 * NW;
   const int ncol = 8 * cnn;
   const FamtL L = famt_layout<NAT>(ncol);
   const double* const fc = famt + (int64_t)blockIdx.x * (FAMT_HDR + L.total);
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(512) k_fam_terms(MfmaArgs a, double* u, int64_
   double* const lval = reinterpret_cast<double*>(tab + 2 * ((tabpasses * nmem + 1) & ~1));
   int* const lpk = reinterpret_cast<int*>(lval + ecap);
 
-  for (int e = tid; e < L.total; e += 512) smem[e] = fc[FAMT_HDR + e];
+  for (int e = tid; e < L.total; e += NTH) smem[e] = fc[FAMT_HDR + e];
   if (tid < 8) cdim[tid] = tid < nch ? (hdr[16 + 6 * tid + 1] | (hdr[16 + 6 * tid + 3] << 8)) : 1;
 
   for (int q0 = 0; q0 < npass;) {
@@ -239,7 +243,7 @@ __global__ void __launch_bounds__(512) k_fam_terms(MfmaArgs a, double* u, int64_
     int myp0[2] = {0, 0};                                      // npairs <= 1024 (host): at most two pairs per thread
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int idx = tid + 512 * h;
+      const int idx = tid + NTH * h;
       if (idx < npairs) {
         const int qq = idx / nmem, mem = idx - qq * nmem;
         const int r = (int)blockIdx.y + (q0 + qq) * gy;
@@ -271,7 +275,7 @@ __global__ void __launch_bounds__(512) k_fam_terms(MfmaArgs a, double* u, int64_
     const int ep = max(1, *epfit);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int idx = tid + 512 * h;
+      const int idx = tid + NTH * h;
       if (idx < ep * nmem) {
         const int c = tab[2 * idx], p0 = myp0[h], off = tab[2 * idx + 1];
         const int qq = idx / nmem, mem = idx - qq * nmem;
@@ -424,7 +428,14 @@ __global__ void __launch_bounds__(512) k_fam_terms(MfmaArgs a, double* u, int64_
           }
         }
       };
-      if constexpr (NAT == 4) {
+      if constexpr (NAT == 4 && FAMT_NW > 8) {       // three passes: at most six accumulator tiles live (168 registers, three waves per SIMD)
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::true_type{});
+        pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::false_type{});
+        pass(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::false_type{});
+      } else if constexpr (NAT == 3 && FAMT_NW > 8) {
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::true_type{});
+        pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::false_type{});
+      } else if constexpr (NAT == 4) {
         pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, std::false_type{});
         pass(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::true_type{});
       } else {
