@@ -1023,13 +1023,14 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   }
   const int ncu = D.ncu;
   // one workgroup per CU (LDS), eight right-hand sides in flight per workgroup: split the right-hand sides so that the
-  // grid fills whole rounds; the set-up (tables, entry lists) costs about as much as sixteen passes
+  // grid fills whole rounds; the set-up (tables, entry lists) costs about as much as four passes (half a round of eight: since
+  // the tables reach LDS with eight loads in flight per thread; sixteen before.  synth50k: two slices, seven full rounds)
   int g = 1;
   int64_t best = -1;
   for (int gc = 1; gc <= std::min(nrhs, 32); ++gc) {
     const int64_t rounds = ((int64_t)cnt * gc + ncu - 1) / ncu;
     const int64_t passes = (nrhs + gc - 1) / gc;
-    const int64_t cost = rounds * ((passes + FAMT_NW - 1) / FAMT_NW + 2);
+    const int64_t cost = rounds * (2 * ((passes + FAMT_NW - 1) / FAMT_NW) + 1);
     if (best < 0 || cost < best) { best = cost; g = gc; }
   }
   static int genv = -1;

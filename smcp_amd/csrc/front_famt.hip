@@ -61,9 +61,9 @@ __device__ inline void famt_store(__amdgpu_buffer_rsrc_t r, bool ok, int pos, do
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(famt_u2, v), r, ok ? pos * 8 : -1, 0, SMCP_FAMT_AUX);
 }
 #ifndef SMCP_FAMT_NW
-#define SMCP_FAMT_NW 12
+#define SMCP_FAMT_NW 8
 #endif
-constexpr int FAMT_NW = SMCP_FAMT_NW;   // waves of a k_fam_terms workgroup (12: three per SIMD, 168 registers each; 8: two, 256)
+constexpr int FAMT_NW = SMCP_FAMT_NW;   // waves of a k_fam_terms workgroup: 8 = two per SIMD; 12 (three per SIMD at 168 registers, three passes of at most six tiles) measured 0.82 against 0.80 ms
 constexpr int FAMT_HDR = 32;        // doubles: the header of a record (ints, as FAM2: [0] clique, [1] nn, [2] na, [3] children,
                                     // [4,5] panel offset, [8,9] packed-update offset; child c at 16 + 6 c: clique, nn, na,
                                     // first column in the child tables, -, -)
@@ -113,10 +113,11 @@ __global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int
       if (i >= nn) snK[(i - nn) + j * NA] = -lk[e];
       else if (i >= j) sLi[i + j * 16] = lk[e];
     }
-    for (int e = tid; e < na * na; e += 512) {
-      const int i = e % na, p = e / na;                // R[i][p], i >= p  ->  R^T[p][i]
-      if (i >= p) sRt[p + i * NA] = ys[e];
-    }
+    batched_loop<8>(tid, na * na, 512, [=](int e) { return ys[e]; },
+                    [=](int e, double v) {
+                      const int i = e % na, p = e / na;   // R[i][p], i >= p  ->  R^T[p][i]
+                      if (i >= p) sRt[p + i * NA] = v;
+                    });
   }
   __syncthreads();
   // the parent's own tables -> record (zero-padded to the fixed strides)
@@ -198,6 +199,22 @@ __global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int
   }
 }
 
+// The record of a family -> LDS: sixteen-byte loads, eight in flight per thread (the plain copy loop compiled to one load,
+// s_waitcnt vmcnt(0), one LDS store per trip: 24 dependent round trips per workgroup, ~20 us of every workgroup's life)
+template <int NTH>
+__device__ inline void famt_copy_tables(double* smem, const double* src, int total, int tid) {
+  const double2* const s2 = reinterpret_cast<const double2*>(src);
+  double2* const d2 = reinterpret_cast<double2*>(smem);
+  const int n2 = total >> 1;                                  // every table has an even number of doubles
+  for (int e0 = tid; e0 < n2; e0 += NTH * 8) {
+    double2 v[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = s2[min(e0 + x * NTH, n2 - 1)];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) if (e0 + x * NTH < n2) d2[e0 + x * NTH] = v[x];
+  }
+}
+
 // LDS of k_fam_terms behind the tables (doubles): per wave the descriptors of FAMT_TCAP ordered pairs (scale: 1 double,
 // offsets: 4 ints), then the entry table of k_fam_sparse: per (pass, member) two ints, then the staged entries
 __host__ __device__ inline int famt_desc_doubles() { return FAMT_TCAP * 3; }
@@ -229,7 +246,7 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
   double* const lval = reinterpret_cast<double*>(tab + 2 * ((tabpasses * nmem + 1) & ~1));
   int* const lpk = reinterpret_cast<int*>(lval + ecap);
 
-  for (int e = tid; e < L.total; e += NTH) smem[e] = fc[FAMT_HDR + e];
+  famt_copy_tables<NTH>(smem, fc + FAMT_HDR, L.total, tid);
   if (tid < 8) cdim[tid] = tid < nch ? (hdr[16 + 6 * tid + 1] | (hdr[16 + 6 * tid + 3] << 8)) : 1;
 
   for (int q0 = 0; q0 < npass;) {
@@ -570,11 +587,7 @@ __global__ void __launch_bounds__(512) k_fam_terms_grp(MfmaArgs a, double* u, in
       const int nn = hm[1], nch = hm[3], nf = nn + na;
       const int64_t pblk = (int64_t)(uint32_t)hm[4] | ((int64_t)hm[5] << 32);
       __syncthreads();                                       // the staged entries are in place / the previous tables are consumed
-      {
-        const double2* const src = reinterpret_cast<const double2*>(fcm + FAMT_HDR);
-        double2* const dst = reinterpret_cast<double2*>(smem);
-        for (int e = tid; e < L.total / 2; e += 512) dst[e] = src[e];
-      }
+      famt_copy_tables<512>(smem, fcm + FAMT_HDR, L.total, tid);
       if (tid < 8) cdim[tid] = tid < nch ? (hm[16 + 6 * tid + 1] | (hm[16 + 6 * tid + 3] << 8)) : 1;
       __syncthreads();
       if (!active) continue;

@@ -71,12 +71,13 @@ __global__ void __launch_bounds__(64) k_leaf_tables(LeafGramArgs a, int nfmax, i
   const double* const lk = a.LK + d.blk;
   const double* const ya = a.yaa + d.upd;
   for (int e = lane; e < nf * nn; e += 64) sOm[e] = 0.0;
-  for (int e = lane; e < na * nn; e += 64) { const int r = e % na, c = e / na; sK[e] = lk[(nn + r) + (int64_t)c * nf]; }
+  // (eight loads in flight per lane: as plain copy loops these compiled to one load, s_waitcnt vmcnt(0), one LDS store per
+  // trip -- fifteen dependent round trips for the 31 x 31 block of a synth50k leaf)
+  batched_loop<4>(lane, na * nn, 64, [=](int e) { const int r = e % na, c = e / na; return lk[(nn + r) + (int64_t)c * nf]; },
+                  [=](int e, double v) { sK[e] = v; });
   for (int e = lane; e < nn * nn; e += 64) { const int i = e % nn, j = e / nn; sLi[e] = i >= j ? lk[i + (int64_t)j * nf] : 0.0; }
-  for (int e = lane; e < na * na; e += 64) {
-    const int i = e % na, j = e / na;
-    sPsi[(nn + i) + (nn + j) * nf] = ya[max(i, j) + (int64_t)min(i, j) * na];
-  }
+  batched_loop<8>(lane, na * na, 64, [=](int e) { const int i = e % na, j = e / na; return ya[max(i, j) + (int64_t)min(i, j) * na]; },
+                  [=](int e, double v) { const int i = e % na, j = e / na; sPsi[(nn + i) + (nn + j) * nf] = v; });
   lg_wave_sync();
   // Psi_AN = -(Y_AA K) (both triangles of Psi are kept), Omega_NN = Li^T Li
   for (int e = lane; e < na * ((nn + 3) / 4); e += 64) {     // row r, four columns at a time: K is read by broadcast
