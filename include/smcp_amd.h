@@ -252,9 +252,11 @@ int csp_touch(csp_ctx* ctx, const void* ptr);
                                      family sweep of the Schur complement streams into two multi-GB buffers at once, and how fast
                                      the memory system takes that depends on where the buffers physically lie (+-20 % on that
                                      kernel from one allocation to the next).  A store-only probe of the pattern is timed, the
-                                     packed exchange buffer is moved to up to `tries` fresh allocations and the fastest placement
-                                     kept (a few ms per try, 4 GB of transient memory on the headline problem).  Worth it for runs
-                                     of many Newton steps on one problem; off unless called */
+                                     two buffers -- the packed exchange buffer and the swept stack (which moves with its contents)
+                                     -- are moved in turn to fresh allocations, `tries` in all, and the fastest placement is kept
+                                     (a few ms per try; the buffers set aside are freed at the end: up to 16 GB of transient
+                                     memory).  Call it between Schur complements: the probe overwrites both buffers.  Worth it for
+                                     runs of many Newton steps on one problem; off unless called */
 int csp_tune(csp_ctx* ctx, int what, int64_t value);
 /* out[0], out[1]: milliseconds of the store-pattern probe of the last CSP_TUNE_PLACEMENT before / after (zeros: not run) */
 int csp_tune_report(csp_ctx* ctx, double* out);

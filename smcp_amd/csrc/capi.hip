@@ -2563,16 +2563,28 @@ static int tune_placement(csp_ctx* c, int tries) {
   int rc = probe(best);
   const float first = best;
   std::vector<void*> rejected;                 // kept until the end: a freed buffer would be handed out again at once
+  // The probe stores into BOTH buffers -- the packed updates and the panels of the swept stack -- and either can lie badly
+  // (probe levels seen: 0.38 both well placed, 0.42-0.44 one of them, 0.50 neither): the tries alternate between them.  The
+  // stack moves WITH its contents (a caller may be between a sweep and its Gram accumulation) and only while the buffers set
+  // aside stay under 16 GB.
+  const size_t ubytes = sizeof(double) * (size_t)(D.max_rhs * D.updp_stride);
+  const size_t sbytes = sizeof(double) * (size_t)(D.ustack_cols * c->S.blklen());
+  size_t held = 0;
   for (int q = 0; q < tries && !rc; ++q) {
-    double* old = D.updp;
+    const bool stack = (q & 1) && held + sbytes <= ((size_t)16 << 30);
+    double*& slot = stack ? D.ustack : D.updp;
+    const size_t bytes = stack ? sbytes : ubytes;
+    double* old = slot;
     double* nu = nullptr;
-    if (hipMalloc((void**)&nu, sizeof(double) * (size_t)(D.max_rhs * D.updp_stride)) != hipSuccess) break;   // out of memory: keep what we have
-    D.updp = nu;
+    if (hipMalloc((void**)&nu, bytes) != hipSuccess) break;   // out of memory: keep what we have
+    if (stack && hipMemcpy(nu, old, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(nu); rc = SMCP_EHIP; break; }
+    slot = nu;
     float ms = 0.f;
     rc = probe(ms);
-    if (!rc && ms < best) { best = ms; rejected.push_back(old); }
-    else { D.updp = old; rejected.push_back(nu); }
-    if (best <= 0.82f * first) break;          // from the slow end of the spread to the fast one: good enough
+    if (!rc && ms < 0.985f * best) { best = ms; rejected.push_back(old); }
+    else { slot = old; rejected.push_back(nu); }
+    held += bytes;
+    if (best <= 0.80f * first) break;          // from the slow end of the spread to the fast one: good enough
   }
   for (void* p : rejected) (void)hipFree(p);
   (void)hipFree(dpar);
