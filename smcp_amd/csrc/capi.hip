@@ -534,10 +534,16 @@ static bool pd_deep() {
   if (on < 0) { const char* e = getenv("SMCP_PD"); on = (e && e[0] == '1') ? 0 : 1; }
   return on == 1;
 }
+// (SMCP_PD_WGS: the largest launch, in workgroups per CU, that still takes the sixteen-wave shape; default 1)
+static int64_t pd_wgs() {
+  static int64_t v = -1;
+  if (v < 0) { const char* e = getenv("SMCP_PD_WGS"); v = e ? std::max(1, atoi(e)) : 1; }
+  return v;
+}
 #define LAUNCH_PD(c, kid, kern, grid, blk, ...)                                                        \
   do {                                                                                                 \
     const dim3 g_ = (grid);                                                                            \
-    if (pd_deep() && (int64_t)g_.x * g_.y * g_.z <= (int64_t)(c)->D.ncu) launch(c, kid, kern<4>, g_, dim3(1024), __VA_ARGS__); \
+    if (pd_deep() && (int64_t)g_.x * g_.y * g_.z <= pd_wgs() * (int64_t)(c)->D.ncu) launch(c, kid, kern<4>, g_, dim3(1024), __VA_ARGS__); \
     else launch(c, kid, kern<1>, g_, blk, __VA_ARGS__);                                                \
   } while (0)
 
