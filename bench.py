@@ -276,7 +276,7 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
     # than n / 10 columns and is swept; the max-cut constraints are column-sparse
     kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs, tnzcols=0.0 if args.kktsolver == "qr" else None)
     placement = None
-    if getattr(args, "tune_placement", 0) > 0 and world == 1 and workload == "synth50k":
+    if getattr(args, "tune_placement", 0) > 0 and workload == "synth50k":      # (every rank of an N-rank job tunes its own buffers)
         # csp_tune(CSP_TUNE_PLACEMENT), part of the (untimed) set-up like the symbolic analysis: the packed exchange buffer goes
         # to the fastest of up to N fresh allocations for the store pattern of the family sweep (the
         # same kernel takes 0.80 or 0.98 ms depending on where its two output buffers lie).  --tune-placement 0: as allocated.
@@ -551,7 +551,7 @@ def main():
     ap.add_argument("--cpu-cols", type=int, default=10 ** 9, help="Schur columns timed on the CPU oracle (default: all; at least one per thread)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (a 1-GPU box has a 16-core share)")
     ap.add_argument("--tune-placement", type=int, default=8,
-                    help="tries of csp_tune(CSP_TUNE_PLACEMENT) during set-up (0 = off; N = 1, synth50k only): the two output buffers of the family sweep (packed "
+                    help="tries of csp_tune(CSP_TUNE_PLACEMENT) during set-up (0 = off; synth50k only): the two output buffers of the family sweep (packed "
                          "exchange buffer, swept stack) are moved in turn to fresh allocations, the fastest for its store pattern kept")
     ap.add_argument("--shard", default="subtree", choices=["subtree", "columns"],
                     help="N > 1: subtree sharding + boundary exchange (default) or column sharding of H")
