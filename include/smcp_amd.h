@@ -244,19 +244,22 @@ int csp_touch(csp_ctx* ctx, const void* ptr);
 #define CSP_TUNE_LEAFGRAM 1       /* closed-form Gram blocks of childless small cliques (front_leafgram.hip): 0 never,
                                      1 when the entry lists are short enough to beat the panel route (default), 2 always */
 #define CSP_TUNE_VERIFY_CACHE 2   /* 1: every reuse of a cached derived quantity first checks a fingerprint of the matrix
-                                     it was derived from (one small kernel + a stream synchronisation per reuse); a
-                                     caller that forgot csp_touch gets SMCP_ESTALE instead of stale factors */
+                                     it was derived from -- every entry of every panel, one pass over blkval + a stream
+                                     synchronisation per reuse (which makes csp_lazy_status pointless while it is on: a
+                                     debug aid); a caller that forgot csp_touch gets SMCP_ESTALE instead of stale factors */
 #define CSP_TUNE_DETERMINISTIC 3  /* 1: every sum in a fixed order (no floating-point atomics): results are bit-identical
                                      from run to run; slower */
 #define CSP_TUNE_PLACEMENT 4      /* value = tries (1..16): an ACTION, not a setting -- call it after kkt_set_constraints.  The
                                      family sweep of the Schur complement streams into two multi-GB buffers at once, and how fast
                                      the memory system takes that depends on where the buffers physically lie (+-20 % on that
                                      kernel from one allocation to the next).  A store-only probe of the pattern is timed, the
-                                     two buffers -- the packed exchange buffer and the swept stack (which moves with its contents)
-                                     -- are moved in turn to fresh allocations, `tries` in all, and the fastest placement is kept
-                                     (a few ms per try; the buffers set aside are freed at the end: up to 16 GB of transient
-                                     memory).  Call it between Schur complements: the probe overwrites both buffers.  Worth it for
-                                     runs of many Newton steps on one problem; off unless called */
+                                     two buffers -- the packed exchange buffer and the swept stack -- are moved in turn to fresh
+                                     allocations, `tries` in all, and the fastest placement is kept (a few ms per try; the buffers
+                                     set aside are freed at the end: up to 16 GB of transient memory).  The contents of both
+                                     buffers are NOT preserved (the probe zeroes the family parents' panels and update slots):
+                                     call it between Newton steps; a kkt_qr factor held in the stack is invalidated and
+                                     kkt_qr_solve returns SMCP_EINVAL until the next kkt_qr_factor.  Worth it for runs of many
+                                     Newton steps on one problem; off unless called */
 int csp_tune(csp_ctx* ctx, int what, int64_t value);
 /* out[0], out[1]: milliseconds of the store-pattern probe of the last CSP_TUNE_PLACEMENT before / after (zeros: not run) */
 int csp_tune_report(csp_ctx* ctx, double* out);

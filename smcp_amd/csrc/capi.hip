@@ -690,17 +690,18 @@ static int prep_lk_threads(int nnmax) { return nnmax > 16 ? NT : 128; }
 // ---- cache verification (csp_tune(ctx, CSP_TUNE_VERIFY_CACHE, 1); debug aid) ------------------------------------
 // The derived-quantity caches are keyed by the ADDRESS of the matrix they came from; a caller that rewrites the
 // matrix in place without telling the library (csp_touch) would be served stale factors.  With verification on, a
-// fingerprint of the matrix -- the wrap-around sum of the bit patterns of its diagonal entries, each multiplied by an
-// odd number that depends on its column, so exact and independent of the summation order -- is latched on the device
+// fingerprint of the matrix -- the wrap-around sum of the bit patterns of ALL its panel entries, each multiplied by an
+// odd number that depends on its position, so exact and independent of the summation order -- is latched on the device
 // when a cache entry is created and compared when the entry is reused; a mismatch makes the call return SMCP_ESTALE.
 __global__ void k_diag_fingerprint(const CliqueDesc* cl, int nsn, const double* x, unsigned long long* slot, int* bad, int check) {
+  // every entry of every panel (one pass over blkval: 20 MB on synth50k), weighted by an odd number that depends on its position
   __shared__ unsigned long long part[256];
   unsigned long long s = 0;
   for (int k = blockIdx.x; k < nsn; k += gridDim.x) {
     const CliqueDesc d = cl[k];
-    const int nf = d.nn + d.na;
-    for (int i = threadIdx.x; i < d.nn; i += blockDim.x)
-      s += (unsigned long long)__double_as_longlong(x[d.blk + i + (int64_t)i * nf]) * (2ull * (unsigned long long)(d.first + i) + 1ull);
+    const int64_t len = (int64_t)(d.nn + d.na) * d.nn;
+    for (int64_t e = threadIdx.x; e < len; e += blockDim.x)
+      s += (unsigned long long)__double_as_longlong(x[d.blk + e]) * (2ull * (unsigned long long)(d.blk + e) + 1ull);
   }
   part[threadIdx.x] = s;
   __syncthreads();
@@ -715,11 +716,11 @@ __global__ void k_fingerprint_compare(unsigned long long* slots, int which, int*
 static void fp_record(csp_ctx* c, int which, const double* x, hipStream_t st) {
   if (!c->verify_cache || !c->D.fp) return;
   (void)hipMemsetAsync(c->D.fp + which, 0, sizeof(unsigned long long), st);
-  hipLaunchKernelGGL(k_diag_fingerprint, dim3(64), dim3(256), 0, st, c->D.cl, (int)c->S.nsn, x, c->D.fp + which, c->D.fp_bad, 0);
+  hipLaunchKernelGGL(k_diag_fingerprint, dim3(1024), dim3(256), 0, st, c->D.cl, (int)c->S.nsn, x, c->D.fp + which, c->D.fp_bad, 0);
 }
 static int fp_check(csp_ctx* c, int which, const double* x, hipStream_t st) {
   if (!c->verify_cache || !c->D.fp) return 0;
-  hipLaunchKernelGGL(k_diag_fingerprint, dim3(64), dim3(256), 0, st, c->D.cl, (int)c->S.nsn, x, c->D.fp + which, c->D.fp_bad, 1);
+  hipLaunchKernelGGL(k_diag_fingerprint, dim3(1024), dim3(256), 0, st, c->D.cl, (int)c->S.nsn, x, c->D.fp + which, c->D.fp_bad, 1);
   hipLaunchKernelGGL(k_fingerprint_compare, dim3(1), dim3(64), 0, st, c->D.fp, which, c->D.fp_bad);
   int bad = 0;
   if (hipMemcpyAsync(&bad, c->D.fp_bad, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return SMCP_EHIP;
@@ -1056,10 +1057,13 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   D.lg_nochild = true;
   return true;
 }
-bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+inline bool fam2_disabled() {
   static int off = -1;
   if (off < 0) { const char* e = getenv("SMCP_FAM2"); off = (e && e[0] == '0') ? 1 : 0; }
-  if (off || !a.kc_ptr || !c->D.kc_ij || a.ymode != 2 || !a.ysc) return false;
+  return off != 0;
+}
+bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
+  if (fam2_disabled() || !a.kc_ptr || !c->D.kc_ij || a.ymode != 2 || !a.ysc) return false;
   // short lists only: the children's sweep costs O(entries) here, the dense MFMA sweep of k_hess_up_fam does not
   if (c->D.cnnz > (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m)) return false;
   const int nat = std::max(1, (a.famna + 15) / 16);
@@ -1080,6 +1084,13 @@ bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64
 }
 bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
   if (try_fam2(c, a, cnt, nrhs, U, ldu, st)) return true;
+  if (a.famt_ngrp > 0) {
+    // sibling groups were promised to the levels above (MfmaArgs::chskip: the non-leaders' slots are skipped there): only the
+    // grouped kernel writes the summed updates, so a per-parent fallback would silently drop them -- fail the call instead
+    fprintf(stderr, "smcp_amd: grouped family sweep refused by try_fam2 (conditions of hess_up_fast and try_fam2 disagree)\n");
+    if (!c->launch_err) c->launch_err = -1;
+    return true;
+  }
   return a.kc_ptr ? try_fam_sp<true>(c, a, cnt, nrhs, U, ldu, st) : try_fam_sp<false>(c, a, cnt, nrhs, U, ldu, st);
 }
 
@@ -1153,7 +1164,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
   const bool groups_on = sparse && set == 0 && c->lfsp_any_groups && c->D.lfsp_skip && lfsp_dynamic_ok(c, a0);
   // the same for the sibling groups of family parents (k_fam_terms_grp): on exactly when try_fam2 / launch_famt will take the
   // family launches of this sweep (their conditions, repeated here: the decision must hold for every level of the sweep)
-  const bool fgroups_on = sparse && set == 0 && c->famt_any_groups && c->D.famt_skip && !famt_disabled() && c->D.lg_request &&
+  const bool fgroups_on = sparse && set == 0 && c->famt_any_groups && c->D.famt_skip && !famt_disabled() && !fam2_disabled() && c->D.lg_request &&
                           c->D.kc_ij && a0.ymode == 2 && a0.ysc && c->D.fam_maxterms <= FAMT_TCAP / 2 &&
                           c->D.cnnz <= (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m);
   if (groups_on || fgroups_on) a0.chskip = groups_on && fgroups_on ? c->D.both_skip : (groups_on ? c->D.lfsp_skip : c->D.famt_skip);
@@ -2546,6 +2557,8 @@ static int tune_placement(csp_ctx* c, int tries) {
   for (int64_t k = 0; k < c->S.nsn; ++k)
     if (k < (int64_t)c->fam.size() && c->fam[(size_t)k] == 2) par.push_back((int32_t)k);
   if (par.size() < 64) return 0;               // no family sweep worth tuning for
+  D.qr_valid = false;                          // the probe overwrites panels of the stack (Q of kkt_qr lives there)
+  D.lg_nochild = false;
   int32_t* dpar = nullptr;
   int64_t junk = 0;
   if (int rc = dev_upload(&dpar, par, junk)) return rc;
@@ -2570,9 +2583,11 @@ static int tune_placement(csp_ctx* c, int tries) {
   const float first = best;
   std::vector<void*> rejected;                 // kept until the end: a freed buffer would be handed out again at once
   // The probe stores into BOTH buffers -- the packed updates and the panels of the swept stack -- and either can lie badly
-  // (probe levels seen: 0.38 both well placed, 0.42-0.44 one of them, 0.50 neither): the tries alternate between them.  The
-  // stack moves WITH its contents (a caller may be between a sweep and its Gram accumulation) and only while the buffers set
-  // aside stay under 16 GB.
+  // (probe levels seen: 0.38 both well placed, 0.42-0.44 one of them, 0.50 neither): the tries alternate between them, the
+  // stack only while the buffers set aside stay under 16 GB.  The CONTENTS of both buffers are NOT preserved: the probe
+  // zeroes the family parents' panels in the stack and their slots in the exchange buffer, so whatever was derived from the
+  // stack (the Q factor of kkt_qr, the "children's panels left out" mark of the last sweep) is dropped here -- tune between
+  // Newton steps, not between a sweep and its consumer.
   const size_t ubytes = sizeof(double) * (size_t)(D.max_rhs * D.updp_stride);
   const size_t sbytes = sizeof(double) * (size_t)(D.ustack_cols * c->S.blklen());
   size_t held = 0;
@@ -2582,7 +2597,8 @@ static int tune_placement(csp_ctx* c, int tries) {
     const size_t bytes = stack ? sbytes : ubytes;
     double* old = slot;
     double* nu = nullptr;
-    if (hipMalloc((void**)&nu, bytes) != hipSuccess) break;   // out of memory: keep what we have
+    if (hipMalloc((void**)&nu, bytes) != hipSuccess) { (void)hipGetLastError(); break; }   // out of memory: keep what we have (and leave no sticky error behind)
+    // (the copy keeps the never-written entries of the stack finite, which is all the sweeps ask of it)
     if (stack && hipMemcpy(nu, old, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(nu); rc = SMCP_EHIP; break; }
     slot = nu;
     float ms = 0.f;

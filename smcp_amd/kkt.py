@@ -136,19 +136,19 @@ class ShardedSchur:
     # most doubles kept from the Schur sweeps for the collective-free exchange of solve_'s second Hessian
     KEEP_LIMIT = 1 << 28
 
-    def _exchange_local(self, group, y):
+    def _exchange_local(self, group, y, recv1, kept):
         """The boundary blocks of the second Hessian of solve_ WITHOUT a collective: its input is Aadj(y) - bx
         (solvers.py:528-531), so the other ranks' root blocks are sum_i y_i (blocks gathered for constraint i by the
-        Schur sweeps) - (blocks gathered for bx by the first Hessian) -- both are on this rank already."""
+        Schur sweeps: `kept`, the chunks of the build_schur this solve_ belongs to) - (blocks gathered for bx by the first
+        Hessian of THIS solve_: `recv1`, handed over by the caller) -- both are on this rank already."""
         world, rank = self._world(group)
         P = self.partition
         bufs, sizes1, width1 = self._exchange_plan(group, 1)
-        recv1 = bufs[width1][1]                       # what the first Hessian's exchange gathered
         if ("local", width1) not in bufs:
             bufs[("local", width1)] = torch.empty(width1 * world, dtype=torch.float64, device=self.dev)
         out = bufs[("local", width1)]
         out.copy_(recv1)
-        for n, (j0, j1, recv, width) in enumerate(self._kept):
+        for n, (j0, j1, recv, width) in enumerate(kept):
             self._exchange_combine(P, rank, j1 - j0, y[j0:j1], recv, width, out, width1, 0 if n == 0 else 1)
         self._exchange_unpack_all(P, rank, 1, out, width1, sizes1)
 
@@ -203,6 +203,7 @@ class ShardedSchur:
         keep = (width_m * world * ((self.m + step - 1) // step) <= self.KEEP_LIMIT
                 and os.environ.get("SMCP_SHARD_KEEP", "1") != "0")       # 0: the second Hessian of solve_ exchanges like the first
         self._kept = []
+        self._kept_gen = self.__dict__.get("_kept_gen", 0) + 1          # the kept chunks belong to THIS Schur complement
         for n, j0 in enumerate(range(0, self.m, step)):
             j1 = min(self.m, j0 + step)
             guarded(self._gram_sweep, 1, j0, j1)                         # owned subtrees
@@ -279,17 +280,23 @@ class ShardedSchur:
         self.__dict__["_spair"] = (L, Y, (L.state(), Y.state()))
         return L, Y
 
-    def _solve_sharded(self, L, Y, bx, by, kk, group, complete):
+    def _solve_sharded(self, L, Y, bx, by, kk, group, complete, kept=None):
         """solve_ of kkt_chol (solvers.py:521-541) on a sharded factor: both Hessians run as owned sweep -> exchange ->
         top (up), top -> owned (down); Amap sums over the blkval ranges this rank accounts for and ONE all-reduce
         completes it; the m x m solve is replicated.  With complete=True one all-gather of the owned ranges fills x in on every
-        rank, otherwise x is valid on the owned cliques and the top (what the next sharded sweep needs)."""
+        rank, otherwise x is valid on the owned cliques and the top (what the next sharded sweep needs).
+        kept: the gathered root blocks of the Schur sweeps of the factor() this solve_ came from (None: the second Hessian
+        exchanges like the first)."""
+        first = {}
+
         def W(U, y=None):
             self._hess_part(U, 1, 0)
-            if y is not None and getattr(self, "_kept", None):
-                self._exchange_local(group, y)       # no collective: Aadj(y) - bx is a combination of swept inputs
+            if y is not None and kept and "recv" in first:
+                self._exchange_local(group, y, first["recv"], kept)   # no collective: Aadj(y) - bx is a combination of swept inputs
             else:
-                self._exchange(group, 1)
+                # (a buffer of its own: no other exchange of the same width -- factor_scaling's, say -- can overwrite what the
+                # second Hessian combines)
+                first["recv"], _ = self._exchange(group, 1, keep="solve")
             self._hess_part(U, 2, 0)
             self._hess_part(U, 2, 1)
             self._hess_part(U, 1, 1)
@@ -524,12 +531,17 @@ class KKTSystem(ShardedSchur):
         self.build_schur(L, Y, group)
         self._potrf()
         if self._sharded_pair(L, Y):
+            # the chunks kept by THIS build_schur, with the generation they were gathered in: a solve_ that outlives a later
+            # build_schur (whose sweeps reuse the buffers) falls back to the collective exchange for its second Hessian
+            kept, gen = getattr(self, "_kept", None), self.__dict__.get("_kept_gen", 0)
+
             def solve_sharded(bx, by, kk, complete=True):
                 """Overwrites bx (cspmatrix) with x and by (device vector) with y; sharded sweeps."""
                 self._own()
                 if not self._sharded_pair(L, Y):
                     raise RuntimeError("the sharded factor (L, Y) has been modified or replaced: factor again")
-                return self._solve_sharded(L, Y, bx, by, kk, group, complete)
+                live = kept if self.__dict__.get("_kept_gen", 0) == gen else None
+                return self._solve_sharded(L, Y, bx, by, kk, group, complete, live)
             return solve_sharded
 
         def solve_(bx, by, kk):

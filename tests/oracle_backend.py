@@ -183,7 +183,9 @@ class OracleKKT(kkt.ShardedSchur):
         self.build_schur(L, Y, group)
         self._potrf()
         if self._sharded_pair(L, Y):
-            return lambda bx, by, kk, complete=True: self._solve_sharded(L, Y, bx, by, kk, group, complete)
+            kept, gen = getattr(self, "_kept", None), self.__dict__.get("_kept_gen", 0)
+            return lambda bx, by, kk, complete=True: self._solve_sharded(
+                L, Y, bx, by, kk, group, complete, kept if self.__dict__.get("_kept_gen", 0) == gen else None)
         H = np.asfortranarray(self.H.numpy().T)
 
         def solve_(bx, by, kk):
