@@ -33,6 +33,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC_FILE = "r04_hbm_traffic.json"
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 FP64_PEAK_TFLOPS = 78.6   # vendor fp64 vector = matrix peak
 
@@ -42,6 +43,11 @@ def build_workload(name, seed=0):
     if name == "synth50k":
         pat = problems.nested_block_arrow_pattern(seed=seed)
         m, density, label = 100, 0.005, "synth50k nested block-arrow SDP n=50000, 8073 cliques, m=100"
+    elif name == "synth50k_dense":
+        # the headline pattern with ten times denser constraints (0.05 |V| entries each: ~120 per (family, constraint), beyond the
+        # 48-entry gate of the entry-driven family sweep k_fam_terms): what the step costs when k_fam_sparse / k_hess_up_fam take over
+        pat = problems.nested_block_arrow_pattern(seed=seed)
+        m, density, label = 100, 0.05, "synth50k pattern, m=100 constraints of density 0.05 (family sweep beyond the k_fam_terms gate)"
     elif name == "synth6k":   # reduced copy for quick checks only (NOT the benchmark)
         pat = problems.nested_block_arrow_pattern(nsub=2, nmid=56, seed=seed)
         m, density, label = 100, 0.005, "synth6k (reduced, check only)"
@@ -107,7 +113,48 @@ def git_sha():
         return None
 
 
-def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc, part, rank, world, label):
+def csrc_sha256():
+    """sha256 over the kernel sources (smcp_amd/csrc/*, names and contents, sorted) -- the GPU box has no .git, so this is
+    what ties a committed PMC summary to the code that is running."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "smcp_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        h.update(name.encode())
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def famt_executed_flops(symb, cptr, cidx, chunks):
+    """Flops k_fam_terms EXECUTES per sweep of all chunks (front_famt.hip): one wave per (family parent, right-hand side)
+    issues ks = ceil(2 T / 4) steps of NAT (NAT + 1) / 2 + NAT + 1 v_mfma_f64_16x16x4 (2048 flop each, tile padding
+    included), T = entries of the constraint inside the family (the parent's and its children's, capped at 48).  This is
+    what SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 counts (profiles/r04_mfma_pmc.txt)."""
+    fam = symb.family_roles()
+    nn_, na_ = symb.clique_sizes()
+    par = np.asarray(symb.snpar)
+    blkptr = np.asarray(symb.blkptr)
+    m = len(cptr) - 1
+    parents = np.flatnonzero(fam == 2)
+    if not len(parents):
+        return 0.0
+    pid = -np.ones(symb.Nsn, dtype=np.int64)
+    pid[parents] = np.arange(len(parents))
+    owner = np.where(fam == 2, pid, np.where(fam == 1, pid[np.maximum(par, 0)], -1))
+    clique = np.searchsorted(blkptr, np.asarray(cidx), side="right") - 1
+    con = np.repeat(np.arange(m), np.diff(cptr))
+    o = owner[clique]
+    T = np.zeros((len(parents), m), dtype=np.int64)
+    np.add.at(T, (o[o >= 0], con[o >= 0]), 1)
+    ks = (2 * np.minimum(T, 48) + 3) >> 2
+    nat = (int(na_[parents].max()) + 15) // 16          # the launch's instantiation serves the widest parent
+    per_step = nat * (nat + 1) // 2 + nat + 1
+    nrhs = sum(chunks)
+    return float(ks[:, :nrhs].sum()) * per_step * 2048.0
+
+
+def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc, part, rank, world, label, con=None):
     """roofline object of the dominant kernel `dom` (name as rocprofv3 shows it, without template arguments):
     achieved = ALGORITHMIC bytes (or flops) of its launches in one step / their duration (HIP events).
     B = sum (nn + na) nn (blkval), U = sum na^2, Up = sum na (na + 1) / 2 (packed update blocks)."""
@@ -156,14 +203,22 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
         flops = float((nnk ** 3 + 3 * nak * nnk ** 2 + 3 * nak ** 2 * nnk).sum()) * sum(chunks)
         per_level = sum(8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask].sum() + Upch[fam_mask].sum()) + Bk[fam_mask].sum()) for r in chunks)
         extra = {"per_level_bytes_per_launch": per_level / dom_launches,
-                 "mfma": {"flops_per_launch": flops / dom_launches,
-                          "achieved_tflops": round(flops / (1e-3 * dom_ms) / 1e12, 2),
-                          "frac": round(flops / (1e-3 * dom_ms) / 1e12 / FP64_PEAK_TFLOPS, 4)}}
+                 "mfma_canonical": {"flops_per_launch": flops / dom_launches,
+                                    "achieved_tflops": round(flops / (1e-3 * dom_ms) / 1e12, 2),
+                                    "frac": round(flops / (1e-3 * dom_ms) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                                    "note": "dense-formulation flops of the same sweeps (SURVEY 8d); NOT executed by this kernel"}}
+        if dom == "k_fam_terms" and con is not None and part is None:
+            ex = famt_executed_flops(symb, con[0], con[1], chunks)
+            extra["mfma"] = {"flops_per_launch": ex / dom_launches,
+                             "achieved_tflops": round(ex / (1e-3 * dom_ms) / 1e12, 2),
+                             "frac": round(ex / (1e-3 * dom_ms) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                             "note": "EXECUTED v_mfma_f64_16x16x4 x 2048 flop, counted on the host from the entries per (family, "
+                                     "constraint); equals SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 of the PMC pass"}
         if dom == "k_fam_terms":      # tables of the family (record of k_famt_prep) read once per workgroup instead of the constants
             alg = sum(8.0 * r * (panels + Upk[fam_mask & (fam == 2)].sum()) for r in chunks) + 8.0 * Bk[fam_mask].sum()
         note = ("bytes = the parents' output panels%s + the parents' packed updates + the members' constants (the children's "
                 "update matrices never exist); per_level_bytes = SURVEY 8d's per-level figure for the same sweeps; mfma = "
-                "canonical dense-formulation flops" % (" (the children's panels are not formed: their Gram block comes from "
+                "executed matrix-core flops, mfma_canonical = dense-formulation flops" % (" (the children's panels are not formed: their Gram block comes from "
                                                        "k_leaf_pairs in closed form)" if leaf_gram else " + the children's"))
     elif dom == "k_hess_up_fam":
         alg = sum(8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask & (fam == 2)].sum()) + Bk[fam_mask].sum()) for r in chunks)
@@ -206,13 +261,18 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the gfx950
         # guide prescribes), taken from the committed summary of the same command -- with its provenance, and dropped
         # when that summary does not list this kernel for this workload
+        # -- and only when the kernel sources are byte-identical to the ones the counters were collected on (csrc_sha256)
         traffic, source = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
             hits = [v for kname, v in tj.get("kernels", {}).items() if kname.split("<")[0] == dom.split("<")[0]]
             if tj.get("workload") == label and hits and world == 1:
-                traffic = max(v["hbm_bytes_per_launch"] for v in hits)
-                source = "profiles/r03_hbm_traffic.json@%s" % tj.get("git_sha", "?")
+                if tj.get("csrc_sha256") == csrc_sha256():
+                    traffic = max(v["hbm_bytes_per_launch"] for v in hits)
+                    source = "profiles/%s (rocprofv3 --pmc passes, csrc_sha256 %s = the running sources)" % (TRAFFIC_FILE, tj.get("csrc_sha256"))
+                else:
+                    source = "dropped: profiles/%s was collected on other kernel sources (csrc_sha256 %s, running %s)" % (
+                        TRAFFIC_FILE, tj.get("csrc_sha256"), csrc_sha256())
         except Exception:
             traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -220,6 +280,12 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
                     "bytes_per_launch": per_launch, "avg_launch_us": round(1e6 * avg_s, 2),
                     "launches_per_step": dom_launches}
         roofline.update(extra)
+        if "mfma" in roofline:     # the bound is derived, not asserted: arithmetic intensity of the executed work against the ridge
+            ai = roofline["mfma"]["flops_per_launch"] / per_launch
+            ridge = FP64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+            roofline["arithmetic_intensity_flop_per_byte"] = round(ai, 2)
+            roofline["ridge_flop_per_byte"] = round(ridge, 2)
+            roofline["bound"] = "hbm" if ai < ridge else "mfma"
         if note:
             roofline["note"] = note
         return roofline
@@ -247,7 +313,11 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
 
 
 def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
-    """One workload through the timed protocol; returns the result dict on rank 0 (None elsewhere)."""
+    """One workload through the timed protocol; returns the result dict on rank 0 (None elsewhere).
+    want_cpu: False / None = no CPU leg, "full" = the oracle on the whole unit, median of --cpu-repeats (headline), "quick" = one
+    repeat on the host BLAS with one Schur column per thread, scaled (the secondary legs: a few seconds each)."""
+    if want_cpu is True:
+        want_cpu = "full"
     import torch
     import torch.distributed as dist
     from smcp_amd import chordal, problems
@@ -276,14 +346,6 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
     # than n / 10 columns and is swept; the max-cut constraints are column-sparse
     kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs, tnzcols=0.0 if args.kktsolver == "qr" else None)
     placement = None
-    if getattr(args, "tune_placement", 0) > 0 and workload == "synth50k":      # (every rank of an N-rank job tunes its own buffers)
-        # csp_tune(CSP_TUNE_PLACEMENT), part of the (untimed) set-up like the symbolic analysis: the packed exchange buffer goes
-        # to the fastest of up to N fresh allocations for the store pattern of the family sweep (the
-        # same kernel takes 0.80 or 0.98 ms depending on where its two output buffers lie).  --tune-placement 0: as allocated.
-        chordal.tune(symb, chordal.TUNE_PLACEMENT, int(args.tune_placement))
-        rep = (ctypes.c_double * 2)()
-        lib.csp_tune_report(symb.handle, rep)
-        placement = {"tries": int(args.tune_placement), "probe_ms_before": round(rep[0], 4), "probe_ms_after": round(rep[1], 4)}
     part = None
     # max-cut: every constraint is column-sparse (SCMcolumn2 route) -- with N > 1 the factors are replicated (n = 1000: the
     # factorisation is not what costs) and the constraints sharded over the ranks (kkt_schur_gram_part), one all-reduce of H
@@ -353,9 +415,39 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_loop(nsteps):
+        """exactly nsteps steps between barrier + synchronize on both sides; the MAX over the ranks, seconds"""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     for _ in range(warmup):
         step()
     barrier()
+    value_as_allocated = None
+    if getattr(args, "tune_placement", 0) > 0 and workload == "synth50k" and primary:      # (every rank of an N-rank job tunes its own buffers)
+        # The same K steps on the buffers AS ALLOCATED first (what a caller who does not tune gets), then
+        # csp_tune(CSP_TUNE_PLACEMENT) -- untimed set-up like the symbolic analysis: the two output buffers of the family sweep go
+        # to the fastest of up to N fresh allocations for its store pattern (DESIGN.md section 4: the same kernel takes 0.74 or
+        # 0.93 ms depending on where they lie) -- and the measurement proper.  --tune-placement 0: as allocated only.
+        value_as_allocated = steps / timed_loop(steps)
+        if lazy:
+            chordal.check_status(symb)
+        chordal.tune(symb, chordal.TUNE_PLACEMENT, int(args.tune_placement))
+        rep = (ctypes.c_double * 2)()
+        lib.csp_tune_report(symb.handle, rep)
+        placement = {"tries": int(args.tune_placement), "probe_ms_before": round(rep[0], 4), "probe_ms_after": round(rep[1], 4)}
+        for _ in range(max(1, min(warmup, 2))):
+            step()
+        barrier()
     prof = not args.no_profile
     back_solve = None
     nk = int(lib.csp_profile_kinds())
@@ -383,15 +475,7 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         dom0 = max(calib, key=lambda k: calib[k][0])
         lib.csp_profile_filter(h, names.index(dom0))
         lib.csp_profile_read(h, None, None)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_loop(steps)
     ms_per_step = 1e3 * elapsed / steps
     if lazy:
         chordal.lazy_status(symb, False)
@@ -407,7 +491,8 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         breakdown.update(timed)
         dom = dom0
         dom_ms, dom_launches = breakdown[dom]
-        roofline = kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, j1 - j0, part, rank, world, label)
+        roofline = kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, j1 - j0, part, rank, world, label,
+                                   con=(cptr, cidx))
         if args.verbose and rank == 0:
             for k, (t, c) in sorted(breakdown.items(), key=lambda kv: -kv[1][0]):
                 print("  %-26s %9.3f ms/step  %5d launches" % (k, t, c), file=sys.stderr)
@@ -431,16 +516,46 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         back_solve = {"ms": round(bs_ms, 4), "per_s": round(1e3 / bs_ms, 2), "calls": nbs,
                       "what": "kkt_solve (solve_, solvers.py:506-541) on the factored system, right-hand sides reset per call"}
 
+    # ---------------- N > 1: the sharded step against the plain single-rank step on rank 0's device (untimed) --------
+    # y is replicated, x was left sharded: compared on the cliques rank 0 owns and the top
+    sharded_check = None
+    if (world > 1 or force_sharded) and part is not None and rank == 0 and primary and args.kktsolver == "chol" and not args.no_check:
+        try:
+            own = kkt._own_mask.bool().clone()
+            for a_, b_ in part.top_ranges:
+                own[a_:b_] = True
+            xs, ys = bx.blkval.clone(), by.clone()
+            single = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs)
+            L1 = S.copy()
+            chordal.cholesky(L1)
+            Y1 = L1.copy()
+            chordal.projected_inverse(Y1)
+            cx, cy = cspmatrix(symb, bx0.clone()), by0.clone()
+            single.factor(L1, Y1)(cx, cy, 1.0)
+            mskd = torch.from_numpy(msk).to(dev) & own
+            sharded_check = {"x_relerr_on_owned": float("%.2e" % float((xs - cx.blkval).abs()[mskd].max() / cx.blkval.abs()[mskd].max())),
+                             "y_relerr": float("%.2e" % float((ys - cy).abs().max() / cy.abs().max())),
+                             "what": "search direction of the last timed sharded step against the unsharded step on rank 0's device"}
+            del single, L1, Y1, cx, cy
+        except Exception as e:      # the check must not take the line down
+            sharded_check = {"error": repr(e)}
+
     # ---------------- CPU baseline: the oracle on a bounded sample (rank 0, N = 1 only) --------
     cpu = None
     # (the oracle leg times the reference's default kkt_chol path and needs the factored H: not run for --kktsolver qr)
+    if rank == 0 and world == 1 and want_cpu == "quick":
+        from oracle import oracle as orc
+        if not orc.use_blas(True):          # plain triple loops on fronts of 64 ... 4096 columns would take minutes: no quick leg
+            want_cpu = None
+        orc.use_blas(False)
     if rank == 0 and world == 1 and want_cpu and args.kktsolver == "chol":
         from oracle import oracle as orc
         So = orc.Sym(symb)
         K = orc.KKT(So, cptr, cidx, cval)
         Sh = S.blkval.cpu().numpy()
         nthr = max(1, min(args.cpu_threads, os.cpu_count() or 1, m))
-        ncols = min(max(args.cpu_cols, nthr), m)
+        quick = want_cpu == "quick"
+        ncols = min(max(args.cpu_cols if not quick else nthr, nthr), m)      # quick: one Schur column per thread, scaled to m
         Hfac = np.asfortranarray(np.tril(H.cpu().numpy().T))   # factored H from the GPU (to time solve_ and potrf)
         Hfull = Hfac @ Hfac.T
 
@@ -482,24 +597,30 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         def unit_seconds(t):
             return t[0] + t[1] * (m / ncols) + t[2] + t[3]
 
-        first = cpu_unit()                                             # plain loops: the parity checker
+        blas_desc = None
+        if quick:
+            blas_desc = orc.use_blas(True)                              # (the fronts of configs 2 and 3 are 64 ... 4096 columns wide)
+        first = cpu_unit()                                             # headline: plain loops, the parity checker
+        if quick and blas_desc:
+            orc.use_blas(False)
         xo, yo = first[4], first[5]
-        t_loops = unit_seconds(first)
+        t_loops = None if (quick and blas_desc) else unit_seconds(first)
         # the same run doubles as a full-size check of the GPU search direction
         ex = np.linalg.norm((bx.blkval.cpu().numpy() - xo)[msk]) / max(1e-300, np.linalg.norm(xo[msk]))
         ey = np.linalg.norm(by.cpu().numpy() - yo) / max(1e-300, np.linalg.norm(yo))
-        blas_desc = orc.use_blas(True)                                  # per-clique BLAS-3 on the host BLAS from dimension 32 on
         reps = [first]
-        if blas_desc:
-            reps = [cpu_unit() for _ in range(max(1, args.cpu_repeats))]
-            orc.use_blas(False)
+        if not quick:
+            blas_desc = orc.use_blas(True)                              # per-clique BLAS-3 on the host BLAS from dimension 32 on
+            if blas_desc:
+                reps = [cpu_unit() for _ in range(max(1, args.cpu_repeats))]
+                orc.use_blas(False)
         reps.sort(key=unit_seconds)
         med = reps[len(reps) // 2]                                      # the median repeat
         t_fact, t_cols, t_potrf, t_solve = med[:4]
         t_unit = unit_seconds(med)
         cpu = {"value": round(1.0 / t_unit, 5), "unit": "KKT solves/s", "cores": nthr, "threads": nthr, "host_cores": os.cpu_count(),
                "kind": "port", "repeats": len(reps), "value_min_max": [round(1.0 / unit_seconds(reps[-1]), 5), round(1.0 / unit_seconds(reps[0]), 5)],
-               "blas": blas_desc or "none (plain loops)", "value_plain_loops": round(1.0 / t_loops, 5),
+               "blas": blas_desc or "none (plain loops)", "value_plain_loops": round(1.0 / t_loops, 5) if t_loops else None,
                "sample": "median of %d repeats of: cholesky+projected_inverse (%.3fs, 1 thread: sequential over the cliques as CHOMPACK is) + "
                          "%d of %d Schur columns on %d thread(s) of the host's %d cores (%.3fs%s%s) + potrf(H) (%.4fs) + 1 solve_ (%.3fs, 1 thread); "
                          "oracle/chordal_oracle.c with per-clique dense operations of dimension >= 32 on %s"
@@ -507,11 +628,17 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
                             "; trsm x 2 + SCMcolumn2 per column, solvers.py:489-497" if scm else "", t_potrf,
                             t_solve, blas_desc or "plain loops")}
         cpu["gpu_vs_oracle_relerr"] = [float("%.2e" % ex), float("%.2e" % ey)]
+        if scm:
+            cpu["cores_note"] = ("one host thread: the reference's SCMcolumn2 route (solvers.py:489-497) is a sequential Python loop over "
+                                 "the columns, two supernodal triangular solves + one misc.SCMcolumn2 call each on n = 1000 -- BLAS-2 sized "
+                                 "work that a threaded BLAS does not speed up; the oracle restates that loop as it is")
 
     result = None
     if rank == 0:
         out = {
             "metric": "Newton KKT solves/sec", "value": round(steps / elapsed, 4), "unit": "KKT solves/s",
+            "value_tuned": round(steps / elapsed, 4) if value_as_allocated is not None else None,
+            "value_as_allocated": round(value_as_allocated, 4) if value_as_allocated is not None else round(steps / elapsed, 4),
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
@@ -521,8 +648,8 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
                                        ("subtree-sharded Gram + boundary exchange/%d" % world if part is not None
                                         else ("column-sparse constraints by rank (SCMcolumn2)/%d" % world if workload == "maxcut"
                                               else "schur-columns/%d" % world)))},
-            "roofline": roofline, "cpu_baseline": cpu, "back_solve": back_solve,
-            "symbolic_s": round(t_sym, 3),
+            "roofline": roofline, "cpu_baseline": cpu, "back_solve": back_solve, "sharded_vs_single": sharded_check,
+            "symbolic_s": round(t_sym, 3), "csrc_sha256": csrc_sha256(),
             # per-kernel HIP-event times: the dominant kernel from the timed steps, the others from the untimed
             # calibration pass that precedes them (events around every launch)
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
@@ -556,6 +683,7 @@ def main():
     ap.add_argument("--shard", default="subtree", choices=["subtree", "columns"],
                     help="N > 1: subtree sharding + boundary exchange (default) or column sharding of H")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="N > 1: skip the (untimed) comparison of the sharded step with the single-rank step")
     ap.add_argument("--no-back-solve", action="store_true", help="skip the solve_-only timing loop (kernel traces of exactly the timed steps)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the GPU-only figures of configs 2, 3 and 4 after the headline run")
     ap.add_argument("--cpu-repeats", type=int, default=3, help="repeats of the CPU baseline (the median is reported)")
@@ -614,15 +742,18 @@ def main():
     lib = _lib.lib()
 
     env = {"world": world, "rank": rank, "dev": dev, "lib": lib, "force_sharded": force_sharded}
-    out = run_workload(args, args.workload, args.steps, args.warmup, not args.no_cpu, True, env)
+    out = run_workload(args, args.workload, args.steps, args.warmup, None if args.no_cpu else "full", True, env)
     # BASELINE.json's other single-GPU configurations, GPU only: config 2 (one dense 4096 front), config 3 (block-arrow),
     # config 4 (max-cut, column-sparse constraints) -- a few steps each after the headline measurement
     if world == 1 and not force_sharded and args.workload == "synth50k" and not args.no_secondary and args.kktsolver == "chol":
         sec = {}
-        for name in ("dense4096", "arrow", "maxcut"):
+        for name in ("dense4096", "arrow", "maxcut", "synth50k_dense"):
             try:
-                r = run_workload(args, name, 3, 1, name == "maxcut" and not args.no_cpu, False, env)
-                sec[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "back_solve", "cpu_baseline")}
+                # ten timed steps after two warm-up steps each; the CPU leg beside every GPU figure: the oracle on the host BLAS, one
+                # Schur column per thread scaled to m (config 4: its sequential SCMcolumn2 route in full, median of three)
+                cpu_mode = None if args.no_cpu else ("full" if name == "maxcut" else "quick")
+                r = run_workload(args, name, 10, 2, cpu_mode, False, env)
+                sec[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "back_solve", "cpu_baseline")}
                 sec[name]["top_kernels_ms_per_step"] = dict(list(r["kernel_ms_per_step"].items())[:6])
             except Exception as e:      # a secondary workload must not take the headline line down
                 sec[name] = {"error": repr(e)}
@@ -630,6 +761,8 @@ def main():
             out["secondary"] = sec
     if rank == 0 and out is not None:
         print(json.dumps(out), file=real_stdout, flush=True)
+    if world > 1:
+        dist.barrier()          # rank 0 may still be in its untimed checks
     if world > 1 or force_sharded:
         dist.destroy_process_group()
 

@@ -172,7 +172,9 @@ int kkt_solve(csp_ctx* ctx, const double* L, const double* Y, const double* H, i
  * matrix is not positive definite (lapack.geqrf's ArithmeticError at solvers.py:425-428 has no counterpart: a
  * rank-deficient stack shows up here).  any m (factors wider than 320 columns are processed in panels of 256).
  * kkt_qr_solve is its solve_ closure (solvers.py:430-471): overwrites bx (blkval) with x and by (length m) with y;
- * valid until the next call that rewrites the stack (kkt_qr_factor, kkt_schur_*, kkt_solve, kkt_gram_*). */
+ * valid until the next call that rewrites the stack (kkt_qr_factor, kkt_schur_*, kkt_solve, kkt_gram_*).
+ * NOT sharded: Q lives on one device.  After csp_set_partition with more than one owning rank kkt_qr_factor returns
+ * SMCP_EINVAL (the multi-GPU step uses kkt_chol: kkt_gram_* / csp_*_part); a partition of one rank is accepted. */
 int kkt_qr_factor(csp_ctx* ctx, const double* L, const double* Y, int64_t* passes, double* shift, void* stream);
 int kkt_qr_solve(csp_ctx* ctx, const double* L, const double* Y, double kk, double* bx, double* by, void* stream);
 /* test hook: Rt_host (m*m doubles, host, optional) <- R^T (lower, column-major); G_dev (m*m doubles, device,

@@ -223,7 +223,7 @@ struct csp_ctx {
   // boundary exchange of the subtree partition: the subtree roots of all ranks (device: clique, owning rank, offset in
   // doubles per right-hand side inside the owner's region), what every rank contributes per right-hand side, the widest block
   int32_t* xr_roots = nullptr; int32_t* xr_owner = nullptr; int64_t* xr_bptr = nullptr;
-  int64_t xr_n = 0; int xr_me = -1; int64_t xr_npmax = 1;
+  int64_t xr_n = 0; int xr_me = -1; int xr_world = 0; int64_t xr_npmax = 1;
   std::vector<int64_t> xr_size;
   int64_t ntrial = 1;                   // copies of the pattern in S (csp_symbolic_replicate): one failure flag per copy
   // side streams for clique-local launches that do not depend on each other (Fork in capi.hip): created on first use

@@ -1226,7 +1226,7 @@ int csp_set_partition(csp_ctx* c, const int32_t* owner, int rank) {
       }
   for (void* p : {(void*)c->xr_roots, (void*)c->xr_owner, (void*)c->xr_bptr}) if (p) HIPCHK(hipFree(p));
   c->xr_roots = nullptr; c->xr_owner = nullptr; c->xr_bptr = nullptr;
-  c->xr_n = (int64_t)roots.size(); c->xr_me = rank;
+  c->xr_n = (int64_t)roots.size(); c->xr_me = rank; c->xr_world = world;
   if (int rc = dev_upload(&c->xr_roots, roots, c->D.bytes)) return rc;
   if (int rc = dev_upload(&c->xr_owner, own, c->D.bytes)) return rc;
   if (int rc = dev_upload(&c->xr_bptr, bptr, c->D.bytes)) return rc;

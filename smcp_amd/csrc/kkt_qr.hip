@@ -415,6 +415,9 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
   if (!m || use_generic(c)) return SMCP_EINVAL;
   if (D.ns) return SMCP_EINVAL;                 // every constraint must be swept (kkt_set_tnzcols(0) before the constraints)
   if (D.max_rhs < 1 || D.ustack_cols < m) return SMCP_EINVAL;
+  // one device holds the whole Q: under a subtree partition over more than one rank (csp_set_partition) this context's
+  // factors are valid on its own cliques and the top only, and there are no kkt_qr_*_part forms
+  if (c->xr_world > 1) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   D.qr_valid = false;
   if (int rc = qr_alloc(c)) return rc;

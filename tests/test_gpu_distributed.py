@@ -395,3 +395,27 @@ def test_sharded_step_synth50k_full_size(backend, world):
     for k in ("eH", "ex_sharded", "ex_full", "ey"):
         assert r[k] < 1e-10, (k, r)
     assert r["ncoll"] == 4 + r["chunks"] and r["ncoll"] <= 5 + r["chunks"], r
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """The code path the driver's scaling run takes -- `python bench.py --gpus N` starting its own ranks (self_launch) and the
+    N > 1 branch of the timed protocol -- with N = 2 ranks sharing the one GPU over gloo: one JSON line, n_gpus, the partition
+    named, and the sharded search direction equal to the single-rank one (bench.py's own untimed check)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMCP_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu",
+                        "--no-secondary", "--tune-placement", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "strong"
+    assert r["config"]["parallelism"].startswith("subtree-sharded Gram + boundary exchange/2"), r["config"]
+    assert r["value"] > 0 and abs(r["value"] * r["ms_per_step"] - 1e3) < 1.0
+    chk = r["sharded_vs_single"]
+    assert chk and "error" not in chk, chk
+    assert chk["x_relerr_on_owned"] < 1e-10 and chk["y_relerr"] < 1e-10, chk
