@@ -378,6 +378,7 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
     # failure reports deferred: the factorisations latch "not positive definite" on the device and the step reads the
     # latch once, at its end (chordal.lazy_status; SMCP_BENCH_EAGER=1: a read-back after every factorisation)
     lazy = os.environ.get("SMCP_BENCH_EAGER") != "1"
+    split_calls = os.environ.get("SMCP_BENCH_SPLIT") == "1"
     if lazy:
         chordal.lazy_status(symb, True)
 
@@ -398,17 +399,27 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
             kkt.factor(Ls, Ys, dist.group.WORLD)(bx, by, 1.0, complete=os.environ.get("SMCP_BENCH_COMPLETE_X") == "1")
             return
         L.blkval.copy_(S.blkval)
-        chordal.cholesky(L)                  # csp_cholesky
-        Y.blkval.copy_(L.blkval)
-        chordal.projected_inverse(Y)         # csp_projected_inverse (leaves the inverse-form factor of L for the sweeps)
+        if split_calls:                          # SMCP_BENCH_SPLIT=1: the reference's call sequence, one library call each
+            chordal.cholesky(L)                  # csp_cholesky
+            Y.blkval.copy_(L.blkval)
+            chordal.projected_inverse(Y)         # csp_projected_inverse (leaves the inverse-form factor of L for the sweeps)
+        else:
+            # the dual scaling point in one call (solvers.py:881-891): cholesky + projected_inverse + the separator factors
+            # the sweeps need, their independent stages side by side (csp_cholesky_projected_inverse)
+            chordal.cholesky_projected_inverse(L, Y)
         if args.kktsolver == "qr":
             kkt.factor_qr(L, Y, dist.group.WORLD if world > 1 else None)(bx, by, 1.0)
             return
-        # Schur complement: this rank's columns + one RCCL all-reduce (smcp_amd.kkt.ShardedSchur), then potrf
-        kkt.build_schur(L, Y, dist.group.WORLD if world > 1 else None)
-        kkt._potrf()
-        chk(lib.kkt_solve(h, L.blkval.data_ptr(), Y.blkval.data_ptr(), H.data_ptr(), m, 1.0,
-                          bx.blkval.data_ptr(), by.data_ptr(), st()), "solve")
+        if split_calls or world > 1:
+            # Schur complement: this rank's columns + one RCCL all-reduce (smcp_amd.kkt.ShardedSchur), then potrf
+            kkt.build_schur(L, Y, dist.group.WORLD if world > 1 else None)
+            kkt._potrf()
+            chk(lib.kkt_solve(h, L.blkval.data_ptr(), Y.blkval.data_ptr(), H.data_ptr(), m, 1.0,
+                              bx.blkval.data_ptr(), by.data_ptr(), st()), "solve")
+        else:
+            # f = kktsolver(L, Y); f(bx, by) (solvers.py:893, 506-541): kkt_schur_factor + kkt_solve -- with the status deferred
+            # potrf(H) runs beside the first Hessian sweep of solve_
+            kkt.factor(L, Y)(bx, by, 1.0)
 
     def barrier():
         if world > 1:

@@ -99,6 +99,14 @@ int csp_cholesky(csp_ctx* ctx, double* blkval, void* stream);
 int csp_llt(csp_ctx* ctx, double* blkval, void* stream);
 /* chompack.projected_inverse(L): L -> P_V((L L^T)^-1) (solvers.py:891,2361). */
 int csp_projected_inverse(csp_ctx* ctx, double* blkval, void* stream);
+/* The dual scaling point in one call (solvers.py:881-891: `L = S.copy(); cholesky(L); Y = projected_inverse(L)`, and
+ * 2341-2361 in the embedding driver): on entry L holds S, on return L = chol(S) and Y = P_V(S^-1) -- the results of
+ * csp_cholesky(L), a copy into Y and csp_projected_inverse(Y), status as csp_cholesky.  As ONE entry point the clique-local
+ * stages that need finished levels only (the inverse-form factor of the lower levels, the copy into Y, and with
+ * with_factors != 0 the Cholesky factors of the separator blocks Y_AA that the Hessian / Schur sweeps use next -- CHOMPACK's
+ * factored updates) run on side streams beside the few-workgroup chains of the top fronts instead of after them.  L and Y
+ * must be distinct blkval buffers. */
+int csp_cholesky_projected_inverse(csp_ctx* ctx, double* L, double* Y, int with_factors, void* stream);
 /* chompack.completion(X): X -> L with P_V((L L^T)^-1) = X (solvers.py:625,874,...). */
 int csp_completion(csp_ctx* ctx, double* blkval, void* stream);
 /* chompack.hessian(L, Y, U, adj, inv) (solvers.py:405,415,483,524,531,...): U holds nrhs

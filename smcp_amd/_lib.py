@@ -31,6 +31,7 @@ SIGNATURES = {
     "csp_cholesky": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "csp_llt": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "csp_projected_inverse": (ctypes.c_int, [c_vp, c_vp, c_vp]),
+    "csp_cholesky_projected_inverse": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp]),
     "csp_completion": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "csp_hessian": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_int, ctypes.c_int, c_vp]),
     "csp_trsm": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_int, c_vp]),

@@ -96,6 +96,21 @@ def projected_inverse(L):
         note_cache(L.symb, L)
 
 
+def cholesky_projected_inverse(L, Y, factors=True):
+    """The dual scaling point (solvers.py:881-891): L holds S on entry; on return L = cholesky(S) and Y = projected_inverse(L),
+    from ONE library call whose independent stages overlap (csp_cholesky_projected_inverse).  factors: also leave the
+    Cholesky factors of the separator blocks of Y behind (what hessian(adj=False / True) and the Schur sweeps use next)."""
+    _ensure(L.symb)
+    L.touched()
+    Y.touched()
+    try:
+        _chk(_lib.lib().csp_cholesky_projected_inverse(L.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), 1 if factors else 0,
+                                                       _stream()), "cholesky")
+    finally:
+        note_cache(L.symb, L)
+        note_cache(L.symb, Y)
+
+
 def completion(X):
     _ensure(X.symb)
     X.touched()

@@ -95,6 +95,14 @@ inline hipError_t end_call(csp_ctx* c) {
 // few hundred workgroups or of eight: one after the other they leave most of the chip idle.  Fork puts a branch on a
 // side stream that starts after everything already queued on the caller's stream and is joined back before anything
 // that follows (events only, no host synchronisation).  SMCP_FORK=0: everything on the caller's stream.
+// Events that only order streams of ONE device against each other: a device-scope release when they are recorded (the
+// default, a system-scope release with its cache write-back, showed as ~12 us of idle stream behind every record in the
+// rocprofv3 timeline of csp_cholesky_projected_inverse).  SMCP_EVENT_SYSFENCE=1: the default flags.
+inline unsigned sync_event_flags() {
+  static int sys = -1;
+  if (sys < 0) { const char* e = getenv("SMCP_EVENT_SYSFENCE"); sys = (e && e[0] == '1') ? 1 : 0; }
+  return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice);
+}
 struct Fork {
   csp_ctx* c; hipStream_t main; hipStream_t s; int which; bool on;
   static bool enabled() {
@@ -105,7 +113,7 @@ struct Fork {
   static bool trace_on_early() { const char* e = getenv("SMCP_TRACE"); return e && e[0] == '1'; }
   Fork(csp_ctx* c_, hipStream_t st, int which_) : c(c_), main(st), s(st), which(which_), on(false) {
     if (!enabled()) return;
-    if (!c->aux_fork && hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming) != hipSuccess) { c->aux_fork = nullptr; return; }
+    if (!c->aux_fork && hipEventCreateWithFlags(&c->aux_fork, sync_event_flags()) != hipSuccess) { c->aux_fork = nullptr; return; }
     if (!c->aux_stream[which]) {
       // side stream 0 carries the LONG POLE of every forked stage -- a handful of workgroups factoring or inverting the large
       // fronts beside launches of thousands of small-clique workgroups (k_mid_chol on the Y_AA blocks of the eight mid fronts
@@ -115,12 +123,18 @@ struct Fork {
       if (prio == -2) { const char* e = getenv("SMCP_AUX_PRIO"); prio = (e && e[0] == '0') ? 0 : 1; }
       int lo = 0, hi = 0;
       hipError_t rc = hipErrorUnknown;
+      // side stream 1 carries FILLER work (thousands of small-clique workgroups beside a chain on the caller's stream): lowest
+      // priority, so that it does not take the CUs a chain's few workgroups are waiting for (SMCP_AUX_PRIO1=0: default)
+      static int prio1 = -2;
+      if (prio1 == -2) { const char* e = getenv("SMCP_AUX_PRIO1"); prio1 = (e && e[0] == '0') ? 0 : 1; }
       if (which == 0 && prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
         rc = hipStreamCreateWithPriority(&c->aux_stream[which], hipStreamNonBlocking, hi);
+      if (which == 1 && prio1 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+        rc = hipStreamCreateWithPriority(&c->aux_stream[which], hipStreamNonBlocking, lo);
       if (rc != hipSuccess) rc = hipStreamCreateWithFlags(&c->aux_stream[which], hipStreamNonBlocking);
       if (rc != hipSuccess) { c->aux_stream[which] = nullptr; return; }
     }
-    if (!c->aux_join[which] && hipEventCreateWithFlags(&c->aux_join[which], hipEventDisableTiming) != hipSuccess) { c->aux_join[which] = nullptr; return; }
+    if (!c->aux_join[which] && hipEventCreateWithFlags(&c->aux_join[which], sync_event_flags()) != hipSuccess) { c->aux_join[which] = nullptr; return; }
     if (hipEventRecord(c->aux_fork, main) != hipSuccess) return;
     if (hipStreamWaitEvent(c->aux_stream[which], c->aux_fork, 0) != hipSuccess) return;
     s = c->aux_stream[which];
@@ -333,7 +347,8 @@ void gather_all(csp_ctx* c, const double* x, int64_t ldx, int nrhs, double* updb
   });
 }
 
-int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool need_inv = false);
+int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool need_inv = false, bool allow_partial = false);
+void complete_fac(csp_ctx* c, hipStream_t st);
 
 
 // ---- fast path (front_mfma.hip): per level, LDS-class cliques then HBM-class cliques ----------
@@ -434,6 +449,11 @@ static int fact_threads(const MfmaArgs& am, int thr, int kind) {
   if (!t[0]) {
     auto rd = [](const char* n, int d) { const char* e = getenv(n); int v = e ? atoi(e) : d; return (v >= 64 && v <= 1024 && !(v & 63)) ? v : d; };
     t[0] = rd("SMCP_FTHR_CHOL", 128); t[1] = rd("SMCP_FTHR_PINV", 256); t[2] = rd("SMCP_FTHR_YAA", 64);
+  }
+  if (kind == 2 && am.nnmax <= 16 && am.namax > 32 && am.namax <= 64) {      // Y_AA blocks of 33 .. 64 rows (the mid fronts of synth50k)
+    static int tm = 0;
+    if (!tm) { const char* e = getenv("SMCP_FTHR_YAA_MID"); tm = e ? atoi(e) : 256; if (tm < 64 || tm > 1024 || (tm & 63)) tm = 256; }
+    return tm;
   }
   return (am.nnmax <= 16 && am.namax <= 32) ? t[kind] : thr;
 }
@@ -1091,6 +1111,7 @@ bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_
     if (!c->launch_err) c->launch_err = -1;
     return true;
   }
+  if (a.ysc == c->D.fac) complete_fac(c, st);      // k_hess_up_fam scales the children's panels by their own factors
   return a.kc_ptr ? try_fam_sp<true>(c, a, cnt, nrhs, U, ldu, st) : try_fam_sp<false>(c, a, cnt, nrhs, U, ldu, st);
 }
 
@@ -1382,10 +1403,23 @@ inline hipError_t zero_flag(csp_ctx* c, hipStream_t st) {
 }
 // yaa <- separator blocks of Y; fac <- their Cholesky factors (need_fac); faci <- inverses of those (need_inv).
 // Each stage is skipped when the cache already holds it for the matrix at this address (see invalidate_tags).
-int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool need_inv) {
+// chol(Y_AA) of the family children that csp_cholesky_projected_inverse left out (DeviceCtx::fac_partial)
+void complete_fac(csp_ctx* c, hipStream_t st) {
+  if (!c->D.fac_partial) return;
+  c->D.fac_partial = false;
+  MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+  for_level_classes(c, 0, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
+    if (!lds || !am.namax || am.nS <= 0) return;
+    am.t.lev = am.t.lev + (cnt - am.nS);
+    const size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
+    launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(am.nS), dim3(fact_threads(am, 256, 2)), bytes, st, am, (const double*)c->D.yaa, c->D.fac);
+  });
+}
+int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool need_inv, bool allow_partial) {
   TreeArgs a = tree_args(c);
   const bool nocache = cache_off();
   if (need_inv) need_fac = true;
+  if (need_fac && !allow_partial && c->D.fac_partial && c->D.fac_tag == Y && Y && !nocache) complete_fac(c, st);
   if (nocache || c->D.yaa_tag != Y || !Y) {
     gather_all(c, Y, 0, 1, c->D.yaa, st);
     c->D.yaa_tag = Y;
@@ -1422,6 +1456,7 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
       launch(c, KID_factor_yaa, k_factor_yaa, dim3((int)c->S.nsn), dim3(NT), st, a, c->D.yaa, c->D.fac);
     }
     c->D.fac_tag = Y;
+    c->D.fac_partial = false;
     c->D.faci_tag = nullptr;
     c->D.fac_gen++;
   }
@@ -1758,9 +1793,13 @@ int csp_lazy_status(csp_ctx* c, int on) {
   c->lazy_status = on != 0;
   return 0;
 }
+static int flush_pending_potrf(csp_ctx* c, hipStream_t st, const void* only, bool drop);      // kkt.hip
 int csp_status(csp_ctx* c, void* stream) {
   if (int rc = ready(c)) return rc;
   hipStream_t st = (hipStream_t)stream;
+  // a Schur complement that kkt_schur_factor left unfactored (deferred status) and nobody has used yet: its verdict belongs
+  // to this read-out
+  if (int rc = flush_pending_potrf(c, st, nullptr, false)) return rc < 0 ? rc : rc;
   int v = 0;
   HIPCHK(hipMemcpyAsync(c->D.info_host + 16, c->D.info + 16, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -2199,6 +2238,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_mfma<true, WK_DOWN0>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_chol_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      HIPCHK(hipFuncSetAttribute((const void*)k_chol_mfma<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_pinv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_down_inv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       HIPCHK(hipFuncSetAttribute((const void*)k_hess_up_inv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
@@ -2258,9 +2298,9 @@ static int cholesky_impl(csp_ctx* c, double* x, void* stream, int set) {
     for (int64_t l = 0; l < c->S.nlev; ++l)
       for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
         if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(fact_threads(am, thr, 0)),
-                            (size_t)mfma_lds_doubles_for(WK_CHOL, am.nnmax, am.namax) * sizeof(double), st, am, x);   // compact layout: front + update only
+                            (size_t)mfma_lds_doubles_for(WK_CHOL, am.nnmax, am.namax) * sizeof(double), st, am, x, (double*)nullptr);   // compact layout: front + update only
         else if (use_large() && c->D.gp_tptr) lf_chol(c, am, cnt, x, st);
-        else launch_lds(c, KID_chol_mfma_hbm, k_chol_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x);
+        else launch_lds(c, KID_chol_mfma_hbm, k_chol_mfma<false>, dim3(cnt), dim3(thr), 0, st, am, x, (double*)nullptr);
       }, set);
   } else
   for_levels_up(c, [&](const int32_t* lev, int cnt) {
@@ -2347,6 +2387,165 @@ static int projected_inverse_impl(csp_ctx* c, double* x, void* stream, int set) 
   });
   HIPCHK(end_call(c));
   return 0;
+}
+
+// ---- the dual scaling point in one call (solvers.py:881-891: L = cholesky(S); Y = projected_inverse(L)) ---------------
+// The two calls always come as a pair, and as separate entry points they are one dependent chain of ~35 launches, most of
+// them a handful of workgroups: the blocked factorisations and inversions of the top fronts.  In one entry point the
+// clique-local stages that only need FINISHED levels run on side streams beside those chains:
+//   * the inverse-form factor [Li; K] of every level below the last is prepared while the levels above are still being
+//     factored (k_prep_lk of the small cliques and lf_prep of each large level beside the top fronts' Cholesky),
+//   * Y <- L for everything below the last level is copied there too (the tail after the last level),
+//   * with SCALING_FAC: chol(Y_AA) of level l (k_mid_chol / k_factor_yaa_lds, what the Schur sweeps need next:
+//     CHOMPACK's factored updates) starts as soon as the root->leaves pass has left level l and runs beside the levels below.
+// Results and cache tags are those of csp_cholesky(L); copy; csp_projected_inverse(Y) [; prepare_yaa(Y, fac)].
+constexpr int SCALING_FAC = 1;
+static bool leafgram_ok(csp_ctx* c, int64_t mcols);      // kkt.hip
+static bool scaling_overlap_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMCP_SCALING_OVERLAP"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
+static int scaling_impl(csp_ctx* c, double* L, double* Y, int flags, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  const Symbolic& S = c->S;
+  const int64_t bl = S.blklen();
+  // first level from which on there are no LDS-class cliques any more (the side work starts there) and the blkval offset
+  // where the last level begins -- cliques are numbered in postorder, so normally the last level is the tail of blkval; when
+  // a clique of a lower level lies behind it the whole copy waits for the factorisation (tail0 = 0).  Computed once.
+  if (c->scal_lstar < 0) {
+    int64_t ls = S.nlev;
+    while (ls > 0 && c->lvl[(size_t)ls - 1].nI == 0) --ls;
+    c->scal_lstar = ls;
+    std::vector<int> lev_of((size_t)S.nsn, 0);
+    for (int64_t l = 0; l < S.nlev; ++l)
+      for (int64_t q = S.levptr[l]; q < S.levptr[l + 1]; ++q) lev_of[(size_t)S.levidx[q]] = (int)l;
+    int64_t t0 = bl;
+    for (int64_t k = 0; k < S.nsn; ++k) if (lev_of[(size_t)k] == S.nlev - 1) t0 = std::min<int64_t>(t0, S.blkptr[k]);
+    for (int64_t k = 0; k < S.nsn; ++k) if (S.blkptr[k] >= t0 && lev_of[(size_t)k] != S.nlev - 1) { t0 = 0; break; }
+    c->scal_tail0 = t0;
+  }
+  const int64_t lstar = c->scal_lstar;
+  const bool fast = !use_generic(c) && use_large() && D.gp_tptr && !cache_off() && Fork::enabled() && scaling_overlap_on() &&
+                    c->ntrial == 1 && lstar < S.nlev && (lstar > 0 || D.nI_total == 0) && D.yaa && S.updlen() > 0 && !c->verify_cache;
+  if (!fast) {      // the three steps one after the other (any tree, any switch)
+    if (int rc = cholesky_impl(c, L, (void*)st, 0)) return rc;
+    HIPCHK(hipMemcpyAsync(Y, L, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
+    if (int rc = projected_inverse_impl(c, Y, (void*)st, 0)) return rc;
+    c->D.lk_tag_L = L;                      // L itself is intact: LK is its inverse form as well as the pair's
+    if (flags & SCALING_FAC) { if (int rc = prepare_yaa(c, Y, true, st)) return rc; HIPCHK(end_call(c)); }
+    return 0;
+  }
+  invalidate_tags(c, L);
+  invalidate_tags(c, Y);
+  HIPCHK(zero_flag(c, st));
+  const int64_t last = S.nlev - 1;
+  const int64_t tail0 = c->scal_tail0;
+  MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+  a0.LK = nullptr;
+  TreeArgs t = tree_args(c);
+  // small cliques whose supernodes have at most 16 columns leave their inverse-form factor behind as they are factored
+  // (k_chol_mfma<true, true>); only when some LDS class is wider does k_prep_lk run, on the side stream (SMCP_CHOL_PREP=0: always)
+  int nnI = 0;
+  for (const LevelClass& Lc : c->lvl) if (Lc.nI) nnI = std::max(nnI, (int)Lc.nnmaxI);
+  static int cprep = -1;
+  if (cprep < 0) { const char* e = getenv("SMCP_CHOL_PREP"); cprep = (e && e[0] == '0') ? 0 : 1; }
+  const bool fuse_prep = cprep && nnI <= 16;
+  auto chol_level = [&](int64_t l) {
+    for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
+      (void)bytes;
+      const size_t lb = (size_t)mfma_lds_doubles_for(WK_CHOL, am.nnmax, am.namax) * sizeof(double);
+      if (lds && fuse_prep) launch_lds(c, KID_chol_mfma, k_chol_mfma<true, true>, dim3(cnt), dim3(fact_threads(am, thr, 0)), lb, st, am, L, D.lk);
+      else if (lds) launch_lds(c, KID_chol_mfma, k_chol_mfma<true>, dim3(cnt), dim3(fact_threads(am, thr, 0)), lb, st, am, L, (double*)nullptr);
+      else lf_chol(c, am, cnt, L, st);
+    });
+  };
+  // ---- 1. cholesky, leaves -> root.  Every cross-stream dependency costs ~10 us of idle stream on this stack (rocprofv3
+  // timeline: a gap behind each hipEventRecord / hipStreamWaitEvent), so there are exactly two hand-overs to ONE side stream:
+  // before the LAST level's chain (one workgroup for 110 us on synth50k) the side stream takes the inverse-form factor of
+  // everything below it and the head of the copy into Y; after the root->leaves pass has left the large-only levels it
+  // takes the Cholesky factors of their separator blocks.  The side work is queued AFTER the chain it runs beside, so that
+  // the chain's few workgroups are dispatched first.
+  for (int64_t l = 0; l < last; ++l) chol_level(l);
+  std::unique_ptr<Fork> f0;
+  if (last > 0) f0.reset(new Fork(c, st, 1));      // (the mark: the filler stream starts behind levels 0 .. last - 1)
+  hipStream_t s0 = f0 ? f0->s : st;
+  chol_level(last);
+  if (D.nI_total && !fuse_prep) {
+    TreeArgs ts = t;
+    ts.lev = D.lev3idx;
+    launch_lds(c, KID_prep_lk, k_prep_lk, dim3((int)D.nI_total), dim3(prep_lk_threads(nnI)), prep_lk_lds_bytes(nnI), s0, ts, (const double*)L, D.lk);
+  }
+  for (int64_t ll = 0; ll < last; ++ll)
+    for_level_classes(c, ll, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) { if (!lds) lf_prep(c, am, cnt, L, s0); });
+  if (tail0 > 0) (void)hipMemcpyAsync(Y, L, sizeof(double) * tail0, hipMemcpyDeviceToDevice, s0);
+  // ---- 2. the last level's inverse form and the tail of Y on the caller's stream, then the side branch is joined
+  for_level_classes(c, last, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) { if (!lds) lf_prep(c, am, cnt, L, st); });
+  (void)hipMemcpyAsync(Y + tail0, L + tail0, sizeof(double) * (bl - tail0), hipMemcpyDeviceToDevice, st);
+  if (f0) f0->join();
+  D.lk_gen++;
+  D.part_valid = false;
+  // ---- 3. projected inverse, root -> leaves, the separator blocks kept in yaa; chol(Y_AA) of a level beside the levels below
+  MfmaArgs ap = mfma_args(c, nullptr, 0, 1);
+  ap.t.upd = D.yaa;
+  MfmaArgs af = mfma_args(c, nullptr, 0, 1);
+  const bool want_fac = (flags & SCALING_FAC) != 0;
+  // the family children's factors are read by nobody when their block of the Schur complement comes from k_leaf_pairs (the
+  // decision kkt_schur_* will take for the constraints now set): left out, complete_fac supplies them to whoever asks
+  static int skipenv = -1;
+  if (skipenv < 0) { const char* e = getenv("SMCP_FAC_PARTIAL"); skipenv = (e && e[0] == '0') ? 0 : 1; }
+  const bool skip_children = want_fac && skipenv && D.m > 0 && !D.ns && leafgram_ok(c, D.m) && c->leafgram_policy != 0;
+  bool skipped = false;
+  auto factor_level = [&](int64_t l, hipStream_t lds_stream, hipStream_t large_stream) {
+    for_level_classes(c, l, af, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
+      if (!am.namax) return;
+      if (lds) {
+        if (l == 0 && skip_children && am.nS > 0) { cnt -= am.nS; skipped = true; if (!cnt) return; }
+        const size_t bytes = ((size_t)padld(am.namax) * am.namax + 256 + 8) * sizeof(double);
+        launch_lds(c, KID_factor_yaa_lds, k_factor_yaa_lds, dim3(cnt), dim3(fact_threads(am, 256, 2)), bytes, lds_stream, am, (const double*)D.yaa, D.fac);
+      } else {
+        launch(c, KID_axpby, k_copy_upd_blocks, dim3(cnt, umax1(std::min(64, (am.namax * am.namax + 1023) / 1024))), dim3(256), large_stream,
+               am.t, (const double*)D.yaa, D.fac);
+        lf_factor_yaa(c, am, cnt, D.fac, large_stream);
+      }
+    });
+  };
+  auto pinv_level = [&](int64_t l) {
+    for_level_classes(c, l, ap, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
+      (void)bytes;
+      if (lds) launch_lds(c, KID_pinv_mfma, k_pinv_mfma<true>, dim3(cnt), dim3(fact_threads(am, thr, 1)),
+                          (size_t)mfma_lds_doubles_for(WK_PINV, am.nnmax, am.namax) * sizeof(double), st, am, Y);
+      else lf_pinv(c, am, cnt, Y, st);
+    });
+  };
+  // root -> leaves through the large-only levels (lstar .. last); their Y_AA blocks are then all in yaa and their factors go
+  // to the side stream (second hand-over) while the pass goes on through the levels with small cliques; the small cliques'
+  // own factors follow on the caller's stream (clique-local launches of thousands of workgroups: nothing left to hide behind)
+  for (int64_t l = last; l >= lstar; --l) pinv_level(l);
+  bool any_large_sep = false;
+  for (int64_t l = lstar; l <= last; ++l) if (c->lvl[(size_t)l].nII && c->lvl[(size_t)l].namaxII > 0) any_large_sep = true;
+  std::unique_ptr<Fork> f1;
+  if (want_fac && any_large_sep && lstar > 0) f1.reset(new Fork(c, st, 0));
+  hipStream_t s1 = f1 ? f1->s : st;
+  for (int64_t l = lstar - 1; l >= 0; --l) pinv_level(l);
+  if (want_fac) {
+    for (int64_t l = last; l >= lstar; --l) factor_level(l, s1, s1);
+    for (int64_t l = lstar - 1; l >= 0; --l) factor_level(l, st, st);
+  }
+  if (f1) f1->join();
+  D.lk_tag_L = L; D.lk_tag_Y = Y;
+  D.yaa_tag = Y;
+  D.fac_tag = want_fac ? Y : nullptr;
+  D.fac_partial = want_fac && skipped;
+  D.faci_tag = nullptr;
+  if (want_fac) D.fac_gen++;
+  HIPCHK(end_call(c));
+  return fetch_info(c, st);
+}
+int csp_cholesky_projected_inverse(csp_ctx* c, double* L, double* Y, int with_factors, void* stream) {
+  if (int rc = ready(c)) return rc;
+  if (!L || !Y || L == Y) return SMCP_EINVAL;
+  return scaling_impl(c, L, Y, with_factors ? SCALING_FAC : 0, (hipStream_t)stream);
 }
 
 int csp_completion(csp_ctx* c, double* x, void* stream) {

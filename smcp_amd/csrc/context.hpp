@@ -48,6 +48,8 @@ struct DeviceCtx {
   const void* lk_tag_Y = nullptr;   // ... or from the factor whose projected inverse now lives here
   const void* yaa_tag = nullptr;    // yaa holds the separator blocks of the matrix at this address
   const void* fac_tag = nullptr;    // fac = chol(yaa) of the matrix at this address
+  bool fac_partial = false;         // ... except for the family children (childless small cliques whose Gram block comes from
+                                    // k_leaf_pairs: nothing reads their factors on that route); complete_fac fills them in
   const void* faci_tag = nullptr;   // faci = fac^-1 of the matrix at this address
   double* lfd = nullptr;      // 64 x 64 doubles per large front: inverse of the current diagonal block
   int32_t* lev3idx = nullptr; // all LDS-class cliques (any level), then all large fronts: lists for clique-local kernels
@@ -108,6 +110,7 @@ struct DeviceCtx {
   double* hinv = nullptr;    // nblocks * 4096 + 2 n doubles (the tail holds the two work vectors of the solve)
   int64_t hinv_cap = 0, hinv_n = 0;
   const void* hinv_tag = nullptr;   // the factor these inverses belong to
+  double* h_pending = nullptr; int64_t h_pending_n = 0, h_pending_ld = 0;   // a Schur complement left unfactored by kkt_schur_factor (deferred status)
   double* sw = nullptr;      // blklen : sqrt of the inner-product weights (Gram path)
   double* gpart = nullptr;   // partial Gram tiles
   int64_t gpart_len = 0;
@@ -229,6 +232,7 @@ struct csp_ctx {
   // side streams for clique-local launches that do not depend on each other (Fork in capi.hip): created on first use
   hipStream_t aux_stream[2] = {nullptr, nullptr};
   hipEvent_t aux_fork = nullptr, aux_join[2] = {nullptr, nullptr};
+  int64_t scal_lstar = -1, scal_tail0 = 0;              // scaling_impl: first level without small cliques, start of the last level in blkval
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status
   double placement_probe[2] = {0.0, 0.0};   // CSP_TUNE_PLACEMENT: probe time before / after, ms
   bool flags_clean = false;             // lazy mode: the last thing done to the flags was k_latch_status (which leaves them zero)

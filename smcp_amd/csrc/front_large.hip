@@ -1111,12 +1111,90 @@ namespace smcp {
 constexpr int LB = 64;          // block-column width
 constexpr int LBD = LB + 1;     // LDS leading dimension of the diagonal block
 
+// one 16 x 16 output tile by the CALLING WAVE: store(m, n, sum_k A(m, k) B(k, n)), m, n < 16, k < Kd (a multiple of 4)
+template <class FA, class FB, class FC>
+__device__ inline void wave_tile16(int Kd, FA A, FB B, FC store) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < Kd; k0 += 8) {
+    const double a0 = A(l15, k0 + kq), b0 = B(k0 + kq, l15);
+    const bool two = k0 + 4 < Kd;
+    const double a1 = two ? A(l15, k0 + 4 + kq) : 0.0, b1 = two ? B(k0 + 4 + kq, l15) : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc, 0, 0, 0);
+    if (two) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) store(l15, kq + 4 * r, acc[r]);
+}
+// Inverse of a w x w (w <= 64) lower triangular block D in LDS (ld LBD; entries above the diagonal zero) -> Di (ld LBD, zeroed
+// by the caller).  The four 16 x 16 diagonal blocks are inverted side by side, one wave each; the rest by recursive doubling,
+// inv([A 0; B C]) = [Ai 0; -Ci B Ai, Ci]: at block size 16 the two pairs on two waves (the intermediate B Ai stays inside the
+// wave), at block size 32 the four tiles of each product on four waves.  Four workgroup barriers in all, where the
+// block-row scheme of potrf_inv64 runs four one-wave inversions and six tile products one after the other (k_lf_diag_inv on
+// the root of synth50k: 36 us on the critical path of every factorisation).  s16: 1024 doubles of scratch.  Needs >= 4 waves.
+__device__ inline void tri_inv64_rd(double* D, int w, double* Di, double* s16) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int e = tid; e < LB * LB; e += blockDim.x) {          // identity-free padding: rows / columns beyond w read as zero
+    const int i = e % LB, j = e / LB;
+    if (i >= w || j >= w) D[i + j * LBD] = 0.0;
+  }
+  __syncthreads();
+  if (wave < 4 && 16 * wave < w) {                           // diagonal block `wave`
+    const int b0 = 16 * wave, bw = min(16, w - b0);
+    const double* Db = D + b0 + b0 * LBD;
+    double a[16], x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = (lane < bw && j <= lane) ? Db[lane + j * LBD] : ((lane == j && lane < 16) ? 1.0 : 0.0);
+    wave_tri_inv16(a, x, lane);
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) if (lane < bw && j < bw) Di[(b0 + j) + (b0 + lane) * LBD] = x[j];
+    }
+  }
+  __syncthreads();
+  if (wave < 2 && 32 * wave + 16 < w) {                      // pairs (0, 1) and (2, 3) at block size 16
+    const int r0 = 32 * wave;
+    const double* Bm = D + (r0 + 16) + r0 * LBD;
+    const double* Ai = Di + r0 + r0 * LBD;
+    const double* Ci = Di + (r0 + 16) + (r0 + 16) * LBD;
+    double* W = s16 + 256 * wave;
+    wave_tile16(16, [=](int m, int k) { return Bm[m + k * LBD]; }, [=](int k, int n) { return Ai[k + n * LBD]; },
+                [=](int m, int n, double v) { W[m + n * 16] = v; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double* X = Di + (r0 + 16) + r0 * LBD;
+    wave_tile16(16, [=](int m, int k) { return Ci[m + k * LBD]; }, [=](int k, int n) { return W[k + n * 16]; },
+                [=](int m, int n, double v) { X[m + n * LBD] = -v; });
+  }
+  __syncthreads();
+  if (w > 32) {                                              // the pair of 32 x 32 blocks
+    const double* Bm = D + 32;
+    double* W = s16;                                         // 32 x 32, ld 32
+    if (wave < 4) {
+      const int tm = 16 * (wave & 1), tn = 16 * (wave >> 1);
+      wave_tile16(32, [=](int m, int k) { return Bm[(tm + m) + k * LBD]; }, [=](int k, int n) { return Di[k + (tn + n) * LBD]; },
+                  [=](int m, int n, double v) { W[(tm + m) + (tn + n) * 32] = v; });
+    }
+    __syncthreads();
+    if (wave < 4) {
+      const int tm = 16 * (wave & 1), tn = 16 * (wave >> 1);
+      const double* Ci = Di + 32 + 32 * LBD;
+      double* X = Di + 32;
+      wave_tile16(32, [=](int m, int k) { return Ci[(tm + m) + k * LBD]; }, [=](int k, int n) { return W[k + (tn + n) * 32]; },
+                  [=](int m, int n, double v) { X[(tm + m) + (tn + n) * LBD] = -v; });
+    }
+  }
+  __syncthreads();
+}
+
 // In-LDS Cholesky (do_potrf) and inverse of a w x w (w <= 64) lower block D (ld LBD); the inverse goes
 // to Di (ld LBD, zeros above the diagonal).  d16: 256 doubles, s16: 16 x 64 doubles of scratch.
 // Returns 0 or the 1-based failing pivot (uniform).
 __device__ inline int potrf_inv64(double* D, int w, double* Di, double* d16, double* s16, bool do_potrf) {
   for (int e = threadIdx.x; e < LB * LBD; e += blockDim.x) Di[e] = 0.0;
   __syncthreads();
+#ifndef SMCP_TRINV_ROWS
+  if (!do_potrf && blockDim.x >= 256) { tri_inv64_rd(D, w, Di, s16); return 0; }
+#endif
   for (int jb = 0; jb < w; jb += 16) {
     const int bw = min(16, w - jb);
     if (do_potrf) {

@@ -698,8 +698,11 @@ __global__ void k_hess_down_mfma(MfmaArgs a, double* u, int64_t ldu) {
 }
 
 // ------------------------------------------------------------------ Cholesky
-template <bool LDS>
-__global__ void k_chol_mfma(MfmaArgs a, double* x) {
+// PREP (supernodes of at most 16 columns, LDS class): the inverse-form factor [Li; K] of the clique goes to lkout as well -- Li is
+// the inverse of the single diagonal block, which potrf_inv16 has just left in D16, and K = L_AN Li is one small product on
+// the front still in LDS: what k_prep_lk would read back from HBM in a launch of its own
+template <bool LDS, bool PREP = false>
+__global__ void k_chol_mfma(MfmaArgs a, double* x, double* lkout) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int k = a.t.lev[blockIdx.x];
   if (*info_of(a.t, k)) return;
@@ -751,6 +754,21 @@ __global__ void k_chol_mfma(MfmaArgs a, double* x) {
            [=](int m, int n, double acc) { if (m >= n) v.U[m + n * v.ldu] -= acc; }, true);
   }
   __syncthreads();
+  if (LDS && PREP) {
+    double* Li = lkout + d.blk;
+    const double* Dv = v.D16;
+    for (int e = threadIdx.x; e < nn * nn; e += blockDim.x) {
+      int i = e % nn, j = e / nn;
+      Li[i + (int64_t)j * nf] = (i >= j) ? Dv[i + j * 16] : 0.0;
+    }
+    if (na) {
+      const double* La = v.F + nn;
+      double* Kk = Li + nn;
+      wg_mma(na, nn, nn, [=](int m, int kk) { return La[m + kk * v.ldf]; },
+             [=](int kk, int n) { return kk >= n ? Dv[kk + n * 16] : 0.0; },
+             [=](int m, int n, double acc) { Kk[m + (int64_t)n * nf] = acc; });
+    }
+  }
   if (LDS) {
     for (int e = threadIdx.x; e < nf * nn; e += blockDim.x) {
       int i = e % nf, j = e / nf;

@@ -289,6 +289,91 @@ __global__ void __launch_bounds__(256) k_dense_trsv_step(const double* A, int n,
   }
 }
 
+// A x = b with the Cholesky factor A (lower, n x n, 128 < n <= 1024), ONE right-hand side, in ONE launch of one workgroup:
+// the step kernel above is 2 ceil(n / 64) dependent launches of ~21 us (m = 1000, config 4: 32 launches, 0.76 ms per solve_ for
+// 8 MB of factor).  Here the chain is 2 ceil(n / 16) steps of one 16-wide substitution by wavefront 0 (wave_trsv16 on the
+// diagonal blocks, all of them staged in LDS up front: the same arithmetic, so the same backward-stable solve) followed by
+// the update of the other rows, one thread per row, whose sixteen factor entries were fetched a step ahead: the factor is
+// static, so its stream never waits for the chain.  x lives in LDS; barriers wait for LDS traffic only.
+constexpr int POTRS1_MAXN = 1024;
+__host__ __device__ inline size_t potrs_one_lds(int n) { return ((size_t)((n + 15) & ~15) * 17 + 16) * sizeof(double); }
+__global__ void __launch_bounds__(1024) k_dense_potrs_one(const double* A, int n, int64_t lda, double* b) {
+  extern __shared__ __attribute__((aligned(16))) double sm1[];
+  const int tid = threadIdx.x, npad = (n + 15) & ~15, nblk = npad >> 4;
+  double* const x = sm1;
+  double* const t = sm1 + npad;              // 16
+  double* const dg = t + 16;                 // nblk x 256: the diagonal 16 x 16 blocks (ld 16), identity beyond n
+  for (int e = tid; e < nblk * 256; e += 1024) {
+    const int blk = e >> 8, r = e & 15, cc = (e >> 4) & 15, i = 16 * blk + r, j = 16 * blk + cc;
+    dg[e] = (i < n && j < n && i >= j) ? A[i + (int64_t)j * lda] : (r == cc ? 1.0 : 0.0);
+  }
+  for (int e = tid; e < npad; e += 1024) x[e] = e < n ? b[e] : 0.0;
+  const int i = tid;                         // this thread's row (forward) / column (backward)
+  double va[16], vb[16];
+  // ---- L y = b
+  auto fetch_f = [&](int jb, double (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (i < n && i >= jb + 16 && jb + j < n) ? A[i + (int64_t)(jb + j) * lda] : 0.0;
+  };
+  auto step_f = [&](int blk, const double (&cur)[16]) {
+    const int jb = 16 * blk;
+    if (tid < 64) {
+      const double v = wave_trsv16(dg + 256 * blk, 16, 0, 16, tid < 16 ? x[jb + tid] : 0.0, 0);
+      if (tid < 16) t[tid] = v;
+    }
+    lds_barrier();
+    if (tid < 16) x[jb + tid] = t[tid];
+    if (i >= jb + 16 && i < n) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc += cur[j] * t[j];
+      x[i] -= acc;
+    }
+    lds_barrier();
+  };
+  fetch_f(0, va);
+  __syncthreads();
+  for (int blk = 0; blk < nblk; blk += 2) {
+    if (blk + 1 < nblk) fetch_f(16 * (blk + 1), vb);
+    step_f(blk, va);
+    if (blk + 1 < nblk) {
+      if (blk + 2 < nblk) fetch_f(16 * (blk + 2), va);
+      step_f(blk + 1, vb);
+    }
+  }
+  // ---- L^T x = y
+  auto fetch_b = [&](int jb, double (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (i < jb && jb + j < n) ? A[(jb + j) + (int64_t)i * lda] : 0.0;
+  };
+  auto step_b = [&](int blk, const double (&cur)[16]) {
+    const int jb = 16 * blk;
+    if (tid < 64) {
+      const double v = wave_trsv16(dg + 256 * blk, 16, 0, 16, tid < 16 ? x[jb + tid] : 0.0, 1);
+      if (tid < 16) t[tid] = v;
+    }
+    lds_barrier();
+    if (tid < 16) x[jb + tid] = t[tid];
+    if (i < jb) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc += cur[j] * t[j];
+      x[i] -= acc;
+    }
+    lds_barrier();
+  };
+  fetch_b(16 * (nblk - 1), va);
+  for (int blk = nblk - 1; blk >= 0; blk -= 2) {
+    if (blk >= 1) fetch_b(16 * (blk - 1), vb);
+    step_b(blk, va);
+    if (blk >= 1) {
+      if (blk >= 2) fetch_b(16 * (blk - 2), va);
+      step_b(blk - 1, vb);
+    }
+  }
+  if (tid < n) b[tid] = x[tid];
+}
+
 // y = a*y + x (length m), small
 __global__ void k_vec_axpby(int64_t m, double a, const double* x, double b, double* y) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -614,19 +699,18 @@ int kkt_aadj(csp_ctx* c, const double* y, double* X, void* stream) {
   return 0;
 }
 
-int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
-  if (int rc = ready(c)) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  HIPCHK(hipMemsetAsync(c->D.info, 0, sizeof(int), st));
+// launches of the dense Cholesky of A (no status read-back); info: the failure flag the kernels set (the context's flag, or
+// a slot of its own when the factorisation runs on a side stream beside kernels that use the context's flag)
+static int potrf_launch(csp_ctx* c, double* A, int64_t n, int64_t lda, hipStream_t st, int* info) {
+  HIPCHK(hipMemsetAsync(info, 0, sizeof(int), st));
   c->D.hinv_tag = nullptr;
   static int oldp = -1;
   if (oldp < 0) { const char* e = getenv("SMCP_POTRF_OLD"); oldp = (e && e[0] == '1') ? 1 : 0; }
-  if (oldp) {
-    launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
-    HIPCHK(end_call(c));
-    return fetch_info(c, st);
+  if (oldp || use_generic(c)) {
+    launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, info);
+    return 0;
   }
-  if (!use_generic(c) && n <= 2 * LB) {
+  if (n <= 2 * LB) {
     const int64_t need = 8 * 256 + 2 * n;
     if (c->D.hinv_cap < need) {
       if (c->D.hinv) { HIPCHK(hipFree(c->D.hinv)); c->D.bytes -= c->D.hinv_cap * 8; }
@@ -640,35 +724,56 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
       HIPCHK(hipFuncSetAttribute((const void*)k_dense_potrf_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
       attr_set = true;
     }
-    launch_lds(c, KID_dense_potrf, k_dense_potrf_small, dim3(1), potrf_blk(), lds, st, A, (int)n, lda, c->D.info, c->D.hinv);
-  } else if (use_generic(c)) {
-    launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, c->D.info);
-  } else {
-    // blocked right-looking Cholesky, 64-wide block columns: diagonal block by one workgroup, panel and
-    // trailing update as 64 x 64 MFMA tiles over the chip (the kernels of the large fronts, dense view)
-    MfmaArgs a = mfma_args(c, nullptr, 0, 1);
-    a.t.lev = c->D.lev3idx;
-    a.lfd = c->D.lfd_dense;
-    a.dn = (int)n; a.dld = lda;
-    dim3 blk(256);
-    const int64_t nblocks = (n + LB - 1) / LB, need = nblocks * LB * LB + 2 * n;
-    if (c->D.hinv_cap < need) {
-      if (c->D.hinv) { HIPCHK(hipFree(c->D.hinv)); c->D.bytes -= c->D.hinv_cap * 8; }
-      c->D.hinv = nullptr; c->D.hinv_cap = 0;
-      if (int rc = dev_alloc(&c->D.hinv, need, c->D.bytes)) return rc;
-      c->D.hinv_cap = need;
-    }
-    for (int jb = 0; jb < (int)n; jb += LB) {
-      launch_lds(c, KID_lf_diag, k_lf_diag, dim3(1), dim3(512), LF_DIAG_LDS, st, a, A, (double*)nullptr, 5, jb, 1);
-      HIPCHK(hipMemcpyAsync(c->D.hinv + (int64_t)(jb / LB) * LB * LB, c->D.lfd_dense, sizeof(double) * LB * LB, hipMemcpyDeviceToDevice, st));
-      const int mrem = (int)n - jb - LB;
-      if (mrem > 0) {
-        const int mt = tiles64(mrem);
-        launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(mt, 1), blk, st, a, A, (double*)nullptr, 5, jb);
-        launch(c, KID_lf_chol_trail, k_lf_chol_trail, dim3(mt * (mt + 1) / 2, 1), blk, st, a, A, (double*)nullptr, 5, jb);
-      }
+    launch_lds(c, KID_dense_potrf, k_dense_potrf_small, dim3(1), potrf_blk(), lds, st, A, (int)n, lda, info, c->D.hinv);
+    return 0;
+  }
+  // blocked right-looking Cholesky, 64-wide block columns: diagonal block by one workgroup, panel and
+  // trailing update as 64 x 64 MFMA tiles over the chip (the kernels of the large fronts, dense view)
+  MfmaArgs a = mfma_args(c, nullptr, 0, 1);
+  a.t.lev = c->D.lev3idx;
+  a.t.info = info;
+  a.lfd = c->D.lfd_dense;
+  a.dn = (int)n; a.dld = lda;
+  dim3 blk(256);
+  const int64_t nblocks = (n + LB - 1) / LB, need = nblocks * LB * LB + 2 * n;
+  if (c->D.hinv_cap < need) {
+    if (c->D.hinv) { HIPCHK(hipFree(c->D.hinv)); c->D.bytes -= c->D.hinv_cap * 8; }
+    c->D.hinv = nullptr; c->D.hinv_cap = 0;
+    if (int rc = dev_alloc(&c->D.hinv, need, c->D.bytes)) return rc;
+    c->D.hinv_cap = need;
+  }
+  for (int jb = 0; jb < (int)n; jb += LB) {
+    launch_lds(c, KID_lf_diag, k_lf_diag, dim3(1), dim3(512), LF_DIAG_LDS, st, a, A, (double*)nullptr, 5, jb, 1);
+    HIPCHK(hipMemcpyAsync(c->D.hinv + (int64_t)(jb / LB) * LB * LB, c->D.lfd_dense, sizeof(double) * LB * LB, hipMemcpyDeviceToDevice, st));
+    const int mrem = (int)n - jb - LB;
+    if (mrem > 0) {
+      const int mt = tiles64(mrem);
+      launch(c, KID_lf_chol_panel, k_lf_chol_panel, dim3(mt, 1), blk, st, a, A, (double*)nullptr, 5, jb);
+      launch(c, KID_lf_chol_trail, k_lf_chol_trail, dim3(mt * (mt + 1) / 2, 1), blk, st, a, A, (double*)nullptr, 5, jb);
     }
   }
+  return 0;
+}
+// A Schur complement built by kkt_schur_factor under csp_lazy_status is left UNFACTORED until its first use: kkt_solve
+// then factors it on a side stream beside its first Hessian sweep (which does not read H), any other reader factors it
+// where it stands.  Drops the mark without factoring when the caller is about to factor or rebuild that matrix itself.
+static int flush_pending_potrf(csp_ctx* c, hipStream_t st, const void* only, bool drop) {
+  DeviceCtx& D = c->D;
+  if (!D.h_pending || (only && only != (const void*)D.h_pending)) return 0;
+  double* H = D.h_pending;
+  D.h_pending = nullptr;
+  if (drop) return 0;
+  if (int rc = potrf_launch(c, H, D.h_pending_n, D.h_pending_ld, st, c->D.info)) return rc;
+  HIPCHK(end_call(c));
+  int rc = fetch_info(c, st);
+  if (!rc && !use_generic(c)) { D.hinv_tag = H; D.hinv_n = D.h_pending_n; }
+  return rc;
+}
+int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
+  if (int rc = ready(c)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  flush_pending_potrf(c, st, A, true);
+  if (int rc = potrf_launch(c, A, n, lda, st, c->D.info)) return rc;
   HIPCHK(end_call(c));
   int rc = fetch_info(c, st);
   if (!rc && !use_generic(c)) { c->D.hinv_tag = A; c->D.hinv_n = n; }
@@ -690,6 +795,17 @@ static int potrs_impl(csp_ctx* c, const double* A, int64_t n, int64_t lda, doubl
     launch_lds(c, KID_dense_potrs, k_dense_potrs_small, dim3(1), dim3(256), (size_t)n * (n | 1) * sizeof(double), st, A, (int)n, lda,
                (const double*)D.hinv, B);
     return 0;
+  }
+  static int steps_only = -1;
+  if (steps_only < 0) { const char* e = getenv("SMCP_POTRS_STEPS"); steps_only = (e && e[0] == '1') ? 1 : 0; }
+  if (nrhs == 1 && n > 2 * LB && n <= POTRS1_MAXN && !steps_only && !use_generic(c)) {
+    // one launch of one workgroup: the whole substitution chain with the factor streamed a step ahead (k_dense_potrs_one)
+    static bool attr1 = false;
+    if (!attr1) attr1 = hipFuncSetAttribute((const void*)k_dense_potrs_one, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
+    if (attr1 && potrs_one_lds((int)n) <= (size_t)(160 * 1024 - 1024)) {
+      launch_lds(c, KID_dense_potrs, k_dense_potrs_one, dim3(1), dim3(1024), potrs_one_lds((int)n), st, A, (int)n, lda, B);
+      return 0;
+    }
   }
   if (nrhs == 1 && D.hinv_tag == A && D.hinv_n == n && n > 2 * LB) {
     const int64_t nblocks = (n + LB - 1) / LB;
@@ -715,6 +831,7 @@ static int potrs_impl(csp_ctx* c, const double* A, int64_t n, int64_t lda, doubl
 int dense_potrs(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs, int64_t ldb,
                 void* stream) {
   if (int rc = ready(c)) return rc;
+  if (int rc = flush_pending_potrf(c, (hipStream_t)stream, A, false)) return rc;
   if (int rc = potrs_impl(c, A, n, lda, B, nrhs, ldb, (hipStream_t)stream)) return rc;
   HIPCHK(end_call(c));
   return 0;
@@ -729,7 +846,8 @@ static bool use_gram(const csp_ctx* c) {
 // Gram formulation of the whole Schur complement (what kkt_qr implies, solvers.py:414-420):
 // H = G(A)^T G(A) with ONE leaves->root sweep per constraint, then one tall-skinny SYRK.
 // ---- Gram formulation, in steps so that the multi-GPU driver can interleave the boundary exchange
-static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_t st) {
+static bool leafgram_ok(csp_ctx* c, int64_t mcols);
+static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_t st, bool allow_partial_fac = false) {
   DeviceCtx& D = c->D;
   const int64_t m = D.m, bl = c->S.blklen();
   D.qr_valid = false;      // the stack is about to be rewritten
@@ -737,7 +855,7 @@ static int gram_prepare(csp_ctx* c, const double* L, const double* Y, hipStream_
   // the flag read after the sweeps must be theirs: a failed dense_potrf (Schur complement not positive definite) or
   // kkt_qr_factor leaves its own behind
   HIPCHK(zero_flag(c, st));
-  prepare_yaa(c, Y, true, st);
+  prepare_yaa(c, Y, true, st, false, allow_partial_fac);
   if (int rc = prep_lk_cached(c, L, Y, st)) return rc;
   if (!D.kc_ptr) {   // the sweeps read their input from the stack: clear it and scatter the constraints into it
     HIPCHK(hipMemsetAsync(D.ustack, 0, sizeof(double) * m * bl, st));
@@ -1003,7 +1121,8 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
   const int64_t m = D.m, bl = c->S.blklen();
   if (!D.ns) {
     if (part) return 0;
-    if (int rc = gram_prepare(c, L, Y, st)) return rc;
+    // (sweeps that take the family children's Gram block from k_leaf_pairs do not read those children's chol(Y_AA))
+    if (int rc = gram_prepare(c, L, Y, st, leafgram_ok(c, m) && m <= D.max_rhs)) return rc;
     // (Accumulating the Gram tiles of the lower levels on a side stream while the large fronts are still swept was
     // measured in round 2 and dropped: 5.92 against 5.61 ms per step -- the two stages only take CUs from each other.)
     D.lg_request = leafgram_ok(c, m);
@@ -1120,6 +1239,7 @@ int kkt_schur_columns(csp_ctx* c, const double* L, const double* Y, double* H, i
   if (!m || ldh < m || j0 < 0 || j1 > m || j0 > j1) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   D.qr_valid = false;
+  flush_pending_potrf(c, st, H, true);
   HIPCHK(zero_flag(c, st));
   if (j0 == 0 && j1 == m && use_gram(c)) return schur_gram(c, L, Y, H, ldh, st);
   prepare_yaa(c, Y, false, st);
@@ -1148,6 +1268,7 @@ int kkt_schur_gram_part(csp_ctx* c, const double* L, const double* Y, double* H,
   if (!D.m || ldh < D.m || nparts < 1 || part < 0 || part >= nparts || !use_gram(c)) return SMCP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   D.qr_valid = false;
+  flush_pending_potrf(c, st, H, true);
   HIPCHK(zero_flag(c, st));
   return schur_gram(c, L, Y, H, ldh, st, part, nparts);
 }
@@ -1159,8 +1280,20 @@ int kkt_constraint_classes(csp_ctx* c, int64_t* counts) {
   counts[1] = c->D.ns;
   return 0;
 }
+static bool potrf_defer_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMCP_POTRF_DEFER"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
 int kkt_schur_factor(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, void* stream) {
   if (int rc = kkt_schur_columns(c, L, Y, H, ldh, 0, c ? c->D.m : 0, stream)) return rc;
+  if (c->lazy_status && !use_generic(c) && potrf_defer_on() && Fork::enabled()) {
+    // deferred status: nobody waits for potrf's verdict here, so the factorisation itself can wait for the first solve_
+    // (kkt_solve runs it beside its first Hessian sweep) or for whoever reads H first (flush_pending_potrf)
+    c->D.h_pending = H; c->D.h_pending_n = c->D.m; c->D.h_pending_ld = ldh;
+    c->D.hinv_tag = nullptr;
+    return 0;
+  }
   return dense_potrf(c, H, c->D.m, ldh, stream);
 }
 
@@ -1179,6 +1312,25 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
     ytmp = D.ustack + bl;
   }
   HIPCHK(zero_flag(c, st));
+  // a Schur complement that kkt_schur_factor left unfactored (deferred status): its Cholesky on a side stream beside the first
+  // Hessian sweep, which does not read H -- with a failure flag of its own, latched by the branch itself
+  std::unique_ptr<Fork> hf;
+  if (D.h_pending && (const void*)D.h_pending == (const void*)H) {
+    double* Hw = D.h_pending;
+    D.h_pending = nullptr;
+    hf.reset(new Fork(c, st, 0));
+    if (hf->on) {
+      int* pinfo = c->D.info + 20;
+      if (int rc = potrf_launch(c, Hw, m, ldh, hf->s, pinfo)) return rc;
+      hipLaunchKernelGGL(k_latch_status, dim3(1), dim3(64), 0, hf->s, pinfo, 1, c->D.info + 16);
+    } else {                                    // no side stream: where it stands, status latched as after dense_potrf
+      hf.reset();
+      if (int rc = potrf_launch(c, Hw, m, ldh, st, c->D.info)) return rc;
+      if (int rc = fetch_info(c, st)) return rc;
+      HIPCHK(zero_flag(c, st));
+    }
+    if (!use_generic(c)) { D.hinv_tag = H; D.hinv_n = m; }
+  } else if (int rc = flush_pending_potrf(c, st, nullptr, false)) return rc;    // (another matrix is pending: factor it where it stands)
   // the Y_AA cache must correspond to (L, Y): recompute (cheap, one gather sweep)
   if (!(c->D.yaa_tag == Y && c->D.yaa_tag)) prepare_yaa(c, Y, false, st);
   if (!use_generic(c)) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
@@ -1186,6 +1338,7 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   hessian_impl(c, L, r1, 1, bl, 2, 0, st);                      // r1 = W(bx)
   amap_impl(c, r1, 0, 1, ytmp, 0, st);                          // Amap(r1)
   launch(c, KID_vec_axpby, k_vec_axpby, dim3((unsigned)((m + 255) / 256)), dim3(256), st, m, 1.0, ytmp, kk, by);  // y = kk*by + Amap(r1)
+  if (hf) hf->join();                                           // H is factored from here on
   if (int rc = potrs_impl(c, H, m, ldh, by, 1, m, st)) return rc;
   if (int rc = aadj_impl(c, by, r1, st)) return rc;             // r1 = Aadj(y)
   launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 1.0, (const double*)r1, -1.0, bx);  // bx = Aadj(y) - bx

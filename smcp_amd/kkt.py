@@ -528,8 +528,17 @@ class KKTSystem(ShardedSchur):
         (safe: no index depends on a value), and the caller must read the verdict with chordal.check_status before
         it trusts them.  (The sharded build reads the latch itself, once, before H's all-reduce, because every rank
         has to agree on the outcome.)  The interior-point drivers run eagerly."""
-        self.build_schur(L, Y, group)
-        self._potrf()
+        world, _ = self._world(group)
+        if world == 1 and not (self.force_sharded and self.partition is not None and group is not None):
+            # kkt_schur_factor: the Schur complement and its Cholesky factor in one call -- under chordal.lazy_status the
+            # factorisation of H itself waits for the first solve_ and runs beside its first Hessian sweep (smcp_amd.h)
+            self._own()
+            sync_cache(self.symb, L, Y)
+            _chk(_lib.lib().kkt_schur_factor(self.symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), self.H.data_ptr(), self.m,
+                                             _stream()), "kkt_schur_factor")
+        else:
+            self.build_schur(L, Y, group)
+            self._potrf()
         if self._sharded_pair(L, Y):
             # the chunks kept by THIS build_schur, with the generation they were gathered in: a solve_ that outlives a later
             # build_schur (whose sweeps reuse the buffers) falls back to the collective exchange for its second Hessian

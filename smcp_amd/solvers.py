@@ -491,9 +491,8 @@ def chordalsolver_esd(A, b, primalstart=None, dualstart=None, scaling="primal", 
                 Y = X
             else:
                 L = S.copy()
-                chordal.cholesky(L)
-                Y = L.copy()
-                chordal.projected_inverse(Y)
+                Y = cspmatrix(S.symb, torch.empty_like(L.blkval))
+                chordal.cholesky_projected_inverse(L, Y)     # solvers.py:2341-2361 as one library call
         except ArithmeticError:
             status = "unknown"
             break

@@ -211,12 +211,19 @@ class OracleKKT(kkt.ShardedSchur):
 @contextlib.contextmanager
 def oracle_backend():
     saved = {k: getattr(chordal, k) for k in ("cholesky", "llt", "projected_inverse", "completion", "hessian",
-                                              "dot", "logdiagsum", "trsm")}
+                                              "dot", "logdiagsum", "trsm", "cholesky_projected_inverse")}
     saved_kkt, saved_skkt = kkt.KKTSystem, solvers.KKTSystem
     chordal.cholesky = lambda X: orc.cholesky(_S(X.symb), _np(X))
     chordal.llt = lambda X: orc.llt(_S(X.symb), _np(X))
     chordal.projected_inverse = lambda X: orc.projected_inverse(_S(X.symb), _np(X))
     chordal.completion = lambda X: orc.completion(_S(X.symb), _np(X))
+
+    def cholesky_projected_inverse(L, Y, factors=True):
+        orc.cholesky(_S(L.symb), _np(L))
+        Y.blkval.copy_(L.blkval)
+        orc.projected_inverse(_S(Y.symb), _np(Y))
+
+    chordal.cholesky_projected_inverse = cholesky_projected_inverse
 
     def hessian(L, Y, U, adj=False, inv=False):
         Us = [U] if isinstance(U, cspmatrix) else U

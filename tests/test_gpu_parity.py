@@ -1078,3 +1078,100 @@ def test_kkt_qr_rank_deficient_stack_fails_instead_of_looping():
     cptr2, cidx2, cval2 = problems.random_constraints(symb, 5, density=0.5, seed=63)
     sys2 = KKTSystem(symb, cptr2, cidx2, cval2, max_rhs=4, tnzcols=0.0)
     sys2.factor_qr(dev(symb, L), dev(symb, Yh))
+
+
+@pytest.mark.parametrize("name", sorted(GPU_PATTERNS))
+def test_dual_scaling_point_in_one_call(name):
+    """csp_cholesky_projected_inverse (solvers.py:881-891 as ONE entry point, its independent stages on side streams) against
+    the oracle's cholesky + projected_inverse, against the two separate library calls, and -- the caches it leaves behind:
+    inverse-form factor, Y_AA blocks, their Cholesky factors -- through a whole KKT factor + solve right after it."""
+    symb, S, A, msk = setup(name, 11)
+    Lref = A.copy()
+    orc.cholesky(S, Lref)
+    Yref = Lref.copy()
+    orc.projected_inverse(S, Yref)
+    L = dev(symb, A)
+    Y = cspmatrix(symb, torch.full((symb.blklen,), float("nan"), dtype=torch.float64, device="cuda"))   # output only
+    chordal.cholesky_projected_inverse(L, Y)
+    assert rel(host(L)[msk], Lref[msk]) < TOL and rel(host(Y)[msk], Yref[msk]) < TOL
+    assert not np.isnan(host(Y)).any()
+    L2 = dev(symb, A)
+    chordal.cholesky(L2)
+    Y2 = L2.copy()
+    chordal.projected_inverse(Y2)
+    assert rel(host(L), host(L2)) < 1e-13 and rel(host(Y), host(Y2)) < 1e-12
+    m = 7
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.05, seed=9)
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(Lref, Yref)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=4)
+    rng = np.random.default_rng(13)
+    bx, by = rng.standard_normal(symb.blklen) * msk, rng.standard_normal(m)
+    for lazy in (False, True):            # eager: potrf(H) inside factor(); deferred: beside the first Hessian of the first solve_
+        L = dev(symb, A)
+        Y = cspmatrix(symb, torch.empty(symb.blklen, dtype=torch.float64, device="cuda"))
+        chordal.lazy_status(symb, lazy)
+        try:
+            chordal.cholesky_projected_inverse(L, Y)
+            solve = sys.factor(L, Y)
+            for kk in (1.0, 0.5):             # the second call finds H factored
+                xr, yr = K.solve(Lref, Yref, Href, bx, by, kk)
+                bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+                solve(bxd, byd, kk)
+                if lazy:
+                    chordal.check_status(symb)
+                assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+            assert rel(np.tril(sys.H.cpu().numpy().T), np.tril(Href)) < 1e-9
+        finally:
+            chordal.lazy_status(symb, False)
+    # not positive definite: the error of cholesky, and the context stays usable
+    bad = A.copy()
+    bad[symb.blkptr[symb.Nsn // 2]] = -1.0
+    with pytest.raises(ArithmeticError):
+        chordal.cholesky_projected_inverse(dev(symb, bad), cspmatrix(symb, torch.empty(symb.blklen, dtype=torch.float64, device="cuda")))
+    L = dev(symb, A)
+    Y = cspmatrix(symb, torch.empty(symb.blklen, dtype=torch.float64, device="cuda"))
+    chordal.cholesky_projected_inverse(L, Y, factors=False)
+    assert rel(host(Y)[msk], Yref[msk]) < TOL
+
+
+def test_deferred_potrf_of_the_schur_complement():
+    """Under chordal.lazy_status kkt_schur_factor leaves H unfactored until its first reader: dense_potrs, csp_status and
+    kkt_solve all find it; a Schur complement that is not positive definite is reported by the next check_status."""
+    symb, S, A, msk = setup("nested_mid", 21)
+    L = dev(symb, A)
+    Y = cspmatrix(symb, torch.empty(symb.blklen, dtype=torch.float64, device="cuda"))
+    chordal.cholesky_projected_inverse(L, Y)
+    m = 5
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.05, seed=22)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=4)
+    sys.factor(L, Y)
+    Hfac = sys.H.clone()                                   # eager: factored
+    rhs = torch.from_numpy(np.random.default_rng(23).standard_normal(m)).cuda()
+    y0 = rhs.clone()
+    sys._potrs(y0)
+    chordal.lazy_status(symb, True)
+    try:
+        sys.factor(L, Y)                                   # H built, factorisation pending
+        y1 = rhs.clone()
+        sys._potrs(y1)                                     # the first reader factors it
+        chordal.check_status(symb)
+        assert float((y1 - y0).abs().max()) < 1e-12 * float(y0.abs().max())
+        assert float((sys.H - Hfac).abs().max()) < 1e-12 * float(Hfac.abs().max())
+        sys.factor(L, Y)
+        chordal.check_status(symb)                         # ... and so does the status read-out
+        assert float((sys.H - Hfac).abs().max()) < 1e-12 * float(Hfac.abs().max())
+        # linearly dependent constraints: H singular, the deferred potrf must report it
+        cptr2 = np.concatenate([cptr, [cptr[-1] + (cptr[1] - cptr[0])]])
+        cidx2 = np.concatenate([cidx, cidx[cptr[0]:cptr[1]]])
+        cval2 = np.concatenate([cval, cval[cptr[0]:cptr[1]]])
+        sys2 = KKTSystem(symb, cptr2, cidx2, cval2, max_rhs=4)
+        solve = sys2.factor(L, Y)
+        bxd = dev(symb, np.random.default_rng(24).standard_normal(symb.blklen) * msk)
+        byd = torch.from_numpy(np.random.default_rng(25).standard_normal(m + 1)).cuda()
+        solve(bxd, byd, 1.0)
+        with pytest.raises(ArithmeticError):
+            chordal.check_status(symb)
+        chordal.check_status(symb)                         # reported once
+    finally:
+        chordal.lazy_status(symb, False)

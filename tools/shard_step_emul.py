@@ -89,6 +89,10 @@ def main():
                 Y.blkval.copy_(L.blkval)
                 chordal.projected_inverse(Y)
                 kkt.build_schur(L, Y, G)          # columns j0 .. j1 of this rank + the all-reduce of H (world 1: all of them, Gram route)
+                if state["world"] == 1 and "H" not in state:
+                    state["H"] = H.clone()
+                elif state["world"] > 1:
+                    H.copy_(state["H"])           # what the other ranks' columns would have added (an 80 KB copy stands in for the wire)
                 kkt._potrf()
                 rc = lib.kkt_solve(symb.handle, L.blkval.data_ptr(), Y.blkval.data_ptr(), H.data_ptr(), m, 1.0,
                                    bx.blkval.data_ptr(), by.data_ptr(), stq())
