@@ -531,7 +531,8 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   // (the gather plan and the tiled kernel read every child slot: members of sibling groups that did not write theirs in
   // this sweep -- MfmaArgs::chskip -- get them cleared first; the streaming kernel above skips them instead)
   if (a.chskip) launch(c, KID_lf_clear_upd, k_lf_zero_skipped, dim3(cnt, nrhs), dim3(256), st, a);
-  if (clear_first)
+  // (the gather plan lists every position of a large front's update block -- csp_device_init -- and assigns them all)
+  if (clear_first && !(plan && a.t.gp_tptr && c->plan_full_upd))
     launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, nrhs), dim3(256), st, a);
   if (plan && a.t.gp_tptr) {
     // a thread per front position when the launch is small (few fronts, one right-hand side): each position is a chain of
@@ -639,8 +640,7 @@ bool use_mid(int rowsmax) {
 void lf_chol(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) {
   dim3 blk(256);
   const int nfmax = a.nnmax + a.namax;
-  launch(c, KID_lf_clear_upd, k_lf_clear_upd, dim3(umax1(std::min(64, (a.namax * a.namax + 2047) / 2048)), cnt, 1), blk, st, a);
-  lf_assemble(c, a, cnt, 1, x, 0, 0, st);
+  lf_assemble(c, a, cnt, 1, x, 0, 0, st, true);      // (clears the update blocks first where its route does not assign them whole)
   if (use_mid(nfmax)) {
     launch_lds(c, KID_mid_chol, k_mid_chol, dim3(cnt), dim3(1024), mid_chol_lds(nfmax), st, a, x, (double*)nullptr, 0);
     return;
@@ -2108,9 +2108,14 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       // (target code, src offset) pairs of every clique with children, sorted per clique: the cliques are independent,
       // so host threads take them round-robin (5.5 M pairs on synth50k: 0.2 s of the set-up on one thread)
       std::vector<int64_t> par;
-      for (int64_t k = 0; k < nsn1; ++k) if (S.chptr[k + 1] > S.chptr[k]) par.push_back(k);
+      for (int64_t k = 0; k < nsn1; ++k) if (S.chptr[k + 1] > S.chptr[k] || (cl[(size_t)k].pad >= 0 && S.na(k) > 0)) par.push_back(k);
       std::vector<std::vector<std::pair<int32_t, int32_t>>> prs(par.size());
       std::vector<int64_t> ntg(par.size(), 0);     // distinct targets per clique
+      // Large fronts list EVERY position of the lower triangle of their update block as a target, with or without
+      // contributions (marker pairs, dropped again when the sources are laid out): the plan kernels then assign the whole block
+      // and the clear pass before them (k_lf_clear_upd: a 5 us launch in every chain over the top fronts) is not needed
+      constexpr int32_t PLAN_MARK = INT32_MIN;
+      std::vector<int64_t> nmark(par.size(), 0);
       {
         const unsigned hw = std::thread::hardware_concurrency();
         const int nth = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hw ? hw : 1), (int64_t)16, (int64_t)par.size() / 64 + 1}));
@@ -2132,6 +2137,12 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
                   pr.emplace_back(code, (int32_t)(S.updpptr[cc] + j * nac - j * (j - 1) / 2 + (i - j)));
                 }
             }
+            if (cl[(size_t)k].pad >= 0) {
+              const int64_t nak = S.na(k);
+              for (int64_t j = 0; j < nak; ++j)
+                for (int64_t i = j; i < nak; ++i) pr.emplace_back((int32_t)((1 << 30) | (int32_t)i | ((int32_t)j << 15)), PLAN_MARK);
+              nmark[x] = nak * (nak + 1) / 2;
+            }
             std::sort(pr.begin(), pr.end());
             int64_t nd = 0;
             for (size_t e = 0; e < pr.size(); ++e) if (e == 0 || pr[e].first != pr[e - 1].first) ++nd;
@@ -2143,7 +2154,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       clk.mark("plan: sorted pairs");
       // targets (distinct codes) per clique were counted by the workers: the serial part only lays the pieces out
       std::vector<int64_t> tbase(par.size() + 1, 0), sbase(par.size() + 1, 0);
-      for (size_t x = 0; x < par.size(); ++x) { tbase[x + 1] = tbase[x] + ntg[x]; sbase[x + 1] = sbase[x] + (int64_t)prs[x].size(); }
+      for (size_t x = 0; x < par.size(); ++x) { tbase[x + 1] = tbase[x] + ntg[x]; sbase[x + 1] = sbase[x] + (int64_t)prs[x].size() - nmark[x]; }
       const int64_t nt1 = tbase[par.size()], ns1 = sbase[par.size()];
       tgt.resize((size_t)nt1);
       src.resize((size_t)ns1);
@@ -2155,9 +2166,10 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
             const auto& pr = prs[x];
             int64_t tq = tbase[x];
             const int64_t s0 = sbase[x];
+            int64_t w = 0;
             for (size_t e = 0; e < pr.size(); ++e) {
-              if (e == 0 || pr[e].first != pr[e - 1].first) { tgt[(size_t)tq] = pr[e].first; cptr[(size_t)tq] = s0 + (int64_t)e; ++tq; }
-              src[(size_t)(s0 + (int64_t)e)] = pr[e].second;
+              if (e == 0 || pr[e].first != pr[e - 1].first) { tgt[(size_t)tq] = pr[e].first; cptr[(size_t)tq] = s0 + w; ++tq; }
+              if (pr[e].second != PLAN_MARK) src[(size_t)(s0 + w++)] = pr[e].second;
             }
           }
         };
@@ -2197,6 +2209,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
         if ((rc = dev_upload(&D.gp_src, src, D.bytes))) return rc;
       }
     }
+    c->plan_full_upd = true;
     clk.mark("plan: upload");
     if ((rc = dev_alloc(&D.lk, S.blklen(), D.bytes))) return rc;
     HIPCHK(hipMemset(D.lk, 0, sizeof(double) * std::max<int64_t>(S.blklen(), 1)));

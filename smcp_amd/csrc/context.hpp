@@ -233,6 +233,7 @@ struct csp_ctx {
   hipStream_t aux_stream[2] = {nullptr, nullptr};
   hipEvent_t aux_fork = nullptr, aux_join[2] = {nullptr, nullptr};
   int64_t scal_lstar = -1, scal_tail0 = 0;              // scaling_impl: first level without small cliques, start of the last level in blkval
+  bool plan_full_upd = false;           // the gather plans list every update-block position of the large fronts (no clear pass needed)
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status
   double placement_probe[2] = {0.0, 0.0};   // CSP_TUNE_PLACEMENT: probe time before / after, ms
   bool flags_clean = false;             // lazy mode: the last thing done to the flags was k_latch_status (which leaves them zero)

@@ -1132,26 +1132,10 @@ __device__ inline void wave_tile16(int Kd, FA A, FB B, FC store) {
 // wave), at block size 32 the four tiles of each product on four waves.  Four workgroup barriers in all, where the
 // block-row scheme of potrf_inv64 runs four one-wave inversions and six tile products one after the other (k_lf_diag_inv on
 // the root of synth50k: 36 us on the critical path of every factorisation).  s16: 1024 doubles of scratch.  Needs >= 4 waves.
-__device__ inline void tri_inv64_rd(double* D, int w, double* Di, double* s16) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int e = tid; e < LB * LB; e += blockDim.x) {          // identity-free padding: rows / columns beyond w read as zero
-    const int i = e % LB, j = e / LB;
-    if (i >= w || j >= w) D[i + j * LBD] = 0.0;
-  }
-  __syncthreads();
-  if (wave < 4 && 16 * wave < w) {                           // diagonal block `wave`
-    const int b0 = 16 * wave, bw = min(16, w - b0);
-    const double* Db = D + b0 + b0 * LBD;
-    double a[16], x[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = (lane < bw && j <= lane) ? Db[lane + j * LBD] : ((lane == j && lane < 16) ? 1.0 : 0.0);
-    wave_tri_inv16(a, x, lane);
-    if (lane < 16) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) if (lane < bw && j < bw) Di[(b0 + j) + (b0 + lane) * LBD] = x[j];
-    }
-  }
-  __syncthreads();
+// the off-diagonal part: Di holds the inverses of the 16 x 16 diagonal blocks (zeros elsewhere), D the triangle itself with
+// zeros beyond w; two doubling levels, three workgroup barriers
+__device__ inline void tri_inv64_offdiag(const double* D, int w, double* Di, double* s16) {
+  const int wave = threadIdx.x >> 6;
   if (wave < 2 && 32 * wave + 16 < w) {                      // pairs (0, 1) and (2, 3) at block size 16
     const int r0 = 32 * wave;
     const double* Bm = D + (r0 + 16) + r0 * LBD;
@@ -1185,6 +1169,31 @@ __device__ inline void tri_inv64_rd(double* D, int w, double* Di, double* s16) {
   }
   __syncthreads();
 }
+__device__ inline void tri_inv64_pad(double* D, int w) {     // rows / columns beyond w read as zero
+  for (int e = threadIdx.x; e < LB * LB; e += blockDim.x) {
+    const int i = e % LB, j = e / LB;
+    if (i >= w || j >= w) D[i + j * LBD] = 0.0;
+  }
+}
+__device__ inline void tri_inv64_rd(double* D, int w, double* Di, double* s16) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  tri_inv64_pad(D, w);
+  __syncthreads();
+  if (wave < 4 && 16 * wave < w) {                           // diagonal block `wave`
+    const int b0 = 16 * wave, bw = min(16, w - b0);
+    const double* Db = D + b0 + b0 * LBD;
+    double a[16], x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = (lane < bw && j <= lane) ? Db[lane + j * LBD] : ((lane == j && lane < 16) ? 1.0 : 0.0);
+    wave_tri_inv16(a, x, lane);
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) if (lane < bw && j < bw) Di[(b0 + j) + (b0 + lane) * LBD] = x[j];
+    }
+  }
+  __syncthreads();
+  tri_inv64_offdiag(D, w, Di, s16);
+}
 
 // In-LDS Cholesky (do_potrf) and inverse of a w x w (w <= 64) lower block D (ld LBD); the inverse goes
 // to Di (ld LBD, zeros above the diagonal).  d16: 256 doubles, s16: 16 x 64 doubles of scratch.
@@ -1193,7 +1202,11 @@ __device__ inline int potrf_inv64(double* D, int w, double* Di, double* d16, dou
   for (int e = threadIdx.x; e < LB * LBD; e += blockDim.x) Di[e] = 0.0;
   __syncthreads();
 #ifndef SMCP_TRINV_ROWS
-  if (!do_potrf && blockDim.x >= 256) { tri_inv64_rd(D, w, Di, s16); return 0; }
+  const bool doubling = blockDim.x >= 256;
+  if (!do_potrf && doubling) { tri_inv64_rd(D, w, Di, s16); return 0; }
+  if (doubling) tri_inv64_pad(D, w);          // (the potrf steps below begin with a barrier)
+#else
+  const bool doubling = false;
 #endif
   for (int jb = 0; jb < w; jb += 16) {
     const int bw = min(16, w - jb);
@@ -1222,7 +1235,7 @@ __device__ inline int potrf_inv64(double* D, int w, double* Di, double* d16, dou
       if (i >= j) Di[(jb + i) + (jb + j) * LBD] = d16[i + j * 16];
     }
     __syncthreads();
-    if (jb > 0) {
+    if (jb > 0 && !doubling) {
       wg_mma(bw, jb, jb, [=](int m, int kk) { return D[(jb + m) + kk * LBD]; },
              [=](int kk, int n) { return Di[kk + n * LBD]; },
              [=](int m, int n, double acc) { s16[m + n * 16] = acc; });
@@ -1233,6 +1246,8 @@ __device__ inline int potrf_inv64(double* D, int w, double* Di, double* d16, dou
       __syncthreads();
     }
   }
+  // the rest of the inverse by recursive doubling from the diagonal blocks' inverses (three barriers instead of nine)
+  if (doubling) tri_inv64_offdiag(D, w, Di, s16);
   return 0;
 }
 
