@@ -588,14 +588,15 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
             t_fact = time.perf_counter() - t0
             t0 = time.perf_counter()
             if scm:
-                K.schur_scm_columns(Lo, np.zeros((m, m), order="F"), range(ncols))
+                Hc = np.tril(K.schur_scm_columns(Lo, np.zeros((m, m), order="F"), range(ncols)))[:, :ncols]
                 t_cols = time.perf_counter() - t0
             elif nthr > 1:
-                K.schur_columns_threaded(Lo, Yo, 0, ncols, nthr)
+                Hc = K.schur_columns_threaded(Lo, Yo, 0, ncols, nthr)
                 t_cols = K.last_seconds            # without the one-off allocation of the per-thread workspaces
             else:
-                K.schur_factor(Lo, Yo, ncols=ncols)
+                Hc = K.schur_factor(Lo, Yo, ncols=ncols)[:, :ncols]
                 t_cols = time.perf_counter() - t0
+            cpu_unit.Hcols = Hc
             Hc = Hfull.copy(order="F")
             t0 = time.perf_counter()
             orc.dense_potrf(Hc)
@@ -619,6 +620,10 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         # the same run doubles as a full-size check of the GPU search direction
         ex = np.linalg.norm((bx.blkval.cpu().numpy() - xo)[msk]) / max(1e-300, np.linalg.norm(xo[msk]))
         ey = np.linalg.norm(by.cpu().numpy() - yo) / max(1e-300, np.linalg.norm(yo))
+        # ... and of the Schur complement itself: the oracle's columns against L_H L_H^T of the device's factor (the solve above
+        # takes the device's H, so x and y alone would not notice a wrong H)
+        Hg = np.tril(Hfull)[:, :ncols] if scm else Hfull[:, :ncols]
+        eH = np.linalg.norm(Hg - cpu_unit.Hcols) / max(1e-300, np.linalg.norm(cpu_unit.Hcols))
         reps = [first]
         if not quick:
             blas_desc = orc.use_blas(True)                              # per-clique BLAS-3 on the host BLAS from dimension 32 on
@@ -639,6 +644,7 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
                             "; trsm x 2 + SCMcolumn2 per column, solvers.py:489-497" if scm else "", t_potrf,
                             t_solve, blas_desc or "plain loops")}
         cpu["gpu_vs_oracle_relerr"] = [float("%.2e" % ex), float("%.2e" % ey)]
+        cpu["schur_vs_oracle_relerr"] = float("%.2e" % eH)
         if scm:
             cpu["cores_note"] = ("one host thread: the reference's SCMcolumn2 route (solvers.py:489-497) is a sequential Python loop over "
                                  "the columns, two supernodal triangular solves + one misc.SCMcolumn2 call each on n = 1000 -- BLAS-2 sized "

@@ -54,7 +54,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn, KID_lf_zsp, KID_fam_terms_grp,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn, KID_lf_zsp, KID_fam_terms_grp, KID_lf_assemble_fz,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -72,7 +72,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn", "k_lf_zsp", "k_fam_terms_grp"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn", "k_lf_zsp", "k_fam_terms_grp", "k_lf_assemble_fz"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -387,6 +387,8 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.kc_stride = 0; a.kc_j0 = 0;
   a.nnmin = 0;
   a.grp_ptr = nullptr; a.grp_list = nullptr; a.chskip = nullptr; a.famt_ngrp = 0;
+  a.fz_on = 0; a.fz_nat = 0; a.fz_cnn = 0; a.fz_stride = 0; a.fz_recl = 0;
+  a.fz_tab = nullptr; a.fz_no = nullptr; a.fz_slot = nullptr; a.fz_ptr = nullptr; a.fz_pk = nullptr; a.fz_s = nullptr;
   a.level = 0; a.nS = 0; a.famna = a.fampan = a.fampk = a.famcna = a.famnn = a.famcnn = 0;
   return a;
 }
@@ -415,6 +417,7 @@ void for_level_classes(csp_ctx* c, int64_t l, MfmaArgs a, F f, int set = 0) {
   }
   if (L.nII) {
     a.t.lev = base + L.nI;
+    a.level = (int)l;
     a.nnmax = L.nnmaxII;
     a.nnmin = L.nnminII;
     a.namax = L.namaxII;
@@ -484,7 +487,7 @@ static bool alds_route(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, int& nz
   else if (nrhs >= 16 && 2 * pairs <= c->D.ncu && a.nchmax >= 32)
     nz = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)a.nchmax / 16, (int64_t)8, (2 * (int64_t)c->D.ncu + pairs - 1) / pairs}));
   nz = std::max(1, std::min(nz, std::max(1, a.nchmax)));
-  bytes = (size_t)(lf_alds_doubles(nfmax) + 3 * ((a.nchmax + nz - 1) / nz) + 2) * sizeof(double);   // front + child table
+  bytes = (size_t)(lf_alds_doubles(nfmax) + 4 * ((a.nchmax + nz - 1) / nz) + 2) * sizeof(double);   // front + child table (+ the family column of k_lf_assemble_fz)
   if (!(alds && a.nchmax > 0 && pairs * nz >= 32 && nfmax <= LF_ALDS_MAXNF && bytes <= LDS_LIMIT)) return false;   // enough workgroups to fill the chip
   static bool attr = false;
   if (!attr) { attr = hipFuncSetAttribute((const void*)k_lf_assemble_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess; }
@@ -498,9 +501,48 @@ static bool lf_assemble_fills(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs) 
   int nz; size_t bytes;
   return on && a.kc_ptr && alds_route(c, a, cnt, nrhs, nz, bytes) && nz == 1;
 }
+template <int NAT>
+static bool launch_assemble_fz(csp_ctx* c, const MfmaArgs& az, int cnt, int nrhs, double* U, int64_t ldu, int sgn, size_t bytes, int* counter, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) attr = hipFuncSetAttribute((const void*)k_lf_assemble_fz<NAT, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)k_lf_assemble_fz<NAT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
+  if (!attr) return false;
+  // sixteen waves (128 registers each) or eight (256): SMCP_FZ_THREADS=512 selects the latter
+  static int thr = 0;
+  if (!thr) { const char* e = getenv("SMCP_FZ_THREADS"); thr = (e && atoi(e) == 512) ? 512 : 1024; }
+  const dim3 grid((unsigned)std::min<int64_t>(c->D.ncu, (int64_t)cnt * nrhs));
+  if (thr == 512) launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 512>, grid, dim3(512), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter);
+  else launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 1024>, grid, dim3(1024), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter);
+  return true;
+}
 void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, int sgn, hipStream_t st, bool clear_first = false) {
   static int plan = -1;
   if (plan < 0) { const char* e = getenv("SMCP_ASM"); plan = (e && e[0] == 't') ? 0 : 1; }
+  if (c->fz_live && (size_t)a.level < c->fz_levels.size() && c->fz_levels[(size_t)a.level]) {
+    // the family launch of this sweep left its parents' updates to this extend-add: the streaming kernel with the hook that
+    // forms them (k_lf_assemble_fz) -- hess_up_fast has checked that this launch qualifies
+    int nz; size_t bytes;
+    bool ok = alds_route(c, a, cnt, nrhs, nz, bytes) && nz == 1 && c->D.info;
+    if (ok) {
+      MfmaArgs az = a;
+      az.fz_on = 1; az.fz_nat = c->fz_nat; az.fz_cnn = c->fz_cnn; az.fz_recl = c->fz_recl; az.fz_stride = (int)(c->D.m + 1);
+      az.fz_tab = c->D.famc; az.fz_no = c->D.fz_no; az.fz_slot = c->D.fz_slot; az.fz_ptr = c->D.fz_ptr; az.fz_pk = c->D.fz_pk; az.fz_s = c->D.fz_s;
+      int* counter = c->D.info + 24 + (st == c->aux_stream[0] ? 1 : (st == c->aux_stream[1] ? 2 : 0));
+      (void)hipMemsetAsync(counter, 0, sizeof(int), st);
+      switch (c->fz_nat) {
+        case 1: ok = launch_assemble_fz<1>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;
+        case 2: ok = launch_assemble_fz<2>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;
+        case 3: ok = launch_assemble_fz<3>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;
+        case 4: ok = launch_assemble_fz<4>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;
+        default: ok = false;
+      }
+    }
+    if (!ok) {
+      fprintf(stderr, "smcp_amd: fused extend-add not launchable for a level it was promised to\n");
+      if (!c->launch_err) c->launch_err = -1;
+    }
+    return;
+  }
   {
     int nz; size_t bytes;
     if (alds_route(c, a, cnt, nrhs, nz, bytes)) {
@@ -1020,7 +1062,7 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
       return true;
     }
     const int gy = std::min(65535, (nrhs + 7) / 8);
-    launch_lds(c, KID_famt_prep, k_famt_prep<NAT>, dim3(cnt), dim3(512), (size_t)famt_prep_doubles<NAT>(cnn) * sizeof(double), st, a, D.famc, cnn);
+    launch_lds(c, KID_famt_prep, k_famt_prep<NAT>, dim3(cnt), dim3(512), (size_t)famt_prep_doubles<NAT>(cnn) * sizeof(double), st, a, D.famc, cnn, (int32_t*)nullptr);
     launch_lds(c, KID_fam_terms_grp, k_fam_terms_grp<NAT>, dim3(a.famt_ngrp, gy), dim3(512), (size_t)(160 * 1024 - 1024), st, a, U, ldu,
                (const double*)D.famc, cnn, (const int32_t*)D.kc_ij, ecap);
     D.lg_nochild = true;
@@ -1071,7 +1113,21 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   const int64_t left = lim - fixed - tail(tabpasses) - 4;
   const int ecap = (int)std::max<int64_t>(0, (left * 2) / 3 - 2);
   if (9 * D.kc_maxlist > ecap) return false;
-  launch_lds(c, KID_famt_prep, k_famt_prep<NAT>, dim3(cnt), dim3(512), (size_t)prep_doubles * sizeof(double), st, a, D.famc, cnn);
+  if (a.fz_on) {
+    // requested by hess_up_fast (every front above takes the LDS extend-add): the parents' updates are left to that extend-add
+    // (k_lf_assemble_fz), which finds the tables through the context (fz_live: set here, read by lf_assemble)
+    static bool attrz = false;
+    if (!attrz) attrz = hipFuncSetAttribute((const void*)k_fam_terms<NAT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
+    if (attrz && D.fz_slot) {
+      launch_lds(c, KID_famt_prep, k_famt_prep<NAT>, dim3(cnt), dim3(512), (size_t)prep_doubles * sizeof(double), st, a, D.famc, cnn, D.fz_slot);
+      launch_lds(c, KID_fam_terms, k_fam_terms<NAT, false>, dim3(cnt, g), dim3(64 * FAMT_NW), (size_t)lim * 8, st, a, U, ldu,
+                 (const double*)D.famc, cnn, (const int32_t*)D.kc_ij, tabpasses, ecap);
+      D.lg_nochild = true;
+      c->fz_live = true; c->fz_nat = NAT; c->fz_cnn = cnn; c->fz_recl = (int64_t)(FAMT_HDR + L.total);
+      return true;
+    }
+  }
+  launch_lds(c, KID_famt_prep, k_famt_prep<NAT>, dim3(cnt), dim3(512), (size_t)prep_doubles * sizeof(double), st, a, D.famc, cnn, (int32_t*)nullptr);
   launch_lds(c, KID_fam_terms, k_fam_terms<NAT>, dim3(cnt, g), dim3(64 * FAMT_NW), (size_t)lim * 8, st, a, U, ldu,
              (const double*)D.famc, cnn, (const int32_t*)D.kc_ij, tabpasses, ecap);
   D.lg_nochild = true;
@@ -1189,6 +1245,28 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
                           c->D.kc_ij && a0.ymode == 2 && a0.ysc && c->D.fam_maxterms <= FAMT_TCAP / 2 &&
                           c->D.cnnz <= (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m);
   if (groups_on || fgroups_on) a0.chskip = groups_on && fgroups_on ? c->D.both_skip : (groups_on ? c->D.lfsp_skip : c->D.famt_skip);
+  // Fused extend-add of the family parents' updates (front_famt.hip, lf_add_family): requested when the whole tree is swept in
+  // one call with sparse input, the entry-driven family kernel is the route (its conditions, as for the groups above), there
+  // is ONE level of family parents, and every large level with children takes the LDS extend-add that also builds the
+  // panels (lf_assemble_fills); the family launch then decides (csp_ctx::fz_live).  SMCP_FZ=0: never.
+  c->fz_live = false;
+  {
+    static int fzenv = -1;
+    if (fzenv < 0) { const char* e = getenv("SMCP_FZ"); fzenv = (e && e[0] == '0') ? 0 : 1; }
+    bool want = fzenv && sparse && set == 0 && lev_lo == 0 && lev_hi < 0 && !fgroups_on && c->D.fz_ok && !famt_disabled() && !fam2_disabled() &&
+                c->D.lg_request && c->D.kc_ij && a0.ymode == 2 && a0.ysc && c->D.fam_maxterms <= FAMT_TCAP / 2 &&
+                c->D.cnnz <= (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m) && !use_generic(c) && use_large() && c->D.gp_tptr;
+    if (want) {
+      int famlevels = 0;
+      for (int64_t l = 0; l < c->S.nlev; ++l)
+        for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t, int) {
+          if (lds && a.nS > 0 && a.level > 0) ++famlevels;
+          if (!lds && (size_t)a.level < c->fz_levels.size() && c->fz_levels[(size_t)a.level] && !(a.nchmax > 0 && lf_assemble_fills(c, a, cnt, nrhs))) want = false;
+        });
+      if (famlevels != 1) want = false;
+    }
+    if (want) { a0.fz_on = 1; a0.fz_no = c->D.fz_no; }
+  }
   // kernels that read their input from U get dense panels built first (zeros + the constraint's entries)
   auto dense_input_on = [&](MfmaArgs& a, int cnt, double* Ub, int nr, hipStream_t s) {
     if (!sparse) return;
@@ -1957,6 +2035,8 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
         c->lev_namax[l] = std::max(L.namaxI, L.namaxII);
         if (L.nII) { D.nnmaxII_all = std::max(D.nnmaxII_all, L.nnmaxII); D.namaxII_all = std::max(D.namaxII_all, L.namaxII); }
       }
+      c->large_mask.assign((size_t)S.nsn, 0);
+      for (int32_t k : large) c->large_mask[(size_t)k] = 1;
       D.nI_total = (int64_t)lev3.size();
       D.nII_total = (int64_t)large.size();
       {

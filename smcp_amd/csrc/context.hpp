@@ -98,6 +98,10 @@ struct DeviceCtx {
   int32_t* kc_off = nullptr; // cnnz : position inside the clique's panel
   double* kc_val = nullptr;  // cnnz
   int32_t* kc_ij = nullptr;  // cnnz : the same position as (row | column << 16) of the clique's panel (k_fam_sparse)
+  // fused extend-add of the family parents' updates (MfmaArgs::fz_*): clique -> family number, record slot per family (written by
+  // k_famt_prep), static term lists per (family, constraint); fz_ok: every family parent hangs under a front the LDS extend-add takes
+  int32_t* fz_no = nullptr; int32_t* fz_slot = nullptr; int32_t* fz_ptr = nullptr; int32_t* fz_pk = nullptr; double* fz_s = nullptr;
+  int64_t fz_nfam = 0; bool fz_ok = false;
   double* famc = nullptr;    // children's constants of the family parents of one sweep call, in LDS layout (k_fam2_prep)
   int64_t famc_len = 0;
   int64_t kc_maxlist = 0;    // longest entry list of a (clique, constraint) pair among possible family members
@@ -223,6 +227,7 @@ struct csp_ctx {
   bool famt_any_groups = false;
   std::vector<int64_t> fam;     // per clique: family role (CSP_Q_FAMILY)
   std::vector<uint8_t> is_diag_cache;
+  std::vector<uint8_t> large_mask;   // per clique: a large (HBM-class) front
   // boundary exchange of the subtree partition: the subtree roots of all ranks (device: clique, owning rank, offset in
   // doubles per right-hand side inside the owner's region), what every rank contributes per right-hand side, the widest block
   int32_t* xr_roots = nullptr; int32_t* xr_owner = nullptr; int64_t* xr_bptr = nullptr;
@@ -233,6 +238,8 @@ struct csp_ctx {
   hipStream_t aux_stream[2] = {nullptr, nullptr};
   hipEvent_t aux_fork = nullptr, aux_join[2] = {nullptr, nullptr};
   int64_t scal_lstar = -1, scal_tail0 = 0;              // scaling_impl: first level without small cliques, start of the last level in blkval
+  std::vector<uint8_t> fz_levels;       // per level: holds the parent front of some family parent (those levels' extend-add is the fused one)
+  bool fz_live = false; int fz_nat = 0, fz_cnn = 0; int64_t fz_recl = 0;   // the running sweep's family launch left the parents' updates to the extend-add above (k_lf_assemble_fz)
   bool plan_full_upd = false;           // the gather plans list every update-block position of the large fronts (no clear pass needed)
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status
   double placement_probe[2] = {0.0, 0.0};   // CSP_TUNE_PLACEMENT: probe time before / after, ms

@@ -82,7 +82,7 @@ __host__ __device__ inline int famt_prep_doubles(int cnn) { constexpr int NA = 1
 // LDS (136 KB, one workgroup per CU) the chain of dependent global loads of every workgroup was exposed and the launch
 // took 0.16 ms on synth50k.
 template <int NAT>
-__global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int cnn) {
+__global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int cnn, int32_t* fz_slot) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NA = 16 * NAT;
   const int ncol = 8 * cnn;
@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(512) k_famt_prep(MfmaArgs a, double* famt, int
     for (int e = tid; e < (ncol - used) * NA; e += 512) { T[L.oCA + used * NA + e] = 0.0; T[L.oCM + used * NA + e] = 0.0; }
   }
   if (tid == 0) {
+    if (fz_slot && a.fz_no && a.fz_no[k] >= 0) fz_slot[a.fz_no[k]] = (int32_t)blockIdx.x;      // where the fused extend-add finds this family's tables
     int* const hdr = reinterpret_cast<int*>(out);
     hdr[0] = k; hdr[1] = nn; hdr[2] = na; hdr[3] = nch;
     hdr[4] = (int)(d.blk & 0xffffffffll); hdr[5] = (int)(d.blk >> 32);
@@ -222,7 +223,9 @@ __device__ inline void famt_copy_tables(double* smem, const double* src, int tot
 // offsets: 4 ints), then the entry table of k_fam_sparse: per (pass, member) two ints, then the staged entries
 __host__ __device__ inline int famt_desc_doubles() { return FAMT_TCAP * 3; }
 
-template <int NAT>
+// UPD = false: the parents' update matrices are not formed here -- the extend-add of their parent front computes them into the
+// front it holds in LDS (lf_add_family, front_large.hip); one pass with the Q and G_NN tiles only
+template <int NAT, bool UPD = true>
 __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* u, int64_t ldu, const double* famt, int cnn,
                                                    const int32_t* kc_ij, int tabpasses, int ecap) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -383,7 +386,7 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
       auto pass = [&](auto LOc, auto HIc, auto Gc) {
         constexpr int LO = decltype(LOc)::value, HI = decltype(HIc)::value;      // row tiles LO .. HI - 1
         constexpr bool WITHG = decltype(Gc)::value;
-        constexpr int NTU = HI * (HI + 1) / 2 - LO * (LO + 1) / 2;
+        constexpr int NTU = UPD ? HI * (HI + 1) / 2 - LO * (LO + 1) / 2 : 1;
         d4 accU[NTU], accQ[HI - LO], accG = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int x = 0; x < NTU; ++x) accU[x] = d4{0.0, 0.0, 0.0, 0.0};
@@ -399,20 +402,22 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
 #pragma unroll
           for (int t = 0; t < HI; ++t) {
             const int row = 16 * t + l15;
-            aA[t] = sc * (smem[ay + row] + (row == uy ? 1.0 : 0.0));
+            if constexpr (UPD) aA[t] = sc * (smem[ay + row] + (row == uy ? 1.0 : 0.0));
             if (t >= LO) {
-              bA[t - LO] = smem[ax + row] + (row == ux ? 1.0 : 0.0);
+              if constexpr (UPD) bA[t - LO] = smem[ax + row] + (row == ux ? 1.0 : 0.0);
               bM[t - LO] = smem[mx + row];
             }
           }
           const double aN = sc * smem[ny + l15];
 #pragma unroll
           for (int rt = LO; rt < HI; ++rt) {
+            if constexpr (UPD) {
 #pragma unroll
-            for (int ct = 0; ct <= rt; ++ct) {
-              constexpr int base = LO * (LO + 1) / 2;
-              const int x = rt * (rt + 1) / 2 + ct - base;
-              accU[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[ct], bA[rt - LO], accU[x], 0, 0, 0);
+              for (int ct = 0; ct <= rt; ++ct) {
+                constexpr int base = LO * (LO + 1) / 2;
+                const int x = rt * (rt + 1) / 2 + ct - base;
+                accU[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[ct], bA[rt - LO], accU[x], 0, 0, 0);
+              }
             }
             accQ[rt - LO] = __builtin_amdgcn_mfma_f64_16x16x4f64(aN, bM[rt - LO], accQ[rt - LO], 0, 0, 0);
           }
@@ -426,14 +431,16 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
         for (int rt = LO; rt < HI; ++rt) {
           const int m = 16 * rt + l15;
           const bool mok = m < na;
+          if constexpr (UPD) {
 #pragma unroll
-          for (int ct = 0; ct <= rt; ++ct)
+            for (int ct = 0; ct <= rt; ++ct)
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              const int n = 16 * ct + kq + 4 * x;
-              const int cb = (n * (2 * na - 1 - n)) >> 1;                      // packed column start minus the column index
-              famt_store(rU, ct < rt ? mok : (mok && m >= n), cb + m, accU[rt * (rt + 1) / 2 + ct - LO * (LO + 1) / 2][x]);
-            }
+              for (int x = 0; x < 4; ++x) {
+                const int n = 16 * ct + kq + 4 * x;
+                const int cb = (n * (2 * na - 1 - n)) >> 1;                      // packed column start minus the column index
+                famt_store(rU, ct < rt ? mok : (mok && m >= n), cb + m, accU[rt * (rt + 1) / 2 + ct - LO * (LO + 1) / 2][x]);
+              }
+          }
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
             const int n = kq + 4 * x;
@@ -448,7 +455,9 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
           }
         }
       };
-      if constexpr (NAT == 4 && FAMT_NW > 8) {       // three passes: at most six accumulator tiles live (168 registers, three waves per SIMD)
+      if constexpr (!UPD) {                           // Q and G_NN only: five accumulator tiles at most, one pass
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NAT>{}, std::true_type{});
+      } else if constexpr (NAT == 4 && FAMT_NW > 8) {       // three passes: at most six accumulator tiles live (168 registers, three waves per SIMD)
         pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::true_type{});
         pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::false_type{});
         pass(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::false_type{});
@@ -463,6 +472,131 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
       }
     }
     q0 += ep;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused extend-add (round 4): the update matrix of a family parent, Upd = sum_t' s a(x') a(y')^T, is a function of the
+// family's tables and of the constraint's entries alone, and its only reader is the extend-add of the parent front above,
+// which holds that front in LDS.  k_fam_terms<NAT, false> therefore leaves it out, and the extend-add's workgroup for
+// (front, right-hand side) forms it itself: one wave per family child, the term list of (family, constraint) -- static,
+// built by kkt_set_constraints: vector ids and scale of every entry -- one term per lane, the operands a(x)[row] gathered
+// straight from the family's record in global memory (L2 / MALL resident: 88 MB on synth50k, read by the 100 right-hand
+// sides of the front), ten accumulator tiles on MFMA, ds_add_f64 at (rel[i], rel[j]) of the front.  1.49 GB of packed updates
+// written by one kernel and read back by the other per Schur complement never exist.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NAT>
+__device__ inline void lf_add_family(double* T, int nf, const MfmaArgs& a, int z, int64_t pt, const int32_t* rel, int lane) {
+  constexpr int NA = 16 * NAT, NTU = NAT * (NAT + 1) / 2;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int slot = z & 0x7ffff, nnp = (z >> 19) & 31, nap = (z >> 24) & 127;
+  const FamtL L = famt_layout<NAT>(8 * a.fz_cnn);
+  const double* const tab = a.fz_tab + (int64_t)slot * a.fz_recl + FAMT_HDR;
+  const int p0 = (int)(uint32_t)(pt & 0xffffffffll), Tn = min((int)(pt >> 32), FAMT_TCAP / 2);
+  int pk = 0;
+  double sv = 0.0;
+  if (lane < Tn) { pk = a.fz_pk[p0 + lane]; sv = a.fz_s[p0 + lane]; }
+  int relv[NAT];
+#pragma unroll
+  for (int t = 0; t < NAT; ++t) relv[t] = rel[min(16 * t + l15, max(nap - 1, 0))];
+  const int ks = (2 * Tn + 3) >> 2;
+  d4 acc[NTU];
+#pragma unroll
+  for (int x = 0; x < NTU; ++x) acc[x] = d4{0.0, 0.0, 0.0, 0.0};
+  // operands of step s: the a images of the two vectors of ordered pair tp = kq + 4 s (entry tp >> 1 taken as (x, y) or (y, x))
+  auto fetch = [&](int s, double (&aA)[NAT], double (&bA)[NAT], double& se, int& ux, int& uy) {
+    const int tp = kq + 4 * s, e = tp >> 1;
+    const int pke = __shfl(pk, e, 64);
+    se = __shfl(sv, e, 64);                                  // (lanes beyond the list hold a zero scale)
+    const int v0 = pke & 0xffff, v1 = (pke >> 16) & 0xffff;
+    const int vx = (tp & 1) ? v1 : v0, vy = (tp & 1) ? v0 : v1;
+    // a image of a vector id: offset in the record and the index of its unit part (255: none)
+    const int ax = vx >= FAMT_CHILD ? L.oCA + NA * (vx - FAMT_CHILD) : (vx < nnp ? L.onK + NA * vx : L.oZero);
+    ux = (vx < FAMT_CHILD && vx >= nnp) ? vx - nnp : 255;
+    const int ay = vy >= FAMT_CHILD ? L.oCA + NA * (vy - FAMT_CHILD) : (vy < nnp ? L.onK + NA * vy : L.oZero);
+    uy = (vy < FAMT_CHILD && vy >= nnp) ? vy - nnp : 255;
+#pragma unroll
+    for (int t = 0; t < NAT; ++t) {
+      aA[t] = tab[ay + 16 * t + l15];
+      bA[t] = tab[ax + 16 * t + l15];
+    }
+  };
+  auto mma = [&](double (&aA)[NAT], double (&bA)[NAT], double se, int ux, int uy) {
+#pragma unroll
+    for (int t = 0; t < NAT; ++t) {
+      const int row = 16 * t + l15;
+      aA[t] = se * (aA[t] + (row == uy ? 1.0 : 0.0));
+      bA[t] = bA[t] + (row == ux ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < NAT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct <= rt; ++ct)
+        acc[rt * (rt + 1) / 2 + ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[ct], bA[rt], acc[rt * (rt + 1) / 2 + ct], 0, 0, 0);
+  };
+#ifdef SMCP_FZ_PIPE        // operands of step s + 1 in flight during the products of step s (sixteen more registers)
+  double aA0[NAT], bA0[NAT], aA1[NAT], bA1[NAT], se0 = 0.0, se1 = 0.0;
+  int ux0 = 255, uy0 = 255, ux1 = 255, uy1 = 255;
+  if (ks > 0) fetch(0, aA0, bA0, se0, ux0, uy0);
+  for (int s = 0; s < ks; s += 2) {
+    if (s + 1 < ks) fetch(s + 1, aA1, bA1, se1, ux1, uy1);
+    mma(aA0, bA0, se0, ux0, uy0);
+    if (s + 1 < ks) {
+      if (s + 2 < ks) fetch(s + 2, aA0, bA0, se0, ux0, uy0);
+      mma(aA1, bA1, se1, ux1, uy1);
+    }
+  }
+#else
+  for (int s = 0; s < ks; ++s) {
+    double aA[NAT], bA[NAT], se;
+    int ux, uy;
+    fetch(s, aA, bA, se, ux, uy);
+    mma(aA, bA, se, ux, uy);
+  }
+#endif
+  // element (m, n) of the update -> front position (rel[m], rel[n]); packed column start minus the column index as in lf_alds_task
+#pragma unroll
+  for (int rt = 0; rt < NAT; ++rt) {
+    const int m = 16 * rt + l15;
+#pragma unroll
+    for (int ct = 0; ct <= rt; ++ct)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int n = 16 * ct + kq + 4 * x;
+        const int cj = __shfl(relv[ct], kq + 4 * x, 64);
+        const bool ok = m < nap && n < nap && (ct < rt || m >= n);
+        if (ok) unsafeAtomicAdd(&T[cj * nf - ((cj * (cj - 1)) >> 1) - cj + relv[rt]], acc[rt * (rt + 1) / 2 + ct][x]);
+      }
+  }
+}
+template <int NAT>
+struct AldsFam {
+  const MfmaArgs* a;
+  const int64_t* sCu; const int64_t* sCr;
+  __device__ void operator()(double* T, int nf, int r, const int* sFz, int nmine, int wave, int nw, int lane) const {
+    (void)r;
+    for (int qi = wave; qi < nmine; qi += nw) {
+      const int z = sFz[qi];
+      if (z >= 0) lf_add_family<NAT>(T, nf, *a, z, sCu[qi], a->t.relidx + sCr[qi], lane);
+    }
+  }
+};
+// the task-drawing extend-add (k_lf_assemble_lds_dyn) with the hook
+template <int NAT, int NTH>
+__global__ void __launch_bounds__(NTH) k_lf_assemble_fz(MfmaArgs a, double* u, int64_t ldu, int sgn, int cnt, int nrhs, int* counter) {
+  extern __shared__ __attribute__((aligned(16))) double T[];
+  __shared__ int stask;
+  const int total = cnt * nrhs;
+  // (the child table of lf_alds_task behind the front: the hook reads the entries the table phase prepared for it)
+  const int64_t* const sCu = reinterpret_cast<const int64_t*>(T + lf_alds_doubles(a.nnmax + a.namax));
+  const int64_t* const sCr = sCu + a.nchmax;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) stask = atomicAdd(counter, 1);
+    __syncthreads();
+    const int t = stask;
+    if (t >= total) break;
+    lf_alds_task(a, u, ldu, sgn, t % cnt, (t / cnt) % nrhs, 0, 1, T, AldsFam<NAT>{&a, sCu, sCr});
   }
 }
 

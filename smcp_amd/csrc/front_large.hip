@@ -444,7 +444,12 @@ __device__ inline void lf_add_child_tail(double* T, int nf, const double* Uc, co
 // sgn 3 (nz = 1 only): sgn 0 for a sparse right-hand side whose dense input panel has NOT been built -- the constraint's
 // entries of the front (MfmaArgs::kc_*) are added to the front in LDS and the panel is stored whole (no k_panel_fill pass
 // over the panels before, no read of them here: 2 x 79 MB per Schur sweep on synth50k)
-__device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, int sgn, int bx, int by, int bz, int nz, double* T) {
+// fam: hook of the fused extend-add (front_famt.hip: k_lf_assemble_fz) -- fam(T, nf, r, sFz, nmine, wave, nw, lane) adds the
+// update matrices of the children listed in sFz (family parents whose updates were not formed by the family sweep, a.fz_on);
+// the stream skips those children
+struct AldsNoFam { __device__ void operator()(double*, int, int, const int*, int, int, int, int) const {} };
+template <class Fam = AldsNoFam>
+__device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, int sgn, int bx, int by, int bz, int nz, double* T, Fam fam = Fam()) {
   const bool fill = sgn == 3;
   if (fill) sgn = 0;
   const int k = a.t.lev[bx];
@@ -472,11 +477,28 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
   int64_t* const sCu = reinterpret_cast<int64_t*>(T + lf_alds_doubles(a.nnmax + a.namax));
   int64_t* const sCr = sCu + tcap;
   int* const sCn = reinterpret_cast<int*>(sCr + tcap);
+  int* const sFz = sCn + tcap;                 // (a.fz_on only: the launch sizes the table for it)
   for (int qi = tid; qi < nmine; qi += nthr) {
     const int ck = a.t.chidx[d.chbeg + wz + qi * nz];
     const CliqueDesc c = a.t.cl[ck];
-    // (a member of a sibling group that did not write its slot in this sweep -- its sum is in the leader's -- counts as empty)
-    sCu[qi] = c.updp; sCr[qi] = c.rel; sCn[qi] = (a.chskip && a.chskip[ck]) ? 0 : c.na;
+    const bool isfz = a.fz_on && a.fz_no[ck] >= 0;
+    // (a member of a sibling group that did not write its slot in this sweep -- its sum is in the leader's -- counts as empty;
+    // so does a family parent whose update the hook computes)
+    sCu[qi] = c.updp; sCr[qi] = c.rel; sCn[qi] = ((a.chskip && a.chskip[ck]) || isfz) ? 0 : c.na;
+    if (a.fz_on) {
+      // a family child: everything its wave needs to start -- the slot of the family's tables | nn << 19 | na << 24, and (in the
+      // unused packed-update entry) the first term of (family, this right-hand side's constraint) | the term count << 32
+      int z = -1;
+      if (isfz) {
+        const int f = a.fz_no[ck];
+        const int jz = a.kc_ids ? a.kc_ids[a.kc_j0 + by] : a.kc_j0 + by;
+        const int32_t* pp = a.fz_ptr + (int64_t)f * a.fz_stride + jz;
+        const int p0 = pp[0], tn = pp[1] - p0;
+        sCu[qi] = (int64_t)(uint32_t)p0 | ((int64_t)tn << 32);
+        z = a.fz_slot[f] | (c.nn << 19) | (c.na << 24);      // (nn <= 16, na <= 64, fewer than 2^19 families: host-checked)
+      }
+      sFz[qi] = z;
+    }
   }
   for (int e = tid; e < ntot; e += nthr) T[e] = 0.0;
   __syncthreads();
@@ -504,6 +526,7 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
   lf_add_children_stream(T, nf, ubase, a.t.relidx, sCu, sCr, sCn, nmine, wave, nw, lane);
   for (int qi = wave; qi < nmine; qi += nw)
     if (sCn[qi] > 128) lf_add_child_tail(T, nf, ubase + sCu[qi], a.t.relidx + sCr[qi], sCn[qi], lane);
+  if (a.fz_on) fam(T, nf, r, sFz, nmine, wave, nw, lane);
 #endif
   __syncthreads();
   double* P = u + (int64_t)r * ldu + d.blk;

@@ -104,6 +104,15 @@ struct MfmaArgs {
   // grp_list[grp_ptr[g] .. grp_ptr[g + 1]); chskip[k] != 0: the packed update slot of child k is not written in this sweep
   const int32_t* grp_ptr; const int32_t* grp_list; const uint8_t* chskip;
   int famt_ngrp;   // host-side: sibling groups of the family parents of this launch (k_fam_terms_grp), 0 = none
+  // Fused extend-add of the family parents' updates (front_large.hip, lf_add_family): when fz_on the family sweep of this
+  // call (k_fam_terms) does NOT form the parents' update matrices; the extend-add of their parent front computes them from
+  // the families' tables (fz_tab: the records of k_famt_prep, fz_recl doubles each, record of family f at slot fz_slot[f]) and
+  // the static term lists of kkt_set_constraints (terms fz_ptr[f * fz_stride + j] .. [+1) of (fz_pk: vector ids vx | vy << 16,
+  // fz_s: scale); fz_no: clique -> family number or -1) straight into the front it holds in LDS -- the packed updates never
+  // reach HBM
+  int fz_on, fz_nat, fz_cnn, fz_stride;
+  int64_t fz_recl;
+  const double* fz_tab; const int32_t* fz_no; const int32_t* fz_slot; const int32_t* fz_ptr; const int32_t* fz_pk; const double* fz_s;
 };
 
 __device__ __host__ inline int padld(int x) { return x | 1; }

@@ -408,7 +408,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   DeviceCtx& D = c->D;
   const Symbolic& S = c->S;
   HIPCHK(hipSetDevice(D.device));
-  void* old[] = {D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack,
+  void* old[] = {D.fz_no, D.fz_slot, D.fz_ptr, D.fz_pk, D.fz_s, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack,
                  D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.kc_ij, D.scm_owner};
   for (void* p : old) if (p) hipFree(p);
   D.cptr = nullptr; D.cidx = nullptr; D.cval = nullptr; D.cwval = nullptr; D.rpos = nullptr;
@@ -417,6 +417,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   D.scm_owner = nullptr;
   D.vbuf = D.hd = nullptr;
   D.kc_ptr = D.kc_off = nullptr; D.kc_val = nullptr; D.kc_ij = nullptr;
+  D.fz_no = D.fz_slot = D.fz_ptr = D.fz_pk = nullptr; D.fz_s = nullptr; D.fz_nfam = 0; D.fz_ok = false;
   D.md = D.ns = D.vcols = 0;
   D.lg_children = 0; D.lg_nochild = false;
   D.lg_eptr = D.lg_epk = D.lg_remap = nullptr; D.lg_ew = D.lg_tab = nullptr;
@@ -655,6 +656,63 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
       if ((rc = dev_upload(&D.lg_ew, ewv, D.bytes))) return rc;
       if ((rc = dev_upload(&D.lg_remap, remap, D.bytes))) return rc;
       if ((rc = dev_alloc(&D.lg_tab, D.lg_children * D.lg_rec, D.bytes))) return rc;
+    }
+    // Static term lists of the family parents (fused extend-add, front_famt.hip lf_add_family): every entry of constraint j inside
+    // family f -- the parent's own and its children's -- as (vector ids vx | vy << 16, scale), the mapping k_fam_terms does per
+    // launch from the entry lists (front_famt.hip, header): own entry v at (i, j): e_i, e_j, v (v / 2 on the diagonal); child
+    // entry at (separator row a, column j): q~_{c,j}, e_{rel_c[a]}, -v; child entry at (i, j) of its supernode block: q~_{c,i},
+    // q~_{c,j}, v (v / 2).  Only when every family parent hangs under a large front whose packed triangle fits LDS.
+    if (D.fam_maxterms > 0 && D.fam_maxterms <= 48 && !c->fam.empty()) {
+      std::vector<int32_t> fno((size_t)S.nsn, -1);
+      c->fz_levels.assign((size_t)S.nlev, 0);
+      int64_t nfam = 0;
+      bool ok = true;
+      for (int64_t k = 0; k < S.nsn; ++k)
+        if (c->fam[(size_t)k] == 2) {
+          fno[(size_t)k] = (int32_t)nfam++;
+          const int64_t par = S.snpar[k];
+          if (par < 0 || (size_t)par >= c->large_mask.size() || !c->large_mask[(size_t)par] || S.nf(par) > LF_ALDS_MAXNF) ok = false;
+          else c->fz_levels[(size_t)S.level[(size_t)par]] = 1;
+        }
+      if (ok && nfam > 0 && nfam < ((int64_t)1 << 19) && nfam * (m + 1) < ((int64_t)1 << 31)) {
+        std::vector<int32_t> fptr((size_t)(nfam * (m + 1)) + 1, 0), fpk;
+        std::vector<double> fsv;
+        fpk.reserve((size_t)nnz); fsv.reserve((size_t)nnz);
+        for (int64_t k = 0; k < S.nsn; ++k) {
+          const int32_t f = fno[(size_t)k];
+          if (f < 0) continue;
+          for (int64_t j = 0; j < m; ++j) {
+            fptr[(size_t)f * (m + 1) + j] = (int32_t)fpk.size();
+            for (int32_t q = kptr[(size_t)k * (m + 1) + j]; q < kptr[(size_t)k * (m + 1) + j + 1]; ++q) {
+              const int32_t i = kij[q] & 0xffff, jc = kij[q] >> 16;
+              fpk.push_back(i | (jc << 16));
+              fsv.push_back(i == jc ? 0.5 * kval[q] : kval[q]);
+            }
+            int32_t colbase = 0;
+            for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) {
+              const int64_t cc = S.chidx[q2];
+              const int32_t nnc = (int32_t)S.nn(cc);
+              const int32_t* rel = &S.relidx[S.sepptr[cc]];
+              for (int32_t q = kptr[(size_t)cc * (m + 1) + j]; q < kptr[(size_t)cc * (m + 1) + j + 1]; ++q) {
+                const int32_t i = kij[q] & 0xffff, jc = kij[q] >> 16;
+                if (i >= nnc) { fpk.push_back((FAMT_CHILD + colbase + jc) | (rel[i - nnc] << 16)); fsv.push_back(-kval[q]); }
+                else { fpk.push_back((FAMT_CHILD + colbase + i) | ((FAMT_CHILD + colbase + jc) << 16)); fsv.push_back(i == jc ? 0.5 * kval[q] : kval[q]); }
+              }
+              colbase += nnc;
+            }
+          }
+          fptr[(size_t)f * (m + 1) + m] = (int32_t)fpk.size();
+        }
+        fptr[(size_t)(nfam * (m + 1))] = (int32_t)fpk.size();
+        if ((rc = dev_upload(&D.fz_no, fno, D.bytes))) return rc;
+        if ((rc = dev_upload(&D.fz_ptr, fptr, D.bytes))) return rc;
+        if ((rc = dev_upload(&D.fz_pk, fpk, D.bytes))) return rc;
+        if ((rc = dev_upload(&D.fz_s, fsv, D.bytes))) return rc;
+        if ((rc = dev_alloc(&D.fz_slot, nfam, D.bytes))) return rc;
+        HIPCHK(hipMemset(D.fz_slot, 0, sizeof(int32_t) * nfam));
+        D.fz_nfam = nfam;
+        D.fz_ok = true;
+      }
     }
     if ((rc = dev_upload(&D.kc_ij, kij, D.bytes))) return rc;
     if ((rc = dev_upload(&D.kc_ptr, kptr, D.bytes))) return rc;

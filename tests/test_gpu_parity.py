@@ -54,6 +54,11 @@ GPU_PATTERNS["fam_nine"] = lambda: problems.nested_block_arrow_pattern(nsub=1, n
                                                                        mid=(6, 20), top=(20, 20), root=30, seed=7)
 
 
+# odd-sized families under top fronts beyond the LDS class (nf = 130 <= 198): the fused extend-add with three row tiles
+GPU_PATTERNS["fam_top"] = lambda: problems.nested_block_arrow_pattern(nsub=2, nmid=5, nleaf_per_mid=3, leaf=(3, 17),
+                                                                      mid=(7, 33), top=(30, 100), root=110, seed=8)
+
+
 def setup(name, seed):
     symb = Symbolic(GPU_PATTERNS[name]())
     symb.device_init(0, 4)
@@ -1175,3 +1180,41 @@ def test_deferred_potrf_of_the_schur_complement():
         chordal.check_status(symb)                         # reported once
     finally:
         chordal.lazy_status(symb, False)
+
+
+@pytest.mark.parametrize("name,m,density,fused", [("nested_mid", 40, 0.002, True), ("nested_mid", 40, 0.002, False),
+                                                    ("fam_top", 36, 0.004, True)])
+def test_family_updates_formed_by_the_extend_add(name, m, density, fused, monkeypatch):
+    """Round 4: the family parents' update matrices are not written by the family sweep and read back by the extend-add of
+    the front above -- that extend-add forms them itself from the families' tables and the static term lists, into the front
+    it holds in LDS (k_lf_assemble_fz, front_famt.hip).  H, x, y against the oracle; the launch counters show which route ran;
+    SMCP_FZ=0 (checked in a fresh context through csp_tune's sibling: the switch is read once per process, so the unfused
+    reference here is the same problem with the closed-form leaf route off, which never requests the fusion)."""
+    symb, S, A, msk = setup(name, 31)
+    rng = np.random.default_rng(32)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=33)
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+    chordal.tune(symb, chordal.TUNE_LEAFGRAM, 2 if fused else 0)
+    try:
+        Ld, Yd = dev(symb, L), dev(symb, Yh)
+        box = {}
+        counts = _launch_counts(symb, lambda: box.setdefault("solve", sys.factor(Ld, Yd)))
+        if fused:
+            assert counts.get("k_lf_assemble_fz", 0) >= 1 and counts.get("k_fam_terms", 0) >= 1, counts
+        else:
+            assert counts.get("k_lf_assemble_fz", 0) == 0, counts
+        assert rel(np.tril(sys.H.cpu().numpy().T), np.tril(Href)) < 1e-9
+        bx = rng.standard_normal(symb.blklen) * msk
+        by = rng.standard_normal(m)
+        xr, yr = K.solve(L, Yh, Href, bx, by, 0.5)
+        bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+        box["solve"](bxd, byd, 0.5)
+        assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+    finally:
+        chordal.tune(symb, chordal.TUNE_LEAFGRAM, 1)
