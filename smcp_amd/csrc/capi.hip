@@ -527,8 +527,8 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
       MfmaArgs az = a;
       az.fz_on = 1; az.fz_nat = c->fz_nat; az.fz_cnn = c->fz_cnn; az.fz_recl = c->fz_recl; az.fz_stride = (int)(c->D.m + 1);
       az.fz_tab = c->D.famc; az.fz_no = c->D.fz_no; az.fz_slot = c->D.fz_slot; az.fz_ptr = c->D.fz_ptr; az.fz_pk = c->D.fz_pk; az.fz_s = c->D.fz_s;
-      int* counter = c->D.info + 24 + (st == c->aux_stream[0] ? 1 : (st == c->aux_stream[1] ? 2 : 0));
-      (void)hipMemsetAsync(counter, 0, sizeof(int), st);
+      int* counter = c->D.fz_slot + c->D.fz_nfam;       // eight task counters behind the slot table (kkt_set_constraints)
+      (void)hipMemsetAsync(counter, 0, 8 * sizeof(int), st);
       switch (c->fz_nat) {
         case 1: ok = launch_assemble_fz<1>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;
         case 2: ok = launch_assemble_fz<2>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;

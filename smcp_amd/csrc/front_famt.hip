@@ -534,26 +534,12 @@ __device__ inline void lf_add_family(double* T, int nf, const MfmaArgs& a, int z
       for (int ct = 0; ct <= rt; ++ct)
         acc[rt * (rt + 1) / 2 + ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[ct], bA[rt], acc[rt * (rt + 1) / 2 + ct], 0, 0, 0);
   };
-#ifdef SMCP_FZ_PIPE        // operands of step s + 1 in flight during the products of step s (sixteen more registers)
-  double aA0[NAT], bA0[NAT], aA1[NAT], bA1[NAT], se0 = 0.0, se1 = 0.0;
-  int ux0 = 255, uy0 = 255, ux1 = 255, uy1 = 255;
-  if (ks > 0) fetch(0, aA0, bA0, se0, ux0, uy0);
-  for (int s = 0; s < ks; s += 2) {
-    if (s + 1 < ks) fetch(s + 1, aA1, bA1, se1, ux1, uy1);
-    mma(aA0, bA0, se0, ux0, uy0);
-    if (s + 1 < ks) {
-      if (s + 2 < ks) fetch(s + 2, aA0, bA0, se0, ux0, uy0);
-      mma(aA1, bA1, se1, ux1, uy1);
-    }
-  }
-#else
   for (int s = 0; s < ks; ++s) {
     double aA[NAT], bA[NAT], se;
     int ux, uy;
     fetch(s, aA, bA, se, ux, uy);
     mma(aA, bA, se, ux, uy);
   }
-#endif
   // element (m, n) of the update -> front position (rel[m], rel[n]); packed column start minus the column index as in lf_alds_task
 #pragma unroll
   for (int rt = 0; rt < NAT; ++rt) {
@@ -581,22 +567,32 @@ struct AldsFam {
     }
   }
 };
-// the task-drawing extend-add (k_lf_assemble_lds_dyn) with the hook
+// the task-drawing extend-add (k_lf_assemble_lds_dyn) with the hook.  The draw is XCD-aware: workgroups are dealt to the
+// eight XCDs round-robin by block index, and queue q = blockIdx.x & 7 holds the (front, right-hand side) tasks of the fronts
+// q, q + 8, ... -- the hundred right-hand sides of one front gather from the SAME families' tables (11 MB per front on
+// synth50k, 88 MB in all), so a front worked on by one XCD keeps its tables in that XCD's L2 instead of every L2 seeing all
+// of them; a workgroup whose queue is empty takes from the others (counters[0 .. 7], zeroed by the launch).
 template <int NAT, int NTH>
-__global__ void __launch_bounds__(NTH) k_lf_assemble_fz(MfmaArgs a, double* u, int64_t ldu, int sgn, int cnt, int nrhs, int* counter) {
+__global__ void __launch_bounds__(NTH) k_lf_assemble_fz(MfmaArgs a, double* u, int64_t ldu, int sgn, int cnt, int nrhs, int* counters) {
   extern __shared__ __attribute__((aligned(16))) double T[];
   __shared__ int stask;
-  const int total = cnt * nrhs;
   // (the child table of lf_alds_task behind the front: the hook reads the entries the table phase prepared for it)
   const int64_t* const sCu = reinterpret_cast<const int64_t*>(T + lf_alds_doubles(a.nnmax + a.namax));
   const int64_t* const sCr = sCu + a.nchmax;
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) stask = atomicAdd(counter, 1);
-    __syncthreads();
-    const int t = stask;
-    if (t >= total) break;
-    lf_alds_task(a, u, ldu, sgn, t % cnt, (t / cnt) % nrhs, 0, 1, T, AldsFam<NAT>{&a, sCu, sCr});
+  const int q0 = (int)(blockIdx.x & 7);
+  for (int dq = 0; dq < 8; ++dq) {
+    const int q = (q0 + dq) & 7;
+    const int nfq = (cnt - q + 7) >> 3;                 // fronts q, q + 8, ... below cnt
+    const int total = nfq * nrhs;
+    if (total <= 0) continue;
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) stask = atomicAdd(counters + q, 1);
+      __syncthreads();
+      const int t = stask;
+      if (t >= total) break;
+      lf_alds_task(a, u, ldu, sgn, q + 8 * (t / nrhs), t % nrhs, 0, 1, T, AldsFam<NAT>{&a, sCu, sCr});
+    }
   }
 }
 

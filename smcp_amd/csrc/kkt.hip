@@ -708,8 +708,8 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
         if ((rc = dev_upload(&D.fz_ptr, fptr, D.bytes))) return rc;
         if ((rc = dev_upload(&D.fz_pk, fpk, D.bytes))) return rc;
         if ((rc = dev_upload(&D.fz_s, fsv, D.bytes))) return rc;
-        if ((rc = dev_alloc(&D.fz_slot, nfam, D.bytes))) return rc;
-        HIPCHK(hipMemset(D.fz_slot, 0, sizeof(int32_t) * nfam));
+        if ((rc = dev_alloc(&D.fz_slot, nfam + 8, D.bytes))) return rc;      // (+ the eight task counters of k_lf_assemble_fz)
+        HIPCHK(hipMemset(D.fz_slot, 0, sizeof(int32_t) * (nfam + 8)));
         D.fz_nfam = nfam;
         D.fz_ok = true;
       }
