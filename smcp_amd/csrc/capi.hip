@@ -2347,7 +2347,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
       hipLaunchKernelGGL(k_fill_sqrt_weights, dim3((unsigned)std::min<int64_t>(S.nsn, 4096)), dim3(256), 0, 0, D.cl, (int)S.nsn, D.sw);
     }
     if ((rc = dev_alloc(&D.faci, S.updlen(), D.bytes))) return rc;
-    if ((rc = dev_alloc(&D.red, 1024, D.bytes))) return rc;
+    if ((rc = dev_alloc(&D.red, 4096, D.bytes))) return rc;      // [0, 1024): reduction scratch, [1024, 4096): shares of a split Amap (kkt_solve)
     if ((rc = dev_alloc(&D.info, 32, D.bytes))) return rc;      // [0, 16): failure flags of the copies; [16]: status latch
     HIPCHK(hipMemset(D.info, 0, sizeof(int) * 32));
     // pinned mirror: ints [0, 16) the trial flags (csp_trial_flags), [16] the status latch (csp_status), bytes [96, 104) the

@@ -8,14 +8,18 @@ using namespace smcp;
 // y[i] = sum_e w_e a_e X[idx_e], one workgroup per (constraint i, rhs r) with four gathers in flight per thread (a
 // constraint of synth50k has 11 k entries: one wave per constraint walked them in 178 dependent steps);
 // X_r = X + r*ldx; y_r = y + r*ldy.  The partial sums are combined in a fixed order (deterministic).
+// gridDim.z > 1: workgroup z takes the z-th share of the constraint's entries and writes its partial sum to y + z * pstride (the
+// caller adds the shares in order: k_vec_axpby_parts)
 __global__ void __launch_bounds__(1024) k_amap(int64_t m, const int64_t* cptr, const int64_t* cidx, const double* cwval,
-                                               const double* X, int64_t ldx, double* y, int64_t ldy) {
+                                               const double* X, int64_t ldx, double* y, int64_t ldy, int64_t pstride) {
   __shared__ double part[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nthr = blockDim.x;
   const int64_t i = blockIdx.x;
   const int r = blockIdx.y;
   const double* x = X + (int64_t)r * ldx;
-  const int64_t e0 = cptr[i], e1 = cptr[i + 1];
+  const int64_t c0 = cptr[i], c1 = cptr[i + 1], share = (c1 - c0 + gridDim.z - 1) / gridDim.z;
+  const int64_t e0 = c0 + (int64_t)blockIdx.z * share, e1 = e0 + share < c1 ? e0 + share : c1;
+  y += (int64_t)blockIdx.z * pstride;
   double acc = 0.0;
   for (int64_t e = e0 + threadIdx.x; e < e1; e += 4 * nthr) {
     double w[4], v[4];
@@ -46,6 +50,17 @@ __global__ void k_aadj(int64_t rnnz, const int64_t* rpos, const int64_t* rptr, c
   double acc = 0.0;
   for (int64_t e = rptr[q]; e < rptr[q + 1]; ++e) acc += rval[e] * y[rcon[e]];
   X[rpos[q]] = acc;
+}
+
+// X[rpos[q]] -= the same sum: X <- X - Aadj(y) touching only the positions that carry constraint entries (solve_ forms
+// bx - Aadj(y) in place this way: no cleared scratch vector, no pass over the whole of blkval)
+__global__ void k_aadj_sub(int64_t rnnz, const int64_t* rpos, const int64_t* rptr, const int32_t* rcon,
+                           const double* rval, const double* y, double* X) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= rnnz) return;
+  double acc = 0.0;
+  for (int64_t e = rptr[q]; e < rptr[q + 1]; ++e) acc += rval[e] * y[rcon[e]];
+  X[rpos[q]] -= acc;
 }
 
 // U_r (pre-zeroed) <- A_{j0+r} scattered into blkval coordinates
@@ -379,6 +394,14 @@ __global__ void k_vec_axpby(int64_t m, double a, const double* x, double b, doub
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) y[i] = a * x[i] + b * y[i];
 }
+// y = b*y + a*(x_0 + x_1 + ... in order), x_z = x + z * pstride: the shares of a split k_amap
+__global__ void k_vec_axpby_parts(int64_t m, double a, const double* x, int parts, int64_t pstride, double b, double* y) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  double s = 0.0;
+  for (int z = 0; z < parts; ++z) s += x[i + (int64_t)z * pstride];
+  y[i] = a * s + b * y[i];
+}
 
 int amap_impl(csp_ctx* c, const double* X, int64_t ldx, int nrhs, double* y, int64_t ldy, hipStream_t st) {
   const DeviceCtx& D = c->D;
@@ -386,7 +409,7 @@ int amap_impl(csp_ctx* c, const double* X, int64_t ldx, int nrhs, double* y, int
   const int64_t avg = D.m ? D.cnnz / D.m : 0;
   const int thr = avg > 4096 ? 1024 : (avg > 512 ? 256 : 64);
   launch(c, KID_amap, k_amap, dim3((unsigned)D.m, nrhs), dim3(thr), st, D.m,
-                     D.cptr, D.cidx, D.cwval, X, ldx, y, ldy);
+                     D.cptr, D.cidx, D.cwval, X, ldx, y, ldy, (int64_t)0);
   return 0;
 }
 int aadj_impl(csp_ctx* c, const double* y, double* X, hipStream_t st) {
@@ -1394,14 +1417,32 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   if (!use_generic(c)) { if (int rc = prep_lk_cached(c, L, Y, st)) return rc; }
   HIPCHK(hipMemcpyAsync(r1, bx, sizeof(double) * bl, hipMemcpyDeviceToDevice, st));
   hessian_impl(c, L, r1, 1, bl, 2, 0, st);                      // r1 = W(bx)
-  amap_impl(c, r1, 0, 1, ytmp, 0, st);                          // Amap(r1)
-  launch(c, KID_vec_axpby, k_vec_axpby, dim3((unsigned)((m + 255) / 256)), dim3(256), st, m, 1.0, ytmp, kk, by);  // y = kk*by + Amap(r1)
+  {
+    // Amap(r1), then y = kk*by + Amap(r1).  Few long constraints (synth50k: 100 of 11 k entries each) leave most of the chip idle
+    // with one workgroup per constraint, each thread walking three rounds of dependent gathers: the entries are dealt over
+    // `parts` workgroups per constraint and the shares added in order by the update of y (deterministic)
+    const int64_t avg = D.m ? D.cnnz / D.m : 0;
+    int parts = 1;
+    if (avg > 4096 && m <= 400) parts = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)8, (2 * (int64_t)D.ncu) / std::max<int64_t>(m, 1), avg / 2048, (int64_t)3072 / std::max<int64_t>(m, 1)}));
+    if (parts <= 1) {
+      amap_impl(c, r1, 0, 1, ytmp, 0, st);
+      launch(c, KID_vec_axpby, k_vec_axpby, dim3((unsigned)((m + 255) / 256)), dim3(256), st, m, 1.0, ytmp, kk, by);
+    } else {
+      double* const ypart = D.red + 1024;
+      launch(c, KID_amap, k_amap, dim3((unsigned)m, 1, (unsigned)parts), dim3(1024), st, m, D.cptr, D.cidx, D.cwval, (const double*)r1, (int64_t)0,
+             ypart, (int64_t)0, m);
+      launch(c, KID_vec_axpby, k_vec_axpby_parts, dim3((unsigned)((m + 255) / 256)), dim3(256), st, m, 1.0, (const double*)ypart, parts, m, kk, by);
+    }
+  }
   if (hf) hf->join();                                           // H is factored from here on
   if (int rc = potrs_impl(c, H, m, ldh, by, 1, m, st)) return rc;
-  if (int rc = aadj_impl(c, by, r1, st)) return rc;             // r1 = Aadj(y)
-  launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 1.0, (const double*)r1, -1.0, bx);  // bx = Aadj(y) - bx
+  // x = W(Aadj(y) - bx) / kk = -W(bx - Aadj(y)) / kk: the subtraction touches the constraint entries' positions only (no cleared
+  // blkval-sized vector, no axpby over the whole of it: 28 us of three launches on synth50k), the sign rides on the final scaling
+  if (D.rnnz)
+    launch(c, KID_aadj, k_aadj_sub, dim3((unsigned)((D.rnnz + 255) / 256)), dim3(256), st, D.rnnz, D.rpos, D.rptr, D.rcon, D.rval,
+           (const double*)by, bx);
   hessian_impl(c, L, bx, 1, bl, 2, 0, st);
-  launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 0.0, (const double*)nullptr, 1.0 / kk, bx);
+  launch(c, KID_axpby, k_axpby, dim3(1024), dim3(256), st, bl, 0.0, (const double*)nullptr, -1.0 / kk, bx);
   HIPCHK(end_call(c));
   return 0;
 }
