@@ -126,7 +126,7 @@ def csrc_sha256():
     return h.hexdigest()[:16]
 
 
-def famt_executed_flops(symb, cptr, cidx, chunks):
+def famt_executed_flops(symb, cptr, cidx, chunks, tiles="all"):
     """Flops k_fam_terms EXECUTES per sweep of all chunks (front_famt.hip): one wave per (family parent, right-hand side)
     issues ks = ceil(2 T / 4) steps of NAT (NAT + 1) / 2 + NAT + 1 v_mfma_f64_16x16x4 (2048 flop each, tile padding
     included), T = entries of the constraint inside the family (the parent's and its children's, capped at 48).  This is
@@ -149,9 +149,29 @@ def famt_executed_flops(symb, cptr, cidx, chunks):
     np.add.at(T, (o[o >= 0], con[o >= 0]), 1)
     ks = (2 * np.minimum(T, 48) + 3) >> 2
     nat = (int(na_[parents].max()) + 15) // 16          # the launch's instantiation serves the widest parent
-    per_step = nat * (nat + 1) // 2 + nat + 1
+    # tiles per step: update tiles nat (nat + 1) / 2, Q tiles nat, G_NN 1 -- all in k_fam_terms<NAT, true>; with the fused
+    # extend-add k_fam_terms<NAT, false> issues the Q and G_NN tiles and k_lf_assemble_fz the update tiles
+    per_step = {"all": nat * (nat + 1) // 2 + nat + 1, "panels": nat + 1, "updates": nat * (nat + 1) // 2}[tiles]
     nrhs = sum(chunks)
     return float(ks[:, :nrhs].sum()) * per_step * 2048.0
+
+
+def pmc_traffic(dom, label, world):
+    """HBM bytes per launch of kernel `dom` from the committed PMC summary (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as
+    the gfx950 guide prescribes) -- only when it lists this kernel for this workload AND the kernel sources are byte-identical to
+    the ones the counters were collected on (csrc_sha256); otherwise (None, why)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+        hits = [v for kname, v in tj.get("kernels", {}).items() if kname.split("<")[0] == dom.split("<")[0]]
+        if tj.get("workload") == label and hits and world == 1:
+            if tj.get("csrc_sha256") == csrc_sha256():
+                return (max(v["hbm_bytes_per_launch"] for v in hits),
+                        "profiles/%s (rocprofv3 --pmc passes, csrc_sha256 %s = the running sources)" % (TRAFFIC_FILE, tj.get("csrc_sha256")))
+            return None, "dropped: profiles/%s was collected on other kernel sources (csrc_sha256 %s, running %s)" % (
+                TRAFFIC_FILE, tj.get("csrc_sha256"), csrc_sha256())
+    except Exception:
+        pass
+    return None, None
 
 
 def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc, part, rank, world, label, con=None):
@@ -194,11 +214,45 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
     note = None
     extra = {}
     alg = None
+    fused = "k_lf_assemble_fz" in breakdown           # the parents' updates are formed by the extend-add above (front_famt.hip)
+    if dom == "k_lf_assemble_fz" and con is not None and part is None:
+        # Fused extend-add: per launch it HAS to write the assembled fronts (panel + update block of every (front, right-hand side))
+        # and read the families' tables and the static term lists once; the operands it gathers per term come from L2 / MALL
+        # (~2.2 GB per launch on synth50k, not HBM traffic by construction).  Executed matrix-core work: the update tiles.
+        par2 = fam == 2
+        big = np.zeros(symb.Nsn, dtype=bool)
+        big[np.unique(np.asarray(par)[par2])] = True      # the fronts this launch assembles: the parents of the family parents
+        nnb, nab = nn_[big].astype(np.float64), na_[big].astype(np.float64)
+        fronts = 8.0 * sum(chunks) * float(((nnb + nab) * nnb + nab * nab).sum())
+        natz = (int(na_[par2].max()) + 15) // 16
+        cnn = int(nn_[fam == 1].max()) if (fam == 1).any() else 1
+        rec = 256 + 2 * 16 * natz * 16 + (16 * natz) ** 2 + 16 * natz + 8 * cnn * (16 + 2 * 16 * natz)
+        tables = 8.0 * float(par2.sum()) * rec + 12.0 * float(len(con[1]))
+        alg = fronts + tables
+        ex = famt_executed_flops(symb, con[0], con[1], chunks, "updates")
+        avg_s = 1e-3 * dom_ms / dom_launches
+        ai = ex / alg
+        ridge = FP64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        tfl = ex / dom_launches / avg_s / 1e12
+        gbs = alg / dom_launches / avg_s / 1e9
+        mf = {"achieved": round(tfl, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / FP64_PEAK_TFLOPS, 4)}
+        hb = {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        top = mf if ai >= ridge else hb
+        traffic, source = pmc_traffic(dom, label, world)
+        return {"kernel": dom, "bound": "mfma" if ai >= ridge else "hbm", "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+                "frac": top["frac"], "traffic": traffic, "traffic_source": source, "mfma": dict(mf, flops_per_launch=ex / dom_launches),
+                "hbm": dict(hb, bytes_per_launch=alg / dom_launches), "arithmetic_intensity_flop_per_byte": round(ai, 2),
+                "ridge_flop_per_byte": round(ridge, 2), "avg_launch_us": round(1e6 * avg_s, 2), "launches_per_step": dom_launches,
+                "note": "fused extend-add (k_lf_assemble_fz): algorithmic bytes = assembled fronts written + family tables and term lists "
+                        "read once; executed flops = update tiles (v_mfma_f64_16x16x4 x 2048) counted on the host; the bound is derived "
+                        "from their ratio against the ridge.  The packed updates of the family parents (1.49 GB written + 1.49 GB read per "
+                        "launch pair in round 3) no longer exist."}
     if dom in ("k_fam_sparse", "k_fam_terms"):
         # bytes the fused family kernel HAS to move: the parents' output panels (+ the children's when they are formed),
         # the parents' packed updates, the constants of every member once per launch; the children's updates stay in LDS
         panels = Bk[fam_mask & (fam == 2)].sum() + (0.0 if leaf_gram else Bk[fam_mask & (fam == 1)].sum())
-        alg = sum(8.0 * (r * (panels + Upk[fam_mask & (fam == 2)].sum()) + Bk[fam_mask].sum()) for r in chunks)
+        upd_out = 0.0 if fused else Upk[fam_mask & (fam == 2)].sum()      # fused extend-add: the packed updates are never written
+        alg = sum(8.0 * (r * (panels + upd_out) + Bk[fam_mask].sum()) for r in chunks)
         nnk, nak = nn_[fam_mask].astype(np.float64), na_[fam_mask].astype(np.float64)
         flops = float((nnk ** 3 + 3 * nak * nnk ** 2 + 3 * nak ** 2 * nnk).sum()) * sum(chunks)
         per_level = sum(8.0 * (r * (Bk[fam_mask].sum() + Upk[fam_mask].sum() + Upch[fam_mask].sum()) + Bk[fam_mask].sum()) for r in chunks)
@@ -208,14 +262,14 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
                                     "frac": round(flops / (1e-3 * dom_ms) / 1e12 / FP64_PEAK_TFLOPS, 4),
                                     "note": "dense-formulation flops of the same sweeps (SURVEY 8d); NOT executed by this kernel"}}
         if dom == "k_fam_terms" and con is not None and part is None:
-            ex = famt_executed_flops(symb, con[0], con[1], chunks)
+            ex = famt_executed_flops(symb, con[0], con[1], chunks, "panels" if fused else "all")
             extra["mfma"] = {"flops_per_launch": ex / dom_launches,
                              "achieved_tflops": round(ex / (1e-3 * dom_ms) / 1e12, 2),
                              "frac": round(ex / (1e-3 * dom_ms) / 1e12 / FP64_PEAK_TFLOPS, 4),
                              "note": "EXECUTED v_mfma_f64_16x16x4 x 2048 flop, counted on the host from the entries per (family, "
                                      "constraint); equals SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 of the PMC pass"}
         if dom == "k_fam_terms":      # tables of the family (record of k_famt_prep) read once per workgroup instead of the constants
-            alg = sum(8.0 * r * (panels + Upk[fam_mask & (fam == 2)].sum()) for r in chunks) + 8.0 * Bk[fam_mask].sum()
+            alg = sum(8.0 * r * (panels + upd_out) for r in chunks) + 8.0 * Bk[fam_mask].sum()
         note = ("bytes = the parents' output panels%s + the parents' packed updates + the members' constants (the children's "
                 "update matrices never exist); per_level_bytes = SURVEY 8d's per-level figure for the same sweeps; mfma = "
                 "executed matrix-core flops, mfma_canonical = dense-formulation flops" % (" (the children's panels are not formed: their Gram block comes from "
@@ -258,23 +312,7 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
         avg_s = 1e-3 * dom_ms / dom_launches
         per_launch = alg / dom_launches
         achieved = per_launch / avg_s / 1e9
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the gfx950
-        # guide prescribes), taken from the committed summary of the same command -- with its provenance, and dropped
-        # when that summary does not list this kernel for this workload
-        # -- and only when the kernel sources are byte-identical to the ones the counters were collected on (csrc_sha256)
-        traffic, source = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
-            hits = [v for kname, v in tj.get("kernels", {}).items() if kname.split("<")[0] == dom.split("<")[0]]
-            if tj.get("workload") == label and hits and world == 1:
-                if tj.get("csrc_sha256") == csrc_sha256():
-                    traffic = max(v["hbm_bytes_per_launch"] for v in hits)
-                    source = "profiles/%s (rocprofv3 --pmc passes, csrc_sha256 %s = the running sources)" % (TRAFFIC_FILE, tj.get("csrc_sha256"))
-                else:
-                    source = "dropped: profiles/%s was collected on other kernel sources (csrc_sha256 %s, running %s)" % (
-                        TRAFFIC_FILE, tj.get("csrc_sha256"), csrc_sha256())
-        except Exception:
-            traffic = None
+        traffic, source = pmc_traffic(dom, label, world)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
                     "bytes_per_launch": per_launch, "avg_launch_us": round(1e6 * avg_s, 2),

@@ -14,7 +14,7 @@ for sub in ('a','b'):
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(set)
     for r in csv.DictReader(open(f[0])):
         name=r['Kernel_Name'].split('(')[0].replace('void ','').replace('smcp::','')
-        if not any(k in name for k in ('gram_diag','fam_terms','fam_sparse','lf_assemble_lds','leaf_pairs','lf_up2','mid_chol')): continue
+        if not any(k in name for k in ('gram_diag','fam_terms','fam_sparse','lf_assemble_lds','lf_assemble_fz','leaf_pairs','lf_up2','mid_chol')): continue
         agg[name][r['Counter_Name']]+=float(r['Counter_Value']); cnt[name].add(r['Dispatch_Id'])
     for n,c in agg.items():
         print(sub, n, 'launches', len(cnt[n]), {k: v/len(cnt[n]) for k,v in c.items()})
