@@ -732,9 +732,11 @@ def main():
     ap.add_argument("--max-rhs", type=int, default=None)
     ap.add_argument("--cpu-cols", type=int, default=10 ** 9, help="Schur columns timed on the CPU oracle (default: all; at least one per thread)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (a 1-GPU box has a 16-core share)")
-    ap.add_argument("--tune-placement", type=int, default=12,
-                    help="tries of csp_tune(CSP_TUNE_PLACEMENT) during set-up (0 = off; synth50k only): the two output buffers of the family sweep (packed "
-                         "exchange buffer, swept stack) are moved in turn to fresh allocations, the fastest for its store pattern kept")
+    ap.add_argument("--tune-placement", type=int, default=0,
+                    help="tries of csp_tune(CSP_TUNE_PLACEMENT) during set-up (0 = off, the default since round 4: with the fused extend-add the "
+                         "family sweep no longer writes the packed exchange buffer, and the placement of its buffers stopped mattering -- 301 solves/s "
+                         "as allocated against 298 tuned; synth50k only): the two output buffers of the family sweep are moved in turn to fresh "
+                         "allocations, the fastest for its store pattern kept; `value_as_allocated` and `value_tuned` are then both reported")
     ap.add_argument("--shard", default="subtree", choices=["subtree", "columns"],
                     help="N > 1: subtree sharding + boundary exchange (default) or column sharding of H")
     ap.add_argument("--no-cpu", action="store_true")

@@ -15,6 +15,7 @@
 
 #include "../../include/smcp_amd.h"
 #include "context.hpp"
+#include "switches.hpp"
 #include "front_generic.hip"
 #include "front_mfma.hip"
 #include "front_large.hip"
@@ -100,17 +101,17 @@ inline hipError_t end_call(csp_ctx* c) {
 // rocprofv3 timeline of csp_cholesky_projected_inverse).  SMCP_EVENT_SYSFENCE=1: the default flags.
 inline unsigned sync_event_flags() {
   static int sys = -1;
-  if (sys < 0) { const char* e = getenv("SMCP_EVENT_SYSFENCE"); sys = (e && e[0] == '1') ? 1 : 0; }
+  if (sys < 0) { const char* e = sw_str("SMCP_EVENT_SYSFENCE"); sys = (e && e[0] == '1') ? 1 : 0; }
   return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice);
 }
 struct Fork {
   csp_ctx* c; hipStream_t main; hipStream_t s; int which; bool on;
   static bool enabled() {
     static int e = -1;
-    if (e < 0) { const char* v = getenv("SMCP_FORK"); e = (v && v[0] == '0') ? 0 : 1; }
+    if (e < 0) { const char* v = sw_str("SMCP_FORK"); e = (v && v[0] == '0') ? 0 : 1; }
     return e == 1 && !trace_on_early();
   }
-  static bool trace_on_early() { const char* e = getenv("SMCP_TRACE"); return e && e[0] == '1'; }
+  static bool trace_on_early() { static const bool t = [] { const char* e = sw_str("SMCP_TRACE"); return e && e[0] == '1'; }(); return t; }
   Fork(csp_ctx* c_, hipStream_t st, int which_) : c(c_), main(st), s(st), which(which_), on(false) {
     if (!enabled()) return;
     if (!c->aux_fork && hipEventCreateWithFlags(&c->aux_fork, sync_event_flags()) != hipSuccess) { c->aux_fork = nullptr; return; }
@@ -120,13 +121,13 @@ struct Fork {
       // of synth50k: 55 us alone, 140 us beside k_factor_yaa_lds) -- so it is created with the highest priority the device
       // offers: its few workgroups get their CUs first.  SMCP_AUX_PRIO=0: default priority.
       static int prio = -2;
-      if (prio == -2) { const char* e = getenv("SMCP_AUX_PRIO"); prio = (e && e[0] == '0') ? 0 : 1; }
+      if (prio == -2) { const char* e = sw_str("SMCP_AUX_PRIO"); prio = (e && e[0] == '0') ? 0 : 1; }
       int lo = 0, hi = 0;
       hipError_t rc = hipErrorUnknown;
       // side stream 1 carries FILLER work (thousands of small-clique workgroups beside a chain on the caller's stream): lowest
       // priority, so that it does not take the CUs a chain's few workgroups are waiting for (SMCP_AUX_PRIO1=0: default)
       static int prio1 = -2;
-      if (prio1 == -2) { const char* e = getenv("SMCP_AUX_PRIO1"); prio1 = (e && e[0] == '0') ? 0 : 1; }
+      if (prio1 == -2) { const char* e = sw_str("SMCP_AUX_PRIO1"); prio1 = (e && e[0] == '0') ? 0 : 1; }
       if (which == 0 && prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
         rc = hipStreamCreateWithPriority(&c->aux_stream[which], hipStreamNonBlocking, hi);
       if (which == 1 && prio1 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
@@ -153,7 +154,7 @@ struct Fork {
 // is the kernel that faulted)
 inline bool trace_on() {
   static int t = -1;
-  if (t < 0) { const char* e = getenv("SMCP_TRACE"); t = (e && e[0] == '1') ? 1 : 0; }
+  if (t < 0) { const char* e = sw_str("SMCP_TRACE"); t = (e && e[0] == '1') ? 1 : 0; }
   return t == 1;
 }
 inline void trace_launch(int kid, dim3 grid, dim3 block, size_t lds, hipStream_t st, bool before) {
@@ -218,13 +219,13 @@ int dev_alloc(T** dst, int64_t count, int64_t& bytes) {
   size_t n = (size_t)std::max<int64_t>(count, 1) * sizeof(T);
   // SMCP_CONTIG=1 (placement studies): large buffers from physically contiguous memory (hipDeviceMallocContiguous)
   static int contig = -1;
-  if (contig < 0) { const char* e = getenv("SMCP_CONTIG"); contig = (e && e[0] == '1') ? 1 : 0; }
+  if (contig < 0) { const char* e = sw_str("SMCP_CONTIG"); contig = (e && e[0] == '1') ? 1 : 0; }
   hipError_t arc = hipErrorUnknown;
   if (contig && n >= ((size_t)1 << 24)) arc = hipExtMallocWithFlags((void**)dst, n, hipDeviceMallocContiguous);
   if (arc != hipSuccess) { (void)hipGetLastError(); arc = hipMalloc((void**)dst, n); }
   if (arc != hipSuccess) return SMCP_ENOMEM;
   bytes += (int64_t)n;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SMCP_DEBUG_ADDR"); dbg = (e && e[0] == '1') ? 1 : 0; }      // placement studies
+  { static int dbg = -1; if (dbg < 0) { const char* e = sw_str("SMCP_DEBUG_ADDR"); dbg = (e && e[0] == '1') ? 1 : 0; }      // placement studies
     if (dbg && n >= ((size_t)1 << 24)) fprintf(stderr, "smcp_amd: alloc %zu MB at %p\n", n >> 20, (void*)*dst); }
   return 0;
 }
@@ -254,7 +255,7 @@ TreeArgs tree_args(csp_ctx* c) {
 // SMCP_TIMING=1: wall-clock marks of the host-side set-up phases on stderr (csp_device_init, kkt_set_constraints)
 struct SetupClock {
   bool on; const char* what; std::chrono::steady_clock::time_point t0;
-  explicit SetupClock(const char* w) : what(w), t0(std::chrono::steady_clock::now()) { const char* e = getenv("SMCP_TIMING"); on = e && e[0] == '1'; }
+  explicit SetupClock(const char* w) : what(w), t0(std::chrono::steady_clock::now()) { const char* e = sw_str("SMCP_TIMING"); on = e && e[0] == '1'; }
   void mark(const char* step) {
     if (!on) return;
     auto t1 = std::chrono::steady_clock::now();
@@ -356,7 +357,7 @@ constexpr size_t LDS_LIMIT = 160 * 1024 - 2048;   // dynamic working set; the re
 
 bool cache_off() {
   static int nocache = -1;
-  if (nocache < 0) { const char* e = getenv("SMCP_NOCACHE"); nocache = (e && e[0] == '1') ? 1 : 0; }
+  if (nocache < 0) { const char* e = sw_str("SMCP_NOCACHE"); nocache = (e && e[0] == '1') ? 1 : 0; }
   return nocache == 1;
 }
 
@@ -364,7 +365,7 @@ bool cache_off() {
 // csp_tune(ctx, CSP_TUNE_DETERMINISTIC, 1) -- no floating-point atomics anywhere, results bit-identical from run to run
 bool use_generic(const csp_ctx* c) {
   static int g = -1;
-  if (g < 0) { const char* e = getenv("SMCP_GENERIC"); g = (e && e[0] == '1') ? 1 : 0; }
+  if (g < 0) { const char* e = sw_str("SMCP_GENERIC"); g = (e && e[0] == '1') ? 1 : 0; }
   return g == 1 || (c && c->deterministic);
 }
 
@@ -378,7 +379,7 @@ MfmaArgs mfma_args(csp_ctx* c, const double* ysc, int ymode, int nrhs) {
   a.nnmax = a.namax = 0;
   a.nchmax = a.panmax = a.pkmax = a.plansum = 0;
   a.nrhs = nrhs;
-  { static int sk = -1; if (sk < 0) { const char* e = getenv("SMCP_SKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
+  { static int sk = -1; if (sk < 0) { const char* e = sw_str("SMCP_SKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
   a.dbg = (a.skip & 64) ? (unsigned long long*)(c->D.red + 768) : nullptr;
   a.lfd = c->D.lfd;
   a.dn = 0; a.dld = 0;
@@ -439,7 +440,7 @@ void for_all_large(csp_ctx* c, MfmaArgs a, F f) {
 
 bool use_large() {
   static int g = -1;
-  if (g < 0) { const char* e = getenv("SMCP_LARGE"); g = (e && e[0] == '0') ? 0 : 1; }
+  if (g < 0) { const char* e = sw_str("SMCP_LARGE"); g = (e && e[0] == '0') ? 0 : 1; }
   return g == 1;
 }
 inline unsigned umax1(int x) { return (unsigned)std::max(1, x); }
@@ -450,12 +451,12 @@ inline unsigned umax1(int x) { return (unsigned)std::max(1, x); }
 static int fact_threads(const MfmaArgs& am, int thr, int kind) {
   static int t[3] = {0, 0, 0};
   if (!t[0]) {
-    auto rd = [](const char* n, int d) { const char* e = getenv(n); int v = e ? atoi(e) : d; return (v >= 64 && v <= 1024 && !(v & 63)) ? v : d; };
+    auto rd = [](const char* n, int d) { const char* e = sw_str(n); int v = e ? atoi(e) : d; return (v >= 64 && v <= 1024 && !(v & 63)) ? v : d; };
     t[0] = rd("SMCP_FTHR_CHOL", 128); t[1] = rd("SMCP_FTHR_PINV", 256); t[2] = rd("SMCP_FTHR_YAA", 64);
   }
   if (kind == 2 && am.nnmax <= 16 && am.namax > 32 && am.namax <= 64) {      // Y_AA blocks of 33 .. 64 rows (the mid fronts of synth50k)
     static int tm = 0;
-    if (!tm) { const char* e = getenv("SMCP_FTHR_YAA_MID"); tm = e ? atoi(e) : 256; if (tm < 64 || tm > 1024 || (tm & 63)) tm = 256; }
+    if (!tm) { const char* e = sw_str("SMCP_FTHR_YAA_MID"); tm = e ? atoi(e) : 256; if (tm < 64 || tm > 1024 || (tm & 63)) tm = 256; }
     return tm;
   }
   return (am.nnmax <= 16 && am.namax <= 32) ? t[kind] : thr;
@@ -471,13 +472,13 @@ static int fact_threads(const MfmaArgs& am, int thr, int kind) {
 static bool alds_route(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, int& nz, size_t& bytes) {
   // fronts whose packed lower triangle fits LDS: stream the children through it (k_lf_assemble_lds)
   static int alds = -1;
-  if (alds < 0) { const char* e = getenv("SMCP_ALDS"); alds = (e && e[0] == '0') ? 0 : 1; }
+  if (alds < 0) { const char* e = sw_str("SMCP_ALDS"); alds = (e && e[0] == '0') ? 0 : 1; }
   const int nfmax = a.nnmax + a.namax;
   // workgroups per (front, right-hand side): one, unless a front has so many children that one CU would stream them
   // for long (config 3: 1999 children of the root, 100 pairs) -- then the children are dealt over nz workgroups whose
   // partial fronts meet in global memory (atomics; the update blocks are cleared first).  SMCP_ALDS_Z overrides.
   static int zenv = -1;
-  if (zenv < 0) { const char* e = getenv("SMCP_ALDS_Z"); zenv = e ? atoi(e) : 0; }
+  if (zenv < 0) { const char* e = sw_str("SMCP_ALDS_Z"); zenv = e ? atoi(e) : 0; }
   const int64_t pairs = std::max<int64_t>(1, (int64_t)cnt * nrhs);
   nz = 1;
   if (zenv > 0) nz = zenv;
@@ -497,7 +498,7 @@ static bool alds_route(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, int& nz
 // can skip k_panel_fill?  SMCP_ALDS_FILL=0: never.
 static bool lf_assemble_fills(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMCP_ALDS_FILL"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = sw_str("SMCP_ALDS_FILL"); on = (e && e[0] == '0') ? 0 : 1; }
   int nz; size_t bytes;
   return on && a.kc_ptr && alds_route(c, a, cnt, nrhs, nz, bytes) && nz == 1;
 }
@@ -509,7 +510,7 @@ static bool launch_assemble_fz(csp_ctx* c, const MfmaArgs& az, int cnt, int nrhs
   if (!attr) return false;
   // sixteen waves (128 registers each) or eight (256): SMCP_FZ_THREADS=512 selects the latter
   static int thr = 0;
-  if (!thr) { const char* e = getenv("SMCP_FZ_THREADS"); thr = (e && atoi(e) == 512) ? 512 : 1024; }
+  if (!thr) { const char* e = sw_str("SMCP_FZ_THREADS"); thr = (e && atoi(e) == 512) ? 512 : 1024; }
   const dim3 grid((unsigned)std::min<int64_t>(c->D.ncu, (int64_t)cnt * nrhs));
   if (thr == 512) launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 512>, grid, dim3(512), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter);
   else launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 1024>, grid, dim3(1024), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter);
@@ -517,7 +518,7 @@ static bool launch_assemble_fz(csp_ctx* c, const MfmaArgs& az, int cnt, int nrhs
 }
 void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, int sgn, hipStream_t st, bool clear_first = false) {
   static int plan = -1;
-  if (plan < 0) { const char* e = getenv("SMCP_ASM"); plan = (e && e[0] == 't') ? 0 : 1; }
+  if (plan < 0) { const char* e = sw_str("SMCP_ASM"); plan = (e && e[0] == 't') ? 0 : 1; }
   if (c->fz_live && (size_t)a.level < c->fz_levels.size() && c->fz_levels[(size_t)a.level]) {
     // the family launch of this sweep left its parents' updates to this extend-add: the streaming kernel with the hook that
     // forms them (k_lf_assemble_fz) -- hess_up_fast has checked that this launch qualifies
@@ -553,7 +554,7 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
         // more tasks than CUs (one workgroup per CU: the front fills LDS): a persistent grid draws them from a counter, so
         // that the last round does not leave most of the chip idle.  SMCP_ALDS_DYN=0: one workgroup per task.
         static int dyn = -1;
-        if (dyn < 0) { const char* e = getenv("SMCP_ALDS_DYN"); dyn = (e && e[0] == '0') ? 0 : 1; }
+        if (dyn < 0) { const char* e = sw_str("SMCP_ALDS_DYN"); dyn = (e && e[0] == '0') ? 0 : 1; }
         const int64_t tasks = pairs * nz;
         if (dyn && tasks > c->D.ncu && tasks < ((int64_t)1 << 30) && c->D.info) {
           static bool attr2 = false;
@@ -594,13 +595,13 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
 // (the batched sweeps, where the workgroups sharing a CU keep its four SIMDs busy).  SMCP_PD=1: four waves everywhere.
 static bool pd_deep() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMCP_PD"); on = (e && e[0] == '1') ? 0 : 1; }
+  if (on < 0) { const char* e = sw_str("SMCP_PD"); on = (e && e[0] == '1') ? 0 : 1; }
   return on == 1;
 }
 // (SMCP_PD_WGS: the largest launch, in workgroups per CU, that still takes the sixteen-wave shape; default 1)
 static int64_t pd_wgs() {
   static int64_t v = -1;
-  if (v < 0) { const char* e = getenv("SMCP_PD_WGS"); v = e ? std::max(1, atoi(e)) : 1; }
+  if (v < 0) { const char* e = sw_str("SMCP_PD_WGS"); v = e ? std::max(1, atoi(e)) : 1; }
   return v;
 }
 #define LAUNCH_PD(c, kid, kern, grid, blk, ...)                                                        \
@@ -621,7 +622,7 @@ constexpr int ROOT_FUSED_MAXNN = 512;
 // 27 us per Hessian on synth50k (solve_ 0.79 -> 0.74 ms) and is kept for studies only.
 static bool root_fused() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMCP_ROOT_FUSED"); on = (e && e[0] == '1') ? 1 : 0; }
+  if (on < 0) { const char* e = sw_str("SMCP_ROOT_FUSED"); on = (e && e[0] == '1') ? 1 : 0; }
   return on == 1;
 }
 // fill: the input panels have not been built (sparse right-hand sides, lf_assemble_fills): the extend-add builds them
@@ -664,7 +665,7 @@ constexpr size_t LF_DIAG_LDS = (size_t)(2 * LB * LBD + 256 + 16 * LB) * sizeof(d
 // threads of the one-workgroup diagonal-block step (SMCP_DIAG_THREADS, timing studies; multiple of 64, at most 1024)
 static dim3 diag_blk() {
   static int t = 0;
-  if (!t) { const char* e = getenv("SMCP_DIAG_THREADS"); t = e ? atoi(e) : 512; if (t < 64 || t > 1024 || (t & 63)) t = 512; }
+  if (!t) { const char* e = sw_str("SMCP_DIAG_THREADS"); t = e ? atoi(e) : 512; if (t < 64 || t > 1024 || (t & 63)) t = 512; }
   return dim3(t);
 }
 
@@ -673,7 +674,7 @@ static dim3 diag_blk() {
 bool use_mid(int rowsmax) {
   static int g = -1;
   if (g < 0) {
-    const char* e = getenv("SMCP_MID");
+    const char* e = sw_str("SMCP_MID");
     g = (e && e[0] == '0') ? 0 : 1;
     if (g && hipFuncSetAttribute((const void*)k_mid_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_chol_lds(MID_MAXROWS)) != hipSuccess) g = 0;
   }
@@ -719,12 +720,12 @@ void lf_factor_yaa(csp_ctx* c, const MfmaArgs& a, int cnt, double* fac, hipStrea
 void lf_prep(csp_ctx* c, const MfmaArgs& a, int cnt, const double* L, hipStream_t st) {
   dim3 blk(256);
   static int hoist = -1;
-  if (hoist < 0) { const char* e = getenv("SMCP_MID"); hoist = (e && e[0] == '0') ? 0 : 1; }
+  if (hoist < 0) { const char* e = sw_str("SMCP_MID"); hoist = (e && e[0] == '0') ? 0 : 1; }
   if (hoist) {
     // the diagonal blocks' inverses do not depend on each other: one launch for all of them, then the block rows
     launch_lds(c, KID_lf_diag_inv, k_lf_diag_inv, dim3(cnt, tiles64(a.nnmax)), blk, LF_DIAG_LDS, st, a, L, c->D.lk);
     static int rec = -1;
-    if (rec < 0) { const char* e = getenv("SMCP_TRTRI"); rec = (e && e[0] == '0') ? 0 : 1; }
+    if (rec < 0) { const char* e = sw_str("SMCP_TRTRI"); rec = (e && e[0] == '0') ? 0 : 1; }
     if (rec) {
       // recursive doubling: log2(nn / 64) levels of two tile-product launches each (k_lf_trtri)
       for (int b = LB; b < a.nnmax; b *= 2) {
@@ -859,7 +860,7 @@ bool launch_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int
     // set-up latency, and two waves carry the three tile tasks of a phase as well as four: 128 threads put twice as many
     // fronts on a CU (k_hess_up_n16 0.297 -> 0.274 ms per step; 64 threads: 0.286; SMCP_N16_THR_LEAF overrides)
     static int tl = 0;
-    if (!tl) { const char* e = getenv("SMCP_N16_THR_LEAF"); tl = e ? atoi(e) : 128; if (tl < 64 || tl > 512 || (tl & 63)) tl = 128; }
+    if (!tl) { const char* e = sw_str("SMCP_N16_THR_LEAF"); tl = e ? atoi(e) : 128; if (tl < 64 || tl > 512 || (tl & 63)) tl = 128; }
     thr = tl;
   }
   // Split the right-hand sides over g workgroups per clique so that the grid fills a whole number of rounds of
@@ -882,14 +883,14 @@ bool launch_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int
     if (best < 0 || cost < best) { best = cost; g = gc; }
   }
   static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("SMCP_OCC"); dbg = (e && e[0] == '1') ? 1 : 0; }
+  if (dbg < 0) { const char* e = sw_str("SMCP_OCC"); dbg = (e && e[0] == '1') ? 1 : 0; }
   if (dbg) fprintf(stderr, "n16<%d,%d>: cnt %d nrhs %d g %d threads %d lds %zu -> %d workgroups/CU\n", NAT, (int)CH, cnt, nrhs, g, thr, bytes, nb);
   launch_lds(c, KID_hess_up_n16, k_hess_up_n16<NAT, CH>, dim3(cnt, g), dim3(thr), bytes, st, a, U, ldu);
   return true;
 }
 bool try_n16(csp_ctx* c, const MfmaArgs& a, int cnt, int g, double* U, int64_t ldu, hipStream_t st) {
   static int off = -1;
-  if (off < 0) { const char* e = getenv("SMCP_N16"); off = (e && e[0] == '0') ? 1 : 0; }
+  if (off < 0) { const char* e = sw_str("SMCP_N16"); off = (e && e[0] == '0') ? 1 : 0; }
   if (off || a.nnmax > 16 || a.namax > 64) return false;
   const int nat = std::max(1, (a.namax + 15) / 16);
   const bool ch = a.nchmax > 0;
@@ -994,7 +995,7 @@ bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   launch_lds(c, KID_fam2_prep, k_fam2_prep, dim3(cnt), dim3(512), (size_t)8 * fam2_child_layout(cnn, csa).cstride * sizeof(double), st,
              a, D.famc, cnn, csa);
   MfmaArgs a2 = a;
-  { static int stag = -1; if (stag < 0) { const char* e = getenv("SMCP_FAM2_STAG"); stag = e ? atoi(e) : 0; } a2.dn = stag; }
+  { static int stag = -1; if (stag < 0) { const char* e = sw_str("SMCP_FAM2_STAG"); stag = e ? atoi(e) : 0; } a2.dn = stag; }
   // the children's panels are left out when the caller takes their Gram block from k_leaf_gram (D.lg_request)
   if (D.lg_request) {
     launch_lds(c, KID_fam_sparse, k_fam_sparse<NAT, KSN, false>, dim3(cnt, g), dim3(512), (size_t)lim * 8, st, a2, U, ldu,
@@ -1010,7 +1011,7 @@ bool launch_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
 // applicable (the caller falls back to k_fam_sparse).  SMCP_FAMT=0 disables.
 inline bool famt_disabled() {
   static int off = -1;
-  if (off < 0) { const char* e = getenv("SMCP_FAMT"); off = (e && e[0] == '0') ? 1 : 0; }
+  if (off < 0) { const char* e = sw_str("SMCP_FAMT"); off = (e && e[0] == '0') ? 1 : 0; }
   return off != 0;
 }
 // LDS of the grouped kernel: entries it can stage (< 0: the fixed part does not fit); one pass of a group needs at most
@@ -1103,7 +1104,7 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
     if (best < 0 || cost < best) { best = cost; g = gc; }
   }
   static int genv = -1;
-  if (genv < 0) { const char* e = getenv("SMCP_FAMT_G"); genv = e ? atoi(e) : 0; }
+  if (genv < 0) { const char* e = sw_str("SMCP_FAMT_G"); genv = e ? atoi(e) : 0; }
   if (genv > 0) g = std::min(genv, nrhs);
   const int passes = (nrhs + g - 1) / g;
   const double avg = 9.0 * (double)D.cnnz / ((double)c->S.nsn * (double)std::max<int64_t>(1, D.m));   // entries per (family, rhs)
@@ -1135,7 +1136,7 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
 }
 inline bool fam2_disabled() {
   static int off = -1;
-  if (off < 0) { const char* e = getenv("SMCP_FAM2"); off = (e && e[0] == '0') ? 1 : 0; }
+  if (off < 0) { const char* e = sw_str("SMCP_FAM2"); off = (e && e[0] == '0') ? 1 : 0; }
   return off != 0;
 }
 bool try_fam2(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st) {
@@ -1175,7 +1176,7 @@ bool try_fam(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_
 // (front_lfsp.hip).  R^T and R^T K are formed when fac or lk have changed since they were formed last.  SMCP_LFSP=0 disables.
 bool try_lfsp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, hipStream_t st, const csp_ctx::LfspGroups* grp = nullptr) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMCP_LFSP"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = sw_str("SMCP_LFSP"); on = (e && e[0] == '0') ? 0 : 1; }
   DeviceCtx& D = c->D;
   if (!on || !a.kc_ptr || a.nchmax != 0 || a.ymode != 2 || !a.ysc || a.nnmax > 64 || a.namax > 128) return false;
   if (D.kc_maxlist_large <= 0 || D.kc_maxlist_large > LFSP_ECAP || !D.lfsp_cnt) return false;
@@ -1193,7 +1194,7 @@ bool try_lfsp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64
     D.sp_fac_gen = D.fac_gen; D.sp_lk_gen = D.lk_gen;
   }
   static int gdiv = -1;
-  if (gdiv < 0) { const char* e = getenv("SMCP_LFSP_G"); gdiv = e ? std::max(1, atoi(e)) : 1; }
+  if (gdiv < 0) { const char* e = sw_str("SMCP_LFSP_G"); gdiv = e ? std::max(1, atoi(e)) : 1; }
   const int g = std::max(1, (nrhs + gdiv - 1) / gdiv);            // right-hand sides per workgroup: gdiv
   // one launch per phase (Q, Upd, G_NN): fewer live accumulators per wave, three to four waves per SIMD
   const dim3 grid(g, cnt), blk(256);
@@ -1218,7 +1219,7 @@ bool try_lfsp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64
 // would try_lfsp take a class whose static shape qualifies (the conditions that do not depend on the class)
 bool lfsp_dynamic_ok(csp_ctx* c, const MfmaArgs& a) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMCP_LFSP"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = sw_str("SMCP_LFSP"); on = (e && e[0] == '0') ? 0 : 1; }
   const DeviceCtx& D = c->D;
   return on && a.kc_ptr && a.ymode == 2 && a.ysc && D.kc_maxlist_large > 0 && D.kc_maxlist_large <= LFSP_ECAP && D.lfsp_cnt;
 }
@@ -1252,7 +1253,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
   c->fz_live = false;
   {
     static int fzenv = -1;
-    if (fzenv < 0) { const char* e = getenv("SMCP_FZ"); fzenv = (e && e[0] == '0') ? 0 : 1; }
+    if (fzenv < 0) { const char* e = sw_str("SMCP_FZ"); fzenv = (e && e[0] == '0') ? 0 : 1; }
     bool want = fzenv && sparse && set == 0 && lev_lo == 0 && lev_hi < 0 && !fgroups_on && c->D.fz_ok && !famt_disabled() && !fam2_disabled() &&
                 c->D.lg_request && c->D.kc_ij && a0.ymode == 2 && a0.ysc && c->D.fam_maxterms <= FAMT_TCAP / 2 &&
                 c->D.cnnz <= (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m) && !use_generic(c) && use_large() && c->D.gp_tptr;
@@ -1288,7 +1289,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
   for (int64_t l = lev_lo; l < (lev_hi < 0 ? c->S.nlev : lev_hi); ++l)     // [lev_lo, lev_hi): the caller may sweep in two parts
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       static int fam_minrhs = -1;
-      if (fam_minrhs < 0) { const char* e = getenv("SMCP_FAM_MINRHS"); fam_minrhs = e ? atoi(e) : 1; }
+      if (fam_minrhs < 0) { const char* e = sw_str("SMCP_FAM_MINRHS"); fam_minrhs = e ? atoi(e) : 1; }
       if (lds && a.nS > 0 && (sparse || nrhs >= fam_minrhs)) {
         // families: the childless members (level 0) are swept inside their parents' workgroups (k_hess_up_fam);
         // for one or two dense right-hand sides the per-workgroup set-up outweighs the saved exchange (measured)
@@ -1314,7 +1315,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
       if (lds) {
         hipStream_t ls = st;
         static int oldk = -1;
-        if (oldk < 0) { const char* e = getenv("SMCP_OLDLDS"); oldk = (e && e[0] == '1') ? 1 : 0; }
+        if (oldk < 0) { const char* e = sw_str("SMCP_OLDLDS"); oldk = (e && e[0] == '1') ? 1 : 0; }
         size_t pbytes = (size_t)pad_layout(a.nnmax, a.namax, a.nchmax, a.panmax, a.pkmax, a.plansum).total * sizeof(double);
         if (!oldk && try_n16(c, a, cnt, nrhs, U, ldu, ls)) {
         } else if (!oldk && pbytes <= LDS_LIMIT) {
@@ -1338,9 +1339,9 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         // kernels after it are short.  The right-hand sides are independent: two halves on two streams fill each
         // other's tails (every per-right-hand-side buffer is addressed through bases shifted to the half's first one).
         static int split_min = -1;
-        if (split_min < 0) { const char* e = getenv("SMCP_RHS_SPLIT"); split_min = e ? atoi(e) : 16; }
+        if (split_min < 0) { const char* e = sw_str("SMCP_RHS_SPLIT"); split_min = e ? atoi(e) : 16; }
         static int parts = -1;
-        if (parts < 0) { const char* e = getenv("SMCP_RHS_PARTS"); parts = (e && e[0] == '3') ? 3 : 2; }
+        if (parts < 0) { const char* e = sw_str("SMCP_RHS_PARTS"); parts = (e && e[0] == '3') ? 3 : 2; }
         const int ncu_split = c->D.ncu;
         // only when the extend-add needs more than one round of the chip: with fewer (front, right-hand side) pairs than
         // CUs (one rank's share of an 8-rank job: 100 pairs) there is no tail to fill and the halves only add launches
@@ -1350,7 +1351,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         // is for the plain launch only.  Measured with both: 4.50 against 4.55 ms per step -- and the second launch's
         // duration would count its wait for CUs.)
         static int dynsplit = -1;
-        if (dynsplit < 0) { const char* e = getenv("SMCP_ALDS_DYN"); const char* f = getenv("SMCP_RHS_SPLIT_DYN"); dynsplit = ((e && e[0] == '0') || (f && f[0] == '1')) ? 1 : 0; }
+        if (dynsplit < 0) { const char* e = sw_str("SMCP_ALDS_DYN"); const char* f = sw_str("SMCP_RHS_SPLIT_DYN"); dynsplit = ((e && e[0] == '0') || (f && f[0] == '1')) ? 1 : 0; }
         if (dynsplit && split_min > 0 && a.nchmax > 0 && nrhs >= split_min && (int64_t)cnt * nrhs > ncu_split && Fork::enabled()) {
           auto part = [&](int r0, int nr, hipStream_t s) {       // right-hand sides r0 .. r0 + nr - 1 on stream s
             MfmaArgs ap = a;
@@ -1382,7 +1383,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         // instead of a product of two dense triangles, the second phase never reads the input panel -- no dense panel is built
         // at all.  SMCP_ZSP=0: the dense route.
         static int zsp = -1;
-        if (zsp < 0) { const char* e = getenv("SMCP_ZSP"); zsp = (e && e[0] == '0') ? 0 : 1; }
+        if (zsp < 0) { const char* e = sw_str("SMCP_ZSP"); zsp = (e && e[0] == '0') ? 0 : 1; }
         if (zsp && sparse && c->D.kc_sorted && a.nchmax == 0 && a.namax == 0 && lf_sym_split(a.nnmin) && a.nnmax <= LF_ZSP_MAXNN) {
           const int ntN = tiles64(a.nnmax);
           launch_lds(c, KID_lf_zsp, k_lf_zsp, dim3(a.nnmax, cnt, nrhs), dim3(256), (size_t)a.nnmax * sizeof(double), st, a, U, ldu);
@@ -1427,7 +1428,7 @@ void hess_down_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* 
         // (fewer threads per workgroup do NOT help this kernel on the leaves: 0.302 ms per step with 256, 0.330 with 128)
         // small fronts without scaling operand: one wave per (clique, right-hand side), operands in registers (front_n16.hip)
         static int dw = -1;
-        if (dw < 0) { const char* e = getenv("SMCP_DOWN_W"); dw = (e && e[0] == '0') ? 0 : 1; }
+        if (dw < 0) { const char* e = sw_str("SMCP_DOWN_W"); dw = (e && e[0] == '0') ? 0 : 1; }
         if (dw && ymode == 0 && a.nnmax <= 16 && a.namax <= 64 && a.nnmax >= 1) {
           const int gw = rhs_groups((cnt + 3) / 4, nrhs, 4096);
           const dim3 grid((cnt + 3) / 4, gw), blk(256);
@@ -1672,7 +1673,7 @@ int hessian_impl(csp_ctx* c, const double* L, double* U, int64_t nrhs, int64_t l
 
 bool fam_off() {
   static int off = -1;
-  if (off < 0) { const char* e = getenv("SMCP_FAM"); off = (e && e[0] == '0') ? 1 : 0; }
+  if (off < 0) { const char* e = sw_str("SMCP_FAM"); off = (e && e[0] == '0') ? 1 : 0; }
   return off == 1;
 }
 // dynamic LDS of the family kernel instantiation that serves (parent separator famna, child separator famcna)
@@ -2052,7 +2053,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
         // sibling groups for the sparse-input sweep (front_lfsp.hip, k_lfsp_up<..., GRP>): members of a large-front class all
         // of whose fronts that sweep can take (childless, nn <= 64, 0 < na <= 128), under one LARGE parent, with identical
         // relative indices; at most eight per group, in list order.  SMCP_LFSP_GROUP=0: none.
-        const char* ge = getenv("SMCP_LFSP_GROUP");
+        const char* ge = sw_str("SMCP_LFSP_GROUP");
         const bool gon = !(ge && ge[0] == '0');
         std::vector<uint8_t> is_large((size_t)S.nsn, 0), skip((size_t)S.nsn, 0);
         for (int32_t k : large) is_large[(size_t)k] = 1;
@@ -2111,7 +2112,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
         // level under one LARGE front with identical relative indices, at most FAMT_GMAX per group, in list order; the lists
         // hold positions in the level's family list (= record indices of k_famt_prep).  Every family parent of the level is in
         // exactly one group (singletons included).  SMCP_FAMT_GROUP=0: none.
-        const char* fe = getenv("SMCP_FAMT_GROUP");
+        const char* fe = sw_str("SMCP_FAMT_GROUP");
         const bool fon = !(fe && fe[0] == '0');
         std::vector<uint8_t> fskip((size_t)S.nsn, 0);
         c->famt_grp.assign((size_t)S.nlev, csp_ctx::LfspGroups());
@@ -2363,7 +2364,7 @@ int csp_device_init(csp_ctx* c, int device, int64_t max_rhs) {
   }
   int rc = 0;
   if ((rc = dev_alloc(&D.upd, max_rhs * S.updlen(), D.bytes))) return rc;
-  { const char* e = getenv("SMCP_UPDP_PAD"); D.updp_stride = S.updplen() + (e ? std::max(0, atoi(e)) : 0); }
+  { const char* e = sw_str("SMCP_UPDP_PAD"); D.updp_stride = S.updplen() + (e ? std::max(0, atoi(e)) : 0); }
   if ((rc = dev_alloc(&D.updp, max_rhs * D.updp_stride, D.bytes))) return rc;
   if ((rc = dev_alloc(&D.tmp, max_rhs * D.tmplen, D.bytes))) return rc;
   D.max_rhs = max_rhs;
@@ -2496,7 +2497,7 @@ constexpr int SCALING_FAC = 1;
 static bool leafgram_ok(csp_ctx* c, int64_t mcols);      // kkt.hip
 static bool scaling_overlap_on() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMCP_SCALING_OVERLAP"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = sw_str("SMCP_SCALING_OVERLAP"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
 static int scaling_impl(csp_ctx* c, double* L, double* Y, int flags, hipStream_t st) {
@@ -2542,7 +2543,7 @@ static int scaling_impl(csp_ctx* c, double* L, double* Y, int flags, hipStream_t
   int nnI = 0;
   for (const LevelClass& Lc : c->lvl) if (Lc.nI) nnI = std::max(nnI, (int)Lc.nnmaxI);
   static int cprep = -1;
-  if (cprep < 0) { const char* e = getenv("SMCP_CHOL_PREP"); cprep = (e && e[0] == '0') ? 0 : 1; }
+  if (cprep < 0) { const char* e = sw_str("SMCP_CHOL_PREP"); cprep = (e && e[0] == '0') ? 0 : 1; }
   const bool fuse_prep = cprep && nnI <= 16;
   auto chol_level = [&](int64_t l) {
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t bytes, int thr) {
@@ -2586,7 +2587,7 @@ static int scaling_impl(csp_ctx* c, double* L, double* Y, int flags, hipStream_t
   // the family children's factors are read by nobody when their block of the Schur complement comes from k_leaf_pairs (the
   // decision kkt_schur_* will take for the constraints now set): left out, complete_fac supplies them to whoever asks
   static int skipenv = -1;
-  if (skipenv < 0) { const char* e = getenv("SMCP_FAC_PARTIAL"); skipenv = (e && e[0] == '0') ? 0 : 1; }
+  if (skipenv < 0) { const char* e = sw_str("SMCP_FAC_PARTIAL"); skipenv = (e && e[0] == '0') ? 0 : 1; }
   const bool skip_children = want_fac && skipenv && D.m > 0 && !D.ns && leafgram_ok(c, D.m) && c->leafgram_policy != 0;
   bool skipped = false;
   auto factor_level = [&](int64_t l, hipStream_t lds_stream, hipStream_t large_stream) {
@@ -2724,7 +2725,7 @@ int csp_hessian(csp_ctx* c, const double* L, const double* Y, double* U, int64_t
 // is reused, otherwise it is formed from L)
 int trsm_impl(csp_ctx* c, const double* L, const double* Y, double* B, int64_t nrhs, int64_t ldb, int trans, hipStream_t st) {
   static int mm = -1;
-  if (mm < 0) { const char* e = getenv("SMCP_TRSM_MM"); mm = (e && e[0] == '0') ? 0 : 1; }
+  if (mm < 0) { const char* e = sw_str("SMCP_TRSM_MM"); mm = (e && e[0] == '0') ? 0 : 1; }
   if (mm && !use_generic(c) && use_large() && nrhs >= 8) {
     // tile products with the inverse-form factor (front_large.hip: k_trsm_mm_*): the generic kernels below solve every
     // clique's triangle by substitution in one workgroup per sixteen columns -- 0.48 ms per level on config 4
@@ -2904,7 +2905,7 @@ static int tune_placement(csp_ctx* c, int tries) {
   (void)hipFree(dpar);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   static int verbose = -1;
-  if (verbose < 0) { const char* e = getenv("SMCP_TIMING"); verbose = (e && e[0] == '1') ? 1 : 0; }
+  if (verbose < 0) { const char* e = sw_str("SMCP_TIMING"); verbose = (e && e[0] == '1') ? 1 : 0; }
   if (verbose) fprintf(stderr, "smcp_amd: placement of the exchange buffer: store-pattern probe %.3f -> %.3f ms\n", first, best);
   c->placement_probe[0] = first; c->placement_probe[1] = best;
   return rc;

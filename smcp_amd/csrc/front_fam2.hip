@@ -36,11 +36,7 @@
 namespace smcp {
 
 // result stores of the family kernels: streamed once, read again only by the Gram kernel a millisecond later
-#ifdef SMCP_FAM2_NT
-#define FAM2_ST(p, v) __builtin_nontemporal_store((v), (p))
-#else
 #define FAM2_ST(p, v) (*(p) = (v))
-#endif
 
 typedef const int32_t __attribute__((address_space(4))) cs_i32;
 typedef const double __attribute__((address_space(4))) cs_f64;

@@ -58,9 +58,6 @@ __device__ inline __amdgpu_buffer_rsrc_t famt_rsrc(double* base, int doubles) {
 #define SMCP_FAMT_AUX 0          // cache-policy bits of the result stores (2 = nt: streamed once, read ~1 ms later by other kernels)
 #endif
 __device__ inline void famt_store(__amdgpu_buffer_rsrc_t r, bool ok, int pos, double v) {
-#ifdef SMCP_FAMT_NOSTORE        // ablation: the products without their stores (a value that never occurs keeps them alive)
-  ok = ok && v == 1.2345e300;
-#endif
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(famt_u2, v), r, ok ? pos * 8 : -1, 0, SMCP_FAMT_AUX);
 }
 #ifndef SMCP_FAMT_NW

@@ -270,62 +270,7 @@ __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
 __device__ inline double col_at(const double* Uc, int nac, int i, int j) { return Uc[pk_col(j, nac) - j + i]; }
 constexpr int LF_ALDS_MAXNF = 198;
 __host__ __device__ inline int lf_alds_doubles(int nf) { return nf * (nf + 1) / 2; }
-// One child of k_lf_assemble_lds: lane l owns row l (and, TWO, row l + 64) of the child's packed update matrix
-// (separators of up to 128 rows; longer ones finish with a plain loop); each wave load is one contiguous run of a packed
-// column.  CB columns are fetched per batch and the next batch is in flight while the current one is added into the
-// front (LDS atomics: several waves may hit one front column).  Children with at most 64 rows take 16 columns per
-// batch with one row per lane -- the same number of loads in flight, half the latency steps.
-template <int CB, bool TWO>
-__device__ inline void lf_add_child(double* T, int nf, const double* Uc, const int32_t* rel, int nac, int lane, int part, int parts) {
-  auto cb = [nf](int j) { return j * nf - ((j * (j - 1)) >> 1) - j; };
-  constexpr int NR = TWO ? 2 : 1;
-  const int iA = lane, iB = lane + 64;
-  const int rA = iA < nac ? rel[iA] : 0, rB = (TWO && iB < nac) ? rel[iB] : 0;
-  double cur[CB][NR], nxt[CB][NR];
-  auto fetch = [&](int j0, double (&v)[CB][NR]) {
-#pragma unroll
-    for (int x = 0; x < CB; ++x) {
-      const int j = j0 + x;
-#pragma unroll
-      for (int h = 0; h < NR; ++h) v[x][h] = 0.0;
-      if (j < nac) {
-        const double* col = Uc + pk_col(j, nac) - j;               // col[i] = U_c(i, j), i >= j
-#ifdef SMCP_ALDS_NT
-        if (iA >= j && iA < nac) v[x][0] = __builtin_nontemporal_load(&col[iA]);
-        if (TWO && iB >= j && iB < nac) v[x][NR - 1] = __builtin_nontemporal_load(&col[iB]);
-#else
-        if (iA >= j && iA < nac) v[x][0] = col[iA];
-        if (TWO && iB >= j && iB < nac) v[x][NR - 1] = col[iB];
-#endif
-      }
-    }
-  };
-  const int jstep = CB * parts;
-  fetch(CB * part, cur);
-  for (int j0 = CB * part; j0 < nac; j0 += jstep) {
-    if (j0 + jstep < nac) fetch(j0 + jstep, nxt);
-#pragma unroll
-    for (int x = 0; x < CB; ++x) {
-      const int j = j0 + x;
-      if (j < nac) {
-        const int cj = j < 64 ? __builtin_amdgcn_readlane(rA, j & 63) : (j < 128 ? __builtin_amdgcn_readlane(rB, j & 63) : rel[j]);
-        const int cbj = cb(cj);
-        if (iA >= j && iA < nac) unsafeAtomicAdd(&T[cbj + rA], cur[x][0]);
-        if (TWO) {
-          if (iB >= j && iB < nac) unsafeAtomicAdd(&T[cbj + rB], cur[x][NR - 1]);
-          for (int i = lane + 128; i < nac; i += 64)                 // separators beyond 128 rows (rare)
-            if (i >= j) unsafeAtomicAdd(&T[cbj + rel[i]], col_at(Uc, nac, i, j));
-        }
-      }
-    }
-#pragma unroll
-    for (int x = 0; x < CB; ++x)
-#pragma unroll
-      for (int h = 0; h < NR; ++h) cur[x][h] = nxt[x][h];
-  }
-}
-// The children of one wave as ONE stream of column batches (second version of the loop above; -DSMCP_ALDS_V1 keeps the
-// first).  A batch is sixteen wave loads -- sixteen columns of a child with at most 64 rows, eight columns x two row halves
+// The children of one wave as ONE stream of column batches.  A batch is sixteen wave loads -- sixteen columns of a child with at most 64 rows, eight columns x two row halves
 // of a taller one -- plus the two loads of the child's relative indices.  Every load is unconditional (column and row
 // clamped into the child's packed matrix; masked at the add), so the compiler counts them (s_waitcnt vmcnt(N)) instead of
 // draining the queue before the first add as it does for loads under branches: with two batch buffers used in turn the
@@ -382,16 +327,9 @@ __device__ inline void lf_add_children_stream(double* T, int nf, const double* u
     for (int x = 0; x < 16; ++x) {
       const int j = min(it.j0 + (two ? x >> 1 : x), last);
       const int i = min(max(lane + ((two && (x & 1)) ? 64 : 0), j), last);
-#ifndef SMCP_ALDS_TEMPORAL      // read once: non-temporal loads (0.61 -> 0.56 ms per Schur complement on synth50k)
       b.v[x] = __builtin_nontemporal_load(&Uc[pk_col(j, nac) - j + i]);
-#else
-      b.v[x] = Uc[pk_col(j, nac) - j + i];
-#endif
     }
   };
-#ifdef SMCP_ALDS_NOADD
-  double sink = 0.0;
-#endif
   auto process = [&](const AldsBatch& b, const AldsItem& it) {
     const int nac = it.nac, nh = min(nac, 128);
     const bool two = nac > 64;
@@ -402,11 +340,7 @@ __device__ inline void lf_add_children_stream(double* T, int nf, const double* u
       const int i = lane + (hi ? 64 : 0);
       const int jc = min(j, nh - 1);
       const int cj = jc < 64 ? __builtin_amdgcn_readlane(b.rA, jc & 63) : __builtin_amdgcn_readlane(b.rB, jc & 63);
-#ifdef SMCP_ALDS_NOADD        // experiment: the stream without the LDS atomics
-      if (j < nh && i >= j && i < nac) sink += b.v[x] * (double)(cb(cj) + (hi ? b.rB : b.rA));
-#else
       if (j < nh && i >= j && i < nac) unsafeAtomicAdd(&T[cb(cj) + (hi ? b.rB : b.rA)], b.v[x]);
-#endif
     }
   };
   AldsItem it = seq ? norm(0, wave) : normc(wave, 0);
@@ -426,9 +360,6 @@ __device__ inline void lf_add_children_stream(double* T, int nf, const double* u
     if (!v2) break;
     it = n2;
   }
-#ifdef SMCP_ALDS_NOADD
-  if (sink == 123.456) T[0] = sink;
-#endif
 }
 // rows (and with them columns) beyond 128 of a child: plain loop, one wave per child
 __device__ inline void lf_add_child_tail(double* T, int nf, const double* Uc, const int32_t* rel, int nac, int lane) {
@@ -511,23 +442,10 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
   // q mod gridDim.z) and add their partial fronts into the panel / the cleared update block with global atomics: a
   // front with very many children (config 3: 1999 under the root, i.e. 100 workgroups for 13 GB of child blocks) or a
   // launch whose workgroup count leaves a poor last round is spread finer this way
-#ifdef SMCP_ALDS_V1
-  const int parts = nmine < nw ? max(1, nw / max(nmine, 1)) : 1;
-  const int part = parts > 1 ? wave / max(nmine, 1) : 0;
-  for (int qi = parts > 1 ? wave % max(nmine, 1) : wave; qi < nmine && part < parts; qi += nw) {
-    const int nac = sCn[qi];
-    if (nac == 0) continue;
-    const int32_t* rel = a.t.relidx + sCr[qi];
-    const double* Uc = ubase + sCu[qi];
-    if (nac <= 64) lf_add_child<16, false>(T, nf, Uc, rel, nac, lane, part, parts);
-    else lf_add_child<8, true>(T, nf, Uc, rel, nac, lane, part, parts);
-  }
-#else
   lf_add_children_stream(T, nf, ubase, a.t.relidx, sCu, sCr, sCn, nmine, wave, nw, lane);
   for (int qi = wave; qi < nmine; qi += nw)
     if (sCn[qi] > 128) lf_add_child_tail(T, nf, ubase + sCu[qi], a.t.relidx + sCr[qi], sCn[qi], lane);
   if (a.fz_on) fam(T, nf, r, sFz, nmine, wave, nw, lane);
-#endif
   __syncthreads();
   double* P = u + (int64_t)r * ldu + d.blk;
   double* U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
@@ -1224,13 +1142,9 @@ __device__ inline void tri_inv64_rd(double* D, int w, double* Di, double* s16) {
 __device__ inline int potrf_inv64(double* D, int w, double* Di, double* d16, double* s16, bool do_potrf) {
   for (int e = threadIdx.x; e < LB * LBD; e += blockDim.x) Di[e] = 0.0;
   __syncthreads();
-#ifndef SMCP_TRINV_ROWS
   const bool doubling = blockDim.x >= 256;
   if (!do_potrf && doubling) { tri_inv64_rd(D, w, Di, s16); return 0; }
   if (doubling) tri_inv64_pad(D, w);          // (the potrf steps below begin with a barrier)
-#else
-  const bool doubling = false;
-#endif
   for (int jb = 0; jb < w; jb += 16) {
     const int bw = min(16, w - jb);
     if (do_potrf) {

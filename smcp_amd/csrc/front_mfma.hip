@@ -1437,11 +1437,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(co
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int cc = wave + NW * j;
-#ifdef SMCP_GRAM_NT
-      pre[j] = (ein && cc < ni) ? ((skip & 2) ? 1.0 : __builtin_nontemporal_load(&G[(int64_t)cc * ldg + e])) : 0.0;
-#else
       pre[j] = (ein && cc < ni) ? ((skip & 2) ? 1.0 : G[(int64_t)cc * ldg + e]) : 0.0;
-#endif
     }
   };
   if (s_begin < s_end) { window(s_begin); fetch(s_begin); }

@@ -140,7 +140,7 @@ __global__ void k_dense_potrs(const double* A, int n, int64_t lda, double* B, in
 // threads of the one-workgroup factorisation of H (SMCP_POTRF_THREADS, timing studies)
 static dim3 potrf_blk() {
   static int t = 0;
-  if (!t) { const char* e = getenv("SMCP_POTRF_THREADS"); t = e ? atoi(e) : 1024; if (t < 64 || t > 1024 || (t & 63)) t = 1024; }
+  if (!t) { const char* e = sw_str("SMCP_POTRF_THREADS"); t = e ? atoi(e) : 1024; if (t < 64 || t > 1024 || (t & 63)) t = 1024; }
   return dim3(t);
 }
 // m <= 128: the whole factorisation in the LDS of one workgroup -- 16-wide block columns, diagonal blocks factored
@@ -477,7 +477,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   c->h_kptr.assign(1, 0);
   {
     static int off = -1;
-    if (off < 0) { const char* e = getenv("SMCP_SCM"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off < 0) { const char* e = sw_str("SMCP_SCM"); off = (e && e[0] == '0') ? 1 : 0; }
     const int64_t tnz = (int64_t)((double)S.n * c->tnzcols);
     // at most this many columns of S^-1 are formed per constraint (n x |K| doubles of workspace)
     const int64_t kcap = std::min<int64_t>(tnz, std::max<int64_t>(1, ((int64_t)256 << 20) / std::max<int64_t>(1, S.n * 8)));
@@ -786,7 +786,7 @@ static int potrf_launch(csp_ctx* c, double* A, int64_t n, int64_t lda, hipStream
   HIPCHK(hipMemsetAsync(info, 0, sizeof(int), st));
   c->D.hinv_tag = nullptr;
   static int oldp = -1;
-  if (oldp < 0) { const char* e = getenv("SMCP_POTRF_OLD"); oldp = (e && e[0] == '1') ? 1 : 0; }
+  if (oldp < 0) { const char* e = sw_str("SMCP_POTRF_OLD"); oldp = (e && e[0] == '1') ? 1 : 0; }
   if (oldp || use_generic(c)) {
     launch(c, KID_dense_potrf, k_dense_potrf, dim3(1), dim3(1024), st, A, (int)n, lda, info);
     return 0;
@@ -865,7 +865,7 @@ int dense_potrf(csp_ctx* c, double* A, int64_t n, int64_t lda, void* stream) {
 static int potrs_impl(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, int64_t nrhs, int64_t ldb, hipStream_t st) {
   DeviceCtx& D = c->D;
   static int olds = -1;
-  if (olds < 0) { const char* e = getenv("SMCP_POTRS_OLD"); olds = (e && e[0] == '1') ? 1 : 0; }
+  if (olds < 0) { const char* e = sw_str("SMCP_POTRS_OLD"); olds = (e && e[0] == '1') ? 1 : 0; }
   if (olds) {
     launch(c, KID_dense_potrs, k_dense_potrs, dim3(1), dim3(1024), st, A, (int)n, lda, B, (int)nrhs, ldb);
     return 0;
@@ -878,7 +878,7 @@ static int potrs_impl(csp_ctx* c, const double* A, int64_t n, int64_t lda, doubl
     return 0;
   }
   static int steps_only = -1;
-  if (steps_only < 0) { const char* e = getenv("SMCP_POTRS_STEPS"); steps_only = (e && e[0] == '1') ? 1 : 0; }
+  if (steps_only < 0) { const char* e = sw_str("SMCP_POTRS_STEPS"); steps_only = (e && e[0] == '1') ? 1 : 0; }
   if (nrhs == 1 && n > 2 * LB && n <= POTRS1_MAXN && !steps_only && !use_generic(c)) {
     // one launch of one workgroup: the whole substitution chain with the factor streamed a step ahead (k_dense_potrs_one)
     static bool attr1 = false;
@@ -920,7 +920,7 @@ int dense_potrs(csp_ctx* c, const double* A, int64_t n, int64_t lda, double* B, 
 
 static bool use_gram(const csp_ctx* c) {
   static int g = -1;
-  if (g < 0) { const char* e = getenv("SMCP_GRAM"); g = (e && e[0] == '0') ? 0 : 1; }
+  if (g < 0) { const char* e = sw_str("SMCP_GRAM"); g = (e && e[0] == '0') ? 0 : 1; }
   return g == 1 && !use_generic(c);
 }
 
@@ -964,7 +964,7 @@ static std::vector<std::pair<int64_t, int64_t>> gram_merge_ranges(int64_t nrange
 // chunking of a Gram accumulation over `total` rows: ~one resident wave of workgroups (2 per CU) over all ranges
 static int64_t gram_chunk_rows(int64_t total) {
   static int64_t minrows = 0;     // SMCP_GRAM_MINCHUNK (timing studies): smallest chunk of rows per workgroup
-  if (!minrows) { const char* e = getenv("SMCP_GRAM_MINCHUNK"); minrows = e ? atoll(e) : 512; if (minrows < GRAM_KS) minrows = GRAM_KS; }   // 512: one rank's share of an 8-rank job 0.202 -> 0.173 ms (with 2048 rows per workgroup two thirds of the chip idle); large problems are chunked by the second term
+  if (!minrows) { const char* e = sw_str("SMCP_GRAM_MINCHUNK"); minrows = e ? atoll(e) : 512; if (minrows < GRAM_KS) minrows = GRAM_KS; }   // 512: one rank's share of an 8-rank job 0.202 -> 0.173 ms (with 2048 rows per workgroup two thirds of the chip idle); large problems are chunked by the second term
   return std::max<int64_t>(minrows, ((total / 512 + GRAM_KS - 1) / GRAM_KS) * GRAM_KS);
 }
 static int gram_count_chunks(const std::vector<std::pair<int64_t, int64_t>>& rs, int64_t chunk) {
@@ -1053,7 +1053,7 @@ static int gram_tables(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>
 constexpr int LG_ECAP_MAX = 1024;
 static bool leafgram_ok(csp_ctx* c, int64_t mcols) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMCP_LEAFGRAM"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = sw_str("SMCP_LEAFGRAM"); on = (e && e[0] == '0') ? 0 : 1; }
   const DeviceCtx& D = c->D;
   if (!on || !c->leafgram_policy || use_generic(c) || !D.kc_ptr || !D.kc_ij || mcols > GRAM_BLK || mcols < 1 || D.lg_children <= 0) return false;
   if (D.lg_maxent > LG_ECAP_MAX) return false;
@@ -1086,7 +1086,7 @@ static int leafgram_partials(csp_ctx* c, int64_t mcols, const int32_t* ids, hipS
   a.eptr = D.lg_eptr; a.epk = D.lg_epk; a.ew = D.lg_ew; a.remap = ids ? D.lg_remap : nullptr;
   a.nr = (int)mcols; a.ecap = ecap;
   a.part = part; a.info = D.info;
-  { static int sk = -1; if (sk < 0) { const char* e = getenv("SMCP_LGSKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
+  { static int sk = -1; if (sk < 0) { const char* e = sw_str("SMCP_LGSKIP"); sk = e ? atoi(e) : 0; } a.skip = sk; }
   launch_lds(c, KID_leaf_tables, k_leaf_tables, dim3(D.lg_cnt), dim3(64), (size_t)leaftab_doubles(D.lg_nf, D.lg_nn, D.lg_na) * sizeof(double), st,
              a, D.lg_nf, D.lg_nn, D.lg_na);
   const size_t lds = (size_t)(((np + 1) & ~1) + (int64_t)nw * wd) * sizeof(double);
@@ -1143,10 +1143,10 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
     // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
     static int nw = -1;
-    if (nw < 0) { const char* e = getenv("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
+    if (nw < 0) { const char* e = sw_str("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
     const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + nw - 1) / nw;   // lower tiles per wave
     static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
-    if (gskip < 0) { const char* e = getenv("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
+    if (gskip < 0) { const char* e = sw_str("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
     const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
     if (D.gsl_n > 0) {
 #define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_diag128, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nchunk, 1), dim3(1024), lds, st, \
@@ -1213,9 +1213,9 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     // the CUs instead of taking them from each other).  SMCP_LG_SIDE=0: after the sweep, on the caller's stream.
     static int lgside = -1;
     if (lgside < 0) {
-      const char* e = getenv("SMCP_LG_SIDE");
-      const char* d0 = getenv("SMCP_ALDS_DYN");
-      const char* d1 = getenv("SMCP_RHS_SPLIT_DYN");
+      const char* e = sw_str("SMCP_LG_SIDE");
+      const char* d0 = sw_str("SMCP_ALDS_DYN");
+      const char* d1 = sw_str("SMCP_RHS_SPLIT_DYN");
       // (the two-stream split of the right-hand sides -- the plain extend-add launch, hess_up_fast -- uses the same side streams)
       lgside = ((e && e[0] == '0') || (d0 && d0[0] == '0') || (d1 && d1[0] == '1')) ? 0 : 1;
     }
@@ -1363,7 +1363,7 @@ int kkt_constraint_classes(csp_ctx* c, int64_t* counts) {
 }
 static bool potrf_defer_on() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMCP_POTRF_DEFER"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) { const char* e = sw_str("SMCP_POTRF_DEFER"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
 int kkt_schur_factor(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, void* stream) {

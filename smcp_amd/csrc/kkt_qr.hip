@@ -443,7 +443,7 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
     hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st, 0, D.kc_ptr ? jb : -1);
   }
   static int npass_env = -1;
-  if (npass_env < 0) { const char* e = getenv("SMCP_QR_PASSES"); npass_env = e ? std::max(1, atoi(e)) : 0; }
+  if (npass_env < 0) { const char* e = sw_str("SMCP_QR_PASSES"); npass_env = e ? std::max(1, atoi(e)) : 0; }
   int npass = npass_env ? npass_env : 2;
   double shift = 0.0;
   const int64_t range[2] = {0, bl};
@@ -478,9 +478,9 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
     if (pass == 0 && shift_out) *shift_out = shift;
     shift = 0.0;                     // the next pass sees a better-conditioned stack and starts unshifted again
     static int fake = -1;      // timing experiment only, vector-FMA kernel (SMCP_QR_FAKE=1: every update reads the same block of R)
-    if (fake < 0) { const char* e = getenv("SMCP_QR_FAKE"); fake = e ? atoi(e) : 0; }
+    if (fake < 0) { const char* e = sw_str("SMCP_QR_FAKE"); fake = e ? atoi(e) : 0; }
     static int vfma = -1;      // SMCP_QR_TRSM=fma: the vector-FMA kernel (k_stack_trsm) instead of the MFMA one
-    if (vfma < 0) { const char* e = getenv("SMCP_QR_TRSM"); vfma = (e && e[0] == 'f') ? 1 : 0; }
+    if (vfma < 0) { const char* e = sw_str("SMCP_QR_TRSM"); vfma = (e && e[0] == 'f') ? 1 : 0; }
     const int64_t ldr = vfma ? ldr8 : ldr16;
     launch(c, KID_qr_small, k_qr_pack, dim3((unsigned)std::min<int64_t>(256, (ldr * ldr + 255) / 256)), dim3(256), st,
            (const double*)T, (int)m, m, X, (int)ldr);
@@ -510,7 +510,7 @@ int kkt_qr_factor(csp_ctx* c, const double* L, const double* Y, int64_t* passes_
       if (m > 320) return SMCP_ENOMEM;            // the vector-FMA variant keeps all rows of a position in registers
       static int pv = -1;
       const int nwv = 4;
-      if (pv < 0) { const char* e = getenv("SMCP_QR_P"); pv = (e && e[0] == '2') ? 2 : 1; }
+      if (pv < 0) { const char* e = sw_str("SMCP_QR_P"); pv = (e && e[0] == '2') ? 2 : 1; }
       const int nbw = (int)((ldr / QR_JB + nwv - 1) / nwv);
       int P = pv;
       if (nbw * P > 10) P = nbw > 5 ? 1 : 2;        // register budget: 8 NBW P accumulators per lane
