@@ -1162,7 +1162,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
 #undef SMCP_GRAM_CASE
     }
     if (side) { side->join(); delete side; }      // the leaf partials of the side branch
-    launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(256), st, (const double*)D.gpart, ngram + nl, (int)m, H, ldh);
+    launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(ngram + nl >= 64 ? 1024 : 256), st, (const double*)D.gpart, ngram + nl, (int)m, H, ldh);
     HIPCHK(end_call(c));
     return 0;
   }
@@ -1187,7 +1187,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
       }
     coff += nc;
   }
-  launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
+  launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(nchunk >= 64 ? 1024 : 256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
   HIPCHK(end_call(c));
   return 0;
 }
@@ -1223,7 +1223,9 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
     if (lgside && D.lg_request && m <= D.max_rhs && Fork::enabled() && (m + GRAM_BLK - 1) / GRAM_BLK == 1) {
       c->side_work = [c, m, bl](hipStream_t side) {
         DeviceCtx& D = c->D;
-        if (!D.lg_nochild) return;                   // the family launch kept the children's panels: the Gram kernel takes them
+        // (started before the family launch has decided -- SMCP_LG_EARLY -- the work is discarded by gram_accumulate when that launch
+        // kept the children's panels after all: D.lg_nochild false)
+        if (!D.lg_nochild && !D.lg_request) return;  // the family launch kept the children's panels: the Gram kernel takes them
         const int64_t range[2] = {0, bl};
         const std::vector<std::pair<int64_t, int64_t>> rs = gram_merge_ranges(1, range);
         if (gram_tables(c, rs, true, side)) return;
@@ -1236,6 +1238,17 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
         if (leafgram_partials(c, m, nullptr, side, D.gpart + (int64_t)ngram * (64 * 256), &nl)) return;
         c->gpre.valid = true; c->gpre.ngram = ngram; c->gpre.nchunk = nchunk; c->gpre.spw = spw; c->gpre.nl = nl;
       };
+    }
+    // The closed-form leaf blocks start at once (SMCP_LG_EARLY=0: beside the phase kernels of the top fronts, as in round 3), beside the first launches of the sweep (the stray leaves, the
+    // families' tables), instead of beside the phase kernels of the top fronts
+    static int lgearly = -1;
+    if (lgearly < 0) lgearly = sw_on("SMCP_LG_EARLY", 1);
+    if (lgearly && c->side_work) {
+      std::function<void(hipStream_t)> w = std::move(c->side_work);
+      c->side_work = nullptr;
+      Fork* f = new Fork(c, st, 1);
+      c->side_fork = f;
+      w(f->s);
     }
     for (int64_t jb = 0; jb < m; jb += D.max_rhs) {
       int nr = (int)std::min(D.max_rhs, m - jb);
