@@ -1246,7 +1246,8 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
                           c->D.kc_ij && a0.ymode == 2 && a0.ysc && c->D.fam_maxterms <= FAMT_TCAP / 2 &&
                           c->D.cnnz <= (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m);
   if (groups_on || fgroups_on) a0.chskip = groups_on && fgroups_on ? c->D.both_skip : (groups_on ? c->D.lfsp_skip : c->D.famt_skip);
-  // Fused extend-add of the family parents' updates (front_famt.hip, lf_add_family): requested when the whole tree is swept in
+  // Fused extend-add of the family parents' updates (front_famt.hip, lf_add_family): requested when the whole tree (or, sharded,
+  // the whole of this rank's subtrees: set 1, which holds the families together with the fronts above them) is swept in
   // one call with sparse input, the entry-driven family kernel is the route (its conditions, as for the groups above), there
   // is ONE level of family parents, and every large level with children takes the LDS extend-add that also builds the
   // panels (lf_assemble_fills); the family launch then decides (csp_ctx::fz_live).  SMCP_FZ=0: never.
@@ -1254,7 +1255,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
   {
     static int fzenv = -1;
     if (fzenv < 0) { const char* e = sw_str("SMCP_FZ"); fzenv = (e && e[0] == '0') ? 0 : 1; }
-    bool want = fzenv && sparse && set == 0 && lev_lo == 0 && lev_hi < 0 && !fgroups_on && c->D.fz_ok && !famt_disabled() && !fam2_disabled() &&
+    bool want = fzenv && sparse && (set == 0 || (set == 1 && c->fz_set1_ok)) && lev_lo == 0 && lev_hi < 0 && !fgroups_on && c->D.fz_ok && !famt_disabled() && !fam2_disabled() &&
                 c->D.lg_request && c->D.kc_ij && a0.ymode == 2 && a0.ysc && c->D.fam_maxterms <= FAMT_TCAP / 2 &&
                 c->D.cnnz <= (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m) && !use_generic(c) && use_large() && c->D.gp_tptr;
     if (want) {
@@ -1263,7 +1264,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
         for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t, int) {
           if (lds && a.nS > 0 && a.level > 0) ++famlevels;
           if (!lds && (size_t)a.level < c->fz_levels.size() && c->fz_levels[(size_t)a.level] && !(a.nchmax > 0 && lf_assemble_fills(c, a, cnt, nrhs))) want = false;
-        });
+        }, set);
       if (famlevels != 1) want = false;
     }
     if (want) { a0.fz_on = 1; a0.fz_no = c->D.fz_no; }

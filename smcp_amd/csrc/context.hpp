@@ -239,6 +239,7 @@ struct csp_ctx {
   hipEvent_t aux_fork = nullptr, aux_join[2] = {nullptr, nullptr};
   int64_t scal_lstar = -1, scal_tail0 = 0;              // scaling_impl: first level without small cliques, start of the last level in blkval
   std::vector<uint8_t> fz_levels;       // per level: holds the parent front of some family parent (those levels' extend-add is the fused one)
+  bool fz_set1_ok = false;              // csp_set_partition: every family parent this rank owns has its parent front on this rank too
   bool fz_live = false; int fz_nat = 0, fz_cnn = 0; int64_t fz_recl = 0;   // the running sweep's family launch left the parents' updates to the extend-add above (k_lf_assemble_fz)
   bool plan_full_upd = false;           // the gather plans list every update-block position of the large fronts (no clear pass needed)
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status

@@ -1492,6 +1492,11 @@ int csp_set_partition(csp_ctx* c, const int32_t* owner, int rank) {
   for (void* p : {(void*)c->xr_roots, (void*)c->xr_owner, (void*)c->xr_bptr}) if (p) HIPCHK(hipFree(p));
   c->xr_roots = nullptr; c->xr_owner = nullptr; c->xr_bptr = nullptr;
   c->xr_n = (int64_t)roots.size(); c->xr_me = rank; c->xr_world = world;
+  // may the owned sweeps leave the family parents' updates to the extend-add above (fz_on)?  Only when no family parent of this
+  // rank is a subtree root: a root's update is what the boundary exchange packs, so it has to exist in the exchange buffer
+  c->fz_set1_ok = true;
+  for (int64_t k = 0; k < S.nsn; ++k)
+    if (k < (int64_t)c->fam.size() && c->fam[(size_t)k] == 2 && owner[k] == rank && (S.snpar[k] < 0 || owner[S.snpar[k]] != rank)) c->fz_set1_ok = false;
   if (int rc = dev_upload(&c->xr_roots, roots, c->D.bytes)) return rc;
   if (int rc = dev_upload(&c->xr_owner, own, c->D.bytes)) return rc;
   if (int rc = dev_upload(&c->xr_bptr, bptr, c->D.bytes)) return rc;
