@@ -79,8 +79,7 @@ class cspmatrix:
         pos = symb.index_map(I, J)
         if (pos < 0).any():
             raise ValueError("entry outside the sparsity pattern")
-        h = np.zeros(symb.blklen)
-        np.add.at(h, pos, np.asarray(V, dtype=np.float64))
+        h = np.bincount(pos, weights=np.asarray(V, dtype=np.float64), minlength=symb.blklen).astype(np.float64, copy=False)     # repeated entries add up
         X = cls(symb, device=device)
         X.blkval.copy_(torch.from_numpy(h))
         return X

@@ -55,7 +55,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn, KID_lf_zsp, KID_fam_terms_grp, KID_lf_assemble_fz,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn, KID_lf_zsp, KID_fam_terms_grp, KID_lf_assemble_fz, KID_factor_inverse_lds,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -73,7 +73,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn", "k_lf_zsp", "k_fam_terms_grp", "k_lf_assemble_fz"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn", "k_lf_zsp", "k_fam_terms_grp", "k_lf_assemble_fz", "k_factor_inverse_lds"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -1258,16 +1258,22 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
     bool want = fzenv && sparse && (set == 0 || (set == 1 && c->fz_set1_ok)) && lev_lo == 0 && lev_hi < 0 && !fgroups_on && c->D.fz_ok && !famt_disabled() && !fam2_disabled() &&
                 c->D.lg_request && c->D.kc_ij && a0.ymode == 2 && a0.ysc && c->D.fam_maxterms <= FAMT_TCAP / 2 &&
                 c->D.cnnz <= (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m) && !use_generic(c) && use_large() && c->D.gp_tptr;
+    int famlevels = 0, nofill = 0;
     if (want) {
-      int famlevels = 0;
       for (int64_t l = 0; l < c->S.nlev; ++l)
         for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t, int) {
           if (lds && a.nS > 0 && a.level > 0) ++famlevels;
-          if (!lds && (size_t)a.level < c->fz_levels.size() && c->fz_levels[(size_t)a.level] && !(a.nchmax > 0 && lf_assemble_fills(c, a, cnt, nrhs))) want = false;
+          if (!lds && (size_t)a.level < c->fz_levels.size() && c->fz_levels[(size_t)a.level] && !(a.nchmax > 0 && lf_assemble_fills(c, a, cnt, nrhs))) { want = false; ++nofill; }
         }, set);
       if (famlevels != 1) want = false;
     }
     if (want) { a0.fz_on = 1; a0.fz_no = c->D.fz_no; }
+    static int occ = -1;
+    if (occ < 0) occ = sw_on("SMCP_OCC", 0);
+    if (occ && sparse)
+      fprintf(stderr, "fz: want %d famlevels %d nofill %d nlev %d (env %d set %d lev %d..%d fgroups %d fz_ok %d famt_off %d fam2_off %d lg_request %d kc_ij %d ymode %d ysc %d maxterms %d cnnz %lld nsn %lld m %lld generic %d nrhs %d)\n",
+              (int)want, famlevels, nofill, (int)c->S.nlev, fzenv, set, (int)lev_lo, (int)lev_hi, (int)fgroups_on, (int)c->D.fz_ok, (int)famt_disabled(), (int)fam2_disabled(), (int)c->D.lg_request,
+              c->D.kc_ij != nullptr, a0.ymode, a0.ysc != nullptr, (int)c->D.fam_maxterms, (long long)c->D.cnnz, (long long)c->S.nsn, (long long)c->D.m, (int)use_generic(c), nrhs);
   }
   // kernels that read their input from U get dense panels built first (zeros + the constraint's entries)
   auto dense_input_on = [&](MfmaArgs& a, int cnt, double* Ub, int nr, hipStream_t s) {
@@ -1543,8 +1549,25 @@ int prepare_yaa(csp_ctx* c, const double* Y, bool need_fac, hipStream_t st, bool
   if (need_inv && c->D.faci_tag != Y) {
     if (fast) {
       a.lev = c->D.lev3idx;
-      if (c->D.nI_total) launch(c, KID_factor_inverse, k_factor_inverse, dim3((int)c->D.nI_total), dim3(256), st, a, (const double*)c->D.fac, c->D.faci);
       MfmaArgs a0 = mfma_args(c, nullptr, 0, 1);
+      static const bool rd = sw_on("SMCP_FACI_LDS", true);
+      bool all_lds = rd;
+      if (rd)
+        for (int64_t l = 0; l < c->S.nlev; ++l)
+          for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int, size_t, int) { if (lds && am.namax > 64) all_lds = false; });
+      if (!c->D.nI_total) {
+      } else if (!all_lds) {
+        launch(c, KID_factor_inverse, k_factor_inverse, dim3((int)c->D.nI_total), dim3(256), st, a, (const double*)c->D.fac, c->D.faci);
+      } else {
+        for (int64_t l = 0; l < c->S.nlev; ++l)
+          for_level_classes(c, l, a0, [&](bool lds, MfmaArgs am, int cnt, size_t, int) {
+            if (!lds || !am.namax) return;
+            if (am.namax <= 32)
+              launch_lds(c, KID_factor_inverse_lds, k_factor_inverse_lds<33>, dim3(cnt), dim3(128), (2 * 33 * 32 + 256) * sizeof(double), st, am, (const double*)c->D.fac, c->D.faci);
+            else
+              launch_lds(c, KID_factor_inverse_lds, k_factor_inverse_lds<65>, dim3(cnt), dim3(256), (2 * 65 * 64 + 1024) * sizeof(double), st, am, (const double*)c->D.fac, c->D.faci);
+          });
+      }
       for_all_large(c, a0, [&](MfmaArgs am, int cnt) { if (am.namax) lf_factor_inverse(c, am, cnt, st); });
     } else {
       a.lev = c->D.levidx;

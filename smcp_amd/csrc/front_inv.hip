@@ -62,6 +62,32 @@ __device__ inline void wg_tri_inverse(int n, const double* L, int64_t ldl, doubl
 }
 
 // faci[k] <- inverse of the lower-triangular fac[k] (update-matrix layout), one workgroup per clique
+// Ri = R^-1 of the cached Cholesky factor of Y_AA for separators of at most LDM - 1 rows: triangle in LDS, the 16 x 16
+// diagonal blocks inverted side by side and the rest by recursive doubling (tri_inv64_rd), where k_factor_inverse below
+// walks block rows against HBM (0.64 ms per call on the 8064 small fronts of synth50k, once per iteration of the
+// interior-point drivers; this one: see DESIGN.md section 4).  LDM = 65: 256 threads, dynamic LDS (2 * 65 * 64 + 1024) doubles;
+// LDM = 33: 128 threads (two diagonal blocks, one product), (2 * 33 * 32 + 256) doubles.
+template <int LDM>
+__global__ void __launch_bounds__(256) k_factor_inverse_lds(MfmaArgs a, const double* fac, double* faci) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NB = LDM - 1;
+  const int k = a.t.lev[blockIdx.x];
+  const CliqueDesc d = a.t.cl[k];
+  const int na = d.na;
+  if (!na) return;
+  double* const D = smem;
+  double* const Di = smem + NB * LDM;
+  double* const s16 = Di + NB * LDM;
+  const double* src = fac + d.upd;
+  double* dst = faci + d.upd;
+  for (int e = threadIdx.x; e < NB * LDM; e += blockDim.x) Di[e] = 0.0;
+  batched_loop<8>(threadIdx.x, na * na, blockDim.x, [=](int e) { return (e % na) >= (e / na) ? src[e] : 0.0; },
+                  [=](int e, double v) { D[(e % na) + (e / na) * LDM] = v; });
+  __syncthreads();
+  tri_inv64_rd<LDM>(D, na, Di, s16);
+  for (int e = threadIdx.x; e < na * na; e += blockDim.x) dst[e] = Di[(e % na) + (e / na) * LDM];
+}
+
 __global__ void __launch_bounds__(256) k_factor_inverse(TreeArgs t, const double* fac, double* faci) {
   __shared__ double D16[256], S[16 * 128];
   const int k = t.lev[blockIdx.x];

@@ -1075,6 +1075,7 @@ __device__ inline void wave_tile16(int Kd, FA A, FB B, FC store) {
 // the root of synth50k: 36 us on the critical path of every factorisation).  s16: 1024 doubles of scratch.  Needs >= 4 waves.
 // the off-diagonal part: Di holds the inverses of the 16 x 16 diagonal blocks (zeros elsewhere), D the triangle itself with
 // zeros beyond w; two doubling levels, three workgroup barriers
+template <int LBD = LB + 1>
 __device__ inline void tri_inv64_offdiag(const double* D, int w, double* Di, double* s16) {
   const int wave = threadIdx.x >> 6;
   if (wave < 2 && 32 * wave + 16 < w) {                      // pairs (0, 1) and (2, 3) at block size 16
@@ -1110,15 +1111,19 @@ __device__ inline void tri_inv64_offdiag(const double* D, int w, double* Di, dou
   }
   __syncthreads();
 }
+template <int LBD = LB + 1>
 __device__ inline void tri_inv64_pad(double* D, int w) {     // rows / columns beyond w read as zero
-  for (int e = threadIdx.x; e < LB * LB; e += blockDim.x) {
-    const int i = e % LB, j = e / LB;
+  constexpr int NB = LBD - 1;
+  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+    const int i = e % NB, j = e / NB;
     if (i >= w || j >= w) D[i + j * LBD] = 0.0;
   }
 }
+// (LBD: leading dimension of D and Di in LDS; LBD - 1 = 64 or, for blocks of at most 32 rows, 32)
+template <int LBD = LB + 1>
 __device__ inline void tri_inv64_rd(double* D, int w, double* Di, double* s16) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  tri_inv64_pad(D, w);
+  tri_inv64_pad<LBD>(D, w);
   __syncthreads();
   if (wave < 4 && 16 * wave < w) {                           // diagonal block `wave`
     const int b0 = 16 * wave, bw = min(16, w - b0);
@@ -1133,7 +1138,7 @@ __device__ inline void tri_inv64_rd(double* D, int w, double* Di, double* s16) {
     }
   }
   __syncthreads();
-  tri_inv64_offdiag(D, w, Di, s16);
+  tri_inv64_offdiag<LBD>(D, w, Di, s16);
 }
 
 // In-LDS Cholesky (do_potrf) and inverse of a w x w (w <= 64) lower block D (ld LBD); the inverse goes

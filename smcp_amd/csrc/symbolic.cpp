@@ -4,6 +4,10 @@
 #include <algorithm>
 #include <numeric>
 #include <set>
+#include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace smcp {
 namespace {
@@ -16,18 +20,22 @@ struct Graph {
   std::vector<int32_t> lidx, uidx;
 };
 
-// Build Graph from input pattern with labels mapped through ip (orig -> current).
+// Build Graph from input pattern with labels mapped through ip (orig -> current); only the halves asked for (the
+// elimination tree and the column counts walk the upper lists, the clique row structures the lower ones).
 static int build_graph(int64_t n, const int64_t* colptr, const int64_t* rowind,
-                       const std::vector<int64_t>& ip, Graph& g) {
+                       const std::vector<int64_t>& ip, Graph& g, bool lower, bool upper, bool tidy_lists = true) {
   g.n = n;
   g.lptr.assign(n + 1, 0);
   g.uptr.assign(n + 1, 0);
+  g.lidx.clear();
+  g.uidx.clear();
   for (int64_t j = 0; j < n; ++j) {
+    const int64_t b = ip[j];
     for (int64_t q = colptr[j]; q < colptr[j + 1]; ++q) {
       int64_t i = rowind[q];
       if (i < 0 || i >= n) return -1;
       if (i == j) continue;
-      int64_t a = ip[i], b = ip[j];
+      int64_t a = ip[i];
       int64_t lo = std::min(a, b), hi = std::max(a, b);
       g.lptr[lo + 1]++;  // column lo has row hi below the diagonal
       g.uptr[hi + 1]++;  // column hi has row lo above the diagonal
@@ -37,17 +45,18 @@ static int build_graph(int64_t n, const int64_t* colptr, const int64_t* rowind,
     g.lptr[j + 1] += g.lptr[j];
     g.uptr[j + 1] += g.uptr[j];
   }
-  g.lidx.resize(g.lptr[n]);
-  g.uidx.resize(g.uptr[n]);
+  if (lower) g.lidx.resize(g.lptr[n]);
+  if (upper) g.uidx.resize(g.uptr[n]);
   std::vector<int64_t> lw(g.lptr.begin(), g.lptr.end() - 1), uw(g.uptr.begin(), g.uptr.end() - 1);
   for (int64_t j = 0; j < n; ++j) {
+    const int64_t b = ip[j];
     for (int64_t q = colptr[j]; q < colptr[j + 1]; ++q) {
       int64_t i = rowind[q];
       if (i == j) continue;
-      int64_t a = ip[i], b = ip[j];
+      int64_t a = ip[i];
       int64_t lo = std::min(a, b), hi = std::max(a, b);
-      g.lidx[lw[lo]++] = (int32_t)hi;
-      g.uidx[uw[hi]++] = (int32_t)lo;
+      if (lower) g.lidx[lw[lo]++] = (int32_t)hi;
+      if (upper) g.uidx[uw[hi]++] = (int32_t)lo;
     }
   }
   // sort + dedupe each list (duplicates are harmless for etree/counts but not for sizes)
@@ -56,7 +65,7 @@ static int build_graph(int64_t n, const int64_t* colptr, const int64_t* rowind,
     int64_t w = 0;
     for (int64_t j = 0; j < n; ++j) {
       int64_t b = ptr[j], e = ptr[j + 1];
-      std::sort(idx.begin() + b, idx.begin() + e);
+      if (!std::is_sorted(idx.begin() + b, idx.begin() + e)) std::sort(idx.begin() + b, idx.begin() + e);
       int64_t start = w;
       for (int64_t q = b; q < e; ++q)
         if (w == start || idx[w - 1] != idx[q]) idx[w++] = idx[q];
@@ -65,9 +74,14 @@ static int build_graph(int64_t n, const int64_t* colptr, const int64_t* rowind,
     idx.resize(w);
     ptr.swap(nptr);
   };
-  tidy(g.lptr, g.lidx);
-  tidy(g.uptr, g.uidx);
+  if (lower && tidy_lists) tidy(g.lptr, g.lidx);
+  if (upper && tidy_lists) tidy(g.uptr, g.uidx);
   return 0;
+}
+
+static bool is_identity(const std::vector<int64_t>& order) {
+  for (size_t k = 0; k < order.size(); ++k) if (order[k] != (int64_t)k) return false;
+  return true;
 }
 
 // Liu's elimination tree with path compression.
@@ -147,6 +161,15 @@ static void relabel(const std::vector<int64_t>& order /*new->cur*/, std::vector<
 int symbolic_build(int64_t n, const int64_t* colptr, const int64_t* rowind, const int64_t* perm,
                    Symbolic& S) {
   if (n <= 0) return -1;
+  const char* tenv = std::getenv("SMCP_TIMING");
+  const bool timing = tenv && tenv[0] == '1';
+  auto tprev = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "smcp_amd timing: symbolic_build: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tprev).count());
+    tprev = now;
+  };
   S = Symbolic();
   S.n = n;
   S.p.resize(n);
@@ -164,20 +187,33 @@ int symbolic_build(int64_t n, const int64_t* colptr, const int64_t* rowind, cons
   for (int64_t i = 0; i < n; ++i) S.ip[S.p[i]] = i;
 
   // ---- pass 1: etree + postorder in the user ordering
+  // (each half of the adjacency is built once: the upper lists here for tree and counts, the lower ones in pass 3)
   Graph g;
-  if (build_graph(n, colptr, rowind, S.ip, g)) return -1;
-  int64_t nnz_in = g.lptr[n] + n;
-  std::vector<int64_t> parent, post;
+  if (build_graph(n, colptr, rowind, S.ip, g, false, true)) return -1;
+  int64_t nnz_in = g.uptr[n] + n;
+  mark("upper lists");
+  std::vector<int64_t> parent, post, cc;
   etree(g, parent);
   postorder(parent, post);
-  relabel(post, S.p);
-  for (int64_t i = 0; i < n; ++i) S.ip[S.p[i]] = i;
-
-  // ---- pass 2: in postorder labels: etree, column counts, maximal supernodes (Pothen-Sun)
-  if (build_graph(n, colptr, rowind, S.ip, g)) return -1;
-  etree(g, parent);
-  std::vector<int64_t> cc;
+  mark("etree + postorder");
   colcounts(g, parent, cc);
+  mark("column counts");
+  // ---- pass 2: in postorder labels: etree, column counts, maximal supernodes (Pothen-Sun).  A postorder is an equivalent
+  // reordering (same filled graph, same elimination tree up to the labels): tree and counts are carried over, not recomputed
+  if (!is_identity(post)) {
+    std::vector<int64_t> ipost(n), par2(n), cc1(n);
+    for (int64_t k = 0; k < n; ++k) ipost[post[k]] = k;
+    for (int64_t k = 0; k < n; ++k) {
+      const int64_t pv = parent[post[k]];
+      par2[k] = pv < 0 ? -1 : ipost[pv];
+      cc1[k] = cc[post[k]];
+    }
+    parent.swap(par2);
+    cc.swap(cc1);
+    relabel(post, S.p);
+    for (int64_t i = 0; i < n; ++i) S.ip[S.p[i]] = i;
+    mark("relabel");
+  }
   // supernode membership: vertex j joins the supernode of a child c with cc[c] == cc[j]+1
   std::vector<int64_t> sn(n, -1), snlast;  // snlast[s] = last (largest) vertex of supernode s
   std::vector<int64_t> snfirst;
@@ -236,7 +272,9 @@ int symbolic_build(int64_t n, const int64_t* colptr, const int64_t* rowind, cons
     for (int64_t j = S.snptr[k]; j < S.snptr[k + 1]; ++j) S.snode[j] = k;
 
   // ---- pass 3: final labels: clique row structures
-  if (build_graph(n, colptr, rowind, S.ip, g)) return -1;
+  mark("supernodes");
+  if (build_graph(n, colptr, rowind, S.ip, g, true, false, false)) return -1;      // (the marks below skip repeated rows)
+  mark("lower lists");
   S.chptr.assign(nsn + 1, 0);
   for (int64_t k = 0; k < nsn; ++k)
     if (S.snpar[k] >= 0) S.chptr[S.snpar[k] + 1]++;
@@ -284,6 +322,7 @@ int symbolic_build(int64_t n, const int64_t* colptr, const int64_t* rowind, cons
       for (auto r : tmp) S.rowidx[o++] = r;
     }
   }
+  mark("clique rows");
   // ---- relative indices, block/update pointers, ccs pointers
   S.sepptr.assign(nsn + 1, 0);
   S.blkptr.assign(nsn + 1, 0);
@@ -356,6 +395,7 @@ int symbolic_build(int64_t n, const int64_t* colptr, const int64_t* rowind, cons
     std::vector<int64_t> lw(S.levptr.begin(), S.levptr.end() - 1);
     for (int64_t k = 0; k < nsn; ++k) S.levidx[lw[S.level[k]]++] = k;
   }
+  mark("relative indices, levels");
   return 0;
 }
 
@@ -363,7 +403,7 @@ void maxcardsearch(int64_t n, const int64_t* colptr, const int64_t* rowind, int6
   std::vector<int64_t> id(n);
   std::iota(id.begin(), id.end(), 0);
   Graph g;
-  build_graph(n, colptr, rowind, id, g);
+  build_graph(n, colptr, rowind, id, g, true, true);
   // bucket structure over cardinalities
   std::vector<int64_t> card(n, 0), head(n + 1, -1), nxt(n, -1), prv(n, -1);
   std::vector<char> done(n, 0);
@@ -401,7 +441,7 @@ void mindegree(int64_t n, const int64_t* colptr, const int64_t* rowind, int64_t*
   std::vector<int64_t> id(n);
   std::iota(id.begin(), id.end(), 0);
   Graph g;
-  build_graph(n, colptr, rowind, id, g);
+  build_graph(n, colptr, rowind, id, g, true, true);
   std::vector<std::set<int32_t>> adj(n);
   for (int64_t v = 0; v < n; ++v) {
     for (int64_t q = g.lptr[v]; q < g.lptr[v + 1]; ++q) adj[v].insert(g.lidx[q]);
@@ -431,19 +471,36 @@ void mindegree(int64_t n, const int64_t* colptr, const int64_t* rowind, int64_t*
   }
 }
 
-void index_map(const Symbolic& S, int64_t cnt, const int64_t* I, const int64_t* J, int64_t* out) {
-  for (int64_t e = 0; e < cnt; ++e) {
+// entries e0 .. e1-1; an entry that follows another one of the same column further down (the usual order of a
+// compressed-column input) is looked for right after it before the binary search
+static void index_map_range(const Symbolic& S, int64_t e0, int64_t e1, const int64_t* I, const int64_t* J, int64_t* out) {
+  int64_t pc = -1, pr = -1, pq = 0;          // previous hit: column, row, position in the clique's row list
+  for (int64_t e = e0; e < e1; ++e) {
     out[e] = -1;
-    if (I[e] < 0 || I[e] >= S.n || J[e] < 0 || J[e] >= S.n) continue;
+    if (I[e] < 0 || I[e] >= S.n || J[e] < 0 || J[e] >= S.n) { pc = -1; continue; }
     int64_t a = S.ip[I[e]], b = S.ip[J[e]];
     int64_t c = std::min(a, b), r = std::max(a, b);
     int64_t k = S.snode[c];
     const int32_t* rb = &S.rowidx[S.rowptr[k]];
     int64_t nf = S.nf(k);
-    const int32_t* pos = std::lower_bound(rb, rb + nf, (int32_t)r);
-    if (pos == rb + nf || *pos != r) continue;
+    const int32_t* pos;
+    if (c == pc && r > pr && pq + 1 < nf && rb[pq + 1] == r) pos = rb + pq + 1;
+    else pos = std::lower_bound(rb, rb + nf, (int32_t)r);
+    if (pos == rb + nf || *pos != r) { pc = -1; continue; }
+    pc = c; pr = r; pq = pos - rb;
     out[e] = S.blkptr[k] + (c - S.snptr[k]) * nf + (pos - rb);
   }
+}
+void index_map(const Symbolic& S, int64_t cnt, const int64_t* I, const int64_t* J, int64_t* out) {
+  const int64_t per = 1 << 17;
+  int nth = (int)std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), (cnt + per - 1) / per);
+  if (nth <= 1) { index_map_range(S, 0, cnt, I, J, out); return; }
+  std::vector<std::thread> th;
+  const int64_t chunk = (cnt + nth - 1) / nth;
+  for (int t = 1; t < nth; ++t)
+    th.emplace_back([&, t] { index_map_range(S, t * chunk, std::min(cnt, (t + 1) * chunk), I, J, out); });
+  index_map_range(S, 0, std::min(cnt, chunk), I, J, out);
+  for (auto& x : th) x.join();
 }
 
 }  // namespace smcp

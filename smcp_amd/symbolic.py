@@ -30,8 +30,7 @@ def _lower_csc(A, n=None):
     key = np.unique(j * n + i)
     j, i = key // n, key % n
     cp = np.zeros(n + 1, dtype=np.int64)
-    np.add.at(cp, j + 1, 1)
-    cp = np.cumsum(cp)
+    np.cumsum(np.bincount(j, minlength=n), out=cp[1:])
     return n, cp, np.ascontiguousarray(i)
 
 
@@ -144,29 +143,29 @@ class Symbolic:
         nf = np.diff(self.rowptr)
         return nn, nf - nn
 
+    def _column_offsets(self):
+        """Per column j of supernode k (offset t inside it): clique, t, front size, length of the column in V."""
+        sp, rp = self.snptr, self.rowptr
+        k = np.repeat(np.arange(self.Nsn), np.diff(sp))
+        t = np.arange(self.n) - sp[k]
+        nf = (rp[1:] - rp[:-1])[k]
+        return k, t, nf, nf - t
+
     def sparsity_pattern(self):
         """Filled lower pattern in PERMUTED coordinates as (colptr, rowind)."""
         cp = self.ccsptr
-        ri = np.empty(self.nnz, dtype=np.int64)
-        rp, rows, sp = self.rowptr, self.rowidx, self.snptr
-        for k in range(self.Nsn):
-            r = rows[rp[k]:rp[k + 1]]
-            for t in range(sp[k + 1] - sp[k]):
-                j = sp[k] + t
-                ri[cp[j]:cp[j + 1]] = r[t:]
+        k, t, nf, ln = self._column_offsets()
+        start = self.rowptr[k] + t                       # column j lists the clique's rows from its own on
+        ri = self.rowidx[np.repeat(start - cp[:-1], ln) + np.arange(self.nnz)].astype(np.int64)
         return cp, ri
 
     def ccs_to_blk(self):
         """blkval position of every nonzero of sparsity_pattern(), in CCS order."""
         if "ccs2blk" not in self._cache:
-            out = np.empty(self.nnz, dtype=np.int64)
-            cp, rp, sp, bp = self.ccsptr, self.rowptr, self.snptr, self.blkptr
-            for k in range(self.Nsn):
-                nf = rp[k + 1] - rp[k]
-                for t in range(sp[k + 1] - sp[k]):
-                    j = sp[k] + t
-                    out[cp[j]:cp[j + 1]] = bp[k] + t * nf + np.arange(t, nf)
-            self._cache["ccs2blk"] = out
+            cp = self.ccsptr
+            k, t, nf, ln = self._column_offsets()
+            base = self.blkptr[k] + t * nf + t           # the diagonal entry of column j inside the clique's panel
+            self._cache["ccs2blk"] = np.repeat(base - cp[:-1], ln) + np.arange(self.nnz)
         return self._cache["ccs2blk"]
 
     def index_map(self, I, J):

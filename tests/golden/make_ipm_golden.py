@@ -54,7 +54,14 @@ def run_case(case, base, solvers):
         import scipy.sparse as sp
         low = lambda M: sp.csc_matrix(sp.tril(M)) if sp.issparse(M) else sp.csc_matrix(np.tril(M))
         kw = dict(kw, primalstart={"x": low(P._X0)}, dualstart={"y": P._y0, "s": low(P._S0)})
-    sol = (P.solve_esd if driver == "esd" else P.solve_feas)(**kw)
+    # the stored runs were generated with the reference's ordering sequence (maximum cardinality search): pinned, so that the
+    # fixtures stay comparable to 1e-9 whatever the driver's default choice of perfect elimination order is
+    peo = solvers.options.get("peo", "auto")
+    solvers.options["peo"] = "mcs"
+    try:
+        sol = (P.solve_esd if driver == "esd" else P.solve_feas)(**kw)
+    finally:
+        solvers.options["peo"] = peo
     return dict(name=name, status=sol["status"], iterations=int(sol["iterations"]),
                 pobj=float(sol["primal objective"]), dobj=float(sol["dual objective"]),
                 y=[float(v) for v in sol["y"]])

@@ -366,3 +366,21 @@ def test_phase1_golden_cases_over_the_oracle():
     import ipm_golden
     with oracle_backend():
         ipm_golden.check_phase1(iter_slack=0, obj_tol=1e-9)
+
+
+def test_natural_elimination_order_gives_the_same_optimum():
+    """options['peo'] = 'auto' analyses a pattern that is chordal as given in its own order (the clique tree keeps the
+    generator's nesting: fewer levels for the device to walk); which perfect elimination order is used must not be observable."""
+    from smcp_amd import problems
+    from smcp_amd.symbolic import Symbolic
+    with oracle_backend():
+        res = {}
+        for peo in ("mcs", "auto"):
+            solvers.options["peo"] = peo
+            P = base.pattern_SDP(problems.nested_block_arrow_pattern(nsub=2, nmid=3, nleaf_per_mid=3, leaf=(3, 6), mid=(4, 8), top=(6, 8),
+                                                                      root=10, seed=2), 6, seed=3)
+            sol = P.solve_feas()
+            pr = solvers._Problem(P._A, P._b)
+            res[peo] = (sol["status"], sol["primal objective"], pr.symb.Nsn, int(np.max(pr.symb.level)) + 1 if hasattr(pr.symb, "level") else None)
+        assert res["mcs"][0] == res["auto"][0] == "optimal"
+        assert abs(res["mcs"][1] - res["auto"][1]) < 1e-6 * (1 + abs(res["mcs"][1]))

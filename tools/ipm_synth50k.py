@@ -56,8 +56,16 @@ if os.environ.get("VERIFY_PROBES"):           # every probe against the same tri
         return ok, fac
     chordal.probe_factors = checked
 t0 = time.time()
-sol = solvers.chordalsolver_feas(A, b, primalstart={"x": X0}, dualstart={"y": y0, "s": S0}, scaling="dual", kktsolver=kktsolver)
-dt = time.time() - t0
+if os.environ.get("PROFILE_HOST"):            # host-side view: where the wall time of the driver goes (cProfile, by own time)
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    sol = pr.runcall(solvers.chordalsolver_feas, A, b, primalstart={"x": X0}, dualstart={"y": y0, "s": S0}, scaling="dual", kktsolver=kktsolver)
+    dt = time.time() - t0
+    pstats.Stats(pr).sort_stats("tottime").print_stats(45)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(60)
+else:
+    sol = solvers.chordalsolver_feas(A, b, primalstart={"x": X0}, dualstart={"y": y0, "s": S0}, scaling="dual", kktsolver=kktsolver)
+    dt = time.time() - t0
 if os.environ.get("VERIFY_PROBES"): print("probe check", stats)
 print("kktsolver", kktsolver, "status", sol["status"], "iterations", sol["iterations"], "pobj %.8g dobj %.8g gap %.2e" % (sol["primal objective"], sol["dual objective"], sol["gap"]),
       "total %.2f s, %.3f s/iteration (incl. symbolic setup)" % (dt, dt / max(1, sol["iterations"])), "dimacs", ["%.1e" % v for v in sol["dimacs"]])
