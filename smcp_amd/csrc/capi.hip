@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <atomic>
 #include <thread>
 #include <vector>
 

@@ -454,20 +454,30 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   std::vector<int32_t> ar(nnz), ac(nnz);   // entries in (permuted) matrix coordinates
   std::vector<int32_t> ek(nnz), eoff(nnz); // clique of each entry, position inside that clique's panel
   {
-    // locate clique by binary search on blkptr
-    for (int64_t e = 0; e < nnz; ++e) {
-      int64_t pos = cidx[e];
-      if (pos < 0 || pos >= S.blklen()) return SMCP_EINVAL;
-      int64_t k = (int64_t)(std::upper_bound(S.blkptr.begin(), S.blkptr.end(), pos) - S.blkptr.begin()) - 1;
-      int64_t nf = S.nf(k), off = pos - S.blkptr[k];
-      int64_t col = off / nf, row = off % nf;
-      if (row < col) return SMCP_EINVAL;  // upper triangle of the NN block is not part of V
-      w[e] = (row == col) ? cval[e] : 2.0 * cval[e];
-      ar[e] = (int32_t)S.rowidx[S.rowptr[k] + row];
-      ac[e] = (int32_t)(S.snptr[k] + col);
-      ek[e] = (int32_t)k;
-      eoff[e] = (int32_t)off;
-    }
+    // locate clique by binary search on blkptr (the entry ranges split over host threads)
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hw ? hw : 1), (int64_t)16, nnz / 65536 + 1}));
+    std::atomic<int> bad{0};
+    auto work = [&](int tix) {
+      const int64_t e0 = nnz * tix / nth, e1 = nnz * (tix + 1) / nth;
+      int64_t k = 0;
+      for (int64_t e = e0; e < e1; ++e) {
+        int64_t pos = cidx[e];
+        if (pos < 0 || pos >= S.blklen()) { bad = 1; return; }
+        if (pos < S.blkptr[k] || pos >= S.blkptr[k + 1])      // (runs of entries share their clique)
+          k = (int64_t)(std::upper_bound(S.blkptr.begin(), S.blkptr.end(), pos) - S.blkptr.begin()) - 1;
+        int64_t nf = S.nf(k), off = pos - S.blkptr[k];
+        int64_t col = off / nf, row = off % nf;
+        if (row < col) { bad = 1; return; }  // upper triangle of the NN block is not part of V
+        w[e] = (row == col) ? cval[e] : 2.0 * cval[e];
+        ar[e] = (int32_t)S.rowidx[S.rowptr[k] + row];
+        ac[e] = (int32_t)(S.snptr[k] + col);
+        ek[e] = (int32_t)k;
+        eoff[e] = (int32_t)off;
+      }
+    };
+    run_threads(nth, work);
+    if (bad) return SMCP_EINVAL;
   }
   clk.mark("locate entries");
   // Column-sparse constraints (misc.nzcolumns / misc.matperm, misc.c:682-773, solvers.py:246-268): a constraint
@@ -523,26 +533,51 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   // CSR by position
   // entries ordered by position, ties in constraint order: a counting sort over the positions of V (a comparison sort
   // of the 1.1 M entries of synth50k took 74 ms)
-  std::vector<int64_t> order(nnz);
-  std::vector<int32_t> con(nnz);
-  for (int64_t j = 0; j < m; ++j)
-    for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) con[e] = (int32_t)j;
-  {
-    std::vector<int64_t> start((size_t)S.blklen() + 1, 0);
-    for (int64_t e = 0; e < nnz; ++e) ++start[(size_t)cidx[e] + 1];
-    for (int64_t p = 0; p < S.blklen(); ++p) start[(size_t)p + 1] += start[(size_t)p];
-    for (int64_t e = 0; e < nnz; ++e) order[(size_t)start[(size_t)cidx[e]]++] = e;     // e ascending: stable
-  }
+  // ... split by position range over host threads: every thread walks the entry list for the positions of its range
+  // (counts, then places), so the pieces come out in global order and only their offsets are laid out serially
   std::vector<int64_t> rpos, rptr;
   std::vector<int32_t> rcon(nnz);
   std::vector<double> rval(nnz);
-  for (int64_t q = 0; q < nnz; ++q) {
-    int64_t e = order[q];
-    if (q == 0 || cidx[e] != cidx[order[q - 1]]) { rpos.push_back(cidx[e]); rptr.push_back(q); }
-    rcon[q] = con[e];
-    rval[q] = cval[e];
+  {
+    std::vector<int32_t> con(nnz);
+    for (int64_t j = 0; j < m; ++j)
+      for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) con[e] = (int32_t)j;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hw ? hw : 1), (int64_t)16, nnz / 65536 + 1}));
+    const int64_t P = S.blklen();
+    std::vector<std::vector<int64_t>> start((size_t)nth);          // per thread: first slot of every position of its range
+    std::vector<int64_t> ecount((size_t)nth + 1, 0), dcount((size_t)nth + 1, 0);
+    auto count = [&](int tix) {
+      const int64_t p0 = P * tix / nth, p1 = P * (tix + 1) / nth;
+      std::vector<int64_t>& st = start[(size_t)tix];
+      st.assign((size_t)(p1 - p0) + 1, 0);
+      for (int64_t e = 0; e < nnz; ++e) { const int64_t p = cidx[e]; if (p >= p0 && p < p1) ++st[(size_t)(p - p0) + 1]; }
+      int64_t distinct = 0;
+      for (int64_t p = 0; p < p1 - p0; ++p) { distinct += st[(size_t)p + 1] != 0; st[(size_t)p + 1] += st[(size_t)p]; }
+      ecount[(size_t)tix + 1] = st[(size_t)(p1 - p0)];
+      dcount[(size_t)tix + 1] = distinct;
+    };
+    run_threads(nth, count);
+    for (int t = 0; t < nth; ++t) { ecount[(size_t)t + 1] += ecount[(size_t)t]; dcount[(size_t)t + 1] += dcount[(size_t)t]; }
+    rpos.resize((size_t)dcount[(size_t)nth]);
+    rptr.resize((size_t)dcount[(size_t)nth] + 1);
+    auto place = [&](int tix) {
+      const int64_t p0 = P * tix / nth, p1 = P * (tix + 1) / nth, q0 = ecount[(size_t)tix];
+      std::vector<int64_t>& st = start[(size_t)tix];
+      int64_t d = dcount[(size_t)tix];
+      for (int64_t p = 0; p < p1 - p0; ++p)
+        if (st[(size_t)p + 1] != st[(size_t)p]) { rpos[(size_t)d] = p0 + p; rptr[(size_t)d] = q0 + st[(size_t)p]; ++d; }
+      for (int64_t e = 0; e < nnz; ++e) {                          // e ascending: ties stay in constraint order
+        const int64_t p = cidx[e];
+        if (p < p0 || p >= p1) continue;
+        const int64_t q = q0 + st[(size_t)(p - p0)]++;
+        rcon[(size_t)q] = con[e];
+        rval[(size_t)q] = cval[e];
+      }
+    };
+    run_threads(nth, place);
+    rptr[(size_t)dcount[(size_t)nth]] = nnz;
   }
-  rptr.push_back(nnz);
   clk.mark("CSR by position");
   std::vector<int64_t> vcptr(cptr, cptr + m + 1), vcidx(cidx, cidx + nnz);
   std::vector<double> vcval(cval, cval + nnz);
@@ -579,8 +614,15 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   if (nnz < ((int64_t)1 << 31) && S.nsn * (m + 1) <= ((int64_t)1 << 28)) {
     std::vector<int32_t> kptr((size_t)(S.nsn * (m + 1)) + 1, 0), koff(nnz);
     std::vector<double> kval(nnz);
-    for (int64_t j = 0; j < m; ++j)
+    // (a slot belongs to one constraint: counting and filling run over the constraints on host threads)
+    const unsigned hwc = std::thread::hardware_concurrency();
+    const int nthc = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hwc ? hwc : 1), (int64_t)16, m, nnz / 65536 + 1}));
+    auto over_constraints = [&](auto body) {
+      run_threads(nthc, [&](int tix) { for (int64_t j = tix; j < m; j += nthc) body(j); });
+    };
+    over_constraints([&](int64_t j) {
       for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) kptr[(size_t)ek[e] * (m + 1) + j + 1]++;
+    });
     // exclusive scan over (clique, constraint); slot (k, m) of a clique doubles as the start of clique k + 1
     {
       int64_t run = 0;
@@ -636,29 +678,26 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
         D.lg_rec = std::max<int>(D.lg_rec, (int)(S.nf(k) * S.nf(k) + S.nf(k) * S.nn(k)));
         lg_eptr.push_back(lg_eptr.back() + (int32_t)E);
       }
-    std::vector<int32_t> fill(kptr.begin(), kptr.end() - 1);
-    for (int64_t j = 0; j < m; ++j)
-      for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
-        const int32_t q = fill[(size_t)ek[e] * (m + 1) + j]++;
-        koff[q] = eoff[e];
-        kval[q] = cval[e];
-      }
+    // ... and the same positions as (row | column << 16) of the clique's panel, for k_fam_sparse (its members have < 2^16 rows)
+    std::vector<int32_t> kij(nnz);
+    {
+      std::vector<int32_t> fill(kptr.begin(), kptr.end() - 1);
+      over_constraints([&](int64_t j) {
+        for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+          const int64_t nf = S.nf(ek[e]);
+          const int32_t q = fill[(size_t)ek[e] * (m + 1) + j]++;
+          koff[q] = eoff[e];
+          kval[q] = cval[e];
+          kij[q] = (int32_t)((eoff[e] % nf) & 0xffff) | (int32_t)((eoff[e] / nf) << 16);
+        }
+      });
+    }
     kptr.pop_back();
     D.kc_sorted = true;           // (CCS columns with ascending rows give ascending panel positions per clique)
     for (size_t q = 0; q + 1 < kptr.size() && D.kc_sorted; ++q)
       for (int32_t e = kptr[q] + 1; e < kptr[q + 1]; ++e)
         if (koff[(size_t)e] <= koff[(size_t)e - 1]) { D.kc_sorted = false; break; }
-    // the same positions as (row | column << 16) of the clique's panel, for k_fam_sparse (its members have < 2^16 rows)
-    std::vector<int32_t> kij(nnz);
-    {
-      std::vector<int32_t> fill2(kptr.begin(), kptr.end());
-      for (int64_t j = 0; j < m; ++j)
-        for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
-          const int64_t nf = S.nf(ek[e]);
-          const int32_t q = fill2[(size_t)ek[e] * (m + 1) + j]++;
-          kij[q] = (int32_t)((eoff[e] % nf) & 0xffff) | (int32_t)((eoff[e] / nf) << 16);
-        }
-    }
+    clk.mark("entry tables");
     if (D.lg_children > 0 && m < 32768) {
       std::vector<int32_t> epk((size_t)lg_eptr.back()), remap((size_t)m, -1);
       std::vector<double> ewv((size_t)lg_eptr.back());
@@ -680,6 +719,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
       if ((rc = dev_upload(&D.lg_remap, remap, D.bytes))) return rc;
       if ((rc = dev_alloc(&D.lg_tab, D.lg_children * D.lg_rec, D.bytes))) return rc;
     }
+    clk.mark("leaf Gram tables");
     // Static term lists of the family parents (fused extend-add, front_famt.hip lf_add_family): every entry of constraint j inside
     // family f -- the parent's own and its children's -- as (vector ids vx | vy << 16, scale), the mapping k_fam_terms does per
     // launch from the entry lists (front_famt.hip, header): own entry v at (i, j): e_i, e_j, v (v / 2 on the diagonal); child
@@ -698,35 +738,54 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
           else c->fz_levels[(size_t)S.level[(size_t)par]] = 1;
         }
       if (ok && nfam > 0 && nfam < ((int64_t)1 << 19) && nfam * (m + 1) < ((int64_t)1 << 31)) {
-        std::vector<int32_t> fptr((size_t)(nfam * (m + 1)) + 1, 0), fpk;
-        std::vector<double> fsv;
-        fpk.reserve((size_t)nnz); fsv.reserve((size_t)nnz);
+        // sizes first (a (family, constraint) list holds the parent's entries and its children's), then the lists themselves,
+        // the families spread over host threads
+        std::vector<int32_t> fptr((size_t)(nfam * (m + 1)) + 1, 0);
+        std::vector<int64_t> fam_k((size_t)nfam);
+        int64_t run = 0;
         for (int64_t k = 0; k < S.nsn; ++k) {
           const int32_t f = fno[(size_t)k];
           if (f < 0) continue;
+          fam_k[(size_t)f] = k;
           for (int64_t j = 0; j < m; ++j) {
-            fptr[(size_t)f * (m + 1) + j] = (int32_t)fpk.size();
-            for (int32_t q = kptr[(size_t)k * (m + 1) + j]; q < kptr[(size_t)k * (m + 1) + j + 1]; ++q) {
-              const int32_t i = kij[q] & 0xffff, jc = kij[q] >> 16;
-              fpk.push_back(i | (jc << 16));
-              fsv.push_back(i == jc ? 0.5 * kval[q] : kval[q]);
-            }
-            int32_t colbase = 0;
+            fptr[(size_t)f * (m + 1) + j] = (int32_t)run;
+            run += kptr[(size_t)k * (m + 1) + j + 1] - kptr[(size_t)k * (m + 1) + j];
             for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) {
-              const int64_t cc = S.chidx[q2];
-              const int32_t nnc = (int32_t)S.nn(cc);
-              const int32_t* rel = &S.relidx[S.sepptr[cc]];
-              for (int32_t q = kptr[(size_t)cc * (m + 1) + j]; q < kptr[(size_t)cc * (m + 1) + j + 1]; ++q) {
-                const int32_t i = kij[q] & 0xffff, jc = kij[q] >> 16;
-                if (i >= nnc) { fpk.push_back((FAMT_CHILD + colbase + jc) | (rel[i - nnc] << 16)); fsv.push_back(-kval[q]); }
-                else { fpk.push_back((FAMT_CHILD + colbase + i) | ((FAMT_CHILD + colbase + jc) << 16)); fsv.push_back(i == jc ? 0.5 * kval[q] : kval[q]); }
-              }
-              colbase += nnc;
+              const size_t q = (size_t)S.chidx[q2] * (m + 1) + j;
+              run += kptr[q + 1] - kptr[q];
             }
           }
-          fptr[(size_t)f * (m + 1) + m] = (int32_t)fpk.size();
+          fptr[(size_t)f * (m + 1) + m] = (int32_t)run;
         }
-        fptr[(size_t)(nfam * (m + 1))] = (int32_t)fpk.size();
+        fptr[(size_t)(nfam * (m + 1))] = (int32_t)run;
+        std::vector<int32_t> fpk((size_t)run);
+        std::vector<double> fsv((size_t)run);
+        const int nthf = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hwc ? hwc : 1), (int64_t)16, nfam / 16 + 1}));
+        run_threads(nthf, [&](int tix) {
+          for (int64_t f = tix; f < nfam; f += nthf) {
+            const int64_t k = fam_k[(size_t)f];
+            for (int64_t j = 0; j < m; ++j) {
+              size_t o = (size_t)fptr[(size_t)f * (m + 1) + j];
+              for (int32_t q = kptr[(size_t)k * (m + 1) + j]; q < kptr[(size_t)k * (m + 1) + j + 1]; ++q, ++o) {
+                const int32_t i = kij[q] & 0xffff, jc = kij[q] >> 16;
+                fpk[o] = i | (jc << 16);
+                fsv[o] = i == jc ? 0.5 * kval[q] : kval[q];
+              }
+              int32_t colbase = 0;
+              for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) {
+                const int64_t cc = S.chidx[q2];
+                const int32_t nnc = (int32_t)S.nn(cc);
+                const int32_t* rel = &S.relidx[S.sepptr[cc]];
+                for (int32_t q = kptr[(size_t)cc * (m + 1) + j]; q < kptr[(size_t)cc * (m + 1) + j + 1]; ++q, ++o) {
+                  const int32_t i = kij[q] & 0xffff, jc = kij[q] >> 16;
+                  if (i >= nnc) { fpk[o] = (FAMT_CHILD + colbase + jc) | (rel[i - nnc] << 16); fsv[o] = -kval[q]; }
+                  else { fpk[o] = (FAMT_CHILD + colbase + i) | ((FAMT_CHILD + colbase + jc) << 16); fsv[o] = i == jc ? 0.5 * kval[q] : kval[q]; }
+                }
+                colbase += nnc;
+              }
+            }
+          }
+        });
         if ((rc = dev_upload(&D.fz_no, fno, D.bytes))) return rc;
         if ((rc = dev_upload(&D.fz_ptr, fptr, D.bytes))) return rc;
         if ((rc = dev_upload(&D.fz_pk, fpk, D.bytes))) return rc;
@@ -737,11 +796,13 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
         D.fz_ok = true;
       }
     }
+    clk.mark("family term lists");
     if ((rc = dev_upload(&D.kc_ij, kij, D.bytes))) return rc;
     if ((rc = dev_upload(&D.kc_ptr, kptr, D.bytes))) return rc;
     if ((rc = dev_upload(&D.kc_off, koff, D.bytes))) return rc;
     if ((rc = dev_upload(&D.kc_val, kval, D.bytes))) return rc;
   }
+  clk.mark("table uploads");
   D.ustack_cols = std::max(D.max_rhs, m);
   if ((rc = dev_alloc(&D.ustack, D.ustack_cols * S.blklen(), D.bytes))) return rc;
   // entries the sweeps never write (strict upper triangles of the NN blocks) must stay finite
@@ -751,7 +812,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
     hipLaunchKernelGGL(k_fill_sqrt_weights, dim3((unsigned)std::min<int64_t>(S.nsn, 4096)), dim3(256), 0, 0, D.cl, (int)S.nsn, D.sw);
     HIPCHK(hipDeviceSynchronize());
   }
-  clk.mark("tables + stack");
+  clk.mark("swept stack");
   D.m = m;
   D.cnnz = nnz;
   D.rnnz = (int64_t)rpos.size();

@@ -45,6 +45,9 @@ options = {
     "amalgamate": True,
     # device-resident line search: the bisection probes of the feasible-start solver as concurrent trial factorisations
     "batched_linesearch": True,
+    # ... as long as one trial leaves room on the device: patterns with more than this many stored entries take the trials of
+    # each bisection round one after the other (three instead of eight; same trial points, same result)
+    "batched_linesearch_maxlen": 1 << 20,
 }
 _defaults = _copy.deepcopy(options)
 
@@ -85,7 +88,8 @@ class _Problem:
             raise ValueError("b must have length m")
         A.sum_duplicates()
         rows = A.indices.astype(np.int64)
-        I, J = rows % n, rows // n
+        J = rows // n
+        I = rows - J * n
         if (I < J).any():
             raise ValueError("only lower-triangular entries (i >= j) are allowed in A")
         # aggregate sparsity pattern + diagonal
@@ -609,6 +613,9 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
     P.use_kktsolver(kktsolver)
     n, m, C, bv = P.n, P.m, P.C, P.b
     Amap, Aadj, dot = P.Amap, P.Aadj, chordal.dot
+    # one trial factorisation of a pattern this large fills the device by itself: eight side by side take eight times as
+    # long, and the bisection below then needs three trials per round where the 8-ary round spends eight
+    ONE_AT_A_TIME = P.symb.blklen > int(options.get("batched_linesearch_maxlen", 1 << 20))
     resy0 = max(1.0, _nrm2(bv))
     resx0 = max(1.0, math.sqrt(dot(C, C)))
     st = {}
@@ -676,8 +683,22 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
                 pass
             for _ in range(3):
                 pts = [lo + (hi - lo) * (k + 1) / KP for k in range(KP)]
-                ok = chordal.probe_cone(base_, d, pts, which)
-                kmax = max([k for k in range(KP) if ok[k]], default=-1)
+                if ONE_AT_A_TIME:
+                    # hi is known to lie outside the cone (the full step, or a failed trial of the round before), and
+                    # the feasible steps form an interval: the last feasible one of pts[0..6] by bisection, three
+                    # trial factorisations one after the other instead of eight side by side
+                    ia, ib = -1, KP - 1
+                    while ib - ia > 1:
+                        mid = (ia + ib) // 2
+                        try:
+                            in_cone(base_ + d * pts[mid], which)
+                            ia = mid
+                        except ArithmeticError:
+                            ib = mid
+                    kmax = ia
+                else:
+                    ok = chordal.probe_cone(base_, d, pts, which)
+                    kmax = max([k for k in range(KP) if ok[k]], default=-1)
                 if kmax >= 0:
                     lo = g_ = pts[kmax]
                 if kmax == KP - 1:

@@ -55,6 +55,14 @@ if os.environ.get("VERIFY_PROBES"):           # every probe against the same tri
             print("MISMATCH call", stats["calls"], kind, ["%.4g" % a for a in als], ok, want, flush=True)
         return ok, fac
     chordal.probe_factors = checked
+if os.environ.get("PROBE_STATS"):             # what the batched line searches ask for and which trial they end up taking
+    orig_pf = chordal.probe_factors
+    plog = []
+    def logged(b, d, als, kind):
+        ok, fac = orig_pf(b, d, als, kind)
+        plog.append((kind, len(als), "".join("1" if o else "0" for o in ok)))
+        return ok, fac
+    chordal.probe_factors = logged
 t0 = time.time()
 if os.environ.get("PROFILE_HOST"):            # host-side view: where the wall time of the driver goes (cProfile, by own time)
     import cProfile, pstats
@@ -67,5 +75,8 @@ else:
     sol = solvers.chordalsolver_feas(A, b, primalstart={"x": X0}, dualstart={"y": y0, "s": S0}, scaling="dual", kktsolver=kktsolver)
     dt = time.time() - t0
 if os.environ.get("VERIFY_PROBES"): print("probe check", stats)
+if os.environ.get("PROBE_STATS"):
+    from collections import Counter
+    for key, cnt in sorted(Counter(plog).items()): print("probe", key, "x", cnt)
 print("kktsolver", kktsolver, "status", sol["status"], "iterations", sol["iterations"], "pobj %.8g dobj %.8g gap %.2e" % (sol["primal objective"], sol["dual objective"], sol["gap"]),
       "total %.2f s, %.3f s/iteration (incl. symbolic setup)" % (dt, dt / max(1, sol["iterations"])), "dimacs", ["%.1e" % v for v in sol["dimacs"]])
