@@ -437,11 +437,56 @@ void maxcardsearch(int64_t n, const int64_t* colptr, const int64_t* rowind, int6
   }
 }
 
+// Minimum degree on the explicit elimination graph, ties to the smaller vertex.  Up to 32768 vertices the adjacency is one bit
+// row per vertex (eliminating v ORs its row into its neighbours' rows: deg(v) * n / 64 word operations, where ordered sets
+// of neighbours paid deg(v)^2 log n insertions -- 1.9 s of the 3.1 s interior-point run on the 1000-node max-cut graph,
+// whose last cliques have 500 members); larger graphs keep the sets.  Both hold the same graph, so the order is the same.
+static void mindegree_bits(int64_t n, const Graph& g, int64_t* order) {
+  const int64_t W = (n + 63) / 64;
+  std::vector<uint64_t> adj((size_t)(n * W), 0);
+  auto row = [&](int64_t v) { return adj.data() + (size_t)(v * W); };
+  auto setbit = [&](int64_t v, int64_t u) { row(v)[u >> 6] |= (uint64_t)1 << (u & 63); };
+  for (int64_t v = 0; v < n; ++v) {
+    for (int64_t q = g.lptr[v]; q < g.lptr[v + 1]; ++q) setbit(v, g.lidx[q]);
+    for (int64_t q = g.uptr[v]; q < g.uptr[v + 1]; ++q) setbit(v, g.uidx[q]);
+  }
+  auto count = [&](int64_t v) {
+    int64_t c = 0;
+    const uint64_t* r = row(v);
+    for (int64_t w = 0; w < W; ++w) c += __builtin_popcountll(r[w]);
+    return c;
+  };
+  std::vector<int64_t> deg((size_t)n);
+  std::set<std::pair<int64_t, int64_t>> pq;  // (degree, vertex)
+  for (int64_t v = 0; v < n; ++v) { deg[(size_t)v] = count(v); pq.insert({deg[(size_t)v], v}); }
+  std::vector<int32_t> nb;
+  for (int64_t k = 0; k < n; ++k) {
+    auto it = pq.begin();
+    const int64_t v = it->second;
+    pq.erase(it);
+    order[k] = v;
+    uint64_t* rv = row(v);
+    nb.clear();
+    for (int64_t w = 0; w < W; ++w)
+      for (uint64_t bits = rv[w]; bits; bits &= bits - 1) nb.push_back((int32_t)(64 * w + __builtin_ctzll(bits)));
+    for (int32_t u : nb) {
+      pq.erase({deg[(size_t)u], (int64_t)u});
+      uint64_t* ru = row(u);
+      for (int64_t w = 0; w < W; ++w) ru[w] |= rv[w];
+      ru[v >> 6] &= ~((uint64_t)1 << (v & 63));
+      ru[u >> 6] &= ~((uint64_t)1 << (u & 63));
+      deg[(size_t)u] = count(u);
+      pq.insert({deg[(size_t)u], (int64_t)u});
+    }
+    for (int64_t w = 0; w < W; ++w) rv[w] = 0;
+  }
+}
 void mindegree(int64_t n, const int64_t* colptr, const int64_t* rowind, int64_t* order) {
   std::vector<int64_t> id(n);
   std::iota(id.begin(), id.end(), 0);
   Graph g;
   build_graph(n, colptr, rowind, id, g, true, true);
+  if (n <= 32768) { mindegree_bits(n, g, order); return; }
   std::vector<std::set<int32_t>> adj(n);
   for (int64_t v = 0; v < n; ++v) {
     for (int64_t q = g.lptr[v]; q < g.lptr[v + 1]; ++q) adj[v].insert(g.lidx[q]);
