@@ -13,10 +13,14 @@ from . import _lib
 _has_device = []      # torch.cuda.is_available() asks the runtime every time (25 us): once per process
 
 
-def _stream():
+def has_device():
     if not _has_device:
         _has_device.append(torch.cuda.is_available())
-    return torch.cuda.current_stream().cuda_stream if _has_device[0] else None
+    return _has_device[0]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream if has_device() else None
 
 
 _uid = [0]

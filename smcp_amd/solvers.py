@@ -20,7 +20,7 @@ import scipy.sparse as sp
 import torch
 
 from . import chordal
-from .cspmatrix import cspmatrix
+from .cspmatrix import cspmatrix, has_device
 from .kkt import KKTSystem
 from .symbolic import Symbolic, amalgamate, maxcardsearch, mindegree
 
@@ -208,7 +208,7 @@ def _nrm2(a):
 
 
 def _batched():
-    return bool(options.get("batched_linesearch", True)) and (torch.cuda.is_available()
+    return bool(options.get("batched_linesearch", True)) and (has_device()
                                                                or getattr(chordal, "_probe_emulated", False))
 
 
@@ -593,7 +593,7 @@ def chordalsolver_feas(A, b, primalstart=None, dualstart=None, scaling="primal",
     ALPHA = _opt("alpha", float, 0.0, 0.5, strict_lo=True)
     BETA = _opt("beta", float, 0.0, 1.0, strict_lo=True)
     MINSTEP = _opt("minstep", float, 0.0, strict_lo=True)
-    BATCHED = _opt("batched_linesearch", bool) and (torch.cuda.is_available() or getattr(chordal, "_probe_emulated", False))
+    BATCHED = _opt("batched_linesearch", bool) and (has_device() or getattr(chordal, "_probe_emulated", False))
     LIFTING = _opt("lifting", bool)
     EQUALSTEPS = _opt("equalsteps", bool)
     PREDICTION = _opt("prediction", bool)

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/trace_shard8
 rm -rf $out; mkdir -p $out
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 tools/shard_step_emul.py --worlds 8 --steps 3 > $out/run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 tools/shard_step_emul.py --mode subtree --worlds 8 --steps 3 > $out/run.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/trace_shard8/**/*kernel_trace.csv", recursive=True)[0]
