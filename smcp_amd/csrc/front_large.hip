@@ -126,65 +126,84 @@ __device__ inline void gemm_tile64(d4 (&acc)[2][2], int M, int N, int Kd, int m0
 // both operands are staged row-contiguous (ld 80: k and k + 1 land 32 banks apart, the MFMA operand reads are conflict free)
 // and the staging area is double buffered: one barrier per slice.  On the 4096 front of config 2 (tools/micro/tile_gemm.hip:
 // lower tiles of Z Li^T + Li Z^T, six right-hand sides) 46.9 -> 57.7 TFLOP/s, 62.9 with the widest tiles dispatched first.
-constexpr int LRC = 80;                         // leading dimension of a staged slice
-constexpr int LRC_DOUBLES = 4 * LKC * LRC;      // two operands, two buffers
+constexpr int LRC = 80;                         // leading dimension of a staged slice whose rows are contiguous in memory
+constexpr int LCC = 18;                         // ... of one whose inner index is (k contiguous: k + row * 18, operand reads conflict free)
+constexpr int LRC_DOUBLES = 4 * LKC * LRC;      // two operands, two buffers (a slice: 16 x 80 or 64 x 18 doubles)
 __device__ inline bool rc_aligned(const double* p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ld & 1) == 0); }
-__device__ inline void gemm_tile64_rc(d4 (&acc)[2][2], const double* A, int64_t lda, const double* B, int64_t ldb, int Kd, double* smem) {
+// one operand of the fast product: XC = false: X(row, k) = X[row + k ld], XC = true: X(row, k) = X[k + row ld]; p at (first row, first k)
+template <bool XC>
+struct RcOperand {
   typedef double d2 __attribute__((ext_vector_type(2)));
+  const double* p; int64_t step, second;
+  int st0, st1;                                  // staging offsets of the two pairs
+  d2 r[2];
+  __device__ inline void init(const double* X, int64_t ld) {
+    const int tid = threadIdx.x;
+    if constexpr (XC) {
+      const int k2 = tid & 7, row = tid >> 3;    // pairs (k, k + 1) of rows `row` and `row + 32`
+      p = X + 2 * k2 + (int64_t)row * ld; step = LKC; second = 32 * ld;
+      st0 = 2 * k2 + row * LCC; st1 = st0 + 32 * LCC;
+    } else {
+      const int r2 = tid & 31, kk0 = tid >> 5;   // row pairs (2 r2, 2 r2 + 1) at k = kk0 and kk0 + 8
+      p = X + 2 * r2 + (int64_t)kk0 * ld; step = (int64_t)LKC * ld; second = 8 * ld;
+      st0 = 2 * r2 + kk0 * LRC; st1 = st0 + 8 * LRC;
+    }
+  }
+  __device__ inline void fetch() { r[0] = *reinterpret_cast<const d2*>(p); r[1] = *reinterpret_cast<const d2*>(p + second); p += step; }
+  __device__ inline void stage(double* sX) const { *reinterpret_cast<d2*>(sX + st0) = r[0]; *reinterpret_cast<d2*>(sX + st1) = r[1]; }
+  static __device__ inline double frag(const double* sX, int row, int kk) { return XC ? sX[kk + row * LCC] : sX[row + kk * LRC]; }
+};
+// acc += A[rows of the tile, k0 .. k1) * B[k0 .. k1), columns of the tile]; A at (m0, k0), B at (n0, k0); k1 - k0 a multiple of 16
+template <bool AC, bool BC>
+__device__ inline void gemm_tile64_rc(d4 (&acc)[2][2], const double* A, int64_t lda, const double* B, int64_t ldb, int nk, double* smem) {
   constexpr int SL = LKC * LRC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;
-  const int r2 = tid & 31, kk0 = tid >> 5;      // this thread's row pair and its first k (the second: kk0 + 8)
-  const double* pa = A + 2 * r2 + (int64_t)kk0 * lda;
-  const double* pb = B + 2 * r2 + (int64_t)kk0 * ldb;
-  const int64_t sa = (int64_t)LKC * lda, sb = (int64_t)LKC * ldb;
-  d2 ra[2], rb[2];
-  auto fetch = [&]() {
-    ra[0] = *reinterpret_cast<const d2*>(pa); ra[1] = *reinterpret_cast<const d2*>(pa + 8 * lda);
-    rb[0] = *reinterpret_cast<const d2*>(pb); rb[1] = *reinterpret_cast<const d2*>(pb + 8 * ldb);
-    pa += sa; pb += sb;
-  };
-  auto stage = [&](double* sA, double* sB) {
-    *reinterpret_cast<d2*>(sA + 2 * r2 + kk0 * LRC) = ra[0]; *reinterpret_cast<d2*>(sA + 2 * r2 + (kk0 + 8) * LRC) = ra[1];
-    *reinterpret_cast<d2*>(sB + 2 * r2 + kk0 * LRC) = rb[0]; *reinterpret_cast<d2*>(sB + 2 * r2 + (kk0 + 8) * LRC) = rb[1];
-  };
-  const int ns = Kd / LKC;
+  const int ns = nk / LKC;
   if (ns <= 0) return;
-  fetch();
+  RcOperand<AC> oa;
+  RcOperand<BC> ob;
+  oa.init(A, lda);
+  ob.init(B, ldb);
+  oa.fetch(); ob.fetch();
   __syncthreads();                               // (a previous product of this workgroup may still read the buffers)
-  stage(smem, smem + 2 * SL);
+  oa.stage(smem); ob.stage(smem + 2 * SL);
   __syncthreads();
   for (int s = 0; s < ns; ++s) {
     const double* sA = smem + (s & 1) * SL;
     const double* sB = smem + 2 * SL + (s & 1) * SL;
-    if (s + 1 < ns) fetch();
+    if (s + 1 < ns) { oa.fetch(); ob.fetch(); }
 #pragma unroll
     for (int ks = 0; ks < LKC / 4; ++ks) {
       const int kk = 4 * ks + kq;
-      const double a0 = sA[(32 * wm + l15) + kk * LRC], a1 = sA[(32 * wm + 16 + l15) + kk * LRC];
-      const double b0 = sB[(32 * wn + l15) + kk * LRC], b1 = sB[(32 * wn + 16 + l15) + kk * LRC];
+      const double a0 = RcOperand<AC>::frag(sA, 32 * wm + l15, kk), a1 = RcOperand<AC>::frag(sA, 32 * wm + 16 + l15, kk);
+      const double b0 = RcOperand<BC>::frag(sB, 32 * wn + l15, kk), b1 = RcOperand<BC>::frag(sB, 32 * wn + 16 + l15, kk);
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[1][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[0][1], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
     }
-    if (s + 1 < ns) stage(smem + ((s + 1) & 1) * SL, smem + 2 * SL + ((s + 1) & 1) * SL);
+    if (s + 1 < ns) { oa.stage(smem + ((s + 1) & 1) * SL); ob.stage(smem + 2 * SL + ((s + 1) & 1) * SL); }
     __syncthreads();
   }
 }
-// A(m, k) = A[m + k lda] (M rows), B(k, n) = B[n + k ldb] (N rows): the row-contiguous product where it applies, else the general one
-template <int PD>
-__device__ inline void gemm_tile64_plain(d4 (&acc)[2][2], const double* A, int64_t lda, int M, const double* B, int64_t ldb, int N, int Kd,
+// Plain operands over the inner range [k0, k1), k0 a multiple of the slice: A(m, k) = A[m + k lda] (AC: A[k + m lda]), M rows;
+// B(k, n) = B[n + k ldb] (BC: B[k + n ldb]), N columns.  The fast product where it applies, else the general one.
+template <int PD, bool AC = false, bool BC = false>
+__device__ inline void gemm_tile64_plain(d4 (&acc)[2][2], const double* A, int64_t lda, int M, const double* B, int64_t ldb, int N, int k0, int k1,
                                          int m0, int n0, double* smem) {
+  if (k1 <= k0) return;
   if constexpr (PD == 1) {
-    if (m0 + LT <= M && n0 + LT <= N && (Kd % LKC) == 0 && rc_aligned(A + m0, lda) && rc_aligned(B + n0, ldb)) {
-      gemm_tile64_rc(acc, A + m0, lda, B + n0, ldb, Kd, smem);
+    const double* A0 = AC ? A + k0 + (int64_t)m0 * lda : A + m0 + (int64_t)k0 * lda;
+    const double* B0 = BC ? B + k0 + (int64_t)n0 * ldb : B + n0 + (int64_t)k0 * ldb;
+    if (m0 + LT <= M && n0 + LT <= N && ((k1 - k0) % LKC) == 0 && (k0 % LKC) == 0 && rc_aligned(A0, lda) && rc_aligned(B0, ldb)) {
+      gemm_tile64_rc<AC, BC>(acc, A0, lda, B0, ldb, k1 - k0, smem);
       return;
     }
   }
-  gemm_tile64<PD>(acc, M, N, Kd, m0, n0, [=](int m, int kk) { return A[m + (int64_t)kk * lda]; },
-                  [=](int kk, int n) { return B[n + (int64_t)kk * ldb]; }, smem, smem + LKC * LSA);
+  gemm_tile64<PD>(acc, M, N, k1, m0, n0, [=](int m, int kk) { return AC ? A[kk + (int64_t)m * lda] : A[m + (int64_t)kk * lda]; },
+                  [=](int kk, int n) { return BC ? B[kk + (int64_t)n * ldb] : B[n + (int64_t)kk * ldb]; }, smem, smem + LKC * LSA, k0);
 }
 // accumulator element (a, b, r) of this lane -> (m, n) inside the 64 x 64 tile; false: the lane has no such element
 // (the sixteen-wave shape keeps one MFMA tile per wave in acc[0][0])
@@ -686,7 +705,8 @@ __host__ __device__ inline bool lf_sym_split(int nn) { return nn > 6 * LT; }
 // ---- up-sweep phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place) ; Z = Li Fl (into T)
 template <int PD>
 __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up1(MfmaArgs a, double* u, int64_t ldu) {
-  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  __shared__ __attribute__((aligned(16))) double smem[PD == 1 ? LRC_DOUBLES : LKC * LSA + LT * LSB];
+  double* const sA = smem; double* const sB = smem + LKC * LSA;
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
   const int mtA = tiles64(na), ntN = tiles64(nn);
@@ -715,9 +735,11 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up1(MfmaArgs a, dou
     const double* Li = c.Li;
     if (lf_sym_split(nn)) {
       if (n0 > m0) return;
-      gemm_tile64<PD>(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
+      // (the mask only matters over the tile's own columns; the rows of Fl below them are whole: the plain product)
+      gemm_tile64<PD>(acc, nn, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
                   [=](int kk, int n) { const double v_ = ldm<PD>(kk >= n, &P[kk + (int64_t)n * nf]); return kk == n ? 0.5 * v_ : v_; },
                   sA, sB, n0);
+      gemm_tile64_plain<PD, false, true>(acc, Li, nf, nn, P, nf, nn, n0 + LT, min(nn, m0 + LT), m0, n0, smem);
     } else {
       gemm_tile64<PD>(acc, nn, nn, min(nn, m0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; }, fsym, sA, sB);   // Li(m, k) = 0 for k > m
     }
@@ -801,8 +823,8 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up2(MfmaArgs a, dou
     int tm, tn;
     lower_pair(t, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64_plain<PD>(acc, K, nf, na, E, na, na, nn, m0, n0, smem);        // K E^T
-    gemm_tile64_plain<PD>(acc, E, na, na, K, nf, na, nn, m0, n0, smem);        // + E K^T
+    gemm_tile64_plain<PD>(acc, K, nf, na, E, na, na, 0, nn, m0, n0, smem);     // K E^T
+    gemm_tile64_plain<PD>(acc, E, na, na, K, nf, na, 0, nn, m0, n0, smem);     // + E K^T
     // The parent takes the update from the packed exchange buffer only; the square block is read (what the extend-add
     // assembled) but never written back, and a childless front does not even read it: its assembled block is zero
     // and the host skips clearing / assembling it (lf_up).  For config 3 (1999 childless (64,128) fronts x 100
@@ -817,16 +839,16 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up2(MfmaArgs a, dou
       });
   } else if (t < nU + nG) {
     const int tt = nG - 1 - (t - nU), m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;      // (widest inner ranges first)
-    gemm_tile64_plain<PD>(acc, P + nn, nf, na, Li, nf, nn, min(nn, n0 + LT), m0, n0, smem);      // X Li^T; Li(n, k) = 0 for k > n
+    gemm_tile64_plain<PD>(acc, P + nn, nf, na, Li, nf, nn, 0, min(nn, n0 + LT), m0, n0, smem);      // X Li^T; Li(n, k) = 0 for k > n
     double* G = c.G;
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { G[m + (int64_t)n * na] = v; });
   } else {
     int tm, tn;
     lower_pair_wide_first(t - nU - nG, ntN, tm, tn);
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64_plain<PD>(acc, T, nn, nn, Li, nf, nn, min(nn, n0 + LT), m0, n0, smem);           // Z Li^T  (T holds Z, phase 1)
+    gemm_tile64_plain<PD>(acc, T, nn, nn, Li, nf, nn, 0, min(nn, n0 + LT), m0, n0, smem);           // Z Li^T  (T holds Z, phase 1)
     if (lf_sym_split(nn))
-      gemm_tile64_plain<PD>(acc, Li, nf, nn, T, nn, nn, min(nn, n0 + LT), m0, n0, smem);         // + Li Z^T
+      gemm_tile64_plain<PD>(acc, Li, nf, nn, T, nn, nn, 0, min(nn, n0 + LT), m0, n0, smem);         // + Li Z^T
     double* Pw = c.P;
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
   }
@@ -878,7 +900,8 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up3(MfmaArgs a, dou
 // ---- down-sweep phase 1: QL = Q Li (into E) ; T = G_NN Li        (Q = AN rows of the panel)
 template <int PD>
 __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down1(MfmaArgs a, double* u, int64_t ldu) {
-  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  __shared__ __attribute__((aligned(16))) double smem[PD == 1 ? LRC_DOUBLES : LKC * LSA + LT * LSB];
+  double* const sA = smem; double* const sB = smem + LKC * LSA;
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
   const int mtA = tiles64(na), ntN = tiles64(nn);
@@ -891,7 +914,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down1(MfmaArgs a, d
   tile64_zero(acc);
   if (t < nE) {
     const int m0 = (t % mtA) * LT, n0 = (t / mtA) * LT;
-    gemm_tile64<PD>(acc, na, nn, nn, m0, n0, [=](int m, int kk) { return P[nn + m + (int64_t)kk * nf]; }, li, sA, sB, n0);   // Li(k, n) = 0 for k < n
+    gemm_tile64_plain<PD, false, true>(acc, P + nn, nf, na, Li, nf, nn, n0, nn, m0, n0, smem);   // Li(k, n) = 0 for k < n
     double* E = c.E;
     tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = v; });
   } else {
@@ -900,8 +923,10 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down1(MfmaArgs a, d
       // wide fronts: Z' = Gl Li with Gl = the lower triangle of G_NN, diagonal halved (lower tiles only, k from the tile's
       // first column to its last row); phase 3 forms Li^T G_NN Li = Li^T Z' + Z'^T Li  (see k_lf_up1)
       if (n0 > m0) return;
+      // (columns before the tile's first row are whole columns of Gl: the plain product; the mask only matters from m0 on)
+      gemm_tile64_plain<PD, false, true>(acc, P, nf, nn, Li, nf, nn, n0, m0, m0, n0, smem);
       gemm_tile64<PD>(acc, nn, nn, min(nn, m0 + LT), m0, n0,
-                  [=](int m, int kk) { const double v_ = ldm<PD>(m >= kk, &P[m + (int64_t)kk * nf]); return m == kk ? 0.5 * v_ : v_; }, li, sA, sB, n0);
+                  [=](int m, int kk) { const double v_ = ldm<PD>(m >= kk, &P[m + (int64_t)kk * nf]); return m == kk ? 0.5 * v_ : v_; }, li, sA, sB, m0);
     } else {
       gemm_tile64<PD>(acc, nn, nn, nn, m0, n0,
                   [=](int m, int kk) { return P[max(m, kk) + (int64_t)min(m, kk) * nf]; }, li, sA, sB, n0);
@@ -937,7 +962,8 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down2(MfmaArgs a, d
 // ---- down-sweep phase 3: Z_NN = Li^T T - K^T D - D^T K (lower tiles, into the panel)
 template <int PD>
 __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down3(MfmaArgs a, double* u, int64_t ldu) {
-  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  __shared__ __attribute__((aligned(16))) double smem[PD == 1 ? LRC_DOUBLES : LKC * LSA + LT * LSB];
+  double* const sA = smem; double* const sB = smem + LKC * LSA;
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
   const int ntN = tiles64(nn);
@@ -949,11 +975,9 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down3(MfmaArgs a, d
   const double* Li = c.Li; const double* K = c.K; const double* T = c.T; const double* D = c.G;
   d4 acc[2][2];
   tile64_zero(acc);
-  gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
-              [=](int kk, int n) { return T[kk + (int64_t)n * nn]; }, sA, sB, m0);                 // Li(k, m) = 0 for k < m
+  gemm_tile64_plain<PD, true, true>(acc, Li, nf, nn, T, nn, nn, m0, nn, m0, n0, smem);            // Li^T T; Li(k, m) = 0 for k < m
   if (lf_sym_split(nn))
-    gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return T[kk + (int64_t)m * nn]; },
-                [=](int kk, int n) { return Li[kk + (int64_t)n * nf]; }, sA, sB, m0);             // + Z'^T Li (T holds Z')
+    gemm_tile64_plain<PD, true, true>(acc, T, nn, nn, Li, nf, nn, m0, nn, m0, n0, smem);          // + Z'^T Li (T holds Z')
   gemm_tile64<PD>(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -K[kk + (int64_t)m * nf]; },
               [=](int kk, int n) { return D[kk + (int64_t)n * na]; }, sA, sB);
   gemm_tile64<PD>(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return -D[kk + (int64_t)m * na]; },
