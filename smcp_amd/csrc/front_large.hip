@@ -1346,7 +1346,7 @@ __global__ void __launch_bounds__(1024) k_lf_diag(MfmaArgs a, double* x, double*
 }
 // panel step: rows below the diagonal block <- rows * Dinv^T   (one 64x64 tile per workgroup, in place)
 __global__ void __launch_bounds__(256) k_lf_chol_panel(MfmaArgs a, double* x, double* aux, int mode, int jb) {
-  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  __shared__ __attribute__((aligned(16))) double smem[LRC_DOUBLES];
   const int k = a.t.lev[blockIdx.y];
   if (*info_of(a.t, k)) return;
   const LfMat M = lf_mat(a, k, mode, x, aux);
@@ -1360,14 +1360,13 @@ __global__ void __launch_bounds__(256) k_lf_chol_panel(MfmaArgs a, double* x, do
   const int64_t ld = M.ld;
   d4 acc[2][2];
   tile64_zero(acc);
-  gemm_tile64(acc, mrem, w, w, m0, 0, [=](int m, int kk) { return Pj[m + kk * ld]; },
-              [=](int kk, int n) { return Di[n + kk * w]; }, sA, sB);
+  gemm_tile64_plain<1>(acc, Pj, ld, mrem, Di, w, w, 0, w, m0, 0, smem);
   __syncthreads();   // every thread has consumed its rows before they are overwritten
   tile64_foreach(acc, m0, 0, mrem, w, [=](int m, int n, double v) { Pj[m + n * ld] = v; });
 }
 // trailing step: remaining columns of the panel and the update block -= P P^T (lower tiles)
 __global__ void __launch_bounds__(256) k_lf_chol_trail(MfmaArgs a, double* x, double* aux, int mode, int jb) {
-  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  __shared__ __attribute__((aligned(16))) double smem[LRC_DOUBLES];
   const int k = a.t.lev[blockIdx.y];
   if (*info_of(a.t, k)) return;
   const LfMat M = lf_mat(a, k, mode, x, aux);
@@ -1392,8 +1391,7 @@ __global__ void __launch_bounds__(256) k_lf_chol_trail(MfmaArgs a, double* x, do
     if (t < ntri) lower_pair(t, tm, tn);
     else { const int tt = t - ntri; tm = nt + tt / nt; tn = tt % nt; }
     const int m0 = tm * LT, n0 = tn * LT;
-    gemm_tile64(acc, mrem, ncr, w, m0, n0, [=](int m, int kk) { return Pj[m + kk * ld]; },
-                [=](int kk, int n) { return Pj[n + kk * ld]; }, sA, sB);
+    gemm_tile64_plain<1>(acc, Pj, ld, mrem, Pj, ld, ncr, 0, w, m0, n0, smem);
     double* Tr = M.A + (jb + w) + (int64_t)(jb + w) * M.ld;
     tile64_rmw(acc, m0, n0, mrem, ncr, [=](int m, int n) { return Tr[m + n * ld]; },
                [=](int m, int n, double v, double o) { if (m >= n) Tr[m + n * ld] = o - v; });
@@ -1403,8 +1401,7 @@ __global__ void __launch_bounds__(256) k_lf_chol_trail(MfmaArgs a, double* x, do
     const int m0 = tm * LT, n0 = tn * LT;
     const double* Pa = M.A + M.ncol + (int64_t)jb * M.ld;   // separator rows of block column jb
     const int na = M.na;
-    gemm_tile64(acc, na, na, w, m0, n0, [=](int m, int kk) { return Pa[m + kk * ld]; },
-                [=](int kk, int n) { return Pa[n + kk * ld]; }, sA, sB);
+    gemm_tile64_plain<1>(acc, Pa, ld, na, Pa, ld, na, 0, w, m0, n0, smem);
     double* U = M.upd;
     tile64_rmw(acc, m0, n0, na, na, [=](int m, int n) { return U[m + (int64_t)n * na]; },
                [=](int m, int n, double v, double o) { if (m >= n) U[m + (int64_t)n * na] = o - v; });
