@@ -310,6 +310,10 @@ __global__ void __launch_bounds__(256) k_dense_trsv_step(const double* A, int n,
 // diagonal blocks, all of them staged in LDS up front: the same arithmetic, so the same backward-stable solve) followed by
 // the update of the other rows, one thread per row, whose sixteen factor entries were fetched a step ahead: the factor is
 // static, so its stream never waits for the chain.  x lives in LDS; barriers wait for LDS traffic only.
+// (Round 4 tried 64-wide steps through the diagonal blocks' cached inverses, x_blk = Dinv r_blk, the other rows updated in
+// four sub-steps of sixteen prefetched columns: 0.62 ms against 0.37 here -- a sub-step is 16 multiply-adds, far shorter
+// than the ~2.4 us a request to the 8 MB factor takes, and 128 registers per thread hold only one sub-step ahead, so the
+// kernel ran 256 exposed round trips where this one hides its 126 behind the one-wave substitutions.)
 constexpr int POTRS1_MAXN = 1024;
 __host__ __device__ inline size_t potrs_one_lds(int n) { return ((size_t)((n + 15) & ~15) * 17 + 16) * sizeof(double); }
 __global__ void __launch_bounds__(1024) k_dense_potrs_one(const double* A, int n, int64_t lda, double* b) {
@@ -885,8 +889,8 @@ static int potrf_launch(csp_ctx* c, double* A, int64_t n, int64_t lda, hipStream
     c->D.hinv_cap = need;
   }
   for (int jb = 0; jb < (int)n; jb += LB) {
+    a.lfd = c->D.hinv + (int64_t)(jb / LB) * LB * LB;      // the diagonal block's inverse goes straight to its slot (potrs reads it there)
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(1), dim3(512), LF_DIAG_LDS, st, a, A, (double*)nullptr, 5, jb, 1);
-    HIPCHK(hipMemcpyAsync(c->D.hinv + (int64_t)(jb / LB) * LB * LB, c->D.lfd_dense, sizeof(double) * LB * LB, hipMemcpyDeviceToDevice, st));
     const int mrem = (int)n - jb - LB;
     if (mrem > 0) {
       const int mt = tiles64(mrem);
