@@ -1106,7 +1106,8 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_pinv1(MfmaArgs a, d
 }
 template <int PD>
 __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_pinv2(MfmaArgs a, double* x) {
-  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  __shared__ __attribute__((aligned(16))) double smem[PD == 1 ? LRC_DOUBLES : LKC * LSA + LT * LSB];
+  double* const sA = smem; double* const sB = smem + LKC * LSA;
   const LfCtx c = lf_ctx(a, x, 0);
   const int nn = c.nn, na = c.na, nf = c.nf;
   const int mtA = tiles64(na), ntN = tiles64(nn);
@@ -1122,10 +1123,8 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_pinv2(MfmaArgs a, d
     const double* Li = c.Li; const double* K = c.K;
     d4 acc[2][2];
     tile64_zero(acc);
-    gemm_tile64<PD>(acc, nn, nn, nn, m0, n0, [=](int m, int kk) { return Li[kk + (int64_t)m * nf]; },
-                [=](int kk, int n) { return Li[kk + (int64_t)n * nf]; }, sA, sB, max(m0, n0));
-    gemm_tile64<PD>(acc, nn, nn, na, m0, n0, [=](int m, int kk) { return K[kk + (int64_t)m * nf]; },
-                [=](int kk, int n) { return E[kk + (int64_t)n * na]; }, sA, sB);
+    gemm_tile64_plain<PD, true, true>(acc, Li, nf, nn, Li, nf, nn, max(m0, n0), nn, m0, n0, smem);     // Li^T Li (zeros above the diagonal are stored)
+    gemm_tile64_plain<PD, true, true>(acc, K, nf, nn, E, na, nn, 0, na, m0, n0, smem);                 // + K^T E
     tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { if (m >= n) Pw[m + (int64_t)n * nf] = v; });
   } else {
     const int tt = t - nN, m0 = (tt % mtA) * LT, n0 = (tt / mtA) * LT;
@@ -1619,7 +1618,8 @@ __global__ void __launch_bounds__(256) k_lf_diag_inv(MfmaArgs a, const double* L
 // (pairs x (b/64)^2) tiles -- log2(nn/64) levels with growing parallelism -- where the row-by-row scheme (k_lf_prep_s /
 // k_lf_prep_row per 64-row block) runs nn/64 dependent steps of at most nn/64 workgroups: 4096 front, 18.4 ms -> see DESIGN.
 __global__ void __launch_bounds__(256) k_lf_trtri(MfmaArgs a, const double* L, double* LK, int b, int step) {
-  __shared__ double sA[LKC * LSA], sB[LT * LSB];
+  __shared__ __attribute__((aligned(16))) double smem[LRC_DOUBLES];
+  double* const sA = smem; double* const sB = smem + LKC * LSA;
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
   const InvView V = inv_view(a, k, d, 0, L, LK);
@@ -1640,13 +1640,17 @@ __global__ void __launch_bounds__(256) k_lf_trtri(MfmaArgs a, const double* L, d
   if (step == 0) {
     const double* Bm = Lk + (r0 + b) + (int64_t)r0 * nf;
     const double* Ai = Li + r0 + (int64_t)r0 * nf;
-    gemm_tile64(acc, b2, b, b, m0, n0, [=](int m, int kk) { return Bm[m + (int64_t)kk * nf]; },
-                [=](int kk, int n) { return ldm<1>(kk >= n, &Ai[kk + (int64_t)n * nf]); }, sA, sB, n0);       // Ai(k, n) = 0 for k < n
+    // Ai(k, n) = 0 for k < n: the mask over the tile's own columns, whole columns of Ai below them
+    gemm_tile64(acc, b2, b, min(b, n0 + LT), m0, n0, [=](int m, int kk) { return Bm[m + (int64_t)kk * nf]; },
+                [=](int kk, int n) { return ldm<1>(kk >= n, &Ai[kk + (int64_t)n * nf]); }, sA, sB, n0);
+    gemm_tile64_plain<1, false, true>(acc, Bm, nf, b2, Ai, nf, b, n0 + LT, b, m0, n0, smem);
     tile64_foreach(acc, m0, n0, b2, b, [=](int m, int n, double v) { W[m + (int64_t)n * b] = v; });
   } else {
     const double* Ci = Li + (r0 + b) + (int64_t)(r0 + b) * nf;
+    // Ci(m, k) = 0 for k > m: whole rows of Ci before the tile's first row, the mask from there on
+    gemm_tile64_plain<1, false, true>(acc, Ci, nf, b2, W, b, b, 0, m0, m0, n0, smem);
     gemm_tile64(acc, b2, b, min(b2, m0 + LT), m0, n0, [=](int m, int kk) { return ldm<1>(m >= kk, &Ci[m + (int64_t)kk * nf]); },
-                [=](int kk, int n) { return W[kk + (int64_t)n * b]; }, sA, sB);                               // Ci(m, k) = 0 for k > m
+                [=](int kk, int n) { return W[kk + (int64_t)n * b]; }, sA, sB, m0);
     double* X = Li + (r0 + b) + (int64_t)r0 * nf;
     tile64_foreach(acc, m0, n0, b2, b, [=](int m, int n, double v) { X[m + (int64_t)n * nf] = -v; });
   }
