@@ -513,8 +513,22 @@ static bool launch_assemble_fz(csp_ctx* c, const MfmaArgs& az, int cnt, int nrhs
   static int thr = 0;
   if (!thr) { const char* e = sw_str("SMCP_FZ_THREADS"); thr = (e && atoi(e) == 512) ? 512 : 1024; }
   const dim3 grid((unsigned)std::min<int64_t>(c->D.ncu, (int64_t)cnt * nrhs));
-  if (thr == 512) launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 512>, grid, dim3(512), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter);
-  else launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 1024>, grid, dim3(1024), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter);
+  // a last round less than half full (synth50k: 100 pairs per queue of 32 workgroups: four in the fourth round) is dealt in
+  // shares of the pairs' children (k_lf_assemble_fz, header); SMCP_FZ_TAIL=0: every pair whole
+  int tail_first = -1, nzt = 1;
+  static const bool tsplit = sw_on("SMCP_FZ_TAIL", true);
+  if (tsplit && sgn == 3 && cnt % 8 == 0 && grid.x % 8 == 0 && grid.x >= 8) {
+    const int wq = (int)grid.x / 8, total_q = (cnt / 8) * nrhs, rem = total_q % wq;
+    if (total_q > wq && rem > 0 && 2 * rem <= wq) {
+      nzt = std::min({8, wq / rem, std::max(1, az.nchmax / 8)});
+      if (nzt >= 2) tail_first = total_q - rem;
+      else nzt = 1;
+    }
+  }
+  if (tail_first >= 0)
+    launch(c, KID_lf_clear_upd, k_lf_zero_pairs, dim3(16, (unsigned)((cnt / 8) * nrhs - tail_first), 8), dim3(256), st, az, U, ldu, cnt, nrhs, tail_first);
+  if (thr == 512) launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 512>, grid, dim3(512), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter, tail_first, nzt);
+  else launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 1024>, grid, dim3(1024), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter, tail_first, nzt);
   return true;
 }
 void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t ldu, int sgn, hipStream_t st, bool clear_first = false) {

@@ -500,25 +500,27 @@ __device__ inline void lf_add_family(double* T, int nf, const MfmaArgs& a, int z
   d4 acc[NTU];
 #pragma unroll
   for (int x = 0; x < NTU; ++x) acc[x] = d4{0.0, 0.0, 0.0, 0.0};
-  // operands of step s: the a images of the two vectors of ordered pair tp = kq + 4 s (entry tp >> 1 taken as (x, y) or (y, x))
-  auto fetch = [&](int s, double (&aA)[NAT], double (&bA)[NAT], double& se, int& ux, int& uy) {
+  // operands of step s: the a images of the two vectors of ordered pair tp = kq + 4 s (entry tp >> 1 taken as (x, y) or (y, x)).
+  // The two ordered pairs of an entry sit sixteen lanes apart (kq even / odd) and want the same two images with the roles
+  // swapped: every lane gathers the image of ITS y only and takes the image of its x from the partner lane (lane ^ 16: a
+  // cross-lane move instead of a second 128-byte gather: half the gather traffic, the same time -- the step is a latency chain).
+  auto fetch = [&](int s, double (&aA)[NAT], double& se, int& ux, int& uy) {
     const int tp = kq + 4 * s, e = tp >> 1;
     const int pke = __shfl(pk, e, 64);
     se = __shfl(sv, e, 64);                                  // (lanes beyond the list hold a zero scale)
     const int v0 = pke & 0xffff, v1 = (pke >> 16) & 0xffff;
     const int vx = (tp & 1) ? v1 : v0, vy = (tp & 1) ? v0 : v1;
     // a image of a vector id: offset in the record and the index of its unit part (255: none)
-    const int ax = vx >= FAMT_CHILD ? L.oCA + NA * (vx - FAMT_CHILD) : (vx < nnp ? L.onK + NA * vx : L.oZero);
     ux = (vx < FAMT_CHILD && vx >= nnp) ? vx - nnp : 255;
     const int ay = vy >= FAMT_CHILD ? L.oCA + NA * (vy - FAMT_CHILD) : (vy < nnp ? L.onK + NA * vy : L.oZero);
     uy = (vy < FAMT_CHILD && vy >= nnp) ? vy - nnp : 255;
 #pragma unroll
-    for (int t = 0; t < NAT; ++t) {
-      aA[t] = tab[ay + 16 * t + l15];
-      bA[t] = tab[ax + 16 * t + l15];
-    }
+    for (int t = 0; t < NAT; ++t) aA[t] = tab[ay + 16 * t + l15];
   };
-  auto mma = [&](double (&aA)[NAT], double (&bA)[NAT], double se, int ux, int uy) {
+  auto mma = [&](double (&aA)[NAT], double se, int ux, int uy) {
+    double bA[NAT];
+#pragma unroll
+    for (int t = 0; t < NAT; ++t) bA[t] = __shfl_xor(aA[t], 16, 64);
 #pragma unroll
     for (int t = 0; t < NAT; ++t) {
       const int row = 16 * t + l15;
@@ -531,11 +533,13 @@ __device__ inline void lf_add_family(double* T, int nf, const MfmaArgs& a, int z
       for (int ct = 0; ct <= rt; ++ct)
         acc[rt * (rt + 1) / 2 + ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[ct], bA[rt], acc[rt * (rt + 1) / 2 + ct], 0, 0, 0);
   };
+  // (requesting step s + 1 before the products of step s was measured again with the halved gathers: 34 spilled registers at
+  // sixteen waves, 0.60 ms against 0.53)
   for (int s = 0; s < ks; ++s) {
-    double aA[NAT], bA[NAT], se;
+    double aA[NAT], se;
     int ux, uy;
-    fetch(s, aA, bA, se, ux, uy);
-    mma(aA, bA, se, ux, uy);
+    fetch(s, aA, se, ux, uy);
+    mma(aA, se, ux, uy);
   }
   // element (m, n) of the update -> front position (rel[m], rel[n]); packed column start minus the column index as in lf_alds_task
 #pragma unroll
@@ -569,8 +573,14 @@ struct AldsFam {
 // q, q + 8, ... -- the hundred right-hand sides of one front gather from the SAME families' tables (11 MB per front on
 // synth50k, 88 MB in all), so a front worked on by one XCD keeps its tables in that XCD's L2 instead of every L2 seeing all
 // of them; a workgroup whose queue is empty takes from the others (counters[0 .. 7], zeroed by the launch).
+// The last round: 800 pairs on 256 workgroups are 3.125 rounds, and a pair is one workgroup's task because its front fills
+// LDS.  The pairs from `tail_first` on in every queue (the host passes the ones that would make up a last round less than
+// half full) are therefore dealt in `nzt` shares of their children each: every share gathers its children into a front of
+// its own and adds what it gathered to the panel and update block with global atomics (cleared by k_lf_zero_pairs before
+// the launch; share 0 brings the constraint's own entries).  tail_first < 0: every pair whole.
 template <int NAT, int NTH>
-__global__ void __launch_bounds__(NTH) k_lf_assemble_fz(MfmaArgs a, double* u, int64_t ldu, int sgn, int cnt, int nrhs, int* counters) {
+__global__ void __launch_bounds__(NTH) k_lf_assemble_fz(MfmaArgs a, double* u, int64_t ldu, int sgn, int cnt, int nrhs, int* counters,
+                                                        int tail_first, int nzt) {
   extern __shared__ __attribute__((aligned(16))) double T[];
   __shared__ int stask;
   // (the child table of lf_alds_task behind the front: the hook reads the entries the table phase prepared for it)
@@ -582,13 +592,21 @@ __global__ void __launch_bounds__(NTH) k_lf_assemble_fz(MfmaArgs a, double* u, i
     const int nfq = (cnt - q + 7) >> 3;                 // fronts q, q + 8, ... below cnt
     const int total = nfq * nrhs;
     if (total <= 0) continue;
+    const int full = (tail_first >= 0 && tail_first < total) ? tail_first : total;
+    const int units = full + (total - full) * nzt;
     for (;;) {
       __syncthreads();
       if (threadIdx.x == 0) stask = atomicAdd(counters + q, 1);
       __syncthreads();
       const int t = stask;
-      if (t >= total) break;
-      lf_alds_task(a, u, ldu, sgn, q + 8 * (t / nrhs), t % nrhs, 0, 1, T, AldsFam<NAT>{&a, sCu, sCr});
+      if (t >= units) break;
+      if (t < full) {
+        lf_alds_task(a, u, ldu, sgn, q + 8 * (t / nrhs), t % nrhs, 0, 1, T, AldsFam<NAT>{&a, sCu, sCr});
+      } else {
+        const int s2 = t - full, tt = full + s2 / nzt, share = s2 % nzt;
+        const int tc = (a.nchmax + nzt - 1) / nzt;              // (lf_alds_task lays the child table out for its share)
+        lf_alds_task(a, u, ldu, sgn, q + 8 * (tt / nrhs), tt % nrhs, share, nzt, T, AldsFam<NAT>{&a, sCu, sCu + tc});
+      }
     }
   }
 }

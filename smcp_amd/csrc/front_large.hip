@@ -546,13 +546,26 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
   double* P = u + (int64_t)r * ldu + d.blk;
   double* U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
   if (fill) {
-    const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
-    const int32_t* kp = a.kc_ptr + (int64_t)k * a.kc_stride;
-    for (int p = kp[j] + tid; p < kp[j + 1]; p += nthr) {
-      const int off = a.kc_off[p], i = off % nf, jc = off / nf;
-      if (i >= jc) unsafeAtomicAdd(&T[cb(jc) + i], a.kc_val[p]);
+    if (wz == 0) {       // (shared pairs: the constraint's own entries once)
+      const int j = a.kc_ids ? a.kc_ids[a.kc_j0 + r] : a.kc_j0 + r;
+      const int32_t* kp = a.kc_ptr + (int64_t)k * a.kc_stride;
+      for (int p = kp[j] + tid; p < kp[j + 1]; p += nthr) {
+        const int off = a.kc_off[p], i = off % nf, jc = off / nf;
+        if (i >= jc) unsafeAtomicAdd(&T[cb(jc) + i], a.kc_val[p]);
+      }
     }
     __syncthreads();
+    if (nz > 1) {        // a share of the pair's children: what it gathered goes into the panel and the update block the launch cleared
+      for (int e = tid; e < nf * nn; e += nthr) {
+        const int i = e % nf, jc = e / nf;
+        if (i >= jc) { const double v = T[cb(jc) + i]; if (v != 0.0) unsafeAtomicAdd(&P[e], v); }
+      }
+      for (int e = tid; e < na * na; e += nthr) {
+        const int i = e % na, jc = e / na;
+        if (i >= jc) { const double v = T[cb(nn + jc) + nn + i]; if (v != 0.0) unsafeAtomicAdd(&U[e], v); }
+      }
+      return;
+    }
     for (int e = tid; e < nf * nn; e += nthr) {
       const int i = e % nf, jc = e / nf;
       if (i >= jc) P[e] = T[cb(jc) + i];
@@ -595,6 +608,20 @@ __device__ inline void lf_alds_task(const MfmaArgs& a, double* u, int64_t ldu, i
       if (i >= j) U[e] = T[cb(nn + j) + nn + i];                       // full assignment of the lower triangle
     }
   }
+}
+// panel and update block of the (front, right-hand side) pairs whose children are shared among several workgroups of
+// k_lf_assemble_fz (the pairs tail_first .. of every queue): cleared here, added to there.  grid (chunks, pairs per queue, 8)
+__global__ void k_lf_zero_pairs(MfmaArgs a, double* u, int64_t ldu, int cnt, int nrhs, int tail_first) {
+  const int q = blockIdx.z, tt = tail_first + (int)blockIdx.y;
+  const int f = q + 8 * (tt / nrhs), r = tt % nrhs;
+  if (f >= cnt) return;
+  const CliqueDesc d = a.t.cl[a.t.lev[f]];
+  const int nn = d.nn, na = d.na, nf = nn + na;
+  double* P = u + (int64_t)r * ldu + d.blk;
+  double* U = a.t.upd + (int64_t)r * a.t.updlen + d.upd;
+  const int stride = gridDim.x * blockDim.x, g = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int e = g; e < nf * nn; e += stride) P[e] = 0.0;
+  for (int e = g; e < na * na; e += stride) U[e] = 0.0;
 }
 __global__ void __launch_bounds__(1024) k_lf_assemble_lds(MfmaArgs a, double* u, int64_t ldu, int sgn) {
   extern __shared__ __attribute__((aligned(16))) double T[];

@@ -44,6 +44,7 @@ static const Switch SWITCHES[] = {
   {"SMCP_LG_SIDE", "1", "0: leaf Gram blocks after the sweep on the caller's stream instead of beside the top phases"},
   {"SMCP_LG_EARLY", "1", "0: leaf Gram blocks beside the phase kernels of the top fronts instead of from the start of the sweep"},
   {"SMCP_FACI_LDS", "1", "0: inverse Y_AA factors of the small fronts by block rows against HBM (k_factor_inverse) instead of in LDS"},
+  {"SMCP_FZ_TAIL", "1", "0: every (front, right-hand side) pair of the fused extend-add is one workgroup's task, also in a thin last round"},
   {"SMCP_GRAM", "1", "0: reference (two-sweep) formulation of the Schur complement instead of the Gram formulation"},
   {"SMCP_SCM", "1", "0: column-sparse constraints swept like the others (no SCMcolumn2 route)"},
   {"SMCP_TRSM_MM", "1", "0: csp_trsm through the generic level kernels instead of tile products"},
