@@ -497,14 +497,16 @@ static bool alds_route(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, int& nz
 }
 // (sparse right-hand sides) would lf_assemble build the input panels itself -- sgn 3 of lf_alds_task -- so that the caller
 // can skip k_panel_fill?  SMCP_ALDS_FILL=0: never.
-static bool lf_assemble_fills(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs) {
+// (shares: the caller is the fused extend-add, whose workgroups may share the children of a pair -- k_lf_assemble_fz clears
+// and adds; the plain streaming kernels build panels only with one workgroup per pair)
+static bool lf_assemble_fills(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, bool shares = false) {
   static int on = -1;
   if (on < 0) { const char* e = sw_str("SMCP_ALDS_FILL"); on = (e && e[0] == '0') ? 0 : 1; }
   int nz; size_t bytes;
-  return on && a.kc_ptr && alds_route(c, a, cnt, nrhs, nz, bytes) && nz == 1;
+  return on && a.kc_ptr && alds_route(c, a, cnt, nrhs, nz, bytes) && (nz == 1 || shares);
 }
 template <int NAT>
-static bool launch_assemble_fz(csp_ctx* c, const MfmaArgs& az, int cnt, int nrhs, double* U, int64_t ldu, int sgn, size_t bytes, int* counter, hipStream_t st) {
+static bool launch_assemble_fz(csp_ctx* c, const MfmaArgs& az, int cnt, int nrhs, double* U, int64_t ldu, int sgn, size_t bytes, int* counter, hipStream_t st, int shares) {
   static bool attr = false;
   if (!attr) attr = hipFuncSetAttribute((const void*)k_lf_assemble_fz<NAT, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess &&
                     hipFuncSetAttribute((const void*)k_lf_assemble_fz<NAT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
@@ -512,7 +514,7 @@ static bool launch_assemble_fz(csp_ctx* c, const MfmaArgs& az, int cnt, int nrhs
   // sixteen waves (128 registers each) or eight (256): SMCP_FZ_THREADS=512 selects the latter
   static int thr = 0;
   if (!thr) { const char* e = sw_str("SMCP_FZ_THREADS"); thr = (e && atoi(e) == 512) ? 512 : 1024; }
-  const dim3 grid((unsigned)std::min<int64_t>(c->D.ncu, (int64_t)cnt * nrhs));
+  const dim3 grid((unsigned)std::min<int64_t>(c->D.ncu, (int64_t)cnt * nrhs * std::max(1, shares)));
   // a last round less than half full (synth50k: 100 pairs per queue of 32 workgroups: four in the fourth round) is dealt in
   // shares of the pairs' children (k_lf_assemble_fz, header); SMCP_FZ_TAIL=0: every pair whole
   int tail_first = -1, nzt = 1;
@@ -525,8 +527,13 @@ static bool launch_assemble_fz(csp_ctx* c, const MfmaArgs& az, int cnt, int nrhs
       else nzt = 1;
     }
   }
+  // fewer pairs than half the CUs (one rank's share of a sharded sweep: alds_route asked for `shares` workgroups per pair): every pair shared
+  if (shares > 1) {
+    if (sgn != 3) return false;
+    tail_first = 0; nzt = shares;
+  }
   if (tail_first >= 0)
-    launch(c, KID_lf_clear_upd, k_lf_zero_pairs, dim3(16, (unsigned)((cnt / 8) * nrhs - tail_first), 8), dim3(256), st, az, U, ldu, cnt, nrhs, tail_first);
+    launch(c, KID_lf_clear_upd, k_lf_zero_pairs, dim3(16, (unsigned)(((cnt + 7) / 8) * nrhs - tail_first), 8), dim3(256), st, az, U, ldu, cnt, nrhs, tail_first);
   if (thr == 512) launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 512>, grid, dim3(512), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter, tail_first, nzt);
   else launch_lds(c, KID_lf_assemble_fz, k_lf_assemble_fz<NAT, 1024>, grid, dim3(1024), bytes, st, az, U, ldu, sgn, cnt, nrhs, counter, tail_first, nzt);
   return true;
@@ -538,7 +545,7 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
     // the family launch of this sweep left its parents' updates to this extend-add: the streaming kernel with the hook that
     // forms them (k_lf_assemble_fz) -- hess_up_fast has checked that this launch qualifies
     int nz; size_t bytes;
-    bool ok = alds_route(c, a, cnt, nrhs, nz, bytes) && nz == 1 && c->D.info;
+    bool ok = alds_route(c, a, cnt, nrhs, nz, bytes) && (nz == 1 || sgn == 3) && c->D.info;
     if (ok) {
       MfmaArgs az = a;
       az.fz_on = 1; az.fz_nat = c->fz_nat; az.fz_cnn = c->fz_cnn; az.fz_recl = c->fz_recl; az.fz_stride = (int)(c->D.m + 1);
@@ -546,10 +553,10 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
       int* counter = c->D.fz_slot + c->D.fz_nfam;       // eight task counters behind the slot table (kkt_set_constraints)
       (void)hipMemsetAsync(counter, 0, 8 * sizeof(int), st);
       switch (c->fz_nat) {
-        case 1: ok = launch_assemble_fz<1>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;
-        case 2: ok = launch_assemble_fz<2>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;
-        case 3: ok = launch_assemble_fz<3>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;
-        case 4: ok = launch_assemble_fz<4>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st); break;
+        case 1: ok = launch_assemble_fz<1>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st, nz); break;
+        case 2: ok = launch_assemble_fz<2>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st, nz); break;
+        case 3: ok = launch_assemble_fz<3>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st, nz); break;
+        case 4: ok = launch_assemble_fz<4>(c, az, cnt, nrhs, U, ldu, sgn, bytes, counter, st, nz); break;
         default: ok = false;
       }
     }
@@ -1278,7 +1285,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
       for (int64_t l = 0; l < c->S.nlev; ++l)
         for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t, int) {
           if (lds && a.nS > 0 && a.level > 0) ++famlevels;
-          if (!lds && (size_t)a.level < c->fz_levels.size() && c->fz_levels[(size_t)a.level] && !(a.nchmax > 0 && lf_assemble_fills(c, a, cnt, nrhs))) { want = false; ++nofill; }
+          if (!lds && (size_t)a.level < c->fz_levels.size() && c->fz_levels[(size_t)a.level] && !(a.nchmax > 0 && lf_assemble_fills(c, a, cnt, nrhs, true))) { want = false; ++nofill; }
         }, set);
       if (famlevels != 1) want = false;
     }
@@ -1412,7 +1419,8 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
           LAUNCH_PD(c, KID_lf_up2, k_lf_up2, dim3(umax1(ntN * (ntN + 1) / 2), cnt, nrhs), dim3(256), st, a, U, ldu);
           return;
         }
-        if (sparse && a.nchmax > 0 && lf_assemble_fills(c, a, cnt, nrhs)) {     // no k_panel_fill: the extend-add builds the panels
+        const bool fzlev = c->fz_live && (size_t)a.level < c->fz_levels.size() && c->fz_levels[(size_t)a.level];
+        if (sparse && a.nchmax > 0 && lf_assemble_fills(c, a, cnt, nrhs, fzlev)) {     // no k_panel_fill: the extend-add builds the panels
           lf_up(c, a, cnt, nrhs, U, ldu, st, true);
           return;
         }
