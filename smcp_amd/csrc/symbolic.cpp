@@ -1,5 +1,6 @@
 // Host symbolic analysis. See symbolic.hpp for what it replaces in the reference.
 #include "symbolic.hpp"
+#include "switches.hpp"
 
 #include <algorithm>
 #include <numeric>
@@ -161,8 +162,7 @@ static void relabel(const std::vector<int64_t>& order /*new->cur*/, std::vector<
 int symbolic_build(int64_t n, const int64_t* colptr, const int64_t* rowind, const int64_t* perm,
                    Symbolic& S) {
   if (n <= 0) return -1;
-  const char* tenv = std::getenv("SMCP_TIMING");
-  const bool timing = tenv && tenv[0] == '1';
+  const bool timing = sw_on("SMCP_TIMING", 0) == 1;
   auto tprev = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
     if (!timing) return;
