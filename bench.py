@@ -24,6 +24,7 @@ configs 2, 3 and 4 (dense4096, arrow, maxcut; a few steps each, no CPU leg; --no
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -345,6 +346,21 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
                 "unit": "TFLOP/s", "frac": round(tfl / FP64_PEAK_TFLOPS, 4), "traffic": None,
                 "flops_per_step": lf_flops[dom] * nr, "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2),
                 "launches_per_step": dom_launches}
+    if dom == "k_lf_diag":
+        # the diagonal-block step of the blocked Cholesky factorisations (config 4: the root's front, chol(Y_AA) of the top
+        # fronts, potrf(H)): per 64-wide block one workgroup factors the block and inverts its factor, 2 * 64^3 / 3 flops,
+        # as a dependent chain of four 16 x 16 steps.  Fronts of at most 272 rows take k_mid_chol instead (front_large.hip).
+        nf_ = nn_ + na_
+        blocks = float(np.ceil(nn_[big & (nf_ > 272)] / 64.0).sum() + np.ceil(na_[big & (na_ > 272)] / 64.0).sum() +
+                       (math.ceil(m / 64.0) if m > 128 else 0))
+        fl_step = blocks * 2.0 * 64.0 ** 3 / 3.0
+        tfl = fl_step / (1e-3 * dom_ms) / 1e12
+        return {"kernel": dom, "bound": "mfma", "achieved": round(tfl, 5), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tfl / FP64_PEAK_TFLOPS, 6), "traffic": None, "flops_per_step": fl_step, "diagonal_blocks_per_step": blocks,
+                "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2), "launches_per_step": dom_launches,
+                "note": "latency chain, not a throughput kernel: one workgroup per front factors and inverts ONE 64 x 64 diagonal block per "
+                        "launch (four dependent 16 x 16 steps, ~31 us); the fraction says how far such a chain is from the matrix peak, "
+                        "the quantity to reduce is launches_per_step x avg_launch_us"}
     return {"kernel": dom, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
             "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2), "launches_per_step": dom_launches,
             "note": "no byte / flop model for this kernel in bench.py"}
