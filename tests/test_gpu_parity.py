@@ -3,6 +3,8 @@
 Tolerance: fp64, relative 1e-10 on well-conditioned inputs (the north star's "stated fp64
 tolerance"); the factorisations differ from the oracle only in summation order.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1218,3 +1220,18 @@ def test_family_updates_formed_by_the_extend_add(name, m, density, fused, monkey
         assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
     finally:
         chordal.tune(symb, chordal.TUNE_LEAFGRAM, 1)
+
+
+def test_fused_extend_add_with_shared_pairs():
+    """k_lf_assemble_fz with the children of EVERY (front, right-hand side) pair dealt over three workgroups -- each gathers its
+    share into a front of its own and adds it to the cleared panel / update block with global atomics (k_lf_zero_pairs; one
+    rank's owned sweep of an eight-rank job takes this route by itself, and the thin last round of the headline launch a
+    variant of it).  SMCP_ALDS_Z=3 forces it; the switch is read once per process, so the fused cases above run again in a
+    child interpreter."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SMCP_ALDS_Z="3")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "family_updates_formed_by_the_extend_add and True"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
