@@ -222,8 +222,12 @@ def _backtrack(base, d, which, s, beta, smin, accept=None, batch=8, strict=False
     op = chordal.completion if which == "p" else chordal.cholesky
     first = True
     more = (lambda v: v > smin) if strict else (lambda v: v >= smin)
+    # (a pattern whose single trial fills the device takes its trials one after the other, as in the bisection of
+    # chordalsolver_feas: eight side by side cost eight trials where the search usually needs two to five, and the replicated
+    # pattern they run on is then never built)
+    batched = _batched() and base.symb.blklen <= int(options.get("batched_linesearch_maxlen", 1 << 20))
     while more(s):
-        if first or not _batched():
+        if first or not batched:
             first = False
             T = base + d * s
             try:
