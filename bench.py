@@ -507,7 +507,7 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         if lazy:
             chordal.check_status(symb)
         chordal.tune(symb, chordal.TUNE_PLACEMENT, int(args.tune_placement))
-        rep = (ctypes.c_double * 2)()
+        rep = (ctypes.c_double * 3)()
         lib.csp_tune_report(symb.handle, rep)
         placement = {"tries": int(args.tune_placement), "probe_ms_before": round(rep[0], 4), "probe_ms_after": round(rep[1], 4)}
         for _ in range(max(1, min(warmup, 2))):

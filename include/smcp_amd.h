@@ -144,9 +144,20 @@ int kkt_amap(csp_ctx* ctx, const double* X, double* y, void* stream);
 int kkt_aadj(csp_ctx* ctx, const double* y, double* X, void* stream);
 /* kkt_chol factor step (solvers.py:479-501 + misc.c:620-663): builds the m x m Schur
  * complement H_ij = <A_i, hessian(L,Y)(A_j)> (lower) into H (device, ldh >= m) and factors it
- * in place (lapack.potrf, solvers.py:501). */
+ * in place (lapack.potrf, solvers.py:501).
+ * DEFERRED CONTRACT.  Under csp_lazy_status(ctx, 1) (and unless SMCP_POTRF_DEFER=0) the call returns with H holding the
+ * RAW Schur complement: its Cholesky factorisation waits for the first call of this library that reads H -- kkt_solve
+ * (which runs it on a side stream beside its first Hessian sweep), dense_potrs, csp_status -- and is dropped when
+ * dense_potrf / kkt_schur_columns / kkt_schur_factor is called on the same H again.  Until then the caller must keep H
+ * alive and unmodified and must not read it by its own means (a copy, an all-reduce, its own potrs would see the raw
+ * matrix): call csp_status or dense_potrs first, or factor eagerly (csp_lazy_status(ctx, 0), the default).  ONE matrix
+ * per context can wait: kkt_schur_factor on another H, or kkt_set_constraints, first factors the waiting one where it
+ * stands.  A caller that frees H while it may still be waiting calls kkt_schur_forget first. */
 int kkt_schur_factor(csp_ctx* ctx, const double* L, const double* Y, double* H, int64_t ldh,
                      void* stream);
+/* H is about to be freed or reused: drops what the context remembers about it (the deferred factorisation above, the
+ * cached inverses of its diagonal blocks).  Nothing is launched. */
+int kkt_schur_forget(csp_ctx* ctx, const double* H);
 /* Columns j0..j1-1 of the (unfactored) Schur complement only: the unit that is sharded over
  * GPUs (each rank builds its column range, then one RCCL all-gather of H). */
 int kkt_schur_columns(csp_ctx* ctx, const double* L, const double* Y, double* H, int64_t ldh,
@@ -270,8 +281,17 @@ int csp_touch(csp_ctx* ctx, const void* ptr);
                                      call it between Newton steps; a kkt_qr factor held in the stack is invalidated and
                                      kkt_qr_solve returns SMCP_EINVAL until the next kkt_qr_factor.  Worth it for runs of many
                                      Newton steps on one problem; off unless called */
+#define CSP_TUNE_RACE 5           /* value = seed (0: off), PROCESS-wide: delay injection for race hunting -- a spin kernel of a
+                                     seeded random 5 .. 200 us at the head and tail of every internal side-stream branch, behind every
+                                     fork on the caller's stream and before one launch in four (tools/race_hunt.sh; the environment
+                                     variable SMCP_RACE=<seed> does the same from the first call on).  Results must not change. */
+#define CSP_TUNE_RACE_DROP_JOINS 6 /* 1: the harness's own sensitivity test -- side branches are no longer joined (their join event is
+                                     recorded, the caller's stream does not wait for it): results are WRONG by design and must
+                                     change under CSP_TUNE_RACE, which is what tests/test_gpu_parity.py asserts.  0: back to normal
+                                     (waits for the device).  PROCESS-wide. */
 int csp_tune(csp_ctx* ctx, int what, int64_t value);
-/* out[0], out[1]: milliseconds of the store-pattern probe of the last CSP_TUNE_PLACEMENT before / after (zeros: not run) */
+/* out[0], out[1]: milliseconds of the store-pattern probe of the last CSP_TUNE_PLACEMENT before / after (zeros: not run);
+ * out[2]: delay kernels injected so far in this process (CSP_TUNE_RACE).  out holds three doubles. */
 int csp_tune_report(csp_ctx* ctx, double* out);
 
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------- */

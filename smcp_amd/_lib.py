@@ -42,6 +42,7 @@ SIGNATURES = {
     "kkt_amap": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "kkt_aadj": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "kkt_schur_factor": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kkt_schur_forget": (ctypes.c_int, [c_vp, c_vp]),
     "kkt_schur_columns": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "kkt_schur_gram_part": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "kkt_constraint_classes": (ctypes.c_int, [c_vp, c_vp]),

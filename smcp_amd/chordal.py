@@ -40,7 +40,7 @@ def lazy_status(symb, on=True):
     symb.__dict__["_lazy_status"] = bool(on)
 
 
-TUNE_LEAFGRAM, TUNE_VERIFY_CACHE, TUNE_DETERMINISTIC, TUNE_PLACEMENT = 1, 2, 3, 4
+TUNE_LEAFGRAM, TUNE_VERIFY_CACHE, TUNE_DETERMINISTIC, TUNE_PLACEMENT, TUNE_RACE, TUNE_RACE_DROP_JOINS = 1, 2, 3, 4, 5, 6
 
 
 def tune(symb, what, value):
@@ -49,9 +49,18 @@ def tune(symb, what, value):
     fingerprint of the matrix it came from; a forgotten ``touch`` raises instead of serving stale factors),
     TUNE_DETERMINISTIC (1: fixed-order summation, bit-identical results from run to run), TUNE_PLACEMENT (an action: value =
     tries; after the constraints are set, moves the packed exchange buffer to the fastest of up to `tries` fresh allocations
-    for the store pattern of the family sweep -- for runs of many Newton steps on one problem)."""
+    for the store pattern of the family sweep -- for runs of many Newton steps on one problem), TUNE_RACE (value = seed,
+    0 = off, process-wide: seeded delay injection on every internal stream hand-over, tools/race_hunt.sh)."""
     _ensure(symb)
     _chk(_lib.lib().csp_tune(symb.handle, int(what), int(value)), "csp_tune")
+
+
+def race_injected(symb):
+    """Delay kernels injected so far in this process (csp_tune_report: TUNE_RACE)."""
+    import ctypes
+    rep = (ctypes.c_double * 3)()
+    _chk(_lib.lib().csp_tune_report(symb.handle, rep), "csp_tune_report")
+    return int(rep[2])
 
 
 def touch(X):

@@ -12,6 +12,7 @@
 #include <new>
 #include <atomic>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/smcp_amd.h"
@@ -100,6 +101,50 @@ inline hipError_t end_call(csp_ctx* c) {
 // Events that only order streams of ONE device against each other: a device-scope release when they are recorded (the
 // default, a system-scope release with its cache write-back, showed as ~12 us of idle stream behind every record in the
 // rocprofv3 timeline of csp_cholesky_projected_inverse).  SMCP_EVENT_SYSFENCE=1: the default flags.
+// ---- delay injection (tools/race_hunt.sh, tests/test_gpu_distributed.py::test_sharded_step_under_delay_injection) ------
+// A missing stream edge shows only when the unordered side happens to run late.  With SMCP_RACE=<seed> (or
+// csp_tune(ctx, CSP_TUNE_RACE, seed); process-wide, 0 = off) a one-wave spin kernel of a seeded random 5 .. 200 us is put
+//   * at the head of every side branch (the branch starts late: a consumer that does not wait for its join reads old data),
+//   * on the caller's stream right behind every fork (the caller runs late: a branch that needs something the caller
+//     launches AFTER the fork reads old data),
+//   * at the tail of every side branch, before its join event is recorded,
+//   * before one launch in four of the launch helpers, on whatever stream the launch goes to (host-side readers, copies
+//     and collectives issued by the caller between two library calls meet a device that is still busy).
+// The spin reads the constant 100 MHz counter and gives up after a bounded number of polls: it cannot hang a stream.
+__global__ void k_race_spin(long long ticks) {
+  const long long t0 = wall_clock64();
+  for (int it = 0; it < (1 << 22) && wall_clock64() - t0 < ticks; ++it) __builtin_amdgcn_s_sleep(8);
+}
+struct RaceInject {
+  std::atomic<uint64_t> state{0};
+  std::atomic<int64_t> injected{0};
+  std::atomic<int> drop_joins{0};      // CSP_TUNE_RACE_DROP_JOINS: the harness's own sensitivity test (results are WRONG by design)
+  bool on() const { return state.load(std::memory_order_relaxed) != 0; }
+  void seed(uint64_t s) { state.store(s ? (s * 0x9E3779B97F4A7C15ull) | 1ull : 0ull); }
+  uint64_t next() {
+    uint64_t x = state.load(std::memory_order_relaxed);
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    state.store(x | 1ull, std::memory_order_relaxed);
+    return x;
+  }
+};
+inline RaceInject& race_inject() {
+  static RaceInject r;
+  static const bool init = [] { const char* e = sw_str("SMCP_RACE"); if (e && atoll(e) > 0) r.seed((uint64_t)atoll(e)); return true; }();
+  (void)init;
+  return r;
+}
+// always = false: one call in four injects (the launch helpers)
+inline void race_delay(hipStream_t s, bool always = true) {
+  RaceInject& r = race_inject();
+  if (!r.on()) return;
+  const uint64_t x = r.next();
+  if (!always && (x >> 40) % 4 != 0) return;
+  const long long us = 5 + (long long)((x >> 16) % 196);
+  hipLaunchKernelGGL(k_race_spin, dim3(1), dim3(64), 0, s, us * 100);
+  r.injected.fetch_add(1, std::memory_order_relaxed);
+}
+
 inline unsigned sync_event_flags() {
   static int sys = -1;
   if (sys < 0) { const char* e = sw_str("SMCP_EVENT_SYSFENCE"); sys = (e && e[0] == '1') ? 1 : 0; }
@@ -141,10 +186,14 @@ struct Fork {
     if (hipStreamWaitEvent(c->aux_stream[which], c->aux_fork, 0) != hipSuccess) return;
     s = c->aux_stream[which];
     on = true;
+    race_delay(s);        // (delay injection: the branch starts late, the caller's stream goes on late)
+    race_delay(main);
   }
   void join() {
     if (!on) return;
     on = false;
+    race_delay(s);        // (delay injection: the branch ends late)
+    if (race_inject().drop_joins.load(std::memory_order_relaxed)) { (void)hipEventRecord(c->aux_join[which], s); return; }   // (harness self-test: the edge is removed)
     if (hipEventRecord(c->aux_join[which], s) != hipSuccess || hipStreamWaitEvent(main, c->aux_join[which], 0) != hipSuccess)
       (void)hipStreamSynchronize(s);      // fall back to a host wait: the branch must be complete before the caller goes on
   }
@@ -168,6 +217,7 @@ inline void launch_lds(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, size_
   Profiler& P = c->prof;
   const bool timed = P.want(kid);
   if (timed) (void)hipEventRecord(P.next(), st);
+  race_delay(st, false);
   hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
   note_launch(c, kid);
   if (trace_on()) trace_launch(kid, grid, block, lds, st, false);
@@ -182,6 +232,7 @@ inline void launch(csp_ctx* c, int kid, K kern, dim3 grid, dim3 block, hipStream
   Profiler& P = c->prof;
   const bool timed = P.want(kid);
   if (timed) (void)hipEventRecord(P.next(), st);
+  race_delay(st, false);
   hipLaunchKernelGGL(kern, grid, block, 0, st, args...);
   note_launch(c, kid);
   if (trace_on()) trace_launch(kid, grid, block, 0, st, false);
@@ -226,6 +277,14 @@ int dev_alloc(T** dst, int64_t count, int64_t& bytes) {
   if (arc != hipSuccess) { (void)hipGetLastError(); arc = hipMalloc((void**)dst, n); }
   if (arc != hipSuccess) return SMCP_ENOMEM;
   bytes += (int64_t)n;
+  // SMCP_POISON=1 (hunting reads of never-written workspace): every fp64 buffer starts as 4.5e150 in every entry instead of
+  // whatever the previous owner of the memory left there -- which, in a re-run of the same test, is the same data at the same
+  // addresses and hides the read.  Index arrays are left alone (a poisoned index would fault, not mis-compute).
+  if (std::is_same<T, double>::value) {
+    static int poison = -1;
+    if (poison < 0) poison = sw_on("SMCP_POISON", 0);
+    if (poison && hipMemset((void*)*dst, 0x5F, n) != hipSuccess) return SMCP_EHIP;
+  }
   { static int dbg = -1; if (dbg < 0) { const char* e = sw_str("SMCP_DEBUG_ADDR"); dbg = (e && e[0] == '1') ? 1 : 0; }      // placement studies
     if (dbg && n >= ((size_t)1 << 24)) fprintf(stderr, "smcp_amd: alloc %zu MB at %p\n", n >> 20, (void*)*dst); }
   return 0;
@@ -1944,6 +2003,7 @@ void csp_symbolic_destroy(csp_ctx* c) {
                     D.red, D.info, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack, D.qr_ws,
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc, D.scm_owner};
     if (c->side_fork) { Fork* f = (Fork*)c->side_fork; c->side_fork = nullptr; f->join(); delete f; }
+    D.h_pending = nullptr;      // (a deferred factorisation nobody asked for dies with the context)
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& G : c->lfsp_grp) { if (G.ptr) hipFree(G.ptr); if (G.list) hipFree(G.list); }
     for (auto& G : c->famt_grp) { if (G.ptr) hipFree(G.ptr); if (G.list) hipFree(G.list); }
@@ -2681,7 +2741,12 @@ static int scaling_impl(csp_ctx* c, double* L, double* Y, int flags, hipStream_t
   D.faci_tag = nullptr;
   if (want_fac) D.fac_gen++;
   HIPCHK(end_call(c));
-  return fetch_info(c, st);
+  const int rc = fetch_info(c, st);
+  if (rc) {       // not positive definite (eager status): nothing derived from these buffers may be advertised as a valid cache
+    D.lk_tag_L = D.lk_tag_Y = D.yaa_tag = D.fac_tag = D.faci_tag = nullptr;
+    D.part_valid = false;
+  }
+  return rc;
 }
 int csp_cholesky_projected_inverse(csp_ctx* c, double* L, double* Y, int with_factors, void* stream) {
   if (int rc = ready(c)) return rc;
@@ -2957,10 +3022,12 @@ static int tune_placement(csp_ctx* c, int tries) {
   c->placement_probe[0] = first; c->placement_probe[1] = best;
   return rc;
 }
-// milliseconds of the store-pattern probe before / after the last CSP_TUNE_PLACEMENT (zeros: never run, or nothing to tune)
+// milliseconds of the store-pattern probe before / after the last CSP_TUNE_PLACEMENT (zeros: never run, or nothing to tune);
+// out[2]: delay kernels injected so far in this process (CSP_TUNE_RACE)
 int csp_tune_report(csp_ctx* c, double* out) {
   if (!c || !out) return SMCP_EINVAL;
   out[0] = c->placement_probe[0]; out[1] = c->placement_probe[1];
+  out[2] = (double)race_inject().injected.load();
   return 0;
 }
 
@@ -2986,6 +3053,14 @@ int csp_tune(csp_ctx* c, int what, int64_t value) {
       return 0;
     case CSP_TUNE_DETERMINISTIC:
       c->deterministic = value != 0;
+      return 0;
+    case CSP_TUNE_RACE:
+      if (value < 0) return SMCP_EINVAL;
+      race_inject().seed((uint64_t)value);
+      return 0;
+    case CSP_TUNE_RACE_DROP_JOINS:
+      race_inject().drop_joins.store(value != 0);
+      if (!value && c->D.device >= 0) (void)hipDeviceSynchronize();      // whatever ran unjoined is over before the next (correct) call
       return 0;
   }
   return SMCP_EINVAL;

@@ -114,7 +114,7 @@ struct DeviceCtx {
   double* hinv = nullptr;    // nblocks * 4096 + 2 n doubles (the tail holds the two work vectors of the solve)
   int64_t hinv_cap = 0, hinv_n = 0;
   const void* hinv_tag = nullptr;   // the factor these inverses belong to
-  double* h_pending = nullptr; int64_t h_pending_n = 0, h_pending_ld = 0;   // a Schur complement left unfactored by kkt_schur_factor (deferred status)
+  double* h_pending = nullptr; int64_t h_pending_n = 0, h_pending_ld = 0; hipStream_t h_pending_stream = nullptr;   // a Schur complement left unfactored by kkt_schur_factor (deferred status)
   double* sw = nullptr;      // blklen : sqrt of the inner-product weights (Gram path)
   double* gpart = nullptr;   // partial Gram tiles
   int64_t gpart_len = 0;

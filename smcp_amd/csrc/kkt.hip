@@ -435,6 +435,9 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
   DeviceCtx& D = c->D;
   const Symbolic& S = c->S;
   HIPCHK(hipSetDevice(D.device));
+  // a Schur complement of the OUTGOING constraint set still waiting for its factorisation (deferred status): it is complete
+  // and does not depend on what is replaced here -- factor it where it stands, on the stream it was built on
+  if (D.h_pending) { if (int rc = flush_pending_potrf(c, D.h_pending_stream, nullptr, false)) return rc; }
   void* old[] = {D.fz_no, D.fz_slot, D.fz_ptr, D.fz_pk, D.fz_s, D.lg_eptr, D.lg_epk, D.lg_ew, D.lg_remap, D.lg_tab, D.cptr, D.cidx, D.cval, D.cwval, D.rpos, D.rptr, D.rcon, D.rval, D.ustack,
                  D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.kc_ij, D.scm_owner};
   for (void* p : old) if (p) hipFree(p);
@@ -1445,15 +1448,26 @@ static bool potrf_defer_on() {
   return on == 1;
 }
 int kkt_schur_factor(csp_ctx* c, const double* L, const double* Y, double* H, int64_t ldh, void* stream) {
+  // ONE matrix can wait for its factorisation: a pending Schur complement of another system on this context (two KKT systems
+  // may share a Symbolic) is factored where it stands before this one takes the slot, so its solve_ never meets a raw H
+  if (c && c->D.h_pending && c->D.h_pending != H) { if (int rc = flush_pending_potrf(c, (hipStream_t)stream, nullptr, false)) return rc; }
   if (int rc = kkt_schur_columns(c, L, Y, H, ldh, 0, c ? c->D.m : 0, stream)) return rc;
   if (c->lazy_status && !use_generic(c) && potrf_defer_on() && Fork::enabled()) {
     // deferred status: nobody waits for potrf's verdict here, so the factorisation itself can wait for the first solve_
     // (kkt_solve runs it beside its first Hessian sweep) or for whoever reads H first (flush_pending_potrf)
-    c->D.h_pending = H; c->D.h_pending_n = c->D.m; c->D.h_pending_ld = ldh;
+    c->D.h_pending = H; c->D.h_pending_n = c->D.m; c->D.h_pending_ld = ldh; c->D.h_pending_stream = (hipStream_t)stream;
     c->D.hinv_tag = nullptr;
     return 0;
   }
   return dense_potrf(c, H, c->D.m, ldh, stream);
+}
+// The caller is about to free (or reuse) the memory of H: whatever the context still remembers about it -- the mark of a
+// factorisation that kkt_schur_factor deferred, the cached inverses of its diagonal blocks -- is dropped, nothing is launched.
+int kkt_schur_forget(csp_ctx* c, const double* H) {
+  if (!c || !H) return SMCP_EINVAL;
+  if ((const void*)c->D.h_pending == (const void*)H) c->D.h_pending = nullptr;
+  if (c->D.hinv_tag == (const void*)H) c->D.hinv_tag = nullptr;
+  return 0;
 }
 
 int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int64_t ldh, double kk,
@@ -1477,8 +1491,10 @@ int kkt_solve(csp_ctx* c, const double* L, const double* Y, const double* H, int
   if (D.h_pending && (const void*)D.h_pending == (const void*)H) {
     double* Hw = D.h_pending;
     D.h_pending = nullptr;
-    hf.reset(new Fork(c, st, 0));
-    if (hf->on) {
+    // (only under deferred status: an eager caller -- the status regime may have been switched since kkt_schur_factor -- gets
+    // the verdict of this factorisation as the return value, through the in-stream branch)
+    hf.reset(c->lazy_status ? new Fork(c, st, 0) : nullptr);
+    if (hf && hf->on) {
       int* pinfo = c->D.info + 20;
       if (int rc = potrf_launch(c, Hw, m, ldh, hf->s, pinfo)) return rc;
       hipLaunchKernelGGL(k_latch_status, dim3(1), dim3(64), 0, hf->s, pinfo, 1, c->D.info + 16);

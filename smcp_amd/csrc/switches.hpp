@@ -83,6 +83,8 @@ static const Switch SWITCHES[] = {
   {"SMCP_QR_PASSES", "0", "Cholesky-QR passes of kkt_qr (0: decided by the deviation test)"},
   {"SMCP_QR_P", "1", "positions per lane of the FMA substitution kernel (1 or 2)"},
   // ---- diagnostics
+  {"SMCP_POISON", "0", "1: every fp64 device buffer of the library (and the exchange buffers of smcp_amd/kkt.py) starts as 4.5e150 (hunting reads of never-written workspace)"},
+  {"SMCP_RACE", "0", "seed > 0: delay injection on every internal stream hand-over and one launch in eight (race hunting; results must not change)"},
   {"SMCP_TRACE", "0", "1: every launch named on stderr and waited for (a device fault points at its kernel)"},
   {"SMCP_TIMING", "0", "1: wall-clock marks of the set-up phases on stderr"},
   {"SMCP_OCC", "0", "1: occupancy decisions of k_hess_up_n16 on stderr"},

@@ -15,6 +15,15 @@ from .chordal import _chk, _ensure
 from .cspmatrix import cspmatrix, _stream, sync_cache
 
 
+def _empty(n, dev):
+    """Uninitialised fp64 device buffer -- under SMCP_POISON=1 (smcp_amd/csrc/switches.hpp) filled with 4.5e150, so that a
+    read of a never-written entry shows in the results instead of meeting whatever the allocator left there."""
+    t = torch.empty(n, dtype=torch.float64, device=dev)
+    if os.environ.get("SMCP_POISON") == "1":
+        t.fill_(4.5e150)
+    return t
+
+
 def column_range(m, rank, world):
     """Contiguous block of Schur-complement columns owned by `rank` (balanced to within one column)."""
     return (m * rank) // world, (m * (rank + 1)) // world
@@ -122,8 +131,7 @@ class ShardedSchur:
         bufs, sizes, width = self._exchange_plan(group, nrhs)
         key = width if keep is None else ("keep", keep, width)
         if key not in bufs:
-            bufs[key] = (torch.zeros(width, dtype=torch.float64, device=self.dev),
-                         torch.empty(width * world, dtype=torch.float64, device=self.dev))
+            bufs[key] = (torch.zeros(width, dtype=torch.float64, device=self.dev), _empty(width * world, self.dev))
         send, recv = bufs[key]
         if sizes[rank] and live:
             self._exchange_pack(P.roots_by_rank[rank], nrhs, send[:sizes[rank]])
@@ -145,7 +153,7 @@ class ShardedSchur:
         P = self.partition
         bufs, sizes1, width1 = self._exchange_plan(group, 1)
         if ("local", width1) not in bufs:
-            bufs[("local", width1)] = torch.empty(width1 * world, dtype=torch.float64, device=self.dev)
+            bufs[("local", width1)] = _empty(width1 * world, self.dev)
         out = bufs[("local", width1)]
         out.copy_(recv1)
         for n, (j0, j1, recv, width) in enumerate(kept):
@@ -327,8 +335,7 @@ class ShardedSchur:
         width = max(max(lens), 1)
         bufs = self.__dict__.setdefault("_xchg", {})
         if ("own", width) not in bufs:
-            bufs[("own", width)] = (torch.zeros(width, dtype=torch.float64, device=self.dev),
-                                    torch.empty(width * world, dtype=torch.float64, device=self.dev))
+            bufs[("own", width)] = (torch.zeros(width, dtype=torch.float64, device=self.dev), _empty(width * world, self.dev))
         send, recv = bufs[("own", width)]
         o = 0
         for a, b in P.ranges_by_rank[rank]:
@@ -347,6 +354,15 @@ class ShardedSchur:
     def _exchange_size(self, cliques, nrhs):
         na = np.diff(self.symb.rowptr) - np.diff(self.symb.snptr)
         return int(sum(int(na[k]) * (int(na[k]) + 1) // 2 for k in cliques) * nrhs)
+
+
+def _forget_schur(symb_ref, Hbuf):
+    symb = symb_ref()
+    if symb is not None and getattr(symb, "_h", None):
+        try:
+            _lib.lib().kkt_schur_forget(symb.handle, Hbuf.data_ptr())
+        except Exception:
+            pass
 
 
 class KKTSystem(ShardedSchur):
@@ -371,6 +387,9 @@ class KKTSystem(ShardedSchur):
         # H's all-reduce (factor_scaling(defer_status=True))
         self._Hbuf = torch.zeros(self.m * self.m + 1, dtype=torch.float64, device=self.dev)
         self.H = self._Hbuf[:self.m * self.m].view(self.m, self.m)
+        # the context may remember H by address (a factorisation deferred under chordal.lazy_status, the cached inverses of
+        # its diagonal blocks): it must forget it before the memory goes back to the allocator
+        weakref.finalize(self, _forget_schur, weakref.ref(symb), self._Hbuf)
         self._install()
 
     # The constraint set (entry lists, classification, the swept stack / Q of kkt_qr) lives in the Symbolic's native
@@ -397,13 +416,13 @@ class KKTSystem(ShardedSchur):
 
     def amap(self, X):
         self._own()
-        y = torch.empty(self.m, dtype=torch.float64, device=self.dev)
+        y = _empty(self.m, self.dev)
         _chk(_lib.lib().kkt_amap(self.symb.handle, X.blkval.data_ptr(), y.data_ptr(), _stream()), "kkt_amap")
         return y
 
     def aadj(self, y):
         self._own()
-        X = cspmatrix(self.symb, torch.empty(self.symb.blklen, dtype=torch.float64, device=self.dev))
+        X = cspmatrix(self.symb, _empty(self.symb.blklen, self.dev))
         X.touched()
         _chk(_lib.lib().kkt_aadj(self.symb.handle, y.data_ptr(), X.blkval.data_ptr(), _stream()), "kkt_aadj")
         return X

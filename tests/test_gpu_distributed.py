@@ -403,6 +403,88 @@ def test_sharded_step_synth50k_full_size(backend, world):
     assert r["ncoll"] == 4 + r["chunks"] and r["ncoll"] <= 5 + r["chunks"], r
 
 
+def _race_worker(rank, world, port, out, seeds):
+    """The sharded step at synth50k size, once plain (the reference figures of THIS process) and once per seed with delay
+    injection on (csp_tune CSP_TUNE_RACE): every figure of every seed against the plain run of the same rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from smcp_amd import chordal, problems
+        from smcp_amd.cspmatrix import cspmatrix
+        from smcp_amd.kkt import KKTSystem
+        from smcp_amd.symbolic import Symbolic
+        symb = Symbolic(problems.nested_block_arrow_pattern(seed=0))
+        m = 100
+        cptr, cidx, cval = problems.random_constraints(symb, m, density=0.005, seed=1)
+        sh = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+        S = cspmatrix(symb, torch.from_numpy(problems.random_factor_blkval(symb, 0)).cuda())
+        chordal.llt(S)
+        rng = np.random.default_rng(3)
+        msk = np.zeros(symb.blklen, dtype=bool); msk[symb.ccs_to_blk()] = True
+        mskd = torch.from_numpy(msk).cuda()
+        b0 = torch.from_numpy(rng.standard_normal(symb.blklen) * msk).cuda(); y0 = torch.from_numpy(rng.standard_normal(m)).cuda()
+        P = sh.set_partition(dist.group.WORLD)
+        own = sh._own_mask.bool().clone()
+        for a, b in P.top_ranges:
+            own[a:b] = True
+        own &= mskd
+
+        def step():
+            L, Y = sh.factor_scaling(S, dist.group.WORLD, defer_status=True)
+            solve = sh.factor(L, Y, group=dist.group.WORLD)
+            bx, by = cspmatrix(symb, b0.clone()), y0.clone()
+            solve(bx, by, 1.0, complete=False)               # x left sharded: the first solve_ after build_schur
+            dx, dy = cspmatrix(symb, b0.clone()), y0.clone()
+            solve(dx, dy, 1.0)                               # x completed on every rank
+            torch.cuda.synchronize()
+            return sh.H.clone(), bx.blkval.clone(), by.clone(), dx.blkval.clone(), dy.clone()
+
+        ref = step()
+        rel = lambda a, b, w=None: float(((a - b).abs() if w is None else (a - b).abs()[w]).max() / b.abs().max())
+        worst = {}
+        n0 = chordal.race_injected(symb)
+        for seed in seeds:
+            chordal.tune(symb, chordal.TUNE_RACE, seed)
+            try:
+                got = step()
+            finally:
+                chordal.tune(symb, chordal.TUNE_RACE, 0)
+            fig = dict(eH=rel(got[0], ref[0]), ex_sharded=rel(got[1], ref[1], own), ey=rel(got[2], ref[2]),
+                       ex_full=rel(got[3], ref[3], mskd), ey2=rel(got[4], ref[4]))
+            for k, v in fig.items():
+                if not v < 1e-11:
+                    worst.setdefault("bad", []).append((seed, k, v))
+                worst[k] = max(worst.get(k, 0.0), v)
+        worst["injected"] = chordal.race_injected(symb) - n0
+        out.put((rank, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_step_under_delay_injection():
+    """twenty delay seeds of the subtree-sharded step (two gloo ranks sharing the GPU, synth50k): a seeded
+    random spin kernel behind every internal fork, before every join and before one launch in eight must not change H, the
+    sharded x of the first solve_, the completed x of the second, or y -- on either rank (atomics order aside: 1e-11)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    seeds = list(range(101, 121))
+    procs = [ctx.Process(target=_race_worker, args=(r, 2, port, out, seeds)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0
+    for _ in range(2):
+        rank, worst = out.get()
+        assert "bad" not in worst, "rank %d: results changed under delay injection: %s" % (rank, json.dumps(worst))
+        assert worst["injected"] >= 10 * len(seeds), worst      # the harness did run
+
+
 def test_bench_self_launch_two_ranks_gloo():
     """The code path the driver's scaling run takes -- `python bench.py --gpus N` starting its own ranks (self_launch) and the
     N > 1 branch of the timed protocol -- with N = 2 ranks sharing the one GPU over gloo: one JSON line, n_gpus, the partition

@@ -709,7 +709,7 @@ def test_placement_tuning_moves_the_exchange_buffer_and_changes_nothing_else():
     sys_.factor(Ld, Yd)
     H0 = sys_.H.clone()
     chordal.tune(symb, chordal.TUNE_PLACEMENT, 3)
-    rep = (ctypes.c_double * 2)()
+    rep = (ctypes.c_double * 3)()
     assert _lib.lib().csp_tune_report(symb.handle, rep) == 0
     assert rep[0] > 0.0 and 0.0 < rep[1] <= rep[0]
     solve = sys_.factor(Ld, Yd)
@@ -1180,6 +1180,146 @@ def test_deferred_potrf_of_the_schur_complement():
         with pytest.raises(ArithmeticError):
             chordal.check_status(symb)
         chordal.check_status(symb)                         # reported once
+    finally:
+        chordal.lazy_status(symb, False)
+
+
+def test_two_systems_with_deferred_potrf_on_one_symbolic():
+    """two KKT systems share a Symbolic (the drivers do that for kktsolver='qr'); under chordal.lazy_status each
+    factor() leaves its H waiting for its factorisation, and the context has ONE slot for that.  Both systems factored, then
+    solved in both orders, must give what they give alone; a system that dies while its H waits must not leave the context
+    with a dangling pointer."""
+    symb, S, A, msk = setup("nested_mid", 41)
+    L = dev(symb, A)
+    Y = cspmatrix(symb, torch.empty(symb.blklen, dtype=torch.float64, device="cuda"))
+    chordal.cholesky_projected_inverse(L, Y)
+    cons = [problems.random_constraints(symb, m, density=0.05, seed=sd) for m, sd in ((5, 42), (7, 43))]
+    rng = np.random.default_rng(44)
+    rhs = [(rng.standard_normal(symb.blklen) * msk, rng.standard_normal(len(c[0]) - 1)) for c in cons]
+    # each system alone, eager
+    alone = []
+    for (cptr, cidx, cval), (bx, by) in zip(cons, rhs):
+        sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=4)
+        solve = sys.factor(L, Y)
+        bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+        solve(bxd, byd, 1.0)
+        alone.append((host(bxd), byd.cpu().numpy()))
+    chordal.lazy_status(symb, True)
+    try:
+        for order in ((0, 1), (1, 0)):
+            systems = [KKTSystem(symb, *c, max_rhs=4) for c in cons]
+            solves = [systems[0].factor(L, Y), systems[1].factor(L, Y)]       # A pending, then B takes the slot
+            for q in order:
+                bxd, byd = dev(symb, rhs[q][0]), torch.from_numpy(rhs[q][1].copy()).cuda()
+                solves[q](bxd, byd, 1.0)
+                chordal.check_status(symb)
+                assert rel(host(bxd)[msk], alone[q][0][msk]) < 1e-11, (order, q)
+                assert rel(byd.cpu().numpy(), alone[q][1]) < 1e-11, (order, q)
+        # a system garbage-collected with its H still waiting
+        dead = KKTSystem(symb, *cons[0], max_rhs=4)
+        dead.factor(L, Y)
+        del dead
+        import gc
+        gc.collect()
+        junk = torch.full((64,), float("nan"), dtype=torch.float64, device="cuda")      # may land in the freed H
+        chordal.check_status(symb)                                # must not factor freed memory (no pending mark left)
+        sys = KKTSystem(symb, *cons[1], max_rhs=4)
+        solve = sys.factor(L, Y)
+        bxd, byd = dev(symb, rhs[1][0]), torch.from_numpy(rhs[1][1].copy()).cuda()
+        solve(bxd, byd, 1.0)
+        chordal.check_status(symb)
+        assert rel(byd.cpu().numpy(), alone[1][1]) < 1e-11
+        assert bool(torch.isnan(junk).all())
+    finally:
+        chordal.lazy_status(symb, False)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_kkt_step_under_delay_injection(seed):
+    """Race hunt: the whole single-rank step -- scaling point in one call, Schur complement with the
+    deferred potrf, two solve_ -- with a seeded random spin kernel behind every internal fork, before every join and before
+    one launch in eight (csp_tune CSP_TUNE_RACE).  Every cross-stream edge that is missing shows as a changed result."""
+    symb, S, A, msk = setup("nested_mid", 51)
+    m = 40
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.002, seed=52)
+    rng = np.random.default_rng(53)
+    bx, by = rng.standard_normal(symb.blklen) * msk, rng.standard_normal(m)
+
+    def step(lazy):
+        L = dev(symb, A)
+        Y = cspmatrix(symb, torch.empty(symb.blklen, dtype=torch.float64, device="cuda"))
+        sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+        chordal.lazy_status(symb, lazy)
+        try:
+            chordal.cholesky_projected_inverse(L, Y)
+            solve = sys.factor(L, Y)
+            out = []
+            for _ in range(2):
+                bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+                solve(bxd, byd, 1.0)
+                out.append((host(bxd), byd.cpu().numpy()))
+            if lazy:
+                chordal.check_status(symb)
+            return out, sys.H.cpu().numpy()
+        finally:
+            chordal.lazy_status(symb, False)
+
+    ref, Href = step(False)
+    chordal.tune(symb, chordal.TUNE_RACE, seed)
+    n0 = chordal.race_injected(symb)
+    try:
+        for lazy in (True, False):
+            got, H = step(lazy)
+            assert rel(np.tril(H), np.tril(Href)) < 1e-11, (seed, lazy)
+            for (x, y), (xr, yr) in zip(got, ref):
+                assert rel(x[msk], xr[msk]) < 1e-10 and rel(y, yr) < 1e-10, (seed, lazy, rel(x[msk], xr[msk]), rel(y, yr))
+    finally:
+        chordal.tune(symb, chordal.TUNE_RACE, 0)
+    assert chordal.race_injected(symb) - n0 >= 20          # the harness did run (forks, joins, one launch in eight)
+
+
+def test_delay_injection_detects_a_removed_join():
+    """The harness's own sensitivity: with the joins of the side branches removed (TUNE_RACE_DROP_JOINS) the deferred potrf(H)
+    of kkt_solve is no longer ordered before potrs, and under delay injection the step must come out WRONG for at least one
+    of a few seeds -- a harness that could not see a missing edge would prove nothing by passing."""
+    symb, S, A, msk = setup("nested_mid", 61)
+    m = 40
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.002, seed=62)
+    rng = np.random.default_rng(63)
+    bx, by = rng.standard_normal(symb.blklen) * msk, rng.standard_normal(m)
+    sys = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+
+    def step():
+        L = dev(symb, A)
+        Y = cspmatrix(symb, torch.empty(symb.blklen, dtype=torch.float64, device="cuda"))
+        chordal.cholesky_projected_inverse(L, Y)
+        solve = sys.factor(L, Y)
+        bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+        solve(bxd, byd, 1.0)
+        torch.cuda.synchronize()
+        return byd.cpu().numpy()
+
+    chordal.lazy_status(symb, True)
+    try:
+        ref = step()
+        chordal.check_status(symb)
+        changed = 0
+        chordal.tune(symb, chordal.TUNE_RACE_DROP_JOINS, 1)
+        try:
+            for seed in (71, 72, 73, 74):
+                chordal.tune(symb, chordal.TUNE_RACE, seed)
+                y = step()
+                changed += int(not (rel(y, ref) < 1e-10))            # (NaN counts as changed)
+        finally:
+            chordal.tune(symb, chordal.TUNE_RACE, 0)
+            chordal.tune(symb, chordal.TUNE_RACE_DROP_JOINS, 0)
+        try:
+            chordal.check_status(symb)                                # whatever the broken runs latched is discarded
+        except ArithmeticError:
+            pass
+        assert changed >= 1
+        assert rel(step(), ref) < 1e-12                               # and the context is sound again
+        chordal.check_status(symb)
     finally:
         chordal.lazy_status(symb, False)
 
