@@ -281,7 +281,7 @@ int csp_touch(csp_ctx* ctx, const void* ptr);
                                      call it between Newton steps; a kkt_qr factor held in the stack is invalidated and
                                      kkt_qr_solve returns SMCP_EINVAL until the next kkt_qr_factor.  Worth it for runs of many
                                      Newton steps on one problem; off unless called */
-#define CSP_TUNE_RACE 5           /* value = seed (0: off), PROCESS-wide: delay injection for race hunting -- a spin kernel of a
+#define CSP_TUNE_RACE 5           /* value = seed (low 32 bits; 0: off) | longest delay in us << 32 (0: 200), PROCESS-wide: delay injection for race hunting -- a spin kernel of a
                                      seeded random 5 .. 200 us at the head and tail of every internal side-stream branch, behind every
                                      fork on the caller's stream and before one launch in four (tools/race_hunt.sh; the environment
                                      variable SMCP_RACE=<seed> does the same from the first call on).  Results must not change. */

@@ -104,10 +104,10 @@ inline hipError_t end_call(csp_ctx* c) {
 // ---- delay injection (tools/race_hunt.sh, tests/test_gpu_distributed.py::test_sharded_step_under_delay_injection) ------
 // A missing stream edge shows only when the unordered side happens to run late.  With SMCP_RACE=<seed> (or
 // csp_tune(ctx, CSP_TUNE_RACE, seed); process-wide, 0 = off) a one-wave spin kernel of a seeded random 5 .. 200 us is put
-//   * at the head of every side branch (the branch starts late: a consumer that does not wait for its join reads old data),
-//   * on the caller's stream right behind every fork (the caller runs late: a branch that needs something the caller
-//     launches AFTER the fork reads old data),
-//   * at the tail of every side branch, before its join event is recorded,
+//   * EITHER at the head of a side branch (the branch starts late: a consumer that does not wait for its join reads old
+//     data) OR on the caller's stream right behind the fork (the caller runs late: a branch that needs something the caller
+//     launches AFTER the fork reads old data) -- one of the two per fork, by the draw,
+//   * at the tail of every other side branch, before its join event is recorded,
 //   * before one launch in four of the launch helpers, on whatever stream the launch goes to (host-side readers, copies
 //     and collectives issued by the caller between two library calls meet a device that is still busy).
 // The spin reads the constant 100 MHz counter and gives up after a bounded number of polls: it cannot hang a stream.
@@ -118,6 +118,7 @@ __global__ void k_race_spin(long long ticks) {
 struct RaceInject {
   std::atomic<uint64_t> state{0};
   std::atomic<int64_t> injected{0};
+  std::atomic<int> max_us{200};
   std::atomic<int> drop_joins{0};      // CSP_TUNE_RACE_DROP_JOINS: the harness's own sensitivity test (results are WRONG by design)
   bool on() const { return state.load(std::memory_order_relaxed) != 0; }
   void seed(uint64_t s) { state.store(s ? (s * 0x9E3779B97F4A7C15ull) | 1ull : 0ull); }
@@ -140,7 +141,7 @@ inline void race_delay(hipStream_t s, bool always = true) {
   if (!r.on()) return;
   const uint64_t x = r.next();
   if (!always && (x >> 40) % 4 != 0) return;
-  const long long us = 5 + (long long)((x >> 16) % 196);
+  const long long us = 5 + (long long)((x >> 16) % (uint64_t)std::max(1, r.max_us.load(std::memory_order_relaxed) - 4));
   hipLaunchKernelGGL(k_race_spin, dim3(1), dim3(64), 0, s, us * 100);
   r.injected.fetch_add(1, std::memory_order_relaxed);
 }
@@ -186,13 +187,18 @@ struct Fork {
     if (hipStreamWaitEvent(c->aux_stream[which], c->aux_fork, 0) != hipSuccess) return;
     s = c->aux_stream[which];
     on = true;
-    race_delay(s);        // (delay injection: the branch starts late, the caller's stream goes on late)
-    race_delay(main);
+    // (delay injection: EITHER the branch starts late OR the caller's stream goes on late -- both at once would cancel)
+    // (the harness's self-test, drop_joins: the branch is late by the longest delay, every time -- the removed edge MUST show)
+    if (race_inject().on()) {
+      if (race_inject().drop_joins.load(std::memory_order_relaxed)) {
+        hipLaunchKernelGGL(k_race_spin, dim3(1), dim3(64), 0, s, (long long)race_inject().max_us.load() * 100);
+      } else race_delay((race_inject().next() >> 33) & 1 ? s : main);
+    }
   }
   void join() {
     if (!on) return;
     on = false;
-    race_delay(s);        // (delay injection: the branch ends late)
+    if (race_inject().on() && ((race_inject().next() >> 33) & 1)) race_delay(s);        // (delay injection: the branch ends late)
     if (race_inject().drop_joins.load(std::memory_order_relaxed)) { (void)hipEventRecord(c->aux_join[which], s); return; }   // (harness self-test: the edge is removed)
     if (hipEventRecord(c->aux_join[which], s) != hipSuccess || hipStreamWaitEvent(main, c->aux_join[which], 0) != hipSuccess)
       (void)hipStreamSynchronize(s);      // fall back to a host wait: the branch must be complete before the caller goes on
@@ -3056,7 +3062,8 @@ int csp_tune(csp_ctx* c, int what, int64_t value) {
       return 0;
     case CSP_TUNE_RACE:
       if (value < 0) return SMCP_EINVAL;
-      race_inject().seed((uint64_t)value);
+      race_inject().max_us.store((value >> 32) > 0 ? (int)std::min<int64_t>(value >> 32, 5000) : 200);
+      race_inject().seed((uint64_t)(value & 0xffffffffll));
       return 0;
     case CSP_TUNE_RACE_DROP_JOINS:
       race_inject().drop_joins.store(value != 0);

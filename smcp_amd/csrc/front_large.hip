@@ -381,7 +381,7 @@ __device__ inline int alds_batches(int nac) { return nac > 0 ? (min(nac, 128) + 
 // its waves a few KB apart, instead of sixteen streams 16 KB apart that each stop and start (what the DRAM pages see: 256
 // streams on the chip instead of 4096) -- and a front with fewer children than waves keeps every wave busy without a
 // special case.
-__device__ inline void lf_add_children_stream(double* T, int nf, const double* ubase, const int32_t* relidx, const int64_t* sCu,
+__device__ __forceinline__ void lf_add_children_stream(double* T, int nf, const double* ubase, const int32_t* relidx, const int64_t* sCu,
                                               const int64_t* sCr, const int* sCn, int nmine, int wave, int nw, int lane) {
   auto cb = [nf](int j) { return j * nf - ((j * (j - 1)) >> 1) - j; };
   auto norm = [&](int q, int b) {                       // (child q, batch b of it or of a later child) -> item
@@ -1243,7 +1243,7 @@ __device__ inline void tri_inv64_pad(double* D, int w) {     // rows / columns b
 }
 // (LBD: leading dimension of D and Di in LDS; LBD - 1 = 64 or, for blocks of at most 32 rows, 32)
 template <int LBD = LB + 1>
-__device__ inline void tri_inv64_rd(double* D, int w, double* Di, double* s16) {
+__device__ __forceinline__ void tri_inv64_rd(double* D, int w, double* Di, double* s16) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   tri_inv64_pad<LBD>(D, w);
   __syncthreads();

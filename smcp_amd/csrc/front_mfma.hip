@@ -425,16 +425,21 @@ __device__ inline int potrf_inv16_readlane(double* D, int ld, int w, double* Din
   return fail_flag;
 }
 // The same on the matrix pipe (round 2: potrf_inv16_readlane above costs 6.8 us per call -- 256 dependent v_readlane pairs
-// -- and sits on the critical path of every factorisation kernel; scratch/micro/potrf16_bench.hip).  All 64 lanes hold the
+// -- and sits on the critical path of every factorisation kernel; tools/micro/potrf16_bench.hip).  All 64 lanes hold the
 // block in the accumulator layout of v_mfma_f64_16x16x4: lane (j = lane & 15, q = lane >> 4), register r <-> entry
 // (row j, column q + 4 r).  In that layout a register r of a matrix W is at once the instruction's A operand
 // W[:, 4r:4r+4] and its B operand W[:, 4r:4r+4]^T, and mfma(a from U, b from W) leaves W U^T in the same layout: no
 // data moves between lanes.  Four block steps of four columns: the 4 x 4 diagonal block (ten v_readlane pairs) is
 // factored and inverted redundantly by every lane in closed form, the rows below are scaled by one MFMA
 // (P = M[:, blk] X^T), the trailing block updated by another (M -= P P^T), and the transpose T of the inverse grows
-// by T[0:4b, blk] = -(T11 L21^T) X^T (b + 1 MFMAs, off the critical path).  Same interface and results (to rounding)
-// as potrf_inv16_readlane: 4.0 us for a full block, 2.3 us for w = 5 (the leaves of synth50k).
-__device__ inline int potrf_inv16(double* D, int ld, int w, double* Dinv) {
+// by T[0:4b, blk] = -(T11 L21^T) X^T (b + 1 MFMAs).  Same interface and results as potrf_inv16_readlane.
+// Round 5: the routine is issue-bound (a wave issues ~4.6 cycles per instruction here), so the count is what matters --
+// 1415 instructions inlined as written in round 2, 1110 now: the pivot guards are ONE compare + scalar AND each (a failed
+// pivot lets NaN / Inf run through arithmetic that feeds no address; the caller gets the verdict and stores nothing), the
+// rows of X and L at a lane's column quad come from 0 / 1 lane masks by FMA instead of nested selects, and the routine is
+// FORCED inline: left to the inliner it was an out-of-line function (36 call sites) reaching its LDS operands through flat
+// pointers.  3.90 -> 2.48 us for a full block, 2.23 -> 1.42 us for w = 5 (the leaves of synth50k).  Returns 0 or 1.
+__device__ __forceinline__ int potrf_inv16(double* D, int ld, int w, double* Dinv) {
   __shared__ int fail_flag2;
   __syncthreads();
   if (threadIdx.x < 64) {
@@ -446,9 +451,10 @@ __device__ inline int potrf_inv16(double* D, int ld, int w, double* Dinv) {
       m[r] = (j < w && c <= j) ? D[j + c * ld] : (j == c ? 1.0 : 0.0);
       t[r] = 0.0;
     }
-    int fail = 0;
+    bool ok = true;
     const int nb = (w + 3) >> 2;
     const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    const double e0 = q == 0 ? 1.0 : 0.0, e1 = q == 1 ? 1.0 : 0.0, e2 = q == 2 ? 1.0 : 0.0, e3 = q == 3 ? 1.0 : 0.0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (b < nb) {
@@ -458,56 +464,56 @@ __device__ inline int potrf_inv16(double* D, int ld, int w, double* Dinv) {
                      d31 = readlane_f64(m[b], r0 + 19), d22 = readlane_f64(m[b], r0 + 34), d32 = readlane_f64(m[b], r0 + 35),
                      d33 = readlane_f64(m[b], r0 + 51);
         double l00, l11, l22, l33, i0, i1, i2, i3;
-        if (!(d00 > 0.0) && !fail) fail = r0 + 1;
-        fast_sqrt_rsqrt(fail ? 1.0 : d00, l00, i0);
+        ok = ok && (d00 > 0.0);
+        fast_sqrt_rsqrt(d00, l00, i0);
         const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
         const double p1 = fma(-l10, l10, d11);
-        if (!(p1 > 0.0) && !fail) fail = r0 + 2;
-        fast_sqrt_rsqrt(fail ? 1.0 : p1, l11, i1);
+        ok = ok && (p1 > 0.0);
+        fast_sqrt_rsqrt(p1, l11, i1);
         const double l21 = fma(-l20, l10, d21) * i1, l31 = fma(-l30, l10, d31) * i1;
         const double p2 = fma(-l21, l21, fma(-l20, l20, d22));
-        if (!(p2 > 0.0) && !fail) fail = r0 + 3;
-        fast_sqrt_rsqrt(fail ? 1.0 : p2, l22, i2);
+        ok = ok && (p2 > 0.0);
+        fast_sqrt_rsqrt(p2, l22, i2);
         const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * i2;
         const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
-        if (!(p3 > 0.0) && !fail) fail = r0 + 4;
-        fast_sqrt_rsqrt(fail ? 1.0 : p3, l33, i3);
+        ok = ok && (p3 > 0.0);
+        fast_sqrt_rsqrt(p3, l33, i3);
         // X = inverse of the 4 x 4 factor
         const double x10 = -l10 * i0 * i1, x21 = -l21 * i1 * i2, x32 = -l32 * i2 * i3;
         const double x20 = -fma(l21, x10, l20 * i0) * i2, x31 = -fma(l32, x21, l31 * i1) * i3;
         const double x30 = -fma(l32, x20, fma(l31, x10, l30 * i0)) * i3;
-        // lane (row 4b + u, q): X[u][q] (operand "X at the rows of the block") and the factor's L[u][q]
+        // lane (row 4b + u, q): X[u][q] (operand "X at the rows of the block") and the factor's L[u][q]: rows u = 0 .. 3 of both at
+        // this lane's q from the 0 / 1 masks, then the row this lane's j asks for
         const int u = j - r0;
-        const double xr0 = q == 0 ? i0 : 0.0;
-        const double xr1 = q == 0 ? x10 : (q == 1 ? i1 : 0.0);
-        const double xr2 = q == 0 ? x20 : (q == 1 ? x21 : (q == 2 ? i2 : 0.0));
-        const double xr3 = q == 0 ? x30 : (q == 1 ? x31 : (q == 2 ? x32 : i3));
-        const double xa = u == 0 ? xr0 : (u == 1 ? xr1 : (u == 2 ? xr2 : (u == 3 ? xr3 : 0.0)));
-        const double lr0 = q == 0 ? l00 : 0.0;
-        const double lr1 = q == 0 ? l10 : (q == 1 ? l11 : 0.0);
-        const double lr2 = q == 0 ? l20 : (q == 1 ? l21 : (q == 2 ? l22 : 0.0));
-        const double lr3 = q == 0 ? l30 : (q == 1 ? l31 : (q == 2 ? l32 : l33));
-        const double la = u == 0 ? lr0 : (u == 1 ? lr1 : (u == 2 ? lr2 : (u == 3 ? lr3 : 0.0)));
+        const double xr0 = e0 * i0, xr1 = fma(e0, x10, e1 * i1), xr2 = fma(e0, x20, fma(e1, x21, e2 * i2)),
+                     xr3 = fma(e0, x30, fma(e1, x31, fma(e2, x32, e3 * i3)));
+        const double lr0 = e0 * l00, lr1 = fma(e0, l10, e1 * l11), lr2 = fma(e0, l20, fma(e1, l21, e2 * l22)),
+                     lr3 = fma(e0, l30, fma(e1, l31, fma(e2, l32, e3 * l33)));
+        const bool u0 = u == 0, u1 = u == 1, u2 = u == 2, u3 = u == 3;
+        const double xa = u0 ? xr0 : (u1 ? xr1 : (u2 ? xr2 : (u3 ? xr3 : 0.0)));
+        const double la = u0 ? lr0 : (u1 ? lr1 : (u2 ? lr2 : lr3));
         // rows below the block: P[j][q] = sum_k M[j][4b + k] X[q][k]  (register b of the result)
         const d4 pan = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, m[b], zero4, 0, 0, 0);
-        m[b] = j >= r0 + 4 ? pan[b] : la;
+        const bool below = j >= r0 + 4;
+        m[b] = below ? pan[b] : la;
         if (b + 1 < nb) {            // trailing block -= P P^T
-          const double pb = j >= r0 + 4 ? m[b] : 0.0;
+          const double pb = below ? pan[b] : 0.0;
           const d4 upd = __builtin_amdgcn_mfma_f64_16x16x4f64(pb, pb, zero4, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) if (r > b) m[r] -= upd[r];
         }
         // transpose of the inverse: rows < 4b of the block's columns = -(T11 L21^T) X^T, the block itself X^T
+        const bool inblk = u >= 0 && u < 4;
         d4 g = zero4;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-          if (s < b) g = __builtin_amdgcn_mfma_f64_16x16x4f64((u >= 0 && u < 4) ? m[s] : 0.0, t[s], g, 0, 0, 0);
-        const double wb = j < r0 ? g[b] : ((u >= 0 && u < 4 && u == q) ? -1.0 : 0.0);
+          if (s < b) g = __builtin_amdgcn_mfma_f64_16x16x4f64(inblk ? m[s] : 0.0, t[s], g, 0, 0, 0);
+        const double wb = j < r0 ? g[b] : ((inblk && u == q) ? -1.0 : 0.0);
         const d4 tn = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, wb, zero4, 0, 0, 0);
         t[b] = j < r0 + 4 ? -tn[b] : 0.0;
       }
     }
-    if (!fail) {
+    if (ok) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = q + 4 * r;
@@ -515,13 +521,13 @@ __device__ inline int potrf_inv16(double* D, int ld, int w, double* Dinv) {
         Dinv[c + j * 16] = (c < w && j < w) ? t[r] : 0.0;      // t[r] = X(c, j)
       }
     }
-    if (l == 0) fail_flag2 = fail;
+    if (l == 0) fail_flag2 = ok ? 0 : 1;
   }
   __syncthreads();
   return fail_flag2;
 }
 // inverse only (block already a Cholesky factor / lower triangular)
-__device__ inline void tri_inv16(const double* D, int ld, int w, double* Dinv) {
+__device__ __forceinline__ void tri_inv16(const double* D, int ld, int w, double* Dinv) {
   __syncthreads();
   if (threadIdx.x < 64) {
     const int i = threadIdx.x;

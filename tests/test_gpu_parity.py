@@ -1306,8 +1306,8 @@ def test_delay_injection_detects_a_removed_join():
         changed = 0
         chordal.tune(symb, chordal.TUNE_RACE_DROP_JOINS, 1)
         try:
-            for seed in (71, 72, 73, 74):
-                chordal.tune(symb, chordal.TUNE_RACE, seed)
+            for seed in range(71, 75):
+                chordal.tune(symb, chordal.TUNE_RACE, seed | (2000 << 32))          # every side branch 2 ms late: potrs meets the raw H
                 y = step()
                 changed += int(not (rel(y, ref) < 1e-10))            # (NaN counts as changed)
         finally:
