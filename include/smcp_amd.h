@@ -29,6 +29,8 @@ typedef struct csp_ctx csp_ctx;
 #define SMCP_ENOMEM (-4)
 #define SMCP_ESTALE (-5)  /* the prepared sharded factor was overwritten by another call (kkt_prepare_part again), or -- with
                              CSP_TUNE_VERIFY_CACHE -- a cached quantity is older than the matrix it was derived from */
+#define SMCP_ETIMEOUT (-6) /* a workgroup of the one-launch blocked Cholesky (csrc/front_flow.hip) waited longer than 3 s for a tile
+                             of another workgroup: the launch gave up instead of hanging (never seen; the results are invalid) */
 
 /* ---- symbolic layer (host only, no GPU needed) ------------------------------------- */
 

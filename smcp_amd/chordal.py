@@ -19,7 +19,8 @@ def _chk(rc, what):
         raise RuntimeError("%s failed (%d): %s" % (what, rc, {
             -1: "invalid argument", -2: "no MI355X device initialised (no CPU fallback)",
             -3: "HIP error", -4: "out of memory",
-            -5: "stale derived quantities (prepared sharded factor overwritten, or a matrix changed without csp_touch)"}.get(rc, "?")))
+            -5: "stale derived quantities (prepared sharded factor overwritten, or a matrix changed without csp_touch)",
+            -6: "in-launch dependency wait timed out (one-launch blocked Cholesky)"}.get(rc, "?")))
 
 
 def _ensure(symb, nrhs=1):

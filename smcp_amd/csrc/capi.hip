@@ -28,6 +28,7 @@
 #include "front_lfsp.hip"
 #include "front_leafgram.hip"
 #include "front_famt.hip"
+#include "front_flow.hip"
 
 using namespace smcp;
 
@@ -57,7 +58,7 @@ enum {
   KID_factor_inverse, KID_hess_down_inv_mfma, KID_hess_down_inv_mfma_hbm, KID_hess_up_inv_mfma, KID_hess_up_inv_mfma_hbm,
   KID_completion_mfma, KID_completion_mfma_hbm, KID_lf_copy_an, KID_lf_ri_an, KID_lf_dinv1, KID_lf_dinv2,
   KID_lf_uinv1, KID_lf_uinv2, KID_lf_completion, KID_hess_up_n16, KID_llt_mfma, KID_llt_mfma_hbm, KID_lf_llt,
-  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn, KID_lf_zsp, KID_fam_terms_grp, KID_lf_assemble_fz, KID_factor_inverse_lds,
+  KID_hess_up_fam, KID_qr_rmul, KID_qr_dots, KID_qr_comb, KID_qr_small, KID_fam2_prep, KID_mid_chol, KID_lf_diag_inv, KID_lfsp_up, KID_lfsp_prep, KID_leaf_gram, KID_leaf_tables, KID_fam_sparse, KID_gram_diag128, KID_lf_assemble_lds, KID_fam_terms, KID_famt_prep, KID_lf_assemble_lds_dyn, KID_lf_zsp, KID_fam_terms_grp, KID_lf_assemble_fz, KID_factor_inverse_lds, KID_chol_flow,
   KID_COUNT
 };
 const char* const KID_NAMES[KID_COUNT] = {
@@ -75,7 +76,7 @@ const char* const KID_NAMES[KID_COUNT] = {
   "k_hess_up_inv_mfma<false>", "k_completion_mfma<true>", "k_completion_mfma<false>", "k_lf_copy_an", "k_lf_ri_an",
   "k_lf_dinv1", "k_lf_dinv2", "k_lf_uinv1", "k_lf_uinv2", "k_lf_completion", "k_hess_up_n16",
   "k_llt_mfma<true>", "k_llt_mfma<false>", "k_lf_llt", "k_hess_up_fam",
-  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn", "k_lf_zsp", "k_fam_terms_grp", "k_lf_assemble_fz", "k_factor_inverse_lds"};
+  "k_stack_trsm", "k_stack_dots", "k_stack_comb", "k_qr_small", "k_fam2_prep", "k_mid_chol", "k_lf_diag_inv", "k_lfsp_up", "k_lfsp_prep", "k_leaf_pairs", "k_leaf_tables", "k_fam_sparse", "k_gram_diag128", "k_lf_assemble_lds", "k_fam_terms", "k_famt_prep", "k_lf_assemble_lds_dyn", "k_lf_zsp", "k_fam_terms_grp", "k_lf_assemble_fz", "k_factor_inverse_lds", "k_chol_flow"};
 
 // A launch that the runtime refuses (bad configuration, LDS over the limit, ...) must reach the caller: the helpers
 // record the first failure in the context and every entry point ends with end_call(), which returns it.
@@ -767,6 +768,77 @@ bool use_mid(int rowsmax) {
   }
   return g == 1 && rowsmax <= MID_MAXROWS;
 }
+// ---- one-launch blocked Cholesky with in-launch tile dataflow (front_flow.hip) ---------------------------------------------
+// Factors ONE matrix of order n (129 .. 4096): either the plain dense matrix A (leading dimension ld; fa == nullptr: info /
+// info_val as given) or the matrix of the single front of the launch list of *fa (mode 0: a front without separator, base =
+// the blkval array; mode 2: its Y_AA block, base = fac).  dinv: where the inverses of the diagonal blocks go (64 x 64 slots;
+// nullptr: the workspace's own).  Returns false when the route does not apply or its set-up fails (the caller takes the
+// per-step kernels); SMCP_FLOW=0: never.
+bool flow_chol(csp_ctx* c, hipStream_t st, double* A, int64_t ld, int n, double* dinv, const MfmaArgs* fa, int mode, int* info, int info_val) {
+  static int on = -1, wgs = 0;
+  if (on < 0) { on = sw_on("SMCP_FLOW", 1); wgs = std::max(1, std::min(FLOW_MAXWG, sw_int("SMCP_FLOW_WG", FLOW_MAXWG))); }
+  if (!on || use_generic(c) || n <= 2 * LB || n > FLOW_MAXN || !info) return false;
+  static int attr = -1;
+  if (attr < 0) attr = hipFuncSetAttribute((const void*)k_chol_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_BYTES) == hipSuccess ? 1 : 0;
+  if (!attr) return false;
+  const int nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
+  csp_ctx::FlowWs& W = c->flow_ws[st == c->aux_stream[0] && st ? 1 : (st == c->aux_stream[1] && st ? 2 : 0)];
+  if (W.cap_nt < nt) {
+    // (the buffers may be in use by a launch still queued on this stream: hipFree waits for the device)
+    for (void* q : {(void*)W.P, (void*)W.dinv, (void*)W.flags}) if (q) (void)hipFree(q);
+    W = csp_ctx::FlowWs();
+    int64_t junk = 0;
+    if (dev_alloc(&W.P, (int64_t)ntiles * 4096, junk) || dev_alloc(&W.dinv, (int64_t)nt * 4096, junk) ||
+        hipMalloc((void**)&W.flags, sizeof(unsigned) * (size_t)(ntiles + nt + 4)) != hipSuccess ||
+        hipMemset(W.flags, 0, sizeof(unsigned) * (size_t)(ntiles + nt + 4)) != hipSuccess) {
+      (void)hipGetLastError();
+      for (void* q : {(void*)W.P, (void*)W.dinv, (void*)W.flags}) if (q) (void)hipFree(q);
+      W = csp_ctx::FlowWs();
+      return false;
+    }
+    c->D.bytes += junk + (int64_t)sizeof(unsigned) * (ntiles + nt + 4);
+    W.cap_nt = nt;
+  }
+  auto it = c->flow_plans.find(n);
+  if (it == c->flow_plans.end()) {
+    std::vector<int32_t> optr, otile;
+    // (beyond order 2048 -- 528 tiles -- twice the workgroups: the trailing updates, not the chain of diagonal tiles, set the time there;
+    // two such launches still fit the chip side by side)
+    flow_make_plan(n, n > 2048 ? 2 * wgs : wgs, optr, otile);
+    csp_ctx::FlowPlanDev P;
+    P.nwg = (int)optr.size() - 1;
+    int64_t junk = 0;
+    if (dev_upload(&P.own_ptr, optr, junk) || dev_upload(&P.own_tile, otile, junk)) { (void)hipGetLastError(); return false; }
+    c->D.bytes += junk;
+    it = c->flow_plans.emplace(n, P).first;
+  }
+  FlowArgs f;
+  f.A = A; f.ld = ld; f.n = n;
+  f.dinv = dinv ? dinv : W.dinv;
+  f.P = W.P; f.flags = W.flags;
+  // flags are never cleared: a set flag of this launch carries its epoch.  The words of a SMALLER matrix's launch lie elsewhere
+  // in the array (the offsets depend on nt), but any word ever written holds an older epoch, which never equals a newer one
+  f.epoch = ++W.epoch;
+  f.own_ptr = it->second.own_ptr; f.own_tile = it->second.own_tile;
+  f.info = info; f.info_val = info_val;
+  f.cl = fa ? fa->t.cl : nullptr; f.lev = fa ? fa->t.lev : nullptr; f.mode = mode; f.nsn1 = fa ? fa->t.nsn1 : 1;
+  f.dbg = nullptr;
+  static int stamps = -1;
+  if (stamps < 0) stamps = sw_on("SMCP_FLOW_STAMPS", 0);
+  static long long* dbg = nullptr;
+  if (stamps) { if (!dbg) (void)hipMalloc((void**)&dbg, sizeof(long long) * 16 * FLOW_MAXWG); f.dbg = dbg; }
+  launch_lds(c, KID_chol_flow, k_chol_flow, dim3(it->second.nwg), dim3(256), FLOW_LDS_BYTES, st, f);
+  if (stamps && dbg) {           // timing studies: what the workgroups spent their time on, on stderr
+    std::vector<long long> h((size_t)8 * it->second.nwg);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    for (int w = 0; w < std::min(it->second.nwg, 20); ++w)
+      fprintf(stderr, "flow n %d wg %3d: idle %7.1f us (%lld)  update %7.1f us (%lld)  potrf %7.1f us (%lld)  panel %7.1f us (%lld)\n", n, w,
+              h[8 * w] / 100.0, h[8 * w + 4], h[8 * w + 1] / 100.0, h[8 * w + 5], h[8 * w + 2] / 100.0, h[8 * w + 6], h[8 * w + 3] / 100.0, h[8 * w + 7]);
+  }
+  return true;
+}
+
 void lf_chol(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) {
   dim3 blk(256);
   const int nfmax = a.nnmax + a.namax;
@@ -775,6 +847,8 @@ void lf_chol(csp_ctx* c, const MfmaArgs& a, int cnt, double* x, hipStream_t st) 
     launch_lds(c, KID_mid_chol, k_mid_chol, dim3(cnt), dim3(1024), mid_chol_lds(nfmax), st, a, x, (double*)nullptr, 0);
     return;
   }
+  // ONE front without separator (a root): the whole blocked factorisation in one launch
+  if (cnt == 1 && a.namax == 0 && flow_chol(c, st, x, 0, a.nnmax, nullptr, &a, 0, a.t.info, 0)) return;
   const int mtA = tiles64(a.namax);
   for (int jb = 0; jb < a.nnmax; jb += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, a, x, (double*)nullptr, 0, jb, 1);
@@ -793,6 +867,7 @@ void lf_factor_yaa(csp_ctx* c, const MfmaArgs& a, int cnt, double* fac, hipStrea
     launch_lds(c, KID_mid_chol, k_mid_chol, dim3(cnt), dim3(1024), mid_chol_lds(a.namax), st, a, (double*)nullptr, fac, 2);
     return;
   }
+  if (cnt == 1 && flow_chol(c, st, fac, 0, a.namax, nullptr, &a, 2, a.t.info, 0)) return;
   for (int jb = 0; jb < a.namax; jb += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, a, (double*)nullptr, fac, 2, jb, 1);
     const int mrem = a.namax - jb - 1;
@@ -2010,6 +2085,8 @@ void csp_symbolic_destroy(csp_ctx* c) {
                     D.a_r, D.a_c, D.s_rloc, D.s_cloc, D.dlist, D.slist, D.kidx, D.vbuf, D.hd, D.kc_ptr, D.kc_off, D.kc_val, D.hinv, D.kc_ij, D.famc, D.scm_owner};
     if (c->side_fork) { Fork* f = (Fork*)c->side_fork; c->side_fork = nullptr; f->join(); delete f; }
     D.h_pending = nullptr;      // (a deferred factorisation nobody asked for dies with the context)
+    for (auto& W : c->flow_ws) for (void* q : {(void*)W.P, (void*)W.dinv, (void*)W.flags}) if (q) hipFree(q);
+    for (auto& kv : c->flow_plans) { if (kv.second.own_ptr) hipFree(kv.second.own_ptr); if (kv.second.own_tile) hipFree(kv.second.own_tile); }
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& G : c->lfsp_grp) { if (G.ptr) hipFree(G.ptr); if (G.list) hipFree(G.list); }
     for (auto& G : c->famt_grp) { if (G.ptr) hipFree(G.ptr); if (G.list) hipFree(G.list); }

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <functional>
+#include <map>
 #include <vector>
 
 #include "symbolic.hpp"
@@ -243,6 +244,12 @@ struct csp_ctx {
   bool fz_live = false; int fz_nat = 0, fz_cnn = 0; int64_t fz_recl = 0;   // the running sweep's family launch left the parents' updates to the extend-add above (k_lf_assemble_fz)
   bool plan_full_upd = false;           // the gather plans list every update-block position of the large fronts (no clear pass needed)
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status
+  // one-launch blocked Cholesky with in-launch tile dataflow (front_flow.hip): workspace per stream in use (caller's, side 0,
+  // side 1: two such launches may run side by side) and the ownership plans by matrix order
+  struct FlowWs { double* P = nullptr; double* dinv = nullptr; unsigned* flags = nullptr; int cap_nt = 0; unsigned epoch = 0; };
+  FlowWs flow_ws[3];
+  struct FlowPlanDev { int nwg = 0; int32_t* own_ptr = nullptr; int32_t* own_tile = nullptr; };
+  std::map<int, FlowPlanDev> flow_plans;
   double placement_probe[2] = {0.0, 0.0};   // CSP_TUNE_PLACEMENT: probe time before / after, ms
   bool flags_clean = false;             // lazy mode: the last thing done to the flags was k_latch_status (which leaves them zero)
   int launch_err = 0;                   // first failed kernel launch of the running call (launch helpers); read by end_call

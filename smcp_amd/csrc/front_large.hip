@@ -1263,10 +1263,88 @@ __device__ __forceinline__ void tri_inv64_rd(double* D, int w, double* Di, doubl
   tri_inv64_offdiag<LBD>(D, w, Di, s16);
 }
 
+// Cholesky + inverse of a w x w (w <= 64) lower block D in LDS (ld LBD; EVERYTHING outside the lower triangle of the leading
+// w x w block zero, up to 64 x 64) -> D = L, Di = L^-1 (ld LBD, zeros above the diagonal).  xs: 4 x 256 doubles (the inverses
+// of the four 16 x 16 diagonal blocks), s16: 1024 doubles.  At least four waves.  Returns 0 or 1 (uniform).
+// Round 5: the sixteen-column steps of potrf_inv64 below each ran potrf_inv16 on one wave with the others idle, then two
+// generic wg_mma calls (rows below x the block's inverse; trailing update) and three barriers -- 26 us for a full block on
+// four waves, 2/3 of a 64-column step of the blocked Cholesky whichever way its launches are organised.  Here a step has
+// two barriers and its critical path is wave 0's alone: update of the next diagonal 16 x 16 tile (4 MFMAs), its Cholesky
+// and inverse (wave_potrf_inv16, no barrier inside); the other waves meanwhile do the REST of the previous step's trailing
+// update; after the barrier one wave per 16 x 16 tile scales the rows below (4 MFMAs each).
+__device__ inline int potrf_inv64_fast(double* D, int w, double* Di, double* xs, double* s16) {
+  __shared__ int fail64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  for (int e = tid; e < LB * LBD; e += blockDim.x) Di[e] = 0.0;
+  if (tid == 0) fail64 = 0;
+  const int nb = (w + 15) >> 4;
+  // one 16 x 16 tile product on the calling wave: acc(m, n) = sum_k A[m + k lda] B[n + k ldb], k < 16
+  auto tile_abt = [&](const double* A, int lda, const double* B, int ldb) {
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(B[l15 + (k0 + kq) * ldb], A[l15 + (k0 + kq) * lda], acc, 0, 0, 0);
+    return acc;           // register r <-> (m = l15, n = kq + 4 r)
+  };
+  __syncthreads();
+  for (int b = 0; b < nb; ++b) {
+    const int bw = min(16, w - 16 * b);
+    if (wave == 0) {
+      double* Dbb = D + 16 * b + 16 * b * LBD;
+      if (b > 0) {                      // the diagonal tile's share of the previous step's trailing update
+        const double* P = D + 16 * b + 16 * (b - 1) * LBD;
+        const d4 u = tile_abt(P, LBD, P, LBD);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int n = kq + 4 * r; if (l15 >= n) Dbb[l15 + n * LBD] -= u[r]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      const bool ok = wave_potrf_inv16(Dbb, LBD, bw, xs + 256 * b);
+      if (!ok && lane == 0) fail64 = 1;
+    } else if (b > 0 && wave < 4) {     // the other tiles (r, c), b <= c <= r < nb, (r, c) != (b, b), dealt over waves 1 .. 3
+      int t = 0;
+      for (int c = b; c < nb; ++c)
+        for (int r = c; r < nb; ++r) {
+          if (r == b && c == b) continue;
+          if (t++ % 3 != wave - 1) continue;
+          const double* Pr = D + 16 * r + 16 * (b - 1) * LBD;
+          const double* Pc = D + 16 * c + 16 * (b - 1) * LBD;
+          const d4 u = tile_abt(Pr, LBD, Pc, LBD);
+          double* T = D + 16 * r + 16 * c * LBD;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int n = kq + 4 * q; if (r > c || l15 >= n) T[l15 + n * LBD] -= u[q]; }
+        }
+    }
+    __syncthreads();
+    if (fail64) return 1;
+    // rows below the block x its inverse (transposed), one wave per 16 x 16 tile; the block's inverse to its place in Di
+    if (wave < 4) {
+      const double* X = xs + 256 * b;
+      for (int r = b + 1 + wave; r < nb; r += 4) {
+        double* P = D + 16 * r + 16 * b * LBD;
+        const d4 u = tile_abt(P, LBD, X, 16);          // (P X^T)(m, n) = sum_k P(m, k) X(n, k)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[l15 + (kq + 4 * q) * LBD] = u[q];
+      }
+      if (wave == min(3, nb - b - 1)) {                // the first wave without a tile (or the last one) copies the inverse block
+        for (int e = lane; e < 256; e += 64) { const int i = e & 15, j = e >> 4; if (i >= j) Di[(16 * b + i) + (16 * b + j) * LBD] = X[i + j * 16]; }
+      }
+    }
+    __syncthreads();
+  }
+  tri_inv64_offdiag(D, w, Di, s16);
+  return 0;
+}
+
 // In-LDS Cholesky (do_potrf) and inverse of a w x w (w <= 64) lower block D (ld LBD); the inverse goes
 // to Di (ld LBD, zeros above the diagonal).  d16: 256 doubles, s16: 16 x 64 doubles of scratch.
 // Returns 0 or the 1-based failing pivot (uniform).
 __device__ inline int potrf_inv64(double* D, int w, double* Di, double* d16, double* s16, bool do_potrf) {
+  if (do_potrf && blockDim.x >= 256) {        // the four-wave routine above (s16 serves as its block-inverse buffer as well: disjoint uses)
+    tri_inv64_pad(D, w);
+    __syncthreads();
+    return potrf_inv64_fast(D, w, Di, s16, s16);
+  }
   for (int e = threadIdx.x; e < LB * LBD; e += blockDim.x) Di[e] = 0.0;
   __syncthreads();
   const bool doubling = blockDim.x >= 256;

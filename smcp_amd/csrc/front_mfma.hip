@@ -439,11 +439,10 @@ __device__ inline int potrf_inv16_readlane(double* D, int ld, int w, double* Din
 // rows of X and L at a lane's column quad come from 0 / 1 lane masks by FMA instead of nested selects, and the routine is
 // FORCED inline: left to the inliner it was an out-of-line function (36 call sites) reaching its LDS operands through flat
 // pointers.  3.90 -> 2.48 us for a full block, 2.23 -> 1.42 us for w = 5 (the leaves of synth50k).  Returns 0 or 1.
-__device__ __forceinline__ int potrf_inv16(double* D, int ld, int w, double* Dinv) {
-  __shared__ int fail_flag2;
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int l = threadIdx.x, j = l & 15, q = l >> 4;
+// (the body: called by ONE full wave -- any wave of the workgroup -- with no barrier inside; returns the verdict, wave-uniform)
+__device__ __forceinline__ bool wave_potrf_inv16(double* D, int ld, int w, double* Dinv) {
+  {
+    const int l = threadIdx.x & 63, j = l & 15, q = l >> 4;
     double m[4], t[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -521,7 +520,15 @@ __device__ __forceinline__ int potrf_inv16(double* D, int ld, int w, double* Din
         Dinv[c + j * 16] = (c < w && j < w) ? t[r] : 0.0;      // t[r] = X(c, j)
       }
     }
-    if (l == 0) fail_flag2 = ok ? 0 : 1;
+    return ok;
+  }
+}
+__device__ __forceinline__ int potrf_inv16(double* D, int ld, int w, double* Dinv) {
+  __shared__ int fail_flag2;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const bool ok = wave_potrf_inv16(D, ld, w, Dinv);
+    if (threadIdx.x == 0) fail_flag2 = ok ? 0 : 1;
   }
   __syncthreads();
   return fail_flag2;

@@ -891,6 +891,9 @@ static int potrf_launch(csp_ctx* c, double* A, int64_t n, int64_t lda, hipStream
     if (int rc = dev_alloc(&c->D.hinv, need, c->D.bytes)) return rc;
     c->D.hinv_cap = need;
   }
+  // the whole blocked factorisation in ONE launch (front_flow.hip: tile dataflow inside the launch, the diagonal blocks' inverses
+  // straight to their slots); SMCP_FLOW=0 or beyond 4096: three launches per block column
+  if (flow_chol(c, st, A, lda, (int)n, c->D.hinv, nullptr, 5, info, 1)) return 0;
   for (int jb = 0; jb < (int)n; jb += LB) {
     a.lfd = c->D.hinv + (int64_t)(jb / LB) * LB * LB;      // the diagonal block's inverse goes straight to its slot (potrs reads it there)
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(1), dim3(512), LF_DIAG_LDS, st, a, A, (double*)nullptr, 5, jb, 1);

@@ -55,6 +55,8 @@ static const Switch SWITCHES[] = {
   {"SMCP_ROOT_FUSED", "0", "1: fused two-product sweep of fronts without separator (Y_NN explicit: condition squared; studies only)"},
   {"SMCP_PD", "0", "1: four-wave tile products everywhere (no sixteen-wave shape for small launches)"},
   {"SMCP_POTRF_OLD", "0", "1: generic one-workgroup dense Cholesky"},
+  {"SMCP_FLOW", "1", "0: no one-launch blocked Cholesky with in-launch tile dataflow (front_flow.hip): per-step kernels for dense matrices / single fronts beyond 272 rows"},
+  {"SMCP_FLOW_WG", "112", "workgroups of that launch (at most 112: four launches fit the chip side by side)"},
   {"SMCP_POTRS_OLD", "0", "1: generic one-workgroup dense solve"},
   {"SMCP_POTRS_STEPS", "0", "1: per-block launches of the dense solve instead of k_dense_potrs_one"},
   {"SMCP_POTRF_DEFER", "1", "0: kkt_schur_factor factors H at once even under deferred status"},
@@ -83,6 +85,7 @@ static const Switch SWITCHES[] = {
   {"SMCP_QR_PASSES", "0", "Cholesky-QR passes of kkt_qr (0: decided by the deviation test)"},
   {"SMCP_QR_P", "1", "positions per lane of the FMA substitution kernel (1 or 2)"},
   // ---- diagnostics
+  {"SMCP_FLOW_STAMPS", "0", "1: per-workgroup time accounts of the one-launch blocked Cholesky on stderr (waits for every launch)"},
   {"SMCP_POISON", "0", "1: every fp64 device buffer of the library (and the exchange buffers of smcp_amd/kkt.py) starts as 4.5e150 (hunting reads of never-written workspace)"},
   {"SMCP_RACE", "0", "seed > 0: delay injection on every internal stream hand-over and one launch in eight (race hunting; results must not change)"},
   {"SMCP_TRACE", "0", "1: every launch named on stderr and waited for (a device fault points at its kernel)"},

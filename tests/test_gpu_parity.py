@@ -46,6 +46,11 @@ GPU_PATTERNS["nested_mid"] = lambda: problems.nested_block_arrow_pattern(nsub=2,
 GPU_PATTERNS["dense200"] = lambda: problems.band_pattern(200, 199)
 GPU_PATTERNS["arrow_thin"] = lambda: problems.block_arrow_pattern(6, 2, 150)   # thin cliques, separators beyond LDS
 GPU_PATTERNS["diag"] = lambda: problems.band_pattern(15, 0)          # LP case: every clique is 1 x 1
+# single fronts beyond the one-workgroup class (272 rows): the one-launch blocked Cholesky (front_flow.hip) factors the root
+# (dense600; arrow_one's 310 x 310 root) and the 300 x 300 Y_AA block of arrow_one's only top front
+GPU_PATTERNS["dense600"] = lambda: problems.band_pattern(600, 599)
+GPU_PATTERNS["arrow_one"] = lambda: problems.nested_block_arrow_pattern(nsub=1, nmid=2, nleaf_per_mid=2, leaf=(3, 9), mid=(6, 20), top=(40, 300),
+                                                                        root=310, seed=9)
 # families (front_fam.hip: small parents swept together with their childless children): largest member sizes,
 # odd sizes with few children, and nine children per parent (one more than the waves of a workgroup: no family)
 GPU_PATTERNS["fam_max"] = lambda: problems.nested_block_arrow_pattern(nsub=1, nmid=3, nleaf_per_mid=8, leaf=(16, 32),
@@ -407,27 +412,42 @@ def test_two_kkt_systems_on_one_symbolic_do_not_share_constraints():
         qsolve(dev(symb, x), torch.zeros(q0.m, dtype=torch.float64, device="cuda"), 1.0)
 
 
-@pytest.mark.parametrize("n", [5, 64, 130, 517])
-def test_dense_potrf_potrs(n):
+@pytest.mark.parametrize("n,pad", [(5, 0), (64, 0), (130, 0), (200, 3), (517, 0), (1000, 0), (1027, 5), (2048, 0), (4096, 0)])
+def test_dense_potrf_potrs(n, pad):
     """Schur-complement factor/solve (solvers.py:452,499: lapack.potrf / potrs) at sizes on both sides of the
-    switch from the single-workgroup kernel to the blocked MFMA one."""
+    switch from the single-workgroup kernel to the blocked one -- since round 5 ONE launch with the tile dependencies
+    resolved inside it (front_flow.hip), up to order 4096; a leading dimension beyond the order; a matrix that stops being
+    positive definite at a LATE pivot (the failure must reach the caller from inside the launch, and the next call on the
+    same context must work)."""
     from smcp_amd import _lib
     symb = Symbolic(GPU_PATTERNS["band"]())
     chordal._ensure(symb)
     rng = np.random.default_rng(n)
     M = rng.standard_normal((n, n))
     Hh = M @ M.T + n * np.eye(n)
-    H = torch.from_numpy(Hh.copy()).cuda()
+    ld = n + pad
+    Hp = np.zeros((n, ld))
+    Hp[:, :n] = Hh                                       # (row r of this array = column r of the column-major matrix with ld rows)
+    H = torch.from_numpy(Hp.copy()).cuda()
     b = rng.standard_normal(n)
     bd = torch.from_numpy(b.copy()).cuda()
     lib = _lib.lib()
-    assert lib.dense_potrf(symb.handle, H.data_ptr(), n, n, None) == 0
+    assert lib.dense_potrf(symb.handle, H.data_ptr(), n, ld, None) == 0
     Lref = np.linalg.cholesky(Hh)
-    assert rel(np.tril(H.cpu().numpy().T), Lref) < 1e-12
-    assert lib.dense_potrs(symb.handle, H.data_ptr(), n, n, bd.data_ptr(), 1, n, None) == 0
+    assert rel(np.tril(H.cpu().numpy()[:, :n].T), Lref) < 1e-12
+    assert lib.dense_potrs(symb.handle, H.data_ptr(), n, ld, bd.data_ptr(), 1, n, None) == 0
     assert rel(bd.cpu().numpy(), np.linalg.solve(Hh, b)) < 1e-10
     Hbad = torch.from_numpy((Hh - 2 * np.linalg.eigvalsh(Hh)[1] * np.eye(n)).copy()).cuda()
     assert lib.dense_potrf(symb.handle, Hbad.data_ptr(), n, n, None) > 0
+    if n > 128:
+        # positive definite up to the last 64-column block, not beyond: L L^T with the last pivot's square turned negative
+        Hlate = Hh.copy()
+        Hlate[n - 1, n - 1] = Lref[n - 1, :n - 1] @ Lref[n - 1, :n - 1] - 1e-3
+        Hl = torch.from_numpy(Hlate).cuda()
+        assert lib.dense_potrf(symb.handle, Hl.data_ptr(), n, n, None) > 0
+        H2 = torch.from_numpy(Hh.copy()).cuda()
+        assert lib.dense_potrf(symb.handle, H2.data_ptr(), n, n, None) == 0
+        assert rel(np.tril(H2.cpu().numpy().T), Lref) < 1e-12
 
 
 @pytest.mark.parametrize("name,tnz", [("rand2", 0.3), ("arrow", 0.5), ("nested_mid", 0.2), ("diag", 0.5), ("arrow", 0.0)])
