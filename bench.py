@@ -34,7 +34,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r04_hbm_traffic.json"
+PMC_FILE = "r05_pmc_%s.json"       # per workload key: tools/pmc_step.sh (three rocprofv3 --pmc passes; one step = one period of the launch sequence)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 FP64_PEAK_TFLOPS = 78.6   # vendor fp64 vector = matrix peak
 
@@ -152,30 +152,62 @@ def famt_executed_flops(symb, cptr, cidx, chunks, tiles="all"):
     nat = (int(na_[parents].max()) + 15) // 16          # the launch's instantiation serves the widest parent
     # tiles per step: update tiles nat (nat + 1) / 2, Q tiles nat, G_NN 1 -- all in k_fam_terms<NAT, true>; with the fused
     # extend-add k_fam_terms<NAT, false> issues the Q and G_NN tiles and k_lf_assemble_fz the update tiles
-    per_step = {"all": nat * (nat + 1) // 2 + nat + 1, "panels": nat + 1, "updates": nat * (nat + 1) // 2}[tiles]
+    per_step = {"all": nat * (nat + 1) // 2 + nat + 1, "panels": nat + 1, "updates": nat * (nat + 1) // 2, "useful_updates": 0}[tiles]
     nrhs = sum(chunks)
+    if tiles == "useful_updates":
+        # what the update tiles are FOR: per entry (term) a symmetric rank-2 update s (a(x) a(y)^T + a(y) a(x)^T) of the parent's
+        # na x na update matrix, lower triangle only -- 2 multiply-adds per entry, na (na + 1) / 2 entries: no tile padding (na
+        # rounded up to 16, the full diagonal tiles), no padding of the term count to a multiple of two
+        nap = na_[parents].astype(np.float64)
+        return float((np.minimum(T, 48)[:, :nrhs] * (2.0 * nap * (nap + 1.0))[:, None]).sum())
     return float(ks[:, :nrhs].sum()) * per_step * 2048.0
 
 
-def pmc_traffic(dom, label, world):
-    """HBM bytes per launch of kernel `dom` from the committed PMC summary (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as
-    the gfx950 guide prescribes) -- only when it lists this kernel for this workload AND the kernel sources are byte-identical to
-    the ones the counters were collected on (csrc_sha256); otherwise (None, why)."""
+def pmc_file(workload):
+    """The committed PMC summary of a workload (tools/pmc_step.sh) -- only when the kernel sources are byte-identical to the ones
+    the counters were collected on (csrc_sha256); otherwise (None, why)."""
+    name = PMC_FILE % workload
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
-        hits = [v for kname, v in tj.get("kernels", {}).items() if kname.split("<")[0] == dom.split("<")[0]]
-        if tj.get("workload") == label and hits and world == 1:
-            if tj.get("csrc_sha256") == csrc_sha256():
-                return (max(v["hbm_bytes_per_launch"] for v in hits),
-                        "profiles/%s (rocprofv3 --pmc passes, csrc_sha256 %s = the running sources)" % (TRAFFIC_FILE, tj.get("csrc_sha256")))
-            return None, "dropped: profiles/%s was collected on other kernel sources (csrc_sha256 %s, running %s)" % (
-                TRAFFIC_FILE, tj.get("csrc_sha256"), csrc_sha256())
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
-        pass
-    return None, None
+        return None, "no profiles/%s" % name
+    if tj.get("csrc_sha256") != csrc_sha256():
+        return None, "dropped: profiles/%s was collected on other kernel sources (csrc_sha256 %s, running %s)" % (name, tj.get("csrc_sha256"), csrc_sha256())
+    return tj, "profiles/%s (rocprofv3 --pmc passes, csrc_sha256 %s = the running sources)" % (name, tj.get("csrc_sha256"))
 
 
-def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc, part, rank, world, label, con=None):
+def pmc_traffic(dom, workload, world):
+    """HBM bytes per launch of kernel `dom` from the committed PMC summary (separate rocprofv3 --pmc passes, FETCH_SIZE doubled as
+    the gfx950 guide prescribes), or (None, why)."""
+    if world != 1:
+        return None, None
+    tj, src = pmc_file(workload)
+    if tj is None:
+        return None, src
+    hits = [v for kname, v in tj.get("kernels", {}).items() if kname.split("<")[0] == dom.split("<")[0]]
+    if not hits:
+        return None, "profiles/%s does not list %s" % (PMC_FILE % workload, dom)
+    return max(v["hbm_bytes_per_launch"] for v in hits), src
+
+
+def step_roofline(workload, ms_per_step, world):
+    """The WHOLE step against both roofs: counter traffic of one step / its duration against the HBM peak,
+    matrix-pipe flops executed in one step / its duration against the fp64 MFMA peak -- both sums from the committed PMC
+    summary of this workload, the duration from this run."""
+    if world != 1:
+        return None
+    tj, src = pmc_file(workload)
+    if tj is None:
+        return {"source": src}
+    b, f = float(tj["step"]["hbm_bytes"]), float(tj["step"]["mfma_flops"])
+    gbs, tfl = b / (1e-3 * ms_per_step) / 1e9, f / (1e-3 * ms_per_step) / 1e12
+    return {"hbm": {"bytes_per_step": int(b), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+            "mfma": {"executed_flops_per_step": int(f), "achieved": round(tfl, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tfl / FP64_PEAK_TFLOPS, 4)},
+            "launches_per_step": tj.get("launches_per_step"), "source": src}
+
+
+def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc, part, rank, world, workload, con=None):
     """roofline object of the dominant kernel `dom` (name as rocprofv3 shows it, without template arguments):
     achieved = ALGORITHMIC bytes (or flops) of its launches in one step / their duration (HIP events).
     B = sum (nn + na) nn (blkval), U = sum na^2, Up = sum na (na + 1) / 2 (packed update blocks)."""
@@ -239,9 +271,18 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
         mf = {"achieved": round(tfl, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / FP64_PEAK_TFLOPS, 4)}
         hb = {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
         top = mf if ai >= ridge else hb
-        traffic, source = pmc_traffic(dom, label, world)
-        return {"kernel": dom, "bound": "mfma" if ai >= ridge else "hbm", "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
-                "frac": top["frac"], "traffic": traffic, "traffic_source": source, "mfma": dict(mf, flops_per_launch=ex / dom_launches),
+        traffic, source = pmc_traffic(dom, workload, world)
+        useful = famt_executed_flops(symb, con[0], con[1], chunks, "useful_updates")
+        # (neither pipe is half busy: what bounds the launch is the dependent chain of a task -- gather the operands of a term group
+        # from LDS, 10 MFMAs, the next group -- on one workgroup per CU, not a roof: said so, with the roof the arithmetic intensity
+        # points at kept beside it)
+        latency = max(mf["frac"], hb["frac"]) < 0.5
+        return {"kernel": dom, "bound": "latency" if latency else ("mfma" if ai >= ridge else "hbm"), "bound_by_intensity": "mfma" if ai >= ridge else "hbm",
+                "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+                "frac": top["frac"], "traffic": traffic, "traffic_source": source,
+                "traffic_over_algorithmic": round(traffic / (alg / dom_launches), 2) if traffic else None,
+                "mfma": dict(mf, flops_per_launch=ex / dom_launches, useful_flops_per_launch=useful / dom_launches,
+                             useful_share=round(useful / ex, 3) if ex else None),
                 "hbm": dict(hb, bytes_per_launch=alg / dom_launches), "arithmetic_intensity_flop_per_byte": round(ai, 2),
                 "ridge_flop_per_byte": round(ridge, 2), "avg_launch_us": round(1e6 * avg_s, 2), "launches_per_step": dom_launches,
                 "note": "fused extend-add (k_lf_assemble_fz): algorithmic bytes = assembled fronts written + family tables and term lists "
@@ -313,7 +354,7 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
         avg_s = 1e-3 * dom_ms / dom_launches
         per_launch = alg / dom_launches
         achieved = per_launch / avg_s / 1e9
-        traffic, source = pmc_traffic(dom, label, world)
+        traffic, source = pmc_traffic(dom, workload, world)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
                     "bytes_per_launch": per_launch, "avg_launch_us": round(1e6 * avg_s, 2),
@@ -342,10 +383,29 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
     if dom in lf_flops:
         nr = sum(solve_chunks)
         tfl = lf_flops[dom] * nr / (1e-3 * dom_ms) / 1e12
+        traffic, source = pmc_traffic(dom, workload, world)
         return {"kernel": dom, "bound": "mfma", "achieved": round(tfl, 2), "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(tfl / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(tfl / FP64_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": source,
                 "flops_per_step": lf_flops[dom] * nr, "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2),
                 "launches_per_step": dom_launches}
+    if dom == "k_chol_flow":
+        # one-launch blocked Cholesky (front_flow.hip): per step the single fronts beyond 272 rows without separator (roots), the
+        # Y_AA blocks of single fronts with a separator beyond 272 rows, and H (m > 128).  n^3 / 3 flops each; what bounds it is the
+        # chain of 64-column diagonal blocks (factor + invert + hand-over, ~35 us each), not a roof.
+        nf_ = nn_ + na_
+        sizes = [float(v) for v in nn_[big & (nf_ > 272) & (na_ == 0)]] + [float(v) for v in na_[big & (na_ > 272)]] + ([float(m)] if m > 128 else [])
+        fl_step = sum(v ** 3 / 3.0 for v in sizes)
+        blocks = sum(math.ceil(v / 64.0) for v in sizes)
+        tfl = fl_step / (1e-3 * dom_ms) / 1e12
+        traffic, source = pmc_traffic(dom, workload, world)
+        return {"kernel": dom, "bound": "latency", "bound_by_intensity": "mfma", "achieved": round(tfl, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tfl / FP64_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": source, "flops_per_step": fl_step,
+                "matrix_orders_upper_bound": sizes, "diagonal_blocks_per_step": blocks,
+                "us_per_diagonal_block": round(1e3 * dom_ms / max(blocks, 1), 2),
+                "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2), "launches_per_step": dom_launches,
+                "note": "latency chain: the 64-column diagonal blocks of a factorisation are factored one after the other (potrf + inverse in "
+                        "LDS, four dependent 16 x 16 steps, then the hand-over to the next block's workgroup); panel and trailing tiles run "
+                        "beside the chain inside the same launch.  The quantity to reduce is us_per_diagonal_block."}
     if dom == "k_lf_diag":
         # the diagonal-block step of the blocked Cholesky factorisations (config 4: the root's front, chol(Y_AA) of the top
         # fronts, potrf(H)): per 64-wide block one workgroup factors the block and inverts its factor, 2 * 64^3 / 3 flops,
@@ -355,7 +415,7 @@ def kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, mloc
                        (math.ceil(m / 64.0) if m > 128 else 0))
         fl_step = blocks * 2.0 * 64.0 ** 3 / 3.0
         tfl = fl_step / (1e-3 * dom_ms) / 1e12
-        return {"kernel": dom, "bound": "mfma", "achieved": round(tfl, 5), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        return {"kernel": dom, "bound": "latency", "bound_by_intensity": "mfma", "achieved": round(tfl, 5), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tfl / FP64_PEAK_TFLOPS, 6), "traffic": None, "flops_per_step": fl_step, "diagonal_blocks_per_step": blocks,
                 "avg_launch_us": round(1e3 * dom_ms / dom_launches, 2), "launches_per_step": dom_launches,
                 "note": "latency chain, not a throughput kernel: one workgroup per front factors and inverts ONE 64 x 64 diagonal block per "
@@ -524,6 +584,29 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         lib.csp_profile_read(h, ms, cnt)
         return {names[i]: (ms[i] / nsteps, cnt[i] // nsteps) for i in range(nk) if cnt[i]}
 
+    # ---------------- stage split (NOT timed): events between the three library calls of a step -------------
+    stages = None
+    if world == 1 and part is None and args.kktsolver == "chol" and not split_calls and prof:
+        nst = 5
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(nst)]
+        for q in range(nst):
+            bx.blkval.copy_(bx0); by.copy_(by0); L.blkval.copy_(S.blkval)
+            ev[q][0].record()
+            chordal.cholesky_projected_inverse(L, Y)
+            ev[q][1].record()
+            solve_ = kkt.factor(L, Y)
+            ev[q][2].record()
+            solve_(bx, by, 1.0)
+            ev[q][3].record()
+            if lazy:
+                chordal.check_status(symb)
+        torch.cuda.synchronize()
+        med = lambda a, b: float(np.median([ev[q][a].elapsed_time(ev[q][b]) for q in range(nst)]))
+        stages = {"factorisation_ms": round(med(0, 1), 4), "schur_ms": round(med(1, 2), 4), "solve_ms": round(med(2, 3), 4),
+                  "what": "median of %d untimed steps, HIP events on the caller's stream between the three library calls of a step: "
+                          "csp_cholesky_projected_inverse (scaling point: cholesky + projected_inverse + separator factors), kkt_schur_factor "
+                          "(constraint sweeps + Gram accumulation; with the status deferred potrf(H) is left to solve_), kkt_solve (potrf(H) "
+                          "beside the first Hessian, two Hessians, Amap / Aadj, potrs)" % nst}
     # Calibration pass (NOT timed): HIP events around every launch give the per-kernel breakdown and name the
     # dominant kernel.  Events around ~100 launches per step cost about 1 ms per step, so the timed region below
     # carries events around the dominant kernel's launches only (csp_profile_filter).
@@ -540,6 +623,8 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         dom0 = max(calib, key=lambda k: calib[k][0])
         lib.csp_profile_filter(h, names.index(dom0))
         lib.csp_profile_read(h, None, None)
+    if stages is not None and calib:
+        stages["gram_kernels_ms"] = round(sum(v[0] for k, v in calib.items() if k.startswith("k_gram") or k.startswith("k_leaf")), 4)
     elapsed = timed_loop(steps)
     ms_per_step = 1e3 * elapsed / steps
     if lazy:
@@ -556,8 +641,10 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         breakdown.update(timed)
         dom = dom0
         dom_ms, dom_launches = breakdown[dom]
-        roofline = kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, j1 - j0, part, rank, world, label,
+        roofline = kernel_roofline(dom, dom_ms, dom_launches, breakdown, symb, m, max_rhs, j1 - j0, part, rank, world, workload,
                                    con=(cptr, cidx))
+        if roofline is not None:
+            roofline["step"] = step_roofline(workload, ms_per_step, world)
         if args.verbose and rank == 0:
             for k, (t, c) in sorted(breakdown.items(), key=lambda kv: -kv[1][0]):
                 print("  %-26s %9.3f ms/step  %5d launches" % (k, t, c), file=sys.stderr)
@@ -719,7 +806,7 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
                                        ("subtree-sharded Gram + boundary exchange/%d" % world if part is not None
                                         else ("column-sparse constraints by rank (SCMcolumn2)/%d" % world if workload == "maxcut"
                                               else "schur-columns/%d" % world)))},
-            "roofline": roofline, "cpu_baseline": cpu, "back_solve": back_solve, "sharded_vs_single": sharded_check,
+            "roofline": roofline, "stages": stages, "cpu_baseline": cpu, "back_solve": back_solve, "sharded_vs_single": sharded_check,
             "symbolic_s": round(t_sym, 3), "csrc_sha256": csrc_sha256(),
             # per-kernel HIP-event times: the dominant kernel from the timed steps, the others from the untimed
             # calibration pass that precedes them (events around every launch)
@@ -826,7 +913,7 @@ def main():
                 # Schur column per thread scaled to m (config 4: its sequential SCMcolumn2 route in full, median of three)
                 cpu_mode = None if args.no_cpu else ("full" if name == "maxcut" else "quick")
                 r = run_workload(args, name, 10, 2, cpu_mode, False, env)
-                sec[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "back_solve", "cpu_baseline")}
+                sec[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "stages", "back_solve", "cpu_baseline")}
                 sec[name]["top_kernels_ms_per_step"] = dict(list(r["kernel_ms_per_step"].items())[:6])
             except Exception as e:      # a secondary workload must not take the headline line down
                 sec[name] = {"error": repr(e)}

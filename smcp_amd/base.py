@@ -17,7 +17,11 @@ class SDP:
     """minimize <C,X> s.t. <A_i,X> = b_i, X psd-completable; data as an n^2 x (m+1) sparse matrix
     with columns vec(C), vec(A_1)... (lower triangles), exactly the reference's layout."""
 
-    def __init__(self, filename=None):
+    def __init__(self, filename=None, c=None, G=None, h=None, dims=None):
+        """SDP(fname) reads a problem file.  The reference's constructor also names c, G, h, dims (base.py:62) and then
+        ignores them -- its conelp fills the object in by hand (solvers.py:2493-2534); here SDP(c=, G=, h=, dims=) builds the
+        block-diagonal SDP whose DUAL is the cone program  minimize c'x s.t. Gx + s = h, s in K, exactly as conelp does:
+        column 0 = the embedded h, column j = the embedded j-th column of G, b = -c."""
         self._A = None
         self._b = None
         self._blockstruct = None
@@ -40,6 +44,19 @@ class SDP:
                 self._load(filename)
             else:
                 raise NameError("Unknown file extension")
+        elif c is not None or G is not None or h is not None:
+            if c is None or G is None or h is None:
+                raise ValueError("SDP(c=, G=, h=, dims=): c, G and h are all needed")
+            from .solvers import _embed_columns
+            G = sp.csc_matrix(G)
+            if dims is None:
+                dims = {"l": G.shape[0], "q": [], "s": []}
+            hh = np.asarray(h, dtype=np.float64).reshape(-1, 1)
+            A, n, Nl, Nq, Ns = _embed_columns(sp.hstack([sp.csc_matrix(hh), G]), dims)
+            self._A = sp.csc_matrix(A)
+            self._b = -np.asarray(c, dtype=np.float64).reshape(-1, 1)
+            self._blockstruct = [-int(Nl)] * (1 if Nl else 0) + [int(q) for q in Nq] + [int(s_) for s_ in Ns]
+            self._pname = "conelp"
 
     def __str__(self):
         return "<SDP: n=%i, m=%i, nnz=%i> %s" % (self.n, self.m, self.nnz, self._pname)
@@ -118,10 +135,55 @@ class SDP:
     def blockstruct(self):
         return self._blockstruct
 
+    def _require(self):
+        if self._A is None:
+            raise AttributeError("SDP object has not been initialized")
+
+    @property
+    def I(self):
+        """Aggregate sparsity pattern as absolute indices into vec(X), lower triangle (base.py:110-117; sorted here -- the
+        reference's order is that of a Python set)."""
+        self._require()
+        return np.unique(sp.csc_matrix(self._A).indices).astype(np.int64)
+
     @property
     def nnz(self):
         """Number of nonzeros in the lower triangle of the aggregate sparsity pattern."""
-        return len(np.unique(sp.csc_matrix(self._A).indices))
+        return len(self.I)
+
+    @property
+    def issparse(self):
+        """True if the aggregate sparsity density is at most one half (base.py:128-131)."""
+        return len(self.I) <= 0.5 * (self.n * (self.n + 1) / 2)
+
+    def get_nnz(self, i=None):
+        """Nonzeros in the lower triangles of A_0 (= C), A_1, ..., A_m: the whole vector, or entry i (base.py:279-294)."""
+        self._require()
+        cnt = np.diff(sp.csc_matrix(self._A).indptr).astype(np.int64)
+        if i is None:
+            return cnt
+        if 0 <= i <= self.m:
+            return int(cnt[i])
+        raise ValueError("index out of range")
+
+    def get_nzcols(self, i=None):
+        """Number of nonzero columns (= rows: the matrices are symmetric) of A_1, ..., A_m -- misc.nzcolumns (misc.c:682-730):
+        the distinct row and column indices the stored entries touch; the whole vector, or the figure of A_i, 1 <= i <= m
+        (base.py:300-310)."""
+        self._require()
+        A = sp.csc_matrix(self._A)
+        n = self.n
+        out = np.zeros(self.m, dtype=np.int64)
+        for j in range(self.m):
+            idx = A.indices[A.indptr[j + 1]:A.indptr[j + 2]]
+            out[j] = len(np.union1d(idx % n, idx // n))
+        if i is None:
+            return out
+        if 0 < i <= self.m:
+            return int(out[i - 1])
+        raise ValueError("index out of range")
+
+    nzcols = property(get_nzcols, doc="Vector with number of nonzero columns in A1,..,Am")
 
     @property
     def V(self):
@@ -130,9 +192,7 @@ class SDP:
         idx = np.unique(sp.csc_matrix(self._A).indices)
         return sp.csc_matrix((np.ones(len(idx)), (idx % n, idx // n)), shape=(n, n))
 
-    @property
-    def nnzs(self):
-        return np.diff(sp.csc_matrix(self._A).indptr)
+    nnzs = property(get_nnz, doc="Vector with number of nonzeros in lower triangle of A0,A1,...,Am")
 
     @property
     def ischordal(self):
