@@ -1549,35 +1549,79 @@ __global__ void __launch_bounds__(1024) k_mid_chol(MfmaArgs a, double* x, double
   double* const Pb = smem;
   double* const d16 = Pb + (size_t)ldp * LB;
   const int64_t ld = M.ld;
+  __shared__ int mid_fail;
+  if (tid == 0) mid_fail = 0;
+  const int lane = tid & 63, wave = tid >> 6, nwv = (int)(blockDim.x >> 6), l15 = lane & 15, kq = lane >> 4;
+  // one 16 x 16 tile product on the calling wave: (m, n) = sum_{k < 16} A[m + k lda] B[n + k ldb]; register r <-> (l15, kq + 4 r)
+  auto tile_abt = [&](const double* A, int lda, const double* B, int ldb) {
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(B[l15 + (k0 + kq) * ldb], A[l15 + (k0 + kq) * lda], acc, 0, 0, 0);
+    return acc;
+  };
   for (int jb = 0; jb < M.ncol; jb += LB) {
     const int w = min(LB, M.ncol - jb), rows = M.nrow - jb;
     const double* Ab = M.A + jb + (int64_t)jb * ld;
-    for (int e = tid; e < rows * w; e += 1024) {
-      const int i = e % rows, j = e / rows;
-      Pb[i + j * ldp] = (i >= j) ? Ab[i + (int64_t)j * ld] : 0.0;
+    // the block column, zero-padded to whole 16 x 16 tiles (rows up to a multiple of 16 lie inside ldp; all 64 columns are allocated):
+    // the tile products below read whole tiles, and a stray NaN times a zero of the block inverse would still be a NaN
+    const int rows16 = (rows + 15) & ~15;
+    for (int e = tid; e < rows16 * LB; e += 1024) {
+      const int i = e % rows16, j = e / rows16;
+      Pb[i + j * ldp] = (i < rows && j < w && i >= j) ? Ab[i + (int64_t)j * ld] : 0.0;
     }
     __syncthreads();
-    for (int jj = 0; jj < w; jj += 16) {
-      const int bw = min(16, w - jj);
-      const int f = potrf_inv16(Pb + jj + jj * ldp, ldp, bw, d16);
-      if (f) { if (tid == 0) atomicCAS(info_of(a.t, k), 0, info_val(a.t, k)); return; }
-      const int rbelow = rows - jj - bw, crem = w - jj - bw;
-      if (rbelow > 0) {
-        double* Sb = Pb + (jj + bw) + jj * ldp;          // rows below the diagonal block, this step's columns
-        // one column tile (bw <= 16): a wave reads the whole 16 x bw input of its tile before it stores it
-        wg_mma(rbelow, bw, bw, [=](int m, int kk) { return Sb[m + kk * ldp]; },
-               [=](int kk, int n) { return d16[n + kk * 16]; },
-               [=](int m, int n, double acc) { Sb[m + n * ldp] = acc; });
-        __syncthreads();
-        if (crem > 0) {
-          double* Tb = Pb + (jj + bw) + (jj + bw) * ldp;
-          wg_mma(rbelow, crem, bw, [=](int m, int kk) { return Sb[m + kk * ldp]; },
-                 [=](int kk, int n) { return Sb[n + kk * ldp]; },
-                 [=](int m, int n, double acc) { if (m >= n) Tb[m + n * ldp] -= acc; }, true);
-          __syncthreads();
+    // Sixteen-column steps with TWO barriers each (round 5; was: potrf_inv16 with fifteen waves idle, then two generic products and
+    // three barriers).  Wave 0 alone carries the critical path: its share of the previous step's trailing update -- the next
+    // diagonal 16 x 16 tile --, then that tile's Cholesky and inverse (wave_potrf_inv16: no barrier inside); the other waves do
+    // the rest of that trailing update meanwhile.  After the barrier one wave per tile scales the rows below.
+    const int nbc = (w + 15) >> 4, nbr = rows16 >> 4;
+    for (int b = 0; b < nbc; ++b) {
+      const int bw = min(16, w - 16 * b);
+      if (wave == 0) {
+        double* Dbb = Pb + 16 * b + 16 * b * ldp;
+        if (b > 0) {
+          const double* P = Pb + 16 * b + 16 * (b - 1) * ldp;
+          const d4 u4 = tile_abt(P, ldp, P, ldp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int n = kq + 4 * r; if (l15 >= n) Dbb[l15 + n * ldp] -= u4[r]; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        if (!wave_potrf_inv16(Dbb, ldp, bw, d16) && lane == 0) mid_fail = 1;
+      } else if (b > 0) {
+        // tiles (r, c) of the trailing part, b <= c < nbc, c <= r < nbr, without (b, b): dealt over the waves 1 .. nwv - 1
+        int t = 0;
+        for (int c = b; c < nbc; ++c)
+          for (int r = c; r < nbr; ++r) {
+            if (r == b && c == b) continue;
+            if (t++ % (nwv - 1) != wave - 1) continue;
+            const d4 u4 = tile_abt(Pb + 16 * r + 16 * (b - 1) * ldp, ldp, Pb + 16 * c + 16 * (b - 1) * ldp, ldp);
+            double* T = Pb + 16 * r + 16 * c * ldp;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int n = kq + 4 * q; if (r > c || l15 >= n) T[l15 + n * ldp] -= u4[q]; }
+          }
       }
+      __syncthreads();
+      if (mid_fail) { if (tid == 0) atomicCAS(info_of(a.t, k), 0, info_val(a.t, k)); return; }
+      for (int r = b + 1 + wave; r < nbr; r += nwv) {            // rows below x the block's inverse (transposed)
+        double* P = Pb + 16 * r + 16 * b * ldp;
+        const d4 u4 = tile_abt(P, ldp, d16, 16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[l15 + (kq + 4 * q) * ldp] = u4[q];
+      }
+      if (bw < 16 && wave == nwv - 1) {
+        // a partial last column tile: the rows of ITS row tile beyond the bw x bw diagonal block are rows below as well
+        // (wave_potrf_inv16 left them as they were; the block inverse is zero beyond bw)
+        double* P = Pb + 16 * b + 16 * b * ldp;
+        const d4 u4 = tile_abt(P, ldp, d16, 16);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (l15 >= bw) P[l15 + (kq + 4 * q) * ldp] = u4[q];
+      }
+      __syncthreads();
     }
+    // (the last step's trailing update inside the block column is empty: its columns end with the block)
     // the factored block column goes back; the columns to its right and the update block take -P P^T from the LDS copy
     double* Aw = M.A + jb + (int64_t)jb * ld;
     for (int e = tid; e < rows * w; e += 1024) {

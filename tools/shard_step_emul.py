@@ -149,6 +149,41 @@ def main():
             chordal.lazy_status(symb, False)
         print("subtree: world %d rank %d: %.3f ms per step (%.1f collectives)" % (world, state["rank"], ms, out["subtree_%d" % world]["collectives_per_step"]),
               flush=True)
+    # ---- wire model + SCALE-shaped lines.  NOT a measurement: rank 0's kernels and host logic are timed above
+    # with one-rank collectives (launch cost, no wire time); the wire is modelled from the bytes every rank has to RECEIVE.
+    # xGMI is point-to-point (7 links x ~153 GB/s per GPU, MI355X_MICROARCH.md): in an all-gather the N - 1 peers' chunks arrive over
+    # N - 1 different links at once, so the time is one chunk over one link at LINK_EFF of its peak, plus a per-collective latency;
+    # an all-reduce of a small vector (H: 80 KB, Amap: 800 B) is latency only.
+    LINK_GBS, LINK_EFF, COLL_LAT_US = 153.0, 0.7, 15.0
+    lines = []
+    if args.mode in ("subtree", "both"):
+        base = out.get("subtree_1", {}).get("ms_per_step")
+        single = None
+        for world in [int(w) for w in args.worlds.split(",")]:
+            key = "subtree_%d" % world
+            if key not in out:
+                continue
+            kkt._install_partition(world, min(args.rank, world - 1))
+            state.update(world=world, rank=min(args.rank, world - 1))
+            _, sizes1, width1 = kkt._exchange_plan(G, 1)
+            _, sizesm, widthm = kkt._exchange_plan(G, m)
+            chunk = lambda width: 8.0 * width / (LINK_EFF * LINK_GBS * 1e9) * 1e6 if world > 1 else 0.0          # us: one peer's chunk over one link
+            colls = [("cholesky exchange (all-gather)", chunk(width1)), ("Schur sweeps exchange (all-gather, %d right-hand sides)" % m, chunk(widthm)),
+                     ("H all-reduce", 0.0), ("first Hessian exchange (all-gather)", chunk(width1)), ("Amap all-reduce", 0.0)]
+            wire_us = sum(t + (COLL_LAT_US if world > 1 else 0.0) for _, t in colls)
+            ms = out[key]["ms_per_step"] + 1e-3 * wire_us
+            lines.append({"metric": "Newton KKT solves/sec", "value": round(1e3 / ms, 2), "unit": "KKT solves/s", "n_gpus": world, "ms_per_step": round(ms, 3),
+                          "scaling": "strong", "emulated": True,
+                          "how": "rank %d of %d emulated on ONE GPU through the production host code (kernels with that rank's grid sizes and data "
+                                 "volumes, one-rank RCCL collectives) + modelled wire time" % (state["rank"], world),
+                          "kernels_and_host_ms": out[key]["ms_per_step"], "wire_model_us": round(wire_us, 1),
+                          "wire_model": {"link_GBps": LINK_GBS, "link_efficiency": LINK_EFF, "latency_us_per_collective": COLL_LAT_US,
+                                         "bytes_received_per_rank": {"per_exchange_of_1_rhs": int(8 * width1 * (world - 1)),
+                                                                     "Schur_exchange": int(8 * widthm * (world - 1))},
+                                         "collectives": [{"what": w_, "transfer_us": round(t, 1)} for w_, t in colls]}})
+        out["scale_lines_emulated"] = lines
+        for ln in lines:
+            print(json.dumps(ln), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(out, open("gpurun_out/shard_step_emul.json", "w"), indent=1)
     dist.destroy_process_group()
