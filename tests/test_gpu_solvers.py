@@ -27,11 +27,22 @@ def _certify(P, sol, tol=1e-6):
     return pc, dc
 
 
+@pytest.fixture(params=["mcs", "auto"])
+def peo(request, _reference_elimination_order):
+    """the suite pins options['peo'] = 'mcs' (the stored histories were generated on the reference's ordering
+    sequence); the tests that compare optimum, status and certificates rather than 1e-9 histories also run on the order users
+    get by default ('auto': the given order when it has zero fill -- another clique tree, other level counts and kernel shape
+    classes)."""
+    from smcp_amd import solvers
+    solvers.options["peo"] = request.param
+    return request.param
+
+
 def _starts(P):
     return ({"x": sp.csc_matrix(np.tril(P._X0))}, {"y": P._y0, "s": sp.csc_matrix(np.tril(P._S0))})
 
 
-def test_band_sdp_config1_feas_primal_and_dual_scaling():
+def test_band_sdp_config1_feas_primal_and_dual_scaling(peo):
     """BASELINE config 1: band SDP n=200, half-bandwidth 3, m=100 through the feasible-start
     driver (the reference's benchmark method M1: 36-38 iterations, DIMACS feasibility errors
     ~1e-16, doc band_ex1_*.html)."""
@@ -55,7 +66,7 @@ def test_band_sdp_config1_feas_primal_and_dual_scaling():
     assert pc <= np.sum(np.asarray(P.get_A(0).todense()) * P._X0) + 1e-6    # the start bounds the optimum
 
 
-def test_band_sdp_config1_via_conelp():
+def test_band_sdp_config1_via_conelp(peo):
     """Config 1 "via smcp.solvers.conelp": the same band SDP in CVXOPT cone-LP form (dims s=[n]), which runs
     the self-dual-embedding driver, at the DEFAULT tolerances (feastol 1e-8, abstol/reltol 1e-6), both scalings
     through the embedding driver; the optimum must agree with the feasible-start solver's."""
@@ -77,7 +88,7 @@ def test_band_sdp_config1_via_conelp():
         _certify(P, se)
 
 
-def test_reference_conelp_example():
+def test_reference_conelp_example(peo):
     """The problem of the reference's tests/test_basic.py (CVXOPT manual example, l=2, q=[4,4], s=[3])."""
     from smcp_amd import solvers
     solvers.options["show_progress"] = False
@@ -105,7 +116,7 @@ def test_reference_conelp_example():
     assert np.allclose(x, [-1.22, 0.0966, 3.58], atol=5e-3)
 
 
-def test_lp_against_scipy():
+def test_lp_against_scipy(peo):
     """LP through the LP -> diagonal-SDP mapping (solvers.py:2505-2509) against scipy.optimize.linprog."""
     from scipy.optimize import linprog
     from smcp_amd import solvers
@@ -129,7 +140,7 @@ def test_lp_against_scipy():
     assert abs(c @ sol["x"] - ref.fun) < 1e-5 * (1 + abs(ref.fun))
 
 
-def test_maxcut_config4_shape():
+def test_maxcut_config4_shape(peo):
     """BASELINE config 4 at test size: max-cut SDP on a random non-chordal graph (n = 300, 900 edges; the
     full G51-sized instance n = 1000 / 5909 edges runs in scratch/maxcut.py: optimal in 31 iterations).
     The symbolic layer embeds the pattern with its own minimum-degree ordering; optimality is certified in
