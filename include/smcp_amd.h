@@ -220,6 +220,18 @@ int kkt_gram_accumulate(csp_ctx* ctx, int64_t nranges, const int64_t* ranges, do
 int csp_exchange_sizes(csp_ctx* ctx, int64_t world, int64_t* sizes_per_rhs);
 int csp_exchange_pack(csp_ctx* ctx, int64_t nrhs, double* buf, void* stream);
 int csp_exchange_unpack(csp_ctx* ctx, int64_t nrhs, const double* buf, int64_t width, void* stream);
+/* The exchange BY CONSTRAINT SHARE (the top of the tree sharded by constraint: rank q sweeps the top for its share J_q of the
+ * constraints only, instead of every rank for all of them; SURVEY 8e "one exchange step per sweep", as an all-to-all):
+ * after kkt_gram_sweep(set 1) over a chunk, csp_exchange_pack_range packs the right-hand sides r0 .. r0 + nrhs - 1 of that chunk
+ * -- the share of ONE destination rank -- as [root][rhs][packed block] (once per destination, into that destination's slot of
+ * the all-to-all's send buffer); csp_exchange_unpack_all unpacks the roots of EVERY rank, this one's too, from the receive
+ * buffer (`width` doubles per source rank) into the slots 0 .. nrhs - 1, where kkt_gram_sweep(set 2, c0, c1) of the own share
+ * reads them.  kkt_stack_rows moves the rows [a, b) of the swept stack of the constraints j0 .. j1 - 1 to / from
+ * buf[(j - j0) (b - a) + row - a] (dir 0: stack -> buf, 1: buf -> stack): the top's panels of a share travel to the rank that
+ * accumulates the top's block of H. */
+int csp_exchange_pack_range(csp_ctx* ctx, int64_t r0, int64_t nrhs, double* buf, void* stream);
+int csp_exchange_unpack_all(csp_ctx* ctx, int64_t nrhs, const double* buf, int64_t width, void* stream);
+int kkt_stack_rows(csp_ctx* ctx, int dir, int64_t j0, int64_t j1, int64_t a, int64_t b, double* buf, void* stream);
 /* The boundary blocks of a sweep whose input is a linear combination of inputs that were swept (and exchanged) before
  * need no collective: the second Hessian of solve_ is applied to Aadj(y) - bx (solvers.py:528-531), so the other
  * ranks' root blocks are sum_i y_i (blocks gathered for constraint i during the Schur sweeps) - (blocks gathered for

@@ -62,6 +62,9 @@ SIGNATURES = {
     "csp_exchange_sizes": (ctypes.c_int, [c_vp, c_i64, c_vp]),
     "csp_exchange_pack": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
     "csp_exchange_unpack": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "csp_exchange_pack_range": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "csp_exchange_unpack_all": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "kkt_stack_rows": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "csp_exchange_combine": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, ctypes.c_int, c_vp]),
     "csp_cholesky_part": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp]),
     "csp_projected_inverse_part": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp]),

@@ -2134,15 +2134,18 @@ __global__ void k_exchange_copy(const CliqueDesc* cl, const int64_t* list, const
 // the same for the subtree roots of a partition (csp_set_partition): root q belongs to rank owner[q] and starts bptr[q]
 // doubles (per right-hand side) into its rank's region.  pack: this rank's roots -> buf; unpack: every OTHER rank's roots
 // <- buf + owner * width (the all-gathered regions one after the other).  One launch each, nothing on the host.
+// unpack: 0 = pack this rank's roots, 1 = unpack the other ranks' roots, 2 = unpack EVERY rank's roots (its own too: the
+// exchange by constraint share, where the sender's slots are numbered by the chunk and the receiver's by its share);
+// r0: first slot of the exchange buffer's right-hand sides on the packing side
 __global__ void k_exchange_roots(const CliqueDesc* cl, const int32_t* roots, const int32_t* owner, const int64_t* bptr, int me,
-                                 int nrhs, double* updp, int64_t updplen, double* buf, int64_t width, int unpack) {
+                                 int nrhs, double* updp, int64_t updplen, double* buf, int64_t width, int unpack, int r0 = 0) {
   const int q = blockIdx.y;
-  if (unpack ? owner[q] == me : owner[q] != me) return;
+  if (unpack == 1 ? owner[q] == me : (unpack == 0 && owner[q] != me)) return;
   const CliqueDesc d = cl[roots[q]];
   const int np = d.na * (d.na + 1) / 2;
   const int r = blockIdx.z;
   double* slab = buf + (unpack ? owner[q] * width : 0) + bptr[q] * nrhs + (int64_t)r * np;
-  double* src = updp + (int64_t)r * updplen + d.updp;
+  double* src = updp + (int64_t)(r + (unpack ? 0 : r0)) * updplen + d.updp;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < np; e += gridDim.x * blockDim.x) {
     if (unpack) src[e] = slab[e]; else slab[e] = src[e];
   }

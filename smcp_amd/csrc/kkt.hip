@@ -1700,13 +1700,13 @@ int csp_exchange_sizes(csp_ctx* c, int64_t world, int64_t* sizes) {
   for (int64_t r = 0; r < world; ++r) sizes[r] = r < (int64_t)c->xr_size.size() ? c->xr_size[r] : 0;
   return 0;
 }
-static int exchange_roots(csp_ctx* c, int64_t nrhs, double* buf, int64_t width, int unpack, void* stream) {
+static int exchange_roots(csp_ctx* c, int64_t nrhs, double* buf, int64_t width, int unpack, void* stream, int64_t r0 = 0) {
   if (int rc = ready(c)) return rc;
-  if (c->xr_me < 0 || nrhs < 1 || nrhs > c->D.max_rhs || !buf) return SMCP_EINVAL;
+  if (c->xr_me < 0 || nrhs < 1 || r0 < 0 || r0 + nrhs > c->D.max_rhs || !buf) return SMCP_EINVAL;
   if (!c->xr_n) return 0;
   launch(c, KID_axpby, k_exchange_roots, dim3((unsigned)std::min<int64_t>(32, (c->xr_npmax + 255) / 256), (unsigned)c->xr_n, (unsigned)nrhs),
          dim3(256), (hipStream_t)stream, (const CliqueDesc*)c->D.cl, (const int32_t*)c->xr_roots, (const int32_t*)c->xr_owner,
-         (const int64_t*)c->xr_bptr, c->xr_me, (int)nrhs, c->D.updp, c->D.updp_stride ? c->D.updp_stride : c->S.updplen(), buf, width, unpack);
+         (const int64_t*)c->xr_bptr, c->xr_me, (int)nrhs, c->D.updp, c->D.updp_stride ? c->D.updp_stride : c->S.updplen(), buf, width, unpack, (int)r0);
   HIPCHK(end_call(c));
   return 0;
 }
@@ -1722,6 +1722,33 @@ int csp_exchange_combine(csp_ctx* c, int64_t nrhs, const double* y, const double
   return 0;
 }
 int csp_exchange_pack(csp_ctx* c, int64_t nrhs, double* buf, void* stream) { return exchange_roots(c, nrhs, buf, 0, 0, stream); }
+// The exchange BY CONSTRAINT SHARE (round 5: the top of the tree sharded by constraint instead of replicated for all of them):
+// pack the right-hand sides r0 .. r0 + nrhs - 1 of the sweep that just ran (the share of ONE destination rank) as
+// [root][rhs][packed block]; unpack the roots of EVERY rank -- this one's too -- from the all-to-all's receive buffer (`width`
+// doubles per source rank) into the slots 0 .. nrhs - 1, where the top sweep of this rank's own share reads them.
+int csp_exchange_pack_range(csp_ctx* c, int64_t r0, int64_t nrhs, double* buf, void* stream) { return exchange_roots(c, nrhs, buf, 0, 0, stream, r0); }
+int csp_exchange_unpack_all(csp_ctx* c, int64_t nrhs, const double* buf, int64_t width, void* stream) {
+  return exchange_roots(c, nrhs, const_cast<double*>(buf), width, 2, stream);
+}
+// rows [a, b) of the swept stack of the constraints j0 .. j1 - 1 <-> buf[(j - j0) * (b - a) + (row - a)]   (dir 0: stack -> buf,
+// 1: buf -> stack): the top's panels of a rank's constraint share travel to the rank that accumulates the top's Gram block
+__global__ void k_stack_rows(double* ustack, int64_t bl, int64_t j0, int64_t a, int64_t len, double* buf, int dir) {
+  double* row = ustack + (j0 + blockIdx.y) * bl + a;
+  double* b = buf + (int64_t)blockIdx.y * len;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += (int64_t)gridDim.x * blockDim.x) {
+    if (dir) row[e] = b[e]; else b[e] = row[e];
+  }
+}
+int kkt_stack_rows(csp_ctx* c, int dir, int64_t j0, int64_t j1, int64_t a, int64_t b, double* buf, void* stream) {
+  if (int rc = ready(c)) return rc;
+  DeviceCtx& D = c->D;
+  if (!D.ustack || j0 < 0 || j1 > D.m || j1 < j0 || a < 0 || b > c->S.blklen() || b < a || !buf || dir < 0 || dir > 1) return SMCP_EINVAL;
+  if (j1 == j0 || b == a) return 0;
+  launch(c, KID_axpby, k_stack_rows, dim3((unsigned)std::min<int64_t>(256, (b - a + 255) / 256), (unsigned)(j1 - j0)), dim3(256), (hipStream_t)stream,
+         D.ustack, c->S.blklen(), j0, a, b - a, buf, dir);
+  HIPCHK(end_call(c));
+  return 0;
+}
 int csp_exchange_unpack(csp_ctx* c, int64_t nrhs, const double* buf, int64_t width, void* stream) {
   return exchange_roots(c, nrhs, const_cast<double*>(buf), width, 1, stream);
 }

@@ -107,7 +107,7 @@ inline void sw_check_environment() {
       const char* eq = std::strchr(*e, '=');
       const std::string name(*e, eq ? (size_t)(eq - *e) : std::strlen(*e));
       if (name.rfind("SMCP_BENCH_", 0) == 0 || name.rfind("SMCP_FUZZ_", 0) == 0 || name == "SMCP_CXXFLAGS" || name == "SMCP_STAMPS" ||
-          name == "SMCP_SHARD_KEEP" || name == "SMCP_GIT_SHA" || name == "SMCP_FS_MODE") continue;
+          name == "SMCP_SHARD_KEEP" || name == "SMCP_SHARD_TOP" || name == "SMCP_GIT_SHA" || name == "SMCP_FS_MODE") continue;
       bool known = false;
       for (const Switch& s : SWITCHES) if (name == s.name) known = true;
       if (!known) std::fprintf(stderr, "smcp_amd: unknown switch %s in the environment (see smcp_amd/csrc/switches.hpp)\n", name.c_str());

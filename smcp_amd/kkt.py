@@ -68,6 +68,31 @@ def _all_gather_into(recv, send, group):
         dist.all_gather_into_tensor(recv, send, group=group)
 
 
+def _all_to_all(recv, send, group):
+    """One all-to-all with equal splits: recv (world * w) <- every rank's slice `me` of its send (world * w)."""
+    import torch.distributed as dist
+    if send.is_cuda and _backend_is_gloo(group):
+        h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(h, send.cpu(), group=group)
+        recv.copy_(h)
+    else:
+        dist.all_to_all_single(recv, send, group=group)
+
+
+def _gather_to(dst, recv_list, send, group):
+    """Gather `send` of every rank on rank dst (recv_list: preallocated tensors there, None elsewhere)."""
+    import torch.distributed as dist
+    me = dist.get_rank(group)
+    if send.is_cuda and _backend_is_gloo(group):
+        hs = [torch.empty(send.shape, dtype=send.dtype) for _ in recv_list] if me == dst else None
+        dist.gather(send.cpu(), hs, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+        if me == dst:
+            for o, h in zip(recv_list, hs):
+                o.copy_(h)
+    else:
+        dist.gather(send, recv_list if me == dst else None, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+
+
 class ShardedSchur:
     """Multi-GPU assembly of the Schur complement.
 
@@ -86,6 +111,15 @@ class ShardedSchur:
 
     partition = None
     force_sharded = False    # tests: take the sharded routes (and their collectives) with a group of ONE rank as well
+    # Round 5: the TOP of the tree sharded by constraint.  With top_by_constraint the root blocks of the subtree roots travel in an
+    # all-to-all instead of an all-gather -- rank q receives them for its share J_q of the constraints only (1 / N of the volume)
+    # -- and sweeps the top for J_q only (1 / N of the replicated top's Schur phases); the top's panels of the shares are then
+    # gathered on rank 0, which accumulates the top's block of H as before.  One collective more per Schur complement (the gather),
+    # and the second Hessian of solve_ exchanges like the first (no rank holds every constraint's blocks any more).
+    # Default (set by _install_partition): on from four ranks (emulated N = 4 / 8: 433 / 480 against 424 / 461 solves/s with the
+    # replicated top, profiles/r05_shard_step_emul.json; at N = 2 the gather of the top panels costs what the top sweep saves);
+    # SMCP_SHARD_TOP=constraint / replicated decides for every N.
+    top_by_constraint = os.environ.get("SMCP_SHARD_TOP", "replicated") == "constraint"
 
     def set_partition(self, group):
         """Cut the tree for the ranks of `group` (deterministic: every rank computes the same cut)."""
@@ -96,6 +130,8 @@ class ShardedSchur:
     def _install_partition(self, world, rank):
         from .shard import subtree_partition
         P = self.partition = subtree_partition(self.symb, world)
+        if "SMCP_SHARD_TOP" not in os.environ and "top_by_constraint" not in self.__dict__:
+            self.top_by_constraint = world >= 4
         self._apply_partition(P, rank)
         # blkval positions this rank accounts for in sums over the whole matrix (the top counts once, on rank 0)
         mask = np.zeros(self.symb.blklen)
@@ -140,6 +176,64 @@ class ShardedSchur:
         if live:       # a rank whose sweep has failed only keeps the collective matched
             self._exchange_unpack_all(P, rank, nrhs, recv, width, sizes)
         return recv, width
+
+    def _exchange_by_share(self, group, j0, j1, live=True):
+        """Boundary exchange of the Schur sweeps of the constraints j0 .. j1 - 1 with the top sharded by constraint: ONE all-to-all;
+        returns this rank's share [lo, hi) of the chunk (the constraints whose top sweep it runs next)."""
+        world, rank = self._world(group)
+        P = self.partition
+        bufs, sizes1, _ = self._exchange_plan(group, 1)
+        shares = []
+        for d in range(world):
+            a, b = column_range(self.m, d, world)
+            shares.append((max(j0, a), max(max(j0, a), min(j1, b))))
+        wmax = max(max(sizes1), 1) * max(max(hi - lo for lo, hi in shares), 1)
+        key = ("a2a", wmax)
+        if key not in bufs:
+            bufs[key] = (torch.zeros(wmax * world, dtype=torch.float64, device=self.dev), _empty(wmax * world, self.dev))
+        send, recv = bufs[key]
+        if live and sizes1[rank]:
+            for d, (lo, hi) in enumerate(shares):
+                if hi > lo:
+                    self._exchange_pack_range(P.roots_by_rank[rank], lo - j0, hi - lo, send[d * wmax:d * wmax + sizes1[rank] * (hi - lo)])
+        _all_to_all(recv, send, group)
+        self.collectives += 1
+        lo, hi = shares[rank]
+        if live and hi > lo:
+            self._exchange_unpack_share(P, lo, hi, recv, wmax)
+        return lo, hi
+
+    def _gather_top_panels(self, group, live=True):
+        """The top's rows of the swept stack: every rank holds them for its own share of the constraints; rank 0, which accumulates
+        the top's block of H, receives the others' (one gather)."""
+        world, rank = self._world(group)
+        P = self.partition
+        toplen = sum(b - a for a, b in P.top_ranges)
+        if world == 1 or toplen == 0:
+            return
+        bufs = self.__dict__.setdefault("_xchg", {})
+        width = max(column_range(self.m, d, world)[1] - column_range(self.m, d, world)[0] for d in range(world)) * toplen
+        key = ("top", width)
+        if key not in bufs:
+            bufs[key] = (torch.zeros(width, dtype=torch.float64, device=self.dev),
+                         [_empty(width, self.dev) for _ in range(world)] if rank == 0 else None)
+        send, recv = bufs[key]
+        c0, c1 = column_range(self.m, rank, world)
+        if live and c1 > c0 and rank != 0:
+            off = 0
+            for a, b in P.top_ranges:
+                self._stack_rows(0, c0, c1, a, b, send[off:off + (c1 - c0) * (b - a)])
+                off += (c1 - c0) * (b - a)
+        _gather_to(0, recv, send, group)
+        self.collectives += 1
+        if live and rank == 0:
+            for r in range(1, world):
+                r0, r1 = column_range(self.m, r, world)
+                off = 0
+                for a, b in P.top_ranges:
+                    if r1 > r0:
+                        self._stack_rows(1, r0, r1, a, b, recv[r][off:off + (r1 - r0) * (b - a)])
+                    off += (r1 - r0) * (b - a)
 
     # most doubles kept from the Schur sweeps for the collective-free exchange of solve_'s second Hessian
     KEEP_LIMIT = 1 << 28
@@ -212,15 +306,25 @@ class ShardedSchur:
                 and os.environ.get("SMCP_SHARD_KEEP", "1") != "0")       # 0: the second Hessian of solve_ exchanges like the first
         self._kept = []
         self._kept_gen = self.__dict__.get("_kept_gen", 0) + 1          # the kept chunks belong to THIS Schur complement
+        by_share = self.top_by_constraint
+        if by_share:
+            keep = False
         for n, j0 in enumerate(range(0, self.m, step)):
             j1 = min(self.m, j0 + step)
             guarded(self._gram_sweep, 1, j0, j1)                         # owned subtrees
+            if by_share:
+                lo, hi = self._exchange_by_share(group, j0, j1, live=err[0] is None)
+                if hi > lo:
+                    guarded(self._gram_sweep, 2, lo, hi)                 # the top, for this rank's share of the chunk only
+                continue
             recv, width = self._exchange(group, j1 - j0, live=err[0] is None, keep=n if keep else None)
             if keep:
                 self._kept.append((j0, j1, recv, width))
             guarded(self._gram_sweep, 2, j0, j1)                         # replicated top
         if not keep:
             self._kept = None
+        if by_share:
+            self._gather_top_panels(group, live=err[0] is None)          # the shares' top panels -> rank 0 (one collective)
         ranges = list(P.ranges_by_rank[rank]) + (list(P.top_ranges) if rank == 0 else [])
         guarded(self._gram_accumulate, ranges)
         guarded(self._deferred_status)               # chordal.lazy_status: the one read-back of the step happens here
@@ -497,6 +601,15 @@ class KKTSystem(ShardedSchur):
     def _exchange_pack(self, cliques, nrhs, out):
         # this rank's subtree roots (the list csp_set_partition derived from the owner array: the same cliques)
         _chk(_lib.lib().csp_exchange_pack(self.symb.handle, int(nrhs), out.data_ptr(), _stream()), "csp_exchange_pack")
+
+    def _exchange_pack_range(self, cliques, r0, nrhs, out):
+        _chk(_lib.lib().csp_exchange_pack_range(self.symb.handle, int(r0), int(nrhs), out.data_ptr(), _stream()), "csp_exchange_pack_range")
+
+    def _exchange_unpack_share(self, P, lo, hi, recv, width):
+        _chk(_lib.lib().csp_exchange_unpack_all(self.symb.handle, int(hi - lo), recv.data_ptr(), int(width), _stream()), "csp_exchange_unpack_all")
+
+    def _stack_rows(self, direction, j0, j1, a, b, buf):
+        _chk(_lib.lib().kkt_stack_rows(self.symb.handle, int(direction), int(j0), int(j1), int(a), int(b), buf.data_ptr(), _stream()), "kkt_stack_rows")
 
     def _exchange_combine(self, P, rank, nrhs, y, recv, width, out, owidth, mode):
         _chk(_lib.lib().csp_exchange_combine(self.symb.handle, int(nrhs), y.data_ptr(), recv.data_ptr(), int(width),

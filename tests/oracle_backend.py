@@ -104,6 +104,32 @@ class OracleKKT(kkt.ShardedSchur):
                 u[S.updptr[k]:S.updptr[k + 1]] = b[o:o + n]
                 o += n
 
+    def _exchange_pack_range(self, cliques, r0, nrhs, out):
+        S = self.K.S
+        parts = [u[S.updptr[k]:S.updptr[k + 1]] for k in cliques for u in self._xbufs[r0:r0 + nrhs]]
+        out.copy_(torch.from_numpy(np.concatenate(parts)))
+
+    def _exchange_unpack_share(self, P, lo, hi, recv, width):
+        """numpy form of csp_exchange_unpack_all: the roots of EVERY rank, into the update arrays of the constraints lo .. hi - 1"""
+        S = self.K.S
+        b = recv.numpy()
+        for r, cliques in enumerate(P.roots_by_rank):
+            o = r * width
+            for k in cliques:
+                n = int(S.updptr[k + 1] - S.updptr[k])
+                for u in self._upd[lo:hi]:
+                    u[S.updptr[k]:S.updptr[k + 1]] = b[o:o + n]
+                    o += n
+
+    def _stack_rows(self, direction, j0, j1, a, b, buf):
+        v = buf.numpy()
+        for j in range(j0, j1):
+            seg = slice((j - j0) * (b - a), (j - j0 + 1) * (b - a))
+            if direction:
+                self._G[j][a:b] = v[seg]
+            else:
+                v[seg] = self._G[j][a:b]
+
     def _exchange_combine(self, P, rank, nrhs, y, recv, width, out, owidth, mode):
         """numpy form of csp_exchange_combine on the oracle's exchange layout ([clique][rhs][square block])"""
         S = self.K.S

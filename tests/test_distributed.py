@@ -46,7 +46,8 @@ def _worker(rank, world, port, out, mode):
         sharded = OracleKKT(symb, cptr, cidx, cval)
         if mode == "sparse":        # the constraint-sharded SCMcolumn2 route of the product's host logic (kkt_schur_gram_part)
             sharded.emulate_sparse = True
-        if mode == "factor":
+        if mode in ("factor", "factor_share"):
+            sharded.top_by_constraint = mode == "factor_share"      # the top sharded by constraint: all-to-all + gather of the top panels
             _factor_mode(rank, world, out, symb, sharded, OracleKKT(symb, cptr, cidx, cval), A, Lh, Yh, m)
             return
         if mode == "subtree":
@@ -166,6 +167,20 @@ def test_sharded_factorisation_and_solve_three_ranks_gloo():
     for k in ("eL", "eY", "eH", "ex", "ey", "ep"):
         assert r[k] < 1e-11, (k, r)
     assert r["untouched"] and r["n_solve"] == 3
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_top_sharded_by_constraint_gloo(world):
+    """Round 5: the top of the tree sharded by constraint -- the subtree roots' blocks travel in an all-to-all
+    (rank q receives them for its share of the constraints only), rank q sweeps the top for its share, the top's panels are
+    gathered on rank 0 for the top's block of H.  Same L, Y, H, x, y as the single-rank step; collectives: one all-to-all per
+    chunk + the gather + H's all-reduce per Schur complement, and the second Hessian of solve_ exchanges like the first."""
+    r = _run_two("factor_share", world=world)
+    for k in ("eL", "eY", "eH", "ex", "ey", "ep", "eHd", "exd", "eL3"):
+        assert r[k] < 1e-11, (k, r)
+    assert r["untouched"] and r["agreed"]
+    assert r["n_build"] == r["chunks"] + 2       # one all-to-all per chunk of right-hand sides + the gather of the top panels + H
+    assert r["n_solve"] == 4                     # both Hessians exchange + Amap + completion of x
 
 
 def test_partition_covers_tree():

@@ -38,7 +38,8 @@ def _worker(rank, world, port, out, mode):
         single.factor(L, Y)
         Href = single.H.clone()
         sharded = KKTSystem(symb, cptr, cidx, cval, max_rhs=4)
-        if mode == "factor":
+        if mode in ("factor", "factor_share"):
+            sharded.top_by_constraint = mode == "factor_share"
             _factor_mode(rank, out, symb, S, L, Y, single, sharded, m)
             return
         if mode == "subtree":
@@ -145,6 +146,17 @@ def test_sharded_factorisation_and_solve_two_ranks_one_gpu():
     assert r["agreed"]
 
 
+def test_top_sharded_by_constraint_two_ranks_one_gpu():
+    """Round 5: the top of the tree sharded by constraint (all-to-all of the subtree roots' blocks by constraint share, the top
+    swept for the own share only, the top's panels gathered on rank 0) on the HIP path: csp_exchange_pack_range,
+    csp_exchange_unpack_all, kkt_stack_rows -- against the single-rank step on the same device."""
+    r = _run_two("factor_share")
+    for k in ("eL", "eY", "eH", "ex0", "ey0", "ex1", "ey1", "ep", "eHd", "exd", "eL3"):
+        assert r[k] < 1e-11, (k, r)
+    assert r["untouched"] and r["agreed"]
+    assert r["n_build"] == r["chunks"] + 2 and r["n_solve"] == 4, r
+
+
 @pytest.mark.parametrize("mode", ["columns", "subtree"])
 def test_two_ranks_one_gpu(mode):
     err, spread = _run_two(mode)
@@ -239,13 +251,15 @@ def test_column_sparse_constraints_sharded_by_constraint(world):
     assert ncoll == 1                          # ONE all-reduce of H
 
 
-@pytest.mark.parametrize("world,seed0,ncases", [(2, 5000, 14), (3, 6000, 8)])
-def test_sharded_step_on_random_trees(world, seed0, ncases):
+@pytest.mark.parametrize("world,seed0,ncases,top", [(2, 5000, 14, "replicated"), (3, 6000, 8, "replicated"), (2, 7000, 10, "constraint"),
+                                                    (3, 8000, 8, "constraint")])
+def test_sharded_step_on_random_trees(world, seed0, ncases, top, monkeypatch):
     """Random clique trees of all the pattern families of the parity sweep (tests/fuzz_sharded.py): tops of several cliques
     WITH separators, ranks that own several subtrees or none.  Found in round 2: kkt_prepare_part(set 1) copied the whole
     Y_AA array over fac and so put the unfactored blocks of the top back (invisible while the top was a root without
     separator: H off by 4e-2)."""
     import fuzz_sharded
+    monkeypatch.setenv("SMCP_SHARD_TOP", top)         # (read by the ranks, which are fresh processes, when they import smcp_amd.kkt)
     assert fuzz_sharded.main(ncases, seed0, world) == 0
 
 
@@ -379,12 +393,13 @@ def _synth50k_worker(rank, world, port, out, backend):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
-def test_sharded_step_synth50k_full_size(backend, world):
+@pytest.mark.parametrize("backend,world,top", [("gloo", 2, "replicated"), ("nccl", 1, "replicated"), ("gloo", 2, "constraint")])
+def test_sharded_step_synth50k_full_size(backend, world, top, monkeypatch):
     """the subtree-sharded step at the headline size -- two gloo ranks on one GPU, and the same host
     logic with its collectives over RCCL (a group of one rank: the boxes here have one GPU).  4 + 1 per chunk of
     right-hand sides collectives with x left sharded (cholesky exchange, one exchange per chunk, H, one Hessian exchange,
     Amap; the second Hessian's boundary blocks are combined locally)."""
+    monkeypatch.setenv("SMCP_SHARD_TOP", top)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -400,7 +415,8 @@ def test_sharded_step_synth50k_full_size(backend, world):
     r = out.get()
     bad = [k for k in ("eH", "ex_sharded", "ex_full", "ey") if not r[k] < 1e-10]
     assert not bad, "sharded step differs from the single-rank step in %s: %s" % (bad, json.dumps(r))
-    assert r["ncoll"] == 4 + r["chunks"] and r["ncoll"] <= 5 + r["chunks"], r
+    # replicated top: 4 + 1 per chunk; top by constraint: + the gather of the top panels + the second Hessian's own exchange
+    assert r["ncoll"] == (6 if top == "constraint" else 4) + r["chunks"], r
 
 
 def _race_worker(rank, world, port, out, seeds):

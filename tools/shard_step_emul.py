@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--mode", default="both", choices=("subtree", "columns", "both"))
+    ap.add_argument("--top", default="replicated", choices=("replicated", "constraint", "both"),
+                    help="subtree mode: the top swept by every rank for all constraints (all-gather of the root blocks) or sharded by constraint "
+                         "(all-to-all by share + gather of the top panels on rank 0)")
     ap.add_argument("--defer", type=int, default=1, help="1: the regime bench.py runs with N > 1 (status with H's all-reduce, deferred failure reports, x left sharded)")
     args = ap.parse_args()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -66,6 +69,22 @@ def main():
         dist.all_gather_into_tensor(recv[r * n:(r + 1) * n], send, group=G)
 
     kktmod._all_gather_into = gather
+
+    def a2a(recv, send, group):                         # own slice exchanged with itself through a real one-rank collective, the rest zero
+        recv.zero_()
+        w = send.numel() // state["world"]
+        r = state["rank"]
+        dist.all_to_all_single(recv[r * w:(r + 1) * w], send[r * w:(r + 1) * w], group=G)
+
+    def gather_to(dst, recv_list, send, group):         # rank 0 of N: its own panels only; the others' slots stay as they are
+        if state["rank"] == dst:
+            dist.all_gather_into_tensor(recv_list[dst], send, group=G)
+        else:
+            tmp = torch.empty_like(send)
+            dist.all_gather_into_tensor(tmp, send, group=G)
+
+    kktmod._all_to_all = a2a
+    kktmod._gather_to = gather_to
     kkt._world = lambda group: (state["world"], state["rank"])
     kkt.force_sharded = True
     out = {}
@@ -115,9 +134,11 @@ def main():
             print("columns: world %d rank %d: %.3f ms per step (%.1f collectives)" % (world, state["rank"], ms,
                   out["columns_%d" % world]["collectives_per_step"]), flush=True)
         kkt.force_sharded = True
-    for world in ([int(w) for w in args.worlds.split(",")] if args.mode in ("subtree", "both") else []):
+    tops = ["replicated", "constraint"] if args.top == "both" else [args.top]
+    for top, world in ([(t, int(w)) for t in tops for w in args.worlds.split(",")] if args.mode in ("subtree", "both") else []):
         state.update(world=world, rank=min(args.rank, world - 1))
         kkt._install_partition(world, state["rank"])
+        kkt.top_by_constraint = top == "constraint"        # (after the partition: its default depends on the world size)
         bx = cspmatrix(symb, bx0.clone())
         by = by0.clone()
 
@@ -134,6 +155,28 @@ def main():
 
         if args.defer:
             chordal.lazy_status(symb, True)
+        if top == "constraint" and world > 1:
+            # what rank 0 RECEIVES in the gather of the top panels must be data H stays positive definite with: one step with the
+            # replicated top fills the top's rows of the swept stack for every constraint, and the receive slots of the other
+            # ranks are pre-filled from them (the emulated gather leaves those slots alone; the unpack rewrites the same values)
+            kkt.top_by_constraint = False
+            step()
+            kkt.top_by_constraint = True
+            from smcp_amd.kkt import column_range
+            P = kkt.partition
+            toplen = sum(b - a for a, b in P.top_ranges)
+            width = max(column_range(m, d, world)[1] - column_range(m, d, world)[0] for d in range(world)) * toplen
+            bufs = kkt.__dict__.setdefault("_xchg", {})
+            send = torch.zeros(width, dtype=torch.float64, device="cuda")
+            recv = [torch.zeros(width, dtype=torch.float64, device="cuda") for _ in range(world)] if state["rank"] == 0 else None
+            if recv is not None:
+                for r in range(1, world):
+                    r0, r1 = column_range(m, r, world)
+                    off = 0
+                    for a, b in P.top_ranges:
+                        kkt._stack_rows(0, r0, r1, a, b, recv[r][off:off + (r1 - r0) * (b - a)])
+                        off += (r1 - r0) * (b - a)
+            bufs[("top", width)] = (send, recv)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -143,11 +186,11 @@ def main():
             step()
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / args.steps
-        out["subtree_%d" % world] = dict(ms_per_step=round(ms, 3), collectives_per_step=(kkt.collectives - c0) / args.steps,
-                          rank=state["rank"])
+        skey = "subtree_%d" % world if top == "replicated" else "subtree_topshare_%d" % world
+        out[skey] = dict(ms_per_step=round(ms, 3), collectives_per_step=(kkt.collectives - c0) / args.steps, rank=state["rank"], top=top)
         if args.defer:
             chordal.lazy_status(symb, False)
-        print("subtree: world %d rank %d: %.3f ms per step (%.1f collectives)" % (world, state["rank"], ms, out["subtree_%d" % world]["collectives_per_step"]),
+        print("subtree (top %s): world %d rank %d: %.3f ms per step (%.1f collectives)" % (top, world, state["rank"], ms, out[skey]["collectives_per_step"]),
               flush=True)
     # ---- wire model + SCALE-shaped lines.  NOT a measurement: rank 0's kernels and host logic are timed above
     # with one-rank collectives (launch cost, no wire time); the wire is modelled from the bytes every rank has to RECEIVE.
@@ -157,23 +200,30 @@ def main():
     LINK_GBS, LINK_EFF, COLL_LAT_US = 153.0, 0.7, 15.0
     lines = []
     if args.mode in ("subtree", "both"):
-        base = out.get("subtree_1", {}).get("ms_per_step")
-        single = None
-        for world in [int(w) for w in args.worlds.split(",")]:
-            key = "subtree_%d" % world
+        for top, world in [(t, int(w)) for t in tops for w in args.worlds.split(",")]:
+            key = "subtree_%d" % world if top == "replicated" else "subtree_topshare_%d" % world
             if key not in out:
                 continue
-            kkt._install_partition(world, min(args.rank, world - 1))
             state.update(world=world, rank=min(args.rank, world - 1))
+            kkt._install_partition(world, state["rank"])
             _, sizes1, width1 = kkt._exchange_plan(G, 1)
             _, sizesm, widthm = kkt._exchange_plan(G, m)
             chunk = lambda width: 8.0 * width / (LINK_EFF * LINK_GBS * 1e9) * 1e6 if world > 1 else 0.0          # us: one peer's chunk over one link
-            colls = [("cholesky exchange (all-gather)", chunk(width1)), ("Schur sweeps exchange (all-gather, %d right-hand sides)" % m, chunk(widthm)),
-                     ("H all-reduce", 0.0), ("first Hessian exchange (all-gather)", chunk(width1)), ("Amap all-reduce", 0.0)]
+            if top == "replicated":
+                colls = [("cholesky exchange (all-gather)", chunk(width1)), ("Schur sweeps exchange (all-gather, %d right-hand sides)" % m, chunk(widthm)),
+                         ("H all-reduce", 0.0), ("first Hessian exchange (all-gather)", chunk(width1)), ("Amap all-reduce", 0.0)]
+            else:
+                share = -(-m // world)
+                toplen = sum(b - a for a, b in kkt.partition.top_ranges)
+                colls = [("cholesky exchange (all-gather)", chunk(width1)),
+                         ("Schur sweeps exchange (all-to-all by constraint share, %d right-hand sides per rank)" % share, chunk(width1 * share)),
+                         ("top panels of the shares -> rank 0 (gather)", chunk(share * toplen)),
+                         ("H all-reduce", 0.0), ("first Hessian exchange (all-gather)", chunk(width1)),
+                         ("second Hessian exchange (all-gather)", chunk(width1)), ("Amap all-reduce", 0.0)]
             wire_us = sum(t + (COLL_LAT_US if world > 1 else 0.0) for _, t in colls)
             ms = out[key]["ms_per_step"] + 1e-3 * wire_us
             lines.append({"metric": "Newton KKT solves/sec", "value": round(1e3 / ms, 2), "unit": "KKT solves/s", "n_gpus": world, "ms_per_step": round(ms, 3),
-                          "scaling": "strong", "emulated": True,
+                          "scaling": "strong", "emulated": True, "top": top,
                           "how": "rank %d of %d emulated on ONE GPU through the production host code (kernels with that rank's grid sizes and data "
                                  "volumes, one-rank RCCL collectives) + modelled wire time" % (state["rank"], world),
                           "kernels_and_host_ms": out[key]["ms_per_step"], "wire_model_us": round(wire_us, 1),
