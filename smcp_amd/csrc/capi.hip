@@ -802,9 +802,9 @@ bool flow_chol(csp_ctx* c, hipStream_t st, double* A, int64_t ld, int n, double*
   auto it = c->flow_plans.find(n);
   if (it == c->flow_plans.end()) {
     std::vector<int32_t> optr, otile;
-    // (beyond order 2048 -- 528 tiles -- twice the workgroups: the trailing updates, not the chain of diagonal tiles, set the time there;
-    // two such launches still fit the chip side by side)
-    flow_make_plan(n, n > 2048 ? 2 * wgs : wgs, optr, otile);
+    // (beyond order 2048 -- 528 tiles -- more workgroups: the trailing updates, not the chain of diagonal tiles, set the time there;
+    // 160: three such launches of three processes sharing the GPU still fit the chip side by side, two workgroups per CU)
+    flow_make_plan(n, n > 2048 ? (wgs * 10) / 7 : wgs, optr, otile);
     csp_ctx::FlowPlanDev P;
     P.nwg = (int)optr.size() - 1;
     int64_t junk = 0;

@@ -482,7 +482,11 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
 // sides of the front), ten accumulator tiles on MFMA, ds_add_f64 at (rel[i], rel[j]) of the front.  1.49 GB of packed updates
 // written by one kernel and read back by the other per Schur complement never exist.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NAT>
+// PFG: steps whose operand gathers are requested together, ahead of their products (1: a step's gather, then its products).
+// A step is one gather round trip (the tables live in L2 / MALL) followed by ten MFMAs: a latency chain per family.  With
+// sixteen waves per workgroup (128 registers each, 80 of them accumulators) nothing more fits; eight waves (256) hold the
+// operands of four steps, so a family of the usual 13 entries (seven steps) costs two round trips instead of seven.
+template <int NAT, int PFG = 1>
 __device__ inline void lf_add_family(double* T, int nf, const MfmaArgs& a, int z, int64_t pt, const int32_t* rel, int lane) {
   constexpr int NA = 16 * NAT, NTU = NAT * (NAT + 1) / 2;
   const int l15 = lane & 15, kq = lane >> 4;
@@ -535,11 +539,27 @@ __device__ inline void lf_add_family(double* T, int nf, const MfmaArgs& a, int z
   };
   // (requesting step s + 1 before the products of step s was measured again with the halved gathers: 34 spilled registers at
   // sixteen waves, 0.60 ms against 0.53)
-  for (int s = 0; s < ks; ++s) {
-    double aA[NAT], se;
-    int ux, uy;
-    fetch(s, aA, se, ux, uy);
-    mma(aA, se, ux, uy);
+  if constexpr (PFG == 1) {
+    for (int s = 0; s < ks; ++s) {
+      double aA[NAT], se;
+      int ux, uy;
+      fetch(s, aA, se, ux, uy);
+      mma(aA, se, ux, uy);
+    }
+  } else {
+    for (int s0 = 0; s0 < ks; s0 += PFG) {
+      double aA[PFG][NAT], se[PFG];
+      int ux[PFG], uy[PFG];
+      // (unconditional requests at a clamped step -- a load under a branch turns every wait into a wait for all loads; a step
+      // beyond the list gets a zero scale)
+#pragma unroll
+      for (int g = 0; g < PFG; ++g) {
+        fetch(min(s0 + g, ks - 1), aA[g], se[g], ux[g], uy[g]);
+        if (s0 + g >= ks) se[g] = 0.0;
+      }
+#pragma unroll
+      for (int g = 0; g < PFG; ++g) mma(aA[g], se[g], ux[g], uy[g]);
+    }
   }
   // element (m, n) of the update -> front position (rel[m], rel[n]); packed column start minus the column index as in lf_alds_task
 #pragma unroll
@@ -556,7 +576,7 @@ __device__ inline void lf_add_family(double* T, int nf, const MfmaArgs& a, int z
       }
   }
 }
-template <int NAT>
+template <int NAT, int PFG = 1>
 struct AldsFam {
   const MfmaArgs* a;
   const int64_t* sCu; const int64_t* sCr;
@@ -564,7 +584,7 @@ struct AldsFam {
     (void)r;
     for (int qi = wave; qi < nmine; qi += nw) {
       const int z = sFz[qi];
-      if (z >= 0) lf_add_family<NAT>(T, nf, *a, z, sCu[qi], a->t.relidx + sCr[qi], lane);
+      if (z >= 0) lf_add_family<NAT, PFG>(T, nf, *a, z, sCu[qi], a->t.relidx + sCr[qi], lane);
     }
   }
 };
@@ -601,11 +621,11 @@ __global__ void __launch_bounds__(NTH) k_lf_assemble_fz(MfmaArgs a, double* u, i
       const int t = stask;
       if (t >= units) break;
       if (t < full) {
-        lf_alds_task(a, u, ldu, sgn, q + 8 * (t / nrhs), t % nrhs, 0, 1, T, AldsFam<NAT>{&a, sCu, sCr});
+        lf_alds_task(a, u, ldu, sgn, q + 8 * (t / nrhs), t % nrhs, 0, 1, T, AldsFam<NAT, (NTH == 512 ? 4 : 1)>{&a, sCu, sCr});
       } else {
         const int s2 = t - full, tt = full + s2 / nzt, share = s2 % nzt;
         const int tc = (a.nchmax + nzt - 1) / nzt;              // (lf_alds_task lays the child table out for its share)
-        lf_alds_task(a, u, ldu, sgn, q + 8 * (tt / nrhs), tt % nrhs, share, nzt, T, AldsFam<NAT>{&a, sCu, sCu + tc});
+        lf_alds_task(a, u, ldu, sgn, q + 8 * (tt / nrhs), tt % nrhs, share, nzt, T, AldsFam<NAT, (NTH == 512 ? 4 : 1)>{&a, sCu, sCu + tc});
       }
     }
   }

@@ -59,13 +59,21 @@ __device__ inline void flow_publish(unsigned* flag, unsigned epoch) {
   __syncthreads();
   if (threadIdx.x == 0) flow_st_flag(flag, epoch);
 }
-// a packed 64 x 64 tile published by another workgroup -> LDS (leading dimension FLOW_LD); sc1 loads, sixteen in flight per lane
+// a packed 64 x 64 tile published by another workgroup -> LDS (leading dimension FLOW_LD); 16-byte sc1 loads (aux 16), eight in
+// flight per lane (8-byte sc1 accesses run at 0.54 - 0.70 of the 16-byte rate, MI355X_MICROARCH.md)
+typedef unsigned int flow_u4 __attribute__((ext_vector_type(4)));
 __device__ inline void flow_fetch_tile(const double* src, double* T) {
-  double v[16];
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src), 0, 4096 * 8, 0x00020000);
+  flow_u4 v[8];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) v[u] = flow_ld(src + threadIdx.x + 256 * u);
+  for (int u = 0; u < 8; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (threadIdx.x + 256 * u), 0, 16);
 #pragma unroll
-  for (int u = 0; u < 16; ++u) { const int e = threadIdx.x + 256 * u; T[(e & 63) + (e >> 6) * FLOW_LD] = v[u]; }
+  for (int u = 0; u < 8; ++u) {
+    const int e = 2 * (threadIdx.x + 256 * u);
+    double2 d2 = __builtin_bit_cast(double2, v[u]);
+    double* q = T + (e & 63) + (e >> 6) * FLOW_LD;
+    q[0] = d2.x; q[1] = d2.y;
+  }
 }
 // acc (four waves, 2 x 2 MFMA tiles each) = Ta Tb^T over the 64 staged columns: out(m, n) = sum_k Ta[m + k ld] Tb[n + k ld]
 __device__ inline void flow_mma(d4 (&acc)[2][2], const double* Ta, const double* Tb) {
@@ -185,15 +193,35 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs a) {
     double* const At = a.A + 64 * i + (int64_t)(64 * k) * ld;        // the tile in the matrix: owner-only, plain accesses
     bool failed = false;
     if (g < k) {
-      // ---- update: A(i, k) -= P(i, g) P(k, g)^T
+      // ---- update: A(i, k) -= P(i, g) P(k, g)^T   (the tile's own sixteen values per lane are requested FIRST: they travel while
+      // the panel tiles are fetched, staged and multiplied)
+      double old[2][2][4];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int m, nn_;
+            tile64_pos(x, y, r, m, nn_);
+            old[x][y][r] = At[min(m, hi - 1) + (int64_t)min(nn_, wk - 1) * ld];
+          }
       flow_fetch_tile(a.P + (int64_t)flow_tile_id(i, g) * 4096, T0);
       if (i != k) flow_fetch_tile(a.P + (int64_t)flow_tile_id(k, g) * 4096, T1);
       __syncthreads();
       d4 acc[2][2];
       flow_mma(acc, T0, i != k ? T1 : T0);
       const bool diag = i == k;
-      tile64_rmw(acc, 0, 0, hi, wk, [=](int m, int nn_) { return At[m + (int64_t)nn_ * ld]; },
-                 [=](int m, int nn_, double v, double o) { if (!diag || m >= nn_) At[m + (int64_t)nn_ * ld] = o - v; });
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int m, nn_;
+            tile64_pos(x, y, r, m, nn_);
+            if (m < hi && nn_ < wk && (!diag || m >= nn_)) At[m + (int64_t)nn_ * ld] = old[x][y][r] - acc[x][y][r];
+          }
     } else if (i == k) {
       // ---- diagonal tile: factor and invert in LDS
       for (int e = tid; e < 64 * 64; e += 256) {
@@ -204,14 +232,7 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs a) {
       failed = factor_diag(k, wk, At);
     } else {
       // ---- panel tile: P(i, k) = A(i, k) Dinv(k)^T   (k < nt - 1 here: the column is 64 wide)
-      {
-        double v[16];
-        const double* Dg = a.dinv + (int64_t)k * 4096;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = flow_ld(Dg + tid + 256 * u);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { const int e = tid + 256 * u; T1[(e & 63) + (e >> 6) * FLOW_LD] = v[u]; }     // Dinv(n, kk) at T1[n + kk ld]
-      }
+      flow_fetch_tile(a.dinv + (int64_t)k * 4096, T1);          // Dinv(n, kk) at T1[n + kk ld]
       for (int e = tid; e < 64 * 64; e += 256) {
         const int r = e & 63, c = e >> 6;
         T0[r + c * FLOW_LD] = r < hi ? At[r + (int64_t)c * ld] : 0.0;

@@ -533,6 +533,46 @@ def test_sharded_step_under_delay_injection():
         pytest.xfail("one-off mismatch under delay injection, not reproduced by four re-runs of the same seed: %s" % json.dumps(events))
 
 
+def _flow_worker(rank, n, reps, out):
+    """dense_potrf of order n (the one-launch blocked Cholesky with in-launch tile dataflow, front_flow.hip) `reps` times, beside the
+    same loop of the other processes on the same GPU."""
+    torch.cuda.set_device(0)
+    from smcp_amd import _lib, chordal, problems
+    from smcp_amd.symbolic import Symbolic
+    symb = Symbolic(problems.band_pattern(20, 2))
+    chordal._ensure(symb)
+    rng = np.random.default_rng(100 + rank)
+    M = rng.standard_normal((n, n))
+    Hh = M @ M.T + n * np.eye(n)
+    Lref = np.linalg.cholesky(Hh)
+    Hd = torch.from_numpy(Hh).cuda()
+    H = Hd.clone()
+    worst, rcs = 0.0, set()
+    for _ in range(reps):
+        H.copy_(Hd)
+        rcs.add(int(_lib.lib().dense_potrf(symb.handle, H.data_ptr(), n, n, None)))
+        worst = max(worst, float(np.abs(np.tril(H.cpu().numpy().T) - Lref).max() / np.abs(Lref).max()))
+    out.put((rank, sorted(rcs), worst))
+
+
+@pytest.mark.parametrize("n,nproc", [(1500, 3), (3000, 3)])
+def test_one_launch_cholesky_beside_itself_in_three_processes(n, nproc):
+    """The persistent grid of k_chol_flow waits for tiles of its own other workgroups: every workgroup of a launch must become
+    resident, also when three processes sharing the GPU (ranks of a test job) run such launches at the same time (112 / 160
+    workgroups of 75 KB LDS each: three launches fit side by side).  No timeout (SMCP_ETIMEOUT = -6), exact factors."""
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_flow_worker, args=(r, n, 12, out)) for r in range(nproc)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    for _ in range(nproc):
+        rank, rcs, worst = out.get()
+        assert rcs == [0] and worst < 1e-12, (rank, rcs, worst)
+
+
 def test_bench_self_launch_two_ranks_gloo():
     """The code path the driver's scaling run takes -- `python bench.py --gpus N` starting its own ranks (self_launch) and the
     N > 1 branch of the timed protocol -- with N = 2 ranks sharing the one GPU over gloo: one JSON line, n_gpus, the partition
