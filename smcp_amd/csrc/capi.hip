@@ -719,6 +719,11 @@ void lf_up(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64_t 
   dim3 blk(256);
   if (a.nchmax > 0) {     // a level of childless large fronts has nothing to assemble (k_lf_up2 does not read their update blocks)
     lf_assemble(c, a, cnt, nrhs, U, ldu, fill ? 3 : 0, st, true);
+    if (c->mid_work && a.level >= 2) {      // the levels 0 and 1 are complete and the first extend-add above them is queued: work of the
+      std::function<void(hipStream_t)> w = std::move(c->mid_work);     // caller that only needs their panels, beside the phase kernels
+      c->mid_work = nullptr;
+      w(st);
+    }
     if (c->side_work) {   // independent work of the caller: beside the phase kernels from here on (csp_ctx::side_work)
       std::function<void(hipStream_t)> w = std::move(c->side_work);
       c->side_work = nullptr;
@@ -1455,7 +1460,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
   // (A handful of level-0 fronts outside the families -- synth50k: ONE leaf hangs off a mid front directly -- is a launch of
   // its own in the chain, 15 us for one workgroup.  On a side stream next to the family launch of level 1 it costs as
   // much in event waits: 6 us before and after the family launch, measured.)
-  for (int64_t l = lev_lo; l < (lev_hi < 0 ? c->S.nlev : lev_hi); ++l)     // [lev_lo, lev_hi): the caller may sweep in two parts
+  for (int64_t l = lev_lo; l < (lev_hi < 0 ? c->S.nlev : lev_hi); ++l) {    // [lev_lo, lev_hi): the caller may sweep in two parts
     for_level_classes(c, l, a0, [&](bool lds, MfmaArgs a, int cnt, size_t bytes, int thr) {
       static int fam_minrhs = -1;
       if (fam_minrhs < 0) { const char* e = sw_str("SMCP_FAM_MINRHS"); fam_minrhs = e ? atoi(e) : 1; }
@@ -1575,6 +1580,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
       }
       else { dense_input(a, cnt); launch_lds(c, KID_hess_up_mfma_hbm, k_hess_up_mfma<false>, dim3(cnt, nrhs), dim3(thr), 0, st, a, U, ldu); }
     }, set);
+  }
 }
 // the same for the cliques of a set of the partition (1 = owned, 2 = replicated top), root -> leaves
 void gather_set(csp_ctx* c, int set, const double* x, int64_t ldx, int nrhs, double* updbase, hipStream_t st) {

@@ -122,6 +122,7 @@ struct DeviceCtx {
   // Gram accumulation over slices of the stack (k_gram_diag128) and closed-form blocks of the family children
   // (front_leafgram.hip): tables of the cached set of ranges (csp_ctx::gsl_key)
   int64_t* gsl_start = nullptr; int32_t* gsl_len = nullptr; int64_t gsl_cap = 0; int gsl_n = 0;
+  int gsl_spw = 0, gsl_early = 0;    // table built early rows first: slices per chunk and chunks of the early part (0: plain table)
   int32_t* lg_list = nullptr; int32_t* lg_slot = nullptr; int64_t lg_cap = 0; int lg_cnt = 0;     // family children inside the ranges, their index among all of them
   int32_t* lg_eptr = nullptr; int32_t* lg_epk = nullptr; double* lg_ew = nullptr; int32_t* lg_remap = nullptr;   // static entry lists per family child
   double* lg_tab = nullptr; int lg_rec = 0;                           // per-step tables (Psi, Omega), lg_rec doubles per child
@@ -220,7 +221,11 @@ struct csp_ctx {
   // capi.hip), joined by whoever consumes the results.  gpre: what the side work planned for gram_accumulate.
   std::function<void(hipStream_t)> side_work;
   void* side_fork = nullptr;
-  struct GramPre { bool valid = false; int ngram = 0, nchunk = 0, spw = 0, nl = 0; } gpre;
+  struct GramPre { bool valid = false; int ngram = 0, nchunk = 0, spw = 0, nl = 0; int early = 0; bool early_done = false; } gpre;
+  // (round 5) the Gram accumulation over the panels that are final once the sweep has passed level 1 -- the family parents',
+  // most of the rows -- started on the side branch while the caller's stream goes on with the large fronts: set by schur_gram,
+  // taken (once) by hess_up_fast behind level 1; early = the chunks of that part (the slice table lists those rows first)
+  std::function<void(hipStream_t)> mid_work;
   struct LfspGroups { int32_t* ptr = nullptr; int32_t* list = nullptr; int ngroups = 0; };
   std::vector<LfspGroups> lfsp_grp;   // per level: the groups of its large-front class (device arrays; ngroups 0 = none)
   bool lfsp_any_groups = false;

@@ -1059,19 +1059,36 @@ static int gram_reserve(csp_ctx* c, int64_t m, int nchunk) {
 // Built on the host when the ranges (or the leaf switch) differ from the cached ones: a rank's ranges are the same at
 // every step.  leaf: the panels of the family children are not in the stack -- their rows are left out of the slices and
 // the cliques are listed for k_leaf_gram.
-static int gram_tables(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& rs, bool leaf, hipStream_t st) {
+static int64_t gram_chunk_rows(int64_t total);
+// early_first (leaf tables only): the rows of the cliques of levels 0 and 1 first, padded with empty slices to whole chunks, then
+// the rest -- D.gsl_spw / D.gsl_early tell the consumers (the early part can be accumulated while the sweep is still above)
+static int gram_tables(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>>& rs, bool leaf, hipStream_t st, bool early_first = false) {
   DeviceCtx& D = c->D;
   const Symbolic& S = c->S;
   std::vector<int64_t> key;
   key.reserve(2 * rs.size() + 1);
   for (auto& r : rs) { key.push_back(r.first); key.push_back(r.second); }
-  key.push_back(leaf ? 1 : 0);
+  key.push_back((leaf ? 1 : 0) | (early_first ? 2 : 0));
   if (key == c->gsl_key && D.gsl_start) return 0;
-  std::vector<int64_t> start;
-  std::vector<int32_t> len, list, slot;
+  std::vector<int64_t> start, late_start;
+  std::vector<int32_t> len, late_len, list, slot;
   int nf = 0, nn = 0, na = 0;
   auto add_segment = [&](int64_t lo, int64_t hi) {
-    for (int64_t e = lo; e < hi; e += GRAM_KS) { start.push_back(e); len.push_back((int32_t)std::min<int64_t>(GRAM_KS, hi - e)); }
+    // (early_first: a segment is cut at clique boundaries and each piece goes to the part its clique's level says)
+    if (!early_first) {
+      for (int64_t e = lo; e < hi; e += GRAM_KS) { start.push_back(e); len.push_back((int32_t)std::min<int64_t>(GRAM_KS, hi - e)); }
+      return;
+    }
+    int64_t k = (int64_t)(std::upper_bound(S.blkptr.begin(), S.blkptr.end(), lo) - S.blkptr.begin()) - 1;
+    for (int64_t p = lo; p < hi; ++k) {
+      const int64_t q = std::min(hi, S.blkptr[k + 1]);
+      const bool late = S.level[(size_t)k] >= 2;
+      for (int64_t e = p; e < q; e += GRAM_KS) {
+        (late ? late_start : start).push_back(e);
+        (late ? late_len : len).push_back((int32_t)std::min<int64_t>(GRAM_KS, q - e));
+      }
+      p = q;
+    }
   };
   for (auto& r : rs) {
     if (!leaf) { add_segment(r.first, r.second); continue; }
@@ -1088,6 +1105,16 @@ static int gram_tables(csp_ctx* c, const std::vector<std::pair<int64_t, int64_t>
       nf = std::max(nf, (int)S.nf(k)); nn = std::max(nn, (int)S.nn(k)); na = std::max(na, (int)S.na(k));
     }
     if (r.second > seg_lo) add_segment(seg_lo, r.second);
+  }
+  D.gsl_spw = 0; D.gsl_early = 0;
+  if (early_first) {
+    const int64_t chunk = gram_chunk_rows((int64_t)(start.size() + late_start.size()) * GRAM_KS);
+    const int spw = (int)(chunk / GRAM_KS);
+    while (start.size() % (size_t)spw) { start.push_back(0); len.push_back(0); }       // whole chunks of early rows
+    D.gsl_spw = spw;
+    D.gsl_early = late_start.empty() ? 0 : (int)(start.size() / (size_t)spw);
+    start.insert(start.end(), late_start.begin(), late_start.end());
+    len.insert(len.end(), late_len.begin(), late_len.end());
   }
   auto grow = [&](auto** p, int64_t& cap, int64_t need) -> int {
     if (cap >= need && *p) return 0;
@@ -1179,6 +1206,33 @@ static int leafgram_partials(csp_ctx* c, int64_t mcols, const int32_t* ids, hipS
   return 0;
 }
 
+// k_gram_diag128 over the chunks c0 .. c1 - 1 of the slice table (spw slices each) into the partial slots of the same numbers
+static void gram_launch_chunks(csp_ctx* c, int64_t m, int spw, int c0, int c1, int nchunk_total, hipStream_t st) {
+  DeviceCtx& D = c->D;
+  const int64_t bl = c->S.blklen();
+  static int nw = -1;
+  if (nw < 0) { const char* e = sw_str("SMCP_GRAM_NW"); nw = (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 16); }
+  const int mti = (int)((m + 15) / 16), npw = (mti * (mti + 1) / 2 + nw - 1) / nw;   // lower tiles per wave
+  static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
+  if (gskip < 0) { const char* e = sw_str("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
+  const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
+  const int64_t* ss = D.gsl_start + (int64_t)c0 * spw;
+  const int32_t* sl = D.gsl_len + (int64_t)c0 * spw;
+  const int nsl = std::min<int>(D.gsl_n - c0 * spw, (c1 - c0) * spw);
+  const dim3 grid((unsigned)(c1 - c0), 1);
+#define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_diag128, k_gram_diag128<(N <= 3 ? N : 3), 16>, grid, dim3(1024), lds, st, \
+               (const double*)D.ustack, bl, (int)m, ss, sl, nsl, spw, (const double*)D.sw, D.gpart, c0, nchunk_total, gskip); \
+             else if (nw == 8) launch_lds(c, KID_gram_diag128, k_gram_diag128<(N <= 5 ? N : 5), 8>, grid, dim3(512), lds, st, \
+               (const double*)D.ustack, bl, (int)m, ss, sl, nsl, spw, (const double*)D.sw, D.gpart, c0, nchunk_total, gskip); \
+             else launch_lds(c, KID_gram_diag128, k_gram_diag128<N, 4>, grid, dim3(256), lds, st, \
+               (const double*)D.ustack, bl, (int)m, ss, sl, nsl, spw, (const double*)D.sw, D.gpart, c0, nchunk_total, gskip); break;
+  switch (npw) {
+    SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)
+    SMCP_GRAM_CASE(6) SMCP_GRAM_CASE(7) SMCP_GRAM_CASE(8) SMCP_GRAM_CASE(9)
+  }
+#undef SMCP_GRAM_CASE
+}
+
 // H = sum over the given blkval ranges of G^T W G (ranges: host array of nranges (begin, end) pairs); leaf: the stack
 // lacks the panels of the family children (D.lg_nochild), whose Gram block k_leaf_gram supplies
 static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, double* H, int64_t ldh, hipStream_t st,
@@ -1198,8 +1252,11 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     int spw, nchunk, ngram, nl = 0;
     Fork* side = (Fork*)c->side_fork;
     c->side_fork = nullptr;
+    bool early_done = false;
+    int early = 0;
     if (c->gpre.valid && leaf) {        // planned, and the leaf partials started, beside the large-front stage of the sweep (schur_gram)
       spw = c->gpre.spw; nchunk = c->gpre.nchunk; ngram = c->gpre.ngram; nl = c->gpre.nl;
+      early_done = c->gpre.early_done; early = c->gpre.early;
     } else {
       if (side) { side->join(); delete side; side = nullptr; }
       if (int rc = gram_tables(c, rs, leaf, st)) return rc;
@@ -1210,7 +1267,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
       if (int rc = gram_reserve(c, m, nchunk + (leaf ? leafgram_slots(c) : 0))) return rc;
       if (leaf) { if (int rc = leafgram_partials(c, m, ids, st, D.gpart + (int64_t)ngram * (64 * 256), &nl)) return rc; }
     }
-    c->gpre.valid = false;
+    c->gpre.valid = false; c->gpre.early_done = false;
     // sixteen waves per workgroup (two workgroups per CU: eight waves per SIMD hide the staging and operand latency:
     // 0.96 ms with four waves, 0.75 with eight, 0.72 with sixteen; SMCP_GRAM_NW=4 / 8 select the smaller variants)
     static int nw = -1;
@@ -1219,19 +1276,10 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     static int gskip = -1;     // ablation switch for timing studies only (SMCP_GSKIP: 1 = no MFMA phase, 2 = no global loads)
     if (gskip < 0) { const char* e = sw_str("SMCP_GSKIP"); gskip = e ? atoi(e) : 0; }
     const size_t lds = (size_t)GRAM_BLK * GRAM_LDK * sizeof(double);
-    if (D.gsl_n > 0) {
-#define SMCP_GRAM_CASE(N) case N: if (nw == 16) launch_lds(c, KID_gram_diag128, k_gram_diag128<(N <= 3 ? N : 3), 16>, dim3(nchunk, 1), dim3(1024), lds, st, \
-               (const double*)D.ustack, bl, (int)m, (const int64_t*)D.gsl_start, (const int32_t*)D.gsl_len, D.gsl_n, spw, (const double*)D.sw, D.gpart, 0, nchunk, gskip); \
-             else if (nw == 8) launch_lds(c, KID_gram_diag128, k_gram_diag128<(N <= 5 ? N : 5), 8>, dim3(nchunk, 1), dim3(512), lds, st, \
-               (const double*)D.ustack, bl, (int)m, (const int64_t*)D.gsl_start, (const int32_t*)D.gsl_len, D.gsl_n, spw, (const double*)D.sw, D.gpart, 0, nchunk, gskip); \
-             else launch_lds(c, KID_gram_diag128, k_gram_diag128<N, 4>, dim3(nchunk, 1), dim3(256), lds, st, \
-               (const double*)D.ustack, bl, (int)m, (const int64_t*)D.gsl_start, (const int32_t*)D.gsl_len, D.gsl_n, spw, (const double*)D.sw, D.gpart, 0, nchunk, gskip); break;
-      switch (npw) {
-        SMCP_GRAM_CASE(1) SMCP_GRAM_CASE(2) SMCP_GRAM_CASE(3) SMCP_GRAM_CASE(4) SMCP_GRAM_CASE(5)
-        SMCP_GRAM_CASE(6) SMCP_GRAM_CASE(7) SMCP_GRAM_CASE(8) SMCP_GRAM_CASE(9)
-      }
-#undef SMCP_GRAM_CASE
-    }
+    (void)nw; (void)npw; (void)gskip; (void)lds;
+    // (the chunks before c0 were accumulated beside the large-front stage of the sweep: gpre.early_done)
+    const int c0 = early_done ? early : 0;
+    if (D.gsl_n > 0 && nchunk > c0) gram_launch_chunks(c, m, spw, c0, nchunk, nchunk, st);
     if (side) { side->join(); delete side; }      // the leaf partials of the side branch
     launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(ngram + nl >= 64 ? 1024 : 256), st, (const double*)D.gpart, ngram + nl, (int)m, H, ldh);
     HIPCHK(end_call(c));
@@ -1299,15 +1347,30 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
         if (!D.lg_nochild && !D.lg_request) return;  // the family launch kept the children's panels: the Gram kernel takes them
         const int64_t range[2] = {0, bl};
         const std::vector<std::pair<int64_t, int64_t>> rs = gram_merge_ranges(1, range);
-        if (gram_tables(c, rs, true, side)) return;
+        // (round 5, measured and NOT the default: the Gram chunks of the rows of levels 0 / 1 -- 88 % of them on synth50k -- on the side
+        // branch beside the phase kernels of the top fronts: k_gram_diag128 0.36 -> 0.66 ms, k_lf_up2 0.24 -> 0.50, the step 3.22 ->
+        // 3.37 ms; started earlier still, beside the fused extend-add, that kernel goes 0.45 -> 0.75.  As in round 2: the stages take
+        // CUs, LDS and L2 from each other.  SMCP_GRAM_EARLY=1 runs it.)
+        static const int gearly = sw_on("SMCP_GRAM_EARLY", 0);
+        if (gram_tables(c, rs, true, side, gearly != 0)) return;
         const int64_t chunk = gram_chunk_rows((int64_t)D.gsl_n * GRAM_KS);
-        const int spw = (int)(chunk / GRAM_KS);
+        const int spw = D.gsl_spw ? D.gsl_spw : (int)(chunk / GRAM_KS);
         const int nchunk = std::max(1, (D.gsl_n + spw - 1) / spw);
         const int ngram = D.gsl_n > 0 ? nchunk : 0;
         if (gram_reserve(c, m, nchunk + leafgram_slots(c))) return;
         int nl = 0;
         if (leafgram_partials(c, m, nullptr, side, D.gpart + (int64_t)ngram * (64 * 256), &nl)) return;
         c->gpre.valid = true; c->gpre.ngram = ngram; c->gpre.nchunk = nchunk; c->gpre.spw = spw; c->gpre.nl = nl;
+        c->gpre.early = D.gsl_early; c->gpre.early_done = false;
+      };
+      // behind level 1 of the sweep (hess_up_fast): the panels of the levels 0 and 1 are final -- their chunks of the Gram
+      // accumulation go to the side branch (after the leaf partials already queued there), beside the large fronts above
+      c->mid_work = [c, m](hipStream_t mainst) {
+        Fork* f = (Fork*)c->side_fork;
+        if (!f || !f->on || !c->gpre.valid || c->gpre.early <= 0 || !c->D.lg_nochild) return;
+        if (hipEventRecord(c->aux_fork, mainst) != hipSuccess || hipStreamWaitEvent(f->s, c->aux_fork, 0) != hipSuccess) return;
+        gram_launch_chunks(c, m, c->gpre.spw, 0, c->gpre.early, c->gpre.nchunk, f->s);
+        c->gpre.early_done = true;
       };
     }
     // The closed-form leaf blocks start at once (SMCP_LG_EARLY=0: beside the phase kernels of the top fronts, as in round 3), beside the first launches of the sweep (the stray leaves, the
@@ -1326,6 +1389,7 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
       hess_up_fast(c, D.ustack + jb * bl, nr, bl, D.fac, 2, st, 0, D.kc_ptr ? jb : -1);     // G(A_j) = (G_NN, R^T G_AN)
     }
     c->side_work = nullptr;
+    c->mid_work = nullptr;
     D.lg_request = false;
     const int64_t range[2] = {0, bl};
     if (int rc = gram_accumulate(c, 1, range, H, ldh, st, -1, D.lg_nochild)) return rc;

@@ -42,6 +42,7 @@ static const Switch SWITCHES[] = {
   {"SMCP_ZSP", "1", "0: dense first phase of wide childless fronts instead of k_lf_zsp"},
   {"SMCP_LEAFGRAM", "1", "0: never the closed-form Gram blocks of the family children (k_leaf_tables / k_leaf_pairs)"},
   {"SMCP_LG_SIDE", "1", "0: leaf Gram blocks after the sweep on the caller's stream instead of beside the top phases"},
+  {"SMCP_GRAM_EARLY", "0", "1: the Gram chunks of the levels 0 / 1 rows on the side branch beside the top fronts' phase kernels (measured slower: 3.37 against 3.22 ms per step)"},
   {"SMCP_LG_EARLY", "1", "0: leaf Gram blocks beside the phase kernels of the top fronts instead of from the start of the sweep"},
   {"SMCP_FACI_LDS", "1", "0: inverse Y_AA factors of the small fronts by block rows against HBM (k_factor_inverse) instead of in LDS"},
   {"SMCP_FZ_TAIL", "1", "0: every (front, right-hand side) pair of the fused extend-add is one workgroup's task, also in a thin last round"},
