@@ -1370,6 +1370,21 @@ bool try_lfsp(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, int64
   MfmaArgs bg = b;
   if (grouped) { bg.grp_ptr = grp->ptr; bg.grp_list = grp->list; }
   const dim3 ggrid(g, grouped ? grp->ngroups : cnt);
+  // (SMCP_LFSP_OCC=1, study: the grouped update phase with ONE wave per SIMD -- 512 registers -- instead of two: at two it keeps
+  // sixteen accumulator tiles in 256 registers and spills ~100 of them to scratch)
+  static const int gocc = sw_int("SMCP_LFSP_OCC", 2);
+  if (grouped && gocc == 1) {
+    if (exact) {
+      launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 1, 3, 1, false, true>, grid, blk, st, b, U, ldu);
+      launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 1, 1, false, true, true>, ggrid, blk, st, bg, U, ldu);
+      launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 4, 4, 1, false, true>, grid, blk, st, b, U, ldu);
+    } else {
+      launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 1, 3, 1, false, false>, grid, blk, st, b, U, ldu);
+      launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 1, 1, false, false, true>, ggrid, blk, st, bg, U, ldu);
+      launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 4, 4, 1, false, false>, grid, blk, st, b, U, ldu);
+    }
+    return true;
+  }
   if (exact) {
     launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 1, 3, 1, false, true>, grid, blk, st, b, U, ldu);
     if (grouped) launch(c, KID_lfsp_up, k_lfsp_up<8, 4, 2, 2, 1, false, true, true>, ggrid, blk, st, bg, U, ldu);
