@@ -49,6 +49,12 @@ def build_workload(name, seed=0):
         # 48-entry gate of the entry-driven family sweep k_fam_terms): what the step costs when k_fam_sparse / k_hess_up_fam take over
         pat = problems.nested_block_arrow_pattern(seed=seed)
         m, density, label = 100, 0.05, "synth50k pattern, m=100 constraints of density 0.05 (family sweep beyond the k_fam_terms gate)"
+    elif name == "synth50k_trace":
+        # the headline problem with ONE constraint replaced by a diagonal matrix (the trace constraint of an SDP relaxation): 55 entries
+        # in every (family, constraint) list of that constraint, 13 in the others.  Up to round 4 the longest list chose the route for
+        # the whole set (beyond 48: the dense family sweep, as synth50k_dense); since round 5 the mean does and long lists go in chunks
+        pat = problems.nested_block_arrow_pattern(seed=seed)
+        m, density, label = 100, 0.005, "synth50k with one diagonal (trace) constraint among the 100: one long (family, constraint) list among short ones"
     elif name == "synth6k":   # reduced copy for quick checks only (NOT the benchmark)
         pat = problems.nested_block_arrow_pattern(nsub=2, nmid=56, seed=seed)
         m, density, label = 100, 0.005, "synth6k (reduced, check only)"
@@ -130,7 +136,7 @@ def csrc_sha256():
 def famt_executed_flops(symb, cptr, cidx, chunks, tiles="all"):
     """Flops k_fam_terms EXECUTES per sweep of all chunks (front_famt.hip): one wave per (family parent, right-hand side)
     issues ks = ceil(2 T / 4) steps of NAT (NAT + 1) / 2 + NAT + 1 v_mfma_f64_16x16x4 (2048 flop each, tile padding
-    included), T = entries of the constraint inside the family (the parent's and its children's, capped at 48).  This is
+    included), T = entries of the constraint inside the family (the parent's and its children's; up to 384, in chunks of 48 / 64 entries).  This is
     what SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 counts (profiles/r04_mfma_pmc.txt)."""
     fam = symb.family_roles()
     nn_, na_ = symb.clique_sizes()
@@ -148,7 +154,10 @@ def famt_executed_flops(symb, cptr, cidx, chunks, tiles="all"):
     o = owner[clique]
     T = np.zeros((len(parents), m), dtype=np.int64)
     np.add.at(T, (o[o >= 0], con[o >= 0]), 1)
-    ks = (2 * np.minimum(T, 48) + 3) >> 2
+    T = np.minimum(T, 384)                             # FAMT_TMAX; lists go through in chunks: 48 entries of descriptors in k_fam_terms,
+    chunk = 64 if tiles == "updates" else 48           # 64 terms (one per lane) in the fused extend-add -- steps are padded per chunk
+    full, rest = T // chunk, T % chunk
+    ks = full * ((2 * chunk + 3) >> 2) + ((2 * rest + 3) >> 2)
     nat = (int(na_[parents].max()) + 15) // 16          # the launch's instantiation serves the widest parent
     # tiles per step: update tiles nat (nat + 1) / 2, Q tiles nat, G_NN 1 -- all in k_fam_terms<NAT, true>; with the fused
     # extend-add k_fam_terms<NAT, false> issues the Q and G_NN tiles and k_lf_assemble_fz the update tiles
@@ -159,7 +168,7 @@ def famt_executed_flops(symb, cptr, cidx, chunks, tiles="all"):
         # na x na update matrix, lower triangle only -- 2 multiply-adds per entry, na (na + 1) / 2 entries: no tile padding (na
         # rounded up to 16, the full diagonal tiles), no padding of the term count to a multiple of two
         nap = na_[parents].astype(np.float64)
-        return float((np.minimum(T, 48)[:, :nrhs] * (2.0 * nap * (nap + 1.0))[:, None]).sum())
+        return float((T[:, :nrhs] * (2.0 * nap * (nap + 1.0))[:, None]).sum())
     return float(ks[:, :nrhs].sum()) * per_step * 2048.0
 
 
@@ -456,6 +465,15 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
     max_rhs = (args.max_rhs if primary else None) or int(max(1, min(m, (48 << 30) // per_rhs)))
     if workload != "maxcut":
         cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=1)
+    if workload == "synth50k_trace":
+        ccp, cri = symb.sparsity_pattern()
+        dpos = np.sort(symb.ccs_to_blk()[ccp[:-1]]).astype(np.int64)        # the diagonal entries (first of every column of V)
+        dval = np.random.default_rng(5).standard_normal(len(dpos))
+        cols = [(cidx[cptr[j]:cptr[j + 1]], cval[cptr[j]:cptr[j + 1]]) for j in range(m)]
+        cols[0] = (dpos, dval)
+        cptr = np.concatenate([[0], np.cumsum([len(p_) for p_, _ in cols])]).astype(np.int64)
+        cidx = np.concatenate([p_ for p_, _ in cols]).astype(np.int64)
+        cval = np.concatenate([v_ for _, v_ in cols])
     # the reference's default classification (tnzcols = 0.1): on the synthetic patterns every constraint touches more
     # than n / 10 columns and is swept; the max-cut constraints are column-sparse
     kkt = KKTSystem(symb, cptr, cidx, cval, max_rhs=max_rhs, tnzcols=0.0 if args.kktsolver == "qr" else None)
@@ -907,7 +925,7 @@ def main():
     # config 4 (max-cut, column-sparse constraints) -- a few steps each after the headline measurement
     if world == 1 and not force_sharded and args.workload == "synth50k" and not args.no_secondary and args.kktsolver == "chol":
         sec = {}
-        for name in ("dense4096", "arrow", "maxcut", "synth50k_dense"):
+        for name in ("dense4096", "arrow", "maxcut", "synth50k_dense", "synth50k_trace"):
             try:
                 # ten timed steps after two warm-up steps each; the CPU leg beside every GPU figure: the oracle on the host BLAS, one
                 # Schur column per thread scaled to m (config 4: its sequential SCMcolumn2 route in full, median of three)

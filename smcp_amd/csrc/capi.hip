@@ -1181,6 +1181,16 @@ inline bool famt_disabled() {
   if (off < 0) { const char* e = sw_str("SMCP_FAMT"); off = (e && e[0] == '0') ? 1 : 0; }
   return off != 0;
 }
+// The entry-driven sweeps (k_fam_terms, the fused extend-add) cost in proportion to the entries of the (family, constraint)
+// lists -- 0.87 ms per Schur sweep on synth50k at 13 entries per list -- the dense family sweep (k_hess_up_fam) 2.84 ms
+// whatever the lists hold: break-even near 42 entries per list ON AVERAGE.  Rounds 3 - 4 gated on the LONGEST list (48: one
+// chunk of the descriptor area), so ONE long list -- a multiple of the identity among sparse constraints: 15 + 8 x 5 diagonal
+// entries per family -- sent the whole set to the dense route (1.86 x the step).  Now the kernels take long lists in chunks
+// (FAMT_TMAX) and the gate is the mean.  SMCP_FAMT_MEAN moves it.
+inline bool famt_terms_ok(const DeviceCtx& D) {
+  static const int gate = sw_int("SMCP_FAMT_MEAN", 36);
+  return D.fam_maxterms <= FAMT_TMAX && D.fam_meanterms <= (double)gate;
+}
 // LDS of the grouped kernel: entries it can stage (< 0: the fixed part does not fit); one pass of a group needs at most
 // FAMT_GMAX x FAMT_TCAP / 2 of them
 template <int NAT>
@@ -1241,7 +1251,7 @@ bool launch_famt(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
   const FamtL L = famt_layout<NAT>(8 * cnn);
   const int64_t lim = (160 * 1024 - 1024) / 8;                          // doubles of LDS a workgroup may use
   const int64_t fixed = L.total + FAMT_NW * famt_desc_doubles() + 6;
-  if (D.fam_maxterms > FAMT_TCAP / 2) return false;                      // pairs of one right-hand side: the descriptor area
+  if (!famt_terms_ok(D)) return false;                                   // (long lists: in chunks of the descriptor area)
   if (fixed + 9 * 4 + 64 > lim) return false;
   const int64_t prep_doubles = famt_prep_doubles<NAT>(cnn);
   if (prep_doubles > lim) return false;
@@ -1438,7 +1448,7 @@ void hess_up_fast(csp_ctx* c, double* U, int nrhs, int64_t ldu, const double* ys
     static int fzenv = -1;
     if (fzenv < 0) { const char* e = sw_str("SMCP_FZ"); fzenv = (e && e[0] == '0') ? 0 : 1; }
     bool want = fzenv && sparse && (set == 0 || (set == 1 && c->fz_set1_ok)) && lev_lo == 0 && lev_hi < 0 && !fgroups_on && c->D.fz_ok && !famt_disabled() && !fam2_disabled() &&
-                c->D.lg_request && c->D.kc_ij && a0.ymode == 2 && a0.ysc && c->D.fam_maxterms <= FAMT_TCAP / 2 &&
+                c->D.lg_request && c->D.kc_ij && a0.ymode == 2 && a0.ysc && famt_terms_ok(c->D) &&
                 c->D.cnnz <= (int64_t)4 * c->S.nsn * std::max<int64_t>(1, c->D.m) && !use_generic(c) && use_large() && c->D.gp_tptr;
     int famlevels = 0, nofill = 0;
     if (want) {

@@ -107,6 +107,7 @@ struct DeviceCtx {
   int64_t famc_len = 0;
   int64_t kc_maxlist = 0;    // longest entry list of a (clique, constraint) pair among possible family members
   int64_t fam_maxterms = 0;  // most entries of a (family, constraint) pair: the parent's own + its children's
+  double fam_meanterms = 0;   // ... and their mean over all (family, constraint) pairs (what the entry-driven sweeps cost in proportion to)
   double* vbuf = nullptr;    // n x vcols : S^-1[:, K_s] of the chunk in flight
   double* trsm_x = nullptr; int64_t trsm_x_len = 0;   // scratch image of the right-hand sides of csp_trsm (tile-product route)
   int64_t vcols = 0;

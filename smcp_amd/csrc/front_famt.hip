@@ -68,6 +68,7 @@ constexpr int FAMT_HDR = 32;        // doubles: the header of a record (ints, as
                                     // [4,5] panel offset, [8,9] packed-update offset; child c at 16 + 6 c: clique, nn, na,
                                     // first column in the child tables, -, -)
 constexpr int FAMT_TCAP = 96;       // ordered pairs t' per (parent, right-hand side): 48 entries (host-checked)
+constexpr int FAMT_TMAX = 384;      // longest (family, constraint) list the entry-driven sweeps take (in chunks of FAMT_TCAP / 2; host-checked)
 constexpr int FAMT_CHILD = 128;     // vector ids: < 128 unit vector e_id of the parent's front, >= 128 child column id - 128
 
 // LDS of k_famt_prep (doubles): R^T | -K | Li | per wave q~ (16 + NA) and the a images of its child's columns (cnn x NA)
@@ -326,18 +327,24 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
       int incl = cntm;
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-      const int T = min(__builtin_amdgcn_readlane(incl, 15), FAMT_TCAP / 2);
-      {
+      // (lists of more than FAMT_TCAP / 2 entries -- a constraint with a long list among short ones, e.g. a multiple of the
+      // identity: 15 + 8 x 5 diagonal entries per family -- go through the descriptor area in chunks of that many; the
+      // accumulators of a pass persist across the chunks)
+      const int Ttot = min(__builtin_amdgcn_readlane(incl, 15), FAMT_TMAX);
+      const int ndp = max(1, (Ttot + FAMT_TCAP / 2 - 1) / (FAMT_TCAP / 2));
+      auto build = [&](int dp) {
+        const int e = dp * (FAMT_TCAP / 2) + lane;              // this lane's entry of the concatenated member lists
+        const int T = min(FAMT_TCAP / 2, Ttot - dp * (FAMT_TCAP / 2));
         int mem = 0, base = 0;
 #pragma unroll
         for (int mm = 0; mm < 8; ++mm) {
           const int up = __builtin_amdgcn_readlane(incl, mm);
-          if (lane >= up) { mem = mm + 1; base = up; }
+          if (e >= up) { mem = mm + 1; base = up; }
         }
         if (lane < T) {
           const int where = trow[2 * mem + 1];
-          const int pk = lpk[where + (lane - base)];
-          const double v = lval[where + (lane - base)];
+          const int pk = lpk[where + (e - base)];
+          const double v = lval[where + (e - base)];
           const int i = pk & 0xff, jc = (pk >> 8) & 0xff, rl = (pk >> 16) & 0xff;
           int vx, vy;
           double s;
@@ -368,8 +375,9 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
           int4 z = {L.oZero | (L.oZero << 16), L.oZero | (255 << 16), L.oZero | (L.oZero << 16), 255};
           reinterpret_cast<int4*>(dI)[2 * T + lane] = z;
         }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      };
+      build(0);
       // =================================================================================================
       // products: step s takes the pairs t' = kq + 4 s.  Accumulator register x of lane (l15, kq) of a tile holds
       // (row l15 of the b operand's tile, column kq + 4 x of the a operand's tile)
@@ -377,9 +385,9 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
       // Row tiles in two passes when there are four of them (rows 0..2, then row 3 + G_NN): 15 live accumulator tiles
       // plus the operands of a step exceed the 256 registers of a wave at two waves per SIMD (measured: 35 spilled
       // registers, i.e. scratch loads behind the streaming stores); the operands are re-read from LDS, which is cheap.
-      const int ks = (2 * T + 3) >> 2;
       const __amdgpu_buffer_rsrc_t rP = famt_rsrc(u + (int64_t)r * ldu + pblk, nf * nn);
       const __amdgpu_buffer_rsrc_t rU = famt_rsrc(a.t.updp + (int64_t)r * a.t.updplen + pupdp, (na * (na + 1)) >> 1);
+      bool fresh = true;                     // the descriptor area holds chunk 0
       auto pass = [&](auto LOc, auto HIc, auto Gc) {
         constexpr int LO = decltype(LOc)::value, HI = decltype(HIc)::value;      // row tiles LO .. HI - 1
         constexpr bool WITHG = decltype(Gc)::value;
@@ -389,6 +397,13 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
         for (int x = 0; x < NTU; ++x) accU[x] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int x = 0; x < HI - LO; ++x) accQ[x] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int dp = 0; dp < ndp; ++dp) {
+        if (!(fresh && dp == 0)) {           // (every lane has read the previous chunk's descriptors)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          build(dp);
+        }
+        fresh = ndp == 1;
+        const int ks = (2 * min(FAMT_TCAP / 2, Ttot - dp * (FAMT_TCAP / 2)) + 3) >> 2;
         for (int s = 0; s < ks; ++s) {
           const int tp = kq + 4 * s;
           const double sc = dS[tp];
@@ -422,6 +437,7 @@ __global__ void __launch_bounds__(64 * FAMT_NW) k_fam_terms(MfmaArgs a, double* 
             const double bN = smem[nx + l15];
             accG = __builtin_amdgcn_mfma_f64_16x16x4f64(aN, bN, accG, 0, 0, 0);
           }
+        }
         }
         // results straight from the accumulators: packed update (column-major lower), Q and G_NN into the panel
 #pragma unroll
@@ -493,17 +509,19 @@ __device__ inline void lf_add_family(double* T, int nf, const MfmaArgs& a, int z
   const int slot = z & 0x7ffff, nnp = (z >> 19) & 31, nap = (z >> 24) & 127;
   const FamtL L = famt_layout<NAT>(8 * a.fz_cnn);
   const double* const tab = a.fz_tab + (int64_t)slot * a.fz_recl + FAMT_HDR;
-  const int p0 = (int)(uint32_t)(pt & 0xffffffffll), Tn = min((int)(pt >> 32), FAMT_TCAP / 2);
-  int pk = 0;
-  double sv = 0.0;
-  if (lane < Tn) { pk = a.fz_pk[p0 + lane]; sv = a.fz_s[p0 + lane]; }
+  // (a list of more than 64 terms -- one per lane -- is taken in chunks of 64, the accumulators persist)
+  const int pbase = (int)(uint32_t)(pt & 0xffffffffll), Ttot = min((int)(pt >> 32), FAMT_TMAX);
   int relv[NAT];
 #pragma unroll
   for (int t = 0; t < NAT; ++t) relv[t] = rel[min(16 * t + l15, max(nap - 1, 0))];
-  const int ks = (2 * Tn + 3) >> 2;
   d4 acc[NTU];
 #pragma unroll
   for (int x = 0; x < NTU; ++x) acc[x] = d4{0.0, 0.0, 0.0, 0.0};
+  auto chunk = [&](const int p0, const int Tn) {
+  int pk = 0;
+  double sv = 0.0;
+  if (lane < Tn) { pk = a.fz_pk[p0 + lane]; sv = a.fz_s[p0 + lane]; }
+  const int ks = (2 * Tn + 3) >> 2;
   // operands of step s: the a images of the two vectors of ordered pair tp = kq + 4 s (entry tp >> 1 taken as (x, y) or (y, x)).
   // The two ordered pairs of an entry sit sixteen lanes apart (kq even / odd) and want the same two images with the roles
   // swapped: every lane gathers the image of ITS y only and takes the image of its x from the partner lane (lane ^ 16: a
@@ -561,6 +579,10 @@ __device__ inline void lf_add_family(double* T, int nf, const MfmaArgs& a, int z
       for (int g = 0; g < PFG; ++g) mma(aA[g], se[g], ux[g], uy[g]);
     }
   }
+  };
+  // (the usual list is one chunk: straight-line, as before the chunks existed -- the kernel runs at its register limit)
+  if (Ttot <= 64) chunk(pbase, Ttot);
+  else for (int c0 = 0; c0 < Ttot; c0 += 64) chunk(pbase + c0, min(64, Ttot - c0));
   // element (m, n) of the update -> front position (rel[m], rel[n]); packed column start minus the column index as in lf_alds_task
 #pragma unroll
   for (int rt = 0; rt < NAT; ++rt) {

@@ -652,16 +652,23 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
     // most entries of a (family, constraint) pair: the parent's own + its children's (the entry-driven family sweep of
     // front_famt.hip turns every entry into one term of a rank-T product)
     D.fam_maxterms = 0;
-    for (int64_t k = 0; k < S.nsn; ++k)
-      if (k < (int64_t)c->fam.size() && c->fam[k] == 2)
-        for (int64_t j = 0; j < m; ++j) {
-          int64_t tot = kptr[(size_t)k * (m + 1) + j + 1] - kptr[(size_t)k * (m + 1) + j];
-          for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) {
-            const size_t q = (size_t)S.chidx[q2] * (m + 1) + j;
-            tot += kptr[q + 1] - kptr[q];
+    D.fam_meanterms = 0.0;
+    {
+      int64_t sum = 0, pairs = 0;
+      for (int64_t k = 0; k < S.nsn; ++k)
+        if (k < (int64_t)c->fam.size() && c->fam[k] == 2)
+          for (int64_t j = 0; j < m; ++j) {
+            int64_t tot = kptr[(size_t)k * (m + 1) + j + 1] - kptr[(size_t)k * (m + 1) + j];
+            for (int64_t q2 = S.chptr[k]; q2 < S.chptr[k + 1]; ++q2) {
+              const size_t q = (size_t)S.chidx[q2] * (m + 1) + j;
+              tot += kptr[q + 1] - kptr[q];
+            }
+            D.fam_maxterms = std::max(D.fam_maxterms, tot);
+            sum += tot;
+            ++pairs;
           }
-          D.fam_maxterms = std::max(D.fam_maxterms, tot);
-        }
+      if (pairs) D.fam_meanterms = (double)sum / (double)pairs;
+    }
     D.kc_maxlist_large = 0;       // over the childless fronts beyond the small classes (sparse-input sweep of large fronts)
     for (int64_t k = 0; k < S.nsn; ++k)
       if ((S.nn(k) > 16 || S.na(k) > 64) && S.nn(k) <= 64 && S.na(k) <= 128 && S.chptr[k + 1] == S.chptr[k])
@@ -732,7 +739,7 @@ int kkt_set_constraints(csp_ctx* c, int64_t m, const int64_t* cptr, const int64_
     // launch from the entry lists (front_famt.hip, header): own entry v at (i, j): e_i, e_j, v (v / 2 on the diagonal); child
     // entry at (separator row a, column j): q~_{c,j}, e_{rel_c[a]}, -v; child entry at (i, j) of its supernode block: q~_{c,i},
     // q~_{c,j}, v (v / 2).  Only when every family parent hangs under a large front whose packed triangle fits LDS.
-    if (D.fam_maxterms > 0 && D.fam_maxterms <= 48 && !c->fam.empty()) {
+    if (D.fam_maxterms > 0 && famt_terms_ok(D) && !c->fam.empty()) {
       std::vector<int32_t> fno((size_t)S.nsn, -1);
       c->fz_levels.assign((size_t)S.nlev, 0);
       int64_t nfam = 0;

@@ -79,6 +79,7 @@ static const Switch SWITCHES[] = {
   {"SMCP_FAM_MINRHS", "1", "fewest dense right-hand sides for the family kernel"},
   {"SMCP_FAMT_G", "0", "right-hand-side slices per family of k_fam_terms (0: cost model)"},
   {"SMCP_FAM2_STAG", "0", "stagger of k_fam_sparse's groups (studies)"},
+  {"SMCP_FAMT_MEAN", "36", "entry-driven family sweeps (k_fam_terms, fused extend-add) up to this many entries per (family, constraint) list ON AVERAGE (lists up to 384 entries, in chunks); beyond: the dense family sweep"},
   {"SMCP_LFSP_OCC", "2", "waves per SIMD the grouped update phase of k_lfsp_up is compiled for (1: 512 registers, no spills; 2: 256, ~100 spilled)"},
   {"SMCP_LFSP_G", "1", "right-hand sides per workgroup of k_lfsp_up"},
   {"SMCP_GRAM_NW", "16", "waves per workgroup of k_gram_diag128 (4, 8 or 16)"},

@@ -1395,3 +1395,62 @@ def test_fused_extend_add_with_shared_pairs():
                         "-k", "family_updates_formed_by_the_extend_add and True"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _band_constraint(symb, width, rng):
+    """one constraint holding every entry of V within `width` of the diagonal (permuted coordinates): width 0 = a diagonal
+    matrix -- the trace constraint of an SDP relaxation --, which alone gives a (15, 64) parent with eight (5, 31) leaves a
+    (family, constraint) list of 15 + 8 x 5 = 55 entries; width 1: 101, width 4: 185"""
+    cp, ri = symb.sparsity_pattern()
+    col = np.repeat(np.arange(symb.n), np.diff(cp))
+    pos = np.sort(symb.ccs_to_blk()[(ri - col) <= width])
+    return pos.astype(np.int64), rng.standard_normal(len(pos))
+
+
+@pytest.mark.parametrize("name,width,nlong,m,fz", [("nested_mid", 0, 1, 24, True), ("nested_mid", 1, 1, 24, True), ("nested_mid", 4, 1, 24, True),
+                                                   ("nested_mid", 4, 2, 48, True), ("fam_odd", 4, 1, 24, False), ("fam_top", 2, 1, 24, True),
+                                                   ("nested_mid", 4, -1, 3, None)])
+def test_entry_driven_sweeps_with_long_lists_among_short_ones(name, width, nlong, m, fz):
+    """Round 5: the entry-driven family sweeps take (family, constraint) lists of any length up to 384 in
+    chunks -- 48 entries of descriptors per chunk in k_fam_terms, 64 terms (one per lane) in the fused extend-add -- and the route
+    is chosen by the MEAN list length, not the longest: a trace constraint (55 entries per family) or a band (101, 185: two / four
+    descriptor chunks, two / three term chunks) among sparse constraints no longer sends the whole set to the dense family sweep.
+    H, x, y against the oracle; the launch counters say which route ran.  nlong = -1: every constraint is a band (mean beyond the
+    gate): the dense route, same answers."""
+    symb, S, A, msk = setup(name, 51)
+    rng = np.random.default_rng(52)
+    L = A.copy()
+    orc.cholesky(S, L)
+    Yh = L.copy()
+    orc.projected_inverse(S, Yh)
+    # (m: the fused extend-add wants 32 (front, right-hand side) pairs -- two top fronts x 24 --, and both entry-driven routes a mean
+    # of at most four entries per (clique, constraint))
+    cptr, cidx, cval = problems.random_constraints(symb, m, density=0.002, seed=53)
+    cols = [(cidx[cptr[j]:cptr[j + 1]], cval[cptr[j]:cptr[j + 1]]) for j in range(m)]
+    for j in (range(m) if nlong < 0 else [3, 17][:nlong]):
+        cols[j] = _band_constraint(symb, width, rng)
+    cptr = np.concatenate([[0], np.cumsum([len(p) for p, _ in cols])]).astype(np.int64)
+    cidx = np.concatenate([p for p, _ in cols]).astype(np.int64)
+    cval = np.concatenate([v for _, v in cols])
+    K = orc.KKT(S, cptr, cidx, cval)
+    Href = K.schur_factor(L, Yh)
+    sys_ = KKTSystem(symb, cptr, cidx, cval, max_rhs=m, tnzcols=0.0)
+    chordal.tune(symb, chordal.TUNE_LEAFGRAM, 2)
+    try:
+        Ld, Yd = dev(symb, L), dev(symb, Yh)
+        box = {}
+        counts = _launch_counts(symb, lambda: box.setdefault("solve", sys_.factor(Ld, Yd)))
+        if fz is None:
+            assert counts.get("k_fam_terms", 0) == 0 and counts.get("k_lf_assemble_fz", 0) == 0, counts
+        else:
+            assert counts.get("k_fam_terms", 0) >= 1, counts
+            assert (counts.get("k_lf_assemble_fz", 0) >= 1) == fz, counts
+        assert rel(np.tril(sys_.H.cpu().numpy().T), np.tril(Href)) < 1e-9
+        bx = rng.standard_normal(symb.blklen) * msk
+        by = rng.standard_normal(m)
+        xr, yr = K.solve(L, Yh, Href, bx, by, 0.5)
+        bxd, byd = dev(symb, bx), torch.from_numpy(by.copy()).cuda()
+        box["solve"](bxd, byd, 0.5)
+        assert rel(host(bxd)[msk], xr[msk]) < 1e-9 and rel(byd.cpu().numpy(), yr) < 1e-9
+    finally:
+        chordal.tune(symb, chordal.TUNE_LEAFGRAM, 1)
