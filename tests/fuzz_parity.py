@@ -98,6 +98,19 @@ def run(ncases, seed0=0, verbose=False, patterns=None):
         m = min(m, max(1, nnzv // 2))
         dens = float(rng.choice([0.002, 0.02, 0.2]))
         cptr, cidx, cval = problems.random_constraints(symb, m, density=dens, seed=int(rng.integers(1 << 30)))
+        if case % 3 == 0 and m >= 2:
+            # a long list among short ones (round 5): one or two constraints become a band of V -- width 0 is a diagonal matrix,
+            # the trace constraint of a relaxation -- whose (family, constraint) lists take several chunks of the entry-driven sweeps
+            ccp, cri = symb.sparsity_pattern()
+            ccol = np.repeat(np.arange(symb.n), np.diff(ccp))
+            cols = [(cidx[cptr[j]:cptr[j + 1]], cval[cptr[j]:cptr[j + 1]]) for j in range(m)]
+            for j in rng.choice(m, size=int(rng.integers(1, 3)), replace=False):
+                pos = np.sort(symb.ccs_to_blk()[(cri - ccol) <= int(rng.integers(0, 5))]).astype(np.int64)
+                cols[int(j)] = (pos, rng.standard_normal(len(pos)))
+            cptr = np.concatenate([[0], np.cumsum([len(p_) for p_, _ in cols])]).astype(np.int64)
+            cidx = np.concatenate([p_ for p_, _ in cols]).astype(np.int64)
+            cval = np.concatenate([v_ for _, v_ in cols])
+            tag = tag + " +band" if isinstance(tag, str) else tag
         K = orc.KKT(S, cptr, cidx, cval)
         try:
             Href = K.schur_factor(Lr, Yr)
