@@ -26,7 +26,10 @@ __device__ inline double ldm(bool c, const double* p) {
   else return c ? *p : 0.0;
 }
 // Two shapes of the same tile product.  PD = 1 (256 threads): four waves, 2 x 2 MFMA tiles each -- the batched sweeps, where
-// several workgroups share a CU.  PD = 4 (1024 threads, "W16"): sixteen waves, ONE 16 x 16 MFMA tile each, for launches of
+// several workgroups share a CU.  Every kernel of this shape is compiled for FOUR waves per SIMD (__launch_bounds__(256, 4):
+// 128 registers, accumulators in VGPRs; round 5): left to itself the compiler took 126 - 134 VGPRs + 32 - 64 AGPRs, i.e. two or
+// three workgroups per CU, and a tile's life is mostly the round trips before and after its MFMAs -- k_lf_up2 on the top fronts of
+// synth50k 139 -> 107 us, on the 4096 front of config 2 15.5 -> 14.9 ms, k_lf_down3 there 1.89 -> 1.62 ms (no or <= 6 spills).  PD = 4 (1024 threads, "W16"): sixteen waves, ONE 16 x 16 MFMA tile each, for launches of
 // a few tiles (one right-hand side on the top fronts: the solves of the interior-point iteration).  In-kernel stamps
 // (scratch/stamps_lf.py) showed a slice of the 256-thread shape to cost ~1.3 us on an otherwise idle CU -- 16 MFMAs (64 cycles
 // each), the address arithmetic of 8 loads and two barriers, all on ONE wave per SIMD, instruction bound, not latency
@@ -731,7 +734,7 @@ __global__ void k_lf_clear_upd(MfmaArgs a) {
 __host__ __device__ inline bool lf_sym_split(int nn) { return nn > 6 * LT; }
 // ---- up-sweep phase 1: E = F_AN - K F_NN / 2, X = F_AN - K F_NN (in place) ; Z = Li Fl (into T)
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up1(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_up1(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ __attribute__((aligned(16))) double smem[PD == 1 ? LRC_DOUBLES : LKC * LSA + LT * LSB];
   double* const sA = smem; double* const sB = smem + LKC * LSA;
   const LfCtx c = lf_ctx(a, u, ldu);
@@ -835,7 +838,7 @@ __global__ void __launch_bounds__(256) k_lf_zsp(MfmaArgs a, double* u, int64_t l
 }
 // ---- up-sweep phase 2: U -= K E^T + E K^T (lower tiles) ; G = X Li^T ; G_NN = Z Li^T + Li Z^T (lower, in place)
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up2(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_up2(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ __attribute__((aligned(16))) double smem[PD == 1 ? LRC_DOUBLES : LKC * LSA + LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -882,7 +885,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up2(MfmaArgs a, dou
 }
 // ---- up-sweep phase 3: Q = Ysc G into the AN rows of the panel (X is dead)
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up3(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_up3(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
 #ifdef SMCP_STAMPS
   const bool stamp = a.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && a.nrhs == 1;
@@ -926,7 +929,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_up3(MfmaArgs a, dou
 
 // ---- down-sweep phase 1: QL = Q Li (into E) ; T = G_NN Li        (Q = AN rows of the panel)
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down1(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_down1(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ __attribute__((aligned(16))) double smem[PD == 1 ? LRC_DOUBLES : LKC * LSA + LT * LSB];
   double* const sA = smem; double* const sB = smem + LKC * LSA;
   const LfCtx c = lf_ctx(a, u, ldu);
@@ -964,7 +967,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down1(MfmaArgs a, d
 }
 // ---- down-sweep phase 2: D = QL - Z_AA K / 2 (into G) ; Z_AN = 2D - QL (into the panel)
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down2(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_down2(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -988,7 +991,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down2(MfmaArgs a, d
 }
 // ---- down-sweep phase 3: Z_NN = Li^T T - K^T D - D^T K (lower tiles, into the panel)
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down3(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_down3(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ __attribute__((aligned(16))) double smem[PD == 1 ? LRC_DOUBLES : LKC * LSA + LT * LSB];
   double* const sA = smem; double* const sB = smem + LKC * LSA;
   const LfCtx c = lf_ctx(a, u, ldu);
@@ -1019,7 +1022,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_down3(MfmaArgs a, d
 // (the root of synth50k, one right-hand side: 58 us of the 345 us of a Hessian).  Phase 1 (end of the up sweep, after the
 // extend-add): T = F_NN Y_NN; phase 2 (start of the down sweep): Z_NN = Y_NN T, lower, into the panel.
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_root1(MfmaArgs a, double* u, int64_t ldu, const double* Yb) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_root1(MfmaArgs a, double* u, int64_t ldu, const double* Yb) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, nf = c.nf, ntN = tiles64(nn);
@@ -1036,7 +1039,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_root1(MfmaArgs a, d
   tile64_foreach(acc, m0, n0, nn, nn, [=](int m, int n, double v) { T[m + (int64_t)n * nn] = v; });
 }
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_root2(MfmaArgs a, double* u, int64_t ldu, const double* Yb) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_root2(MfmaArgs a, double* u, int64_t ldu, const double* Yb) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, nf = c.nf, ntN = tiles64(nn);
@@ -1114,7 +1117,7 @@ __global__ void __launch_bounds__(256) k_trsm_mm_bwd(MfmaArgs a, double* B, int 
 
 // ---- projected inverse, large fronts: E = Y_AA K ; Y_NN = Li^T Li + K^T E (lower) ; Y_AN = -E
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_pinv1(MfmaArgs a, double* x) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_pinv1(MfmaArgs a, double* x) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, x, 0);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1132,7 +1135,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_pinv1(MfmaArgs a, d
   tile64_foreach(acc, m0, n0, na, nn, [=](int m, int n, double v) { E[m + (int64_t)n * na] = v; });
 }
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_pinv2(MfmaArgs a, double* x) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_pinv2(MfmaArgs a, double* x) {
   __shared__ __attribute__((aligned(16))) double smem[PD == 1 ? LRC_DOUBLES : LKC * LSA + LT * LSB];
   double* const sA = smem; double* const sB = smem + LKC * LSA;
   const LfCtx c = lf_ctx(a, x, 0);
@@ -1853,7 +1856,7 @@ __global__ void k_lf_copy_an(MfmaArgs a, double* u, int64_t ldu, int dir) {
 }
 // G = Ri^T (AN rows of the panel)  (tr = 1)   or   G = Ri (AN rows)  (tr = 0)
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_ri_an(MfmaArgs a, double* u, int64_t ldu, int tr) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_ri_an(MfmaArgs a, double* u, int64_t ldu, int tr) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1876,7 +1879,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_ri_an(MfmaArgs a, d
 
 // ---- G^-adj phase 1: Q = Z_AN L_NN + Z_AA L_AN (into G) ; Q'' = Z_AN L_NN + Z_AA L_AN / 2 (into E) ; T = Z_NN L_NN
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_dinv1(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_dinv1(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1911,7 +1914,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_dinv1(MfmaArgs a, d
 }
 // ---- G^-adj phase 2: G_NN = L_NN^T T + L_AN^T Q'' + Q''^T L_AN (lower, into the panel) ; AN rows = Q or Ri Q
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_dinv2(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_dinv2(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1949,7 +1952,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_dinv2(MfmaArgs a, d
 }
 // ---- G^-1 phase 1: V = G_AN + L_AN G_NN / 2 (into E) ; T = G_NN L_NN^T
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_uinv1(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_uinv1(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
@@ -1976,7 +1979,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_uinv1(MfmaArgs a, d
 }
 // ---- G^-1 phase 2: U = -(V L_AN^T + L_AN V^T) (lower) ; G = (2V - G_AN) L_NN^T ; F_NN = L_NN T (lower, into the panel)
 template <int PD>
-__global__ void __launch_bounds__(PD == 4 ? 1024 : 256) k_lf_uinv2(MfmaArgs a, double* u, int64_t ldu) {
+__global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_uinv2(MfmaArgs a, double* u, int64_t ldu) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, u, ldu);
   const int nn = c.nn, na = c.na, nf = c.nf;
