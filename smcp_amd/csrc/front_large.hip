@@ -1064,7 +1064,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_root2(MfmaArgs a
 // One workgroup per (64 front rows, clique, 64 columns of B); the cliques of a level are independent, the separator
 // rows of different cliques of a level may coincide (global atomics in the forward sweep).  x_N goes to a scratch image
 // X of B first: other tiles of the same clique still read b_N.
-__global__ void __launch_bounds__(256) k_trsm_mm_fwd(MfmaArgs a, double* B, int nrhs, int64_t ldb, const int32_t* rowidx, double* X) {
+__global__ void __launch_bounds__(256, 4) k_trsm_mm_fwd(MfmaArgs a, double* B, int nrhs, int64_t ldb, const int32_t* rowidx, double* X) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
@@ -1094,7 +1094,7 @@ __global__ void k_trsm_mm_copy(MfmaArgs a, double* B, int nrhs, int64_t ldb, con
     B[d.first + i + col * ldb] = X[d.first + i + col * ldb];
   }
 }
-__global__ void __launch_bounds__(256) k_trsm_mm_bwd(MfmaArgs a, double* B, int nrhs, int64_t ldb, const int32_t* rowidx, double* X) {
+__global__ void __launch_bounds__(256, 4) k_trsm_mm_bwd(MfmaArgs a, double* B, int nrhs, int64_t ldb, const int32_t* rowidx, double* X) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
@@ -1673,7 +1673,7 @@ __device__ inline InvView inv_view(const MfmaArgs& a, int k, const CliqueDesc& d
   }
   return v;
 }
-__global__ void __launch_bounds__(256) k_lf_prep_s(MfmaArgs a, const double* L, double* LK, int ib, int mode) {
+__global__ void __launch_bounds__(256, 4) k_lf_prep_s(MfmaArgs a, const double* L, double* LK, int ib, int mode) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
@@ -1695,7 +1695,7 @@ __global__ void __launch_bounds__(256) k_lf_prep_s(MfmaArgs a, const double* L, 
   tile64_foreach(acc, 0, n0, w, ib, [=](int m, int n, double v) { S[s0 + m * sm + n * sn] = v; });
 }
 // hoisted != 0: the inverses of ALL diagonal blocks are already in place in dst (k_lf_diag_inv)
-__global__ void __launch_bounds__(256) k_lf_prep_row(MfmaArgs a, const double* L, double* LK, int ib, int mode, int hoisted) {
+__global__ void __launch_bounds__(256, 4) k_lf_prep_row(MfmaArgs a, const double* L, double* LK, int ib, int mode, int hoisted) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
@@ -1769,7 +1769,7 @@ __global__ void __launch_bounds__(256) k_lf_diag_inv(MfmaArgs a, const double* L
 // step 0: W = B * Ai into the clique's scratch;  step 1: X[C, A] = -Ci * W.  Every level is two launches of
 // (pairs x (b/64)^2) tiles -- log2(nn/64) levels with growing parallelism -- where the row-by-row scheme (k_lf_prep_s /
 // k_lf_prep_row per 64-row block) runs nn/64 dependent steps of at most nn/64 workgroups: 4096 front, 18.4 ms -> see DESIGN.
-__global__ void __launch_bounds__(256) k_lf_trtri(MfmaArgs a, const double* L, double* LK, int b, int step) {
+__global__ void __launch_bounds__(256, 4) k_lf_trtri(MfmaArgs a, const double* L, double* LK, int b, int step) {
   __shared__ __attribute__((aligned(16))) double smem[LRC_DOUBLES];
   double* const sA = smem; double* const sB = smem + LKC * LSA;
   const int k = a.t.lev[blockIdx.y];
@@ -2021,7 +2021,7 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_uinv2(MfmaArgs a
 
 // ---- completion, large fronts (scratch: T nn x nn | E na x nn | G na x nn | row-block scratch of the inversion)
 // step 0: E = Ri X_AN ; step 1: G = Ri^T E ; step 2: T = reversed(X_NN - X_AN^T G) ; step 3: L_NN = reversed(T^-1)^T, L_AN = -G L_NN
-__global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, int step) {
+__global__ void __launch_bounds__(256, 4) k_lf_completion(MfmaArgs a, double* x, int step) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, x, 0);
   if (*info_of(a.t, c.k)) return;
@@ -2072,7 +2072,7 @@ __global__ void __launch_bounds__(256) k_lf_completion(MfmaArgs a, double* x, in
 // ---- llt, large fronts.  step 0: T = L_NN L_NN^T (lower), G = L_AN L_NN^T, U = L_AN L_AN^T (lower, assigned);
 // step 1: panel <- (T lower, G).  The children are added afterwards by the assemble kernel (sgn 2) and the update
 // block is published packed by k_lf_pack_upd.
-__global__ void __launch_bounds__(256) k_lf_llt(MfmaArgs a, double* x, int step) {
+__global__ void __launch_bounds__(256, 4) k_lf_llt(MfmaArgs a, double* x, int step) {
   __shared__ double sA[LKC * LSA], sB[LT * LSB];
   const LfCtx c = lf_ctx(a, x, 0);
   const int nn = c.nn, na = c.na, nf = c.nf;
