@@ -61,9 +61,13 @@ __device__ inline void famt_store(__amdgpu_buffer_rsrc_t r, bool ok, int pos, do
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(famt_u2, v), r, ok ? pos * 8 : -1, 0, SMCP_FAMT_AUX);
 }
 #ifndef SMCP_FAMT_NW
-#define SMCP_FAMT_NW 8
+#define SMCP_FAMT_NW 12
 #endif
-constexpr int FAMT_NW = SMCP_FAMT_NW;   // waves of a k_fam_terms workgroup: 8 = two per SIMD; 12 (three per SIMD at 168 registers, three passes of at most six tiles) measured 0.82 against 0.80 ms
+// waves of a k_fam_terms workgroup (one workgroup per CU: the tables fill LDS).  Round 3, when the kernel formed the update tiles
+// as well (15 accumulator tiles): 8 = two per SIMD; 12 (168 registers, three passes of at most six tiles) 0.82 against 0.80 ms.
+// Since the fused extend-add took the update tiles (round 4) the headline variant holds five tiles in 115 registers and is a
+// chain of LDS gathers: 12 waves 0.345 against 0.39 ms per Schur sweep of synth50k, 16 waves the same as 12 (round 5)
+constexpr int FAMT_NW = SMCP_FAMT_NW;
 constexpr int FAMT_HDR = 32;        // doubles: the header of a record (ints, as FAM2: [0] clique, [1] nn, [2] na, [3] children,
                                     // [4,5] panel offset, [8,9] packed-update offset; child c at 16 + 6 c: clique, nn, na,
                                     // first column in the child tables, -, -)
