@@ -518,12 +518,13 @@ inline unsigned umax1(int x) { return (unsigned)std::max(1, x); }
 static int fact_threads(const MfmaArgs& am, int thr, int kind) {
   static int t[3] = {0, 0, 0};
   if (!t[0]) {
-    auto rd = [](const char* n, int d) { const char* e = sw_str(n); int v = e ? atoi(e) : d; return (v >= 64 && v <= 1024 && !(v & 63)) ? v : d; };
-    t[0] = rd("SMCP_FTHR_CHOL", 128); t[1] = rd("SMCP_FTHR_PINV", 256); t[2] = rd("SMCP_FTHR_YAA", 64);
+    // (k_factor_yaa_lds is compiled for at most 256 threads: a larger value was a launch failure, SMCP_EHIP, not a tuning)
+    auto rd = [](const char* n, int d, int hi) { const char* e = sw_str(n); int v = e ? atoi(e) : d; return (v >= 64 && v <= hi && !(v & 63)) ? v : d; };
+    t[0] = rd("SMCP_FTHR_CHOL", 128, 1024); t[1] = rd("SMCP_FTHR_PINV", 256, 1024); t[2] = rd("SMCP_FTHR_YAA", 64, 256);
   }
   if (kind == 2 && am.nnmax <= 16 && am.namax > 32 && am.namax <= 64) {      // Y_AA blocks of 33 .. 64 rows (the mid fronts of synth50k)
     static int tm = 0;
-    if (!tm) { const char* e = sw_str("SMCP_FTHR_YAA_MID"); tm = e ? atoi(e) : 256; if (tm < 64 || tm > 1024 || (tm & 63)) tm = 256; }
+    if (!tm) { const char* e = sw_str("SMCP_FTHR_YAA_MID"); tm = e ? atoi(e) : 256; if (tm < 64 || tm > 256 || (tm & 63)) tm = 256; }
     return tm;
   }
   return (am.nnmax <= 16 && am.namax <= 32) ? t[kind] : thr;
@@ -577,7 +578,8 @@ static bool launch_assemble_fz(csp_ctx* c, const MfmaArgs& az, int cnt, int nrhs
   if (!attr) attr = hipFuncSetAttribute((const void*)k_lf_assemble_fz<NAT, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess &&
                     hipFuncSetAttribute((const void*)k_lf_assemble_fz<NAT, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == hipSuccess;
   if (!attr) return false;
-  // sixteen waves (128 registers each) or eight (256): SMCP_FZ_THREADS=512 selects the latter
+  // sixteen waves (128 registers each) or eight (256): SMCP_FZ_THREADS=512 selects the latter (twelve waves -- 166 registers, no
+  // spills either -- measured in round 5: 0.48 against 0.465 ms)
   static int thr = 0;
   if (!thr) { const char* e = sw_str("SMCP_FZ_THREADS"); thr = (e && atoi(e) == 512) ? 512 : 1024; }
   const dim3 grid((unsigned)std::min<int64_t>(c->D.ncu, (int64_t)cnt * nrhs * std::max(1, shares)));

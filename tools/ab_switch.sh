@@ -4,7 +4,7 @@
 set -o pipefail
 SW=$1; VALS=${2:-"0 1"}; WL=${3:-synth50k}; STEPS=${4:-20}
 mkdir -p gpurun_out/ab
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for v in $VALS; do
     env $SW=$v python3 bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu --no-secondary > gpurun_out/ab/${SW}_${v}_${rep}.json 2> gpurun_out/ab/${SW}_${v}_${rep}.err || { echo "bench failed ($SW=$v)"; tail -5 gpurun_out/ab/${SW}_${v}_${rep}.err; exit 1; }
     python3 - gpurun_out/ab/${SW}_${v}_${rep}.json $SW $v <<'PY'
