@@ -763,8 +763,10 @@ __global__ void __launch_bounds__(PD == 4 ? 1024 : 256, 4) k_lf_up1(MfmaArgs a, 
     // T = Li F_NN took nn^3); phase 2 forms G_NN = Z Li^T + Li Z^T.  Tiles above the diagonal are never read.
     const int tt = t - nE, m0 = (tt % ntN) * LT, n0 = (tt / ntN) * LT;
     const double* Li = c.Li;
+    // (tiles above the diagonal are never read in either form: phase 2 forms the lower tiles (tm, tn) of G_NN from T(tm, k <= tn) --
+    // the root of synth50k, four tile rows: ten products instead of sixteen)
+    if (n0 > m0) return;
     if (lf_sym_split(nn)) {
-      if (n0 > m0) return;
       // (the mask only matters over the tile's own columns; the rows of Fl below them are whole: the plain product)
       gemm_tile64<PD>(acc, nn, nn, min(nn, n0 + LT), m0, n0, [=](int m, int kk) { return Li[m + (int64_t)kk * nf]; },
                   [=](int kk, int n) { const double v_ = ldm<PD>(kk >= n, &P[kk + (int64_t)n * nf]); return kk == n ? 0.5 * v_ : v_; },
