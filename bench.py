@@ -55,6 +55,11 @@ def build_workload(name, seed=0):
         # the whole set (beyond 48: the dense family sweep, as synth50k_dense); since round 5 the mean does and long lists go in chunks
         pat = problems.nested_block_arrow_pattern(seed=seed)
         m, density, label = 100, 0.005, "synth50k with one diagonal (trace) constraint among the 100: one long (family, constraint) list among short ones"
+    elif name == "band200":
+        # config 1's problem as a KKT-solve point: band pattern n = 200, half-bandwidth 3, m = 100 constraints DENSE on V (band_SDP,
+        # base.py:617-632) -- the far end of the density range on a pattern of 197 cliques of four columns: launch-bound
+        pat = problems.band_pattern(200, 3)
+        m, density, label = 100, None, "band SDP n=200, half-bandwidth 3, m=100 constraints dense on V (config 1's problem)"
     elif name == "synth6k":   # reduced copy for quick checks only (NOT the benchmark)
         pat = problems.nested_block_arrow_pattern(nsub=2, nmid=56, seed=seed)
         m, density, label = 100, 0.005, "synth6k (reduced, check only)"
@@ -458,13 +463,21 @@ def run_workload(args, workload, steps, warmup, want_cpu, primary, env):
         symb, cptr, cidx, cval = maxcut_problem()
     else:
         symb = Symbolic(pat)
+        if workload == "band200":
+            # as the drivers do (solvers._Problem, options['amalgamate']): a chain of 197 one-column cliques is 197 levels of
+            # launches (15.9 ms per step, 63 solves/s against 1000 on the CPU); merged into cliques of up to 16 columns it is 13
+            from smcp_amd.symbolic import amalgamate
+            emb = amalgamate(symb)
+            if emb is not None:
+                symb = Symbolic(emb[0], emb[1])
     t_sym = time.time() - t0
     fl = symb.flops()
     B, U = fl["B"], fl["U"]
     per_rhs = 8 * (U + 3 * B)
     max_rhs = (args.max_rhs if primary else None) or int(max(1, min(m, (48 << 30) // per_rhs)))
     if workload != "maxcut":
-        cptr, cidx, cval = problems.random_constraints(symb, m, density=density, seed=1)
+        cptr, cidx, cval = (problems.random_constraints(symb, m, density=density, seed=1) if density is not None
+                            else problems.random_constraints(symb, m, seed=1, dense_on_v=True))
     if workload == "synth50k_trace":
         ccp, cri = symb.sparsity_pattern()
         dpos = np.sort(symb.ccs_to_blk()[ccp[:-1]]).astype(np.int64)        # the diagonal entries (first of every column of V)
@@ -925,7 +938,7 @@ def main():
     # config 4 (max-cut, column-sparse constraints) -- a few steps each after the headline measurement
     if world == 1 and not force_sharded and args.workload == "synth50k" and not args.no_secondary and args.kktsolver == "chol":
         sec = {}
-        for name in ("dense4096", "arrow", "maxcut", "synth50k_dense", "synth50k_trace"):
+        for name in ("dense4096", "arrow", "maxcut", "synth50k_dense", "synth50k_trace", "band200"):
             try:
                 # ten timed steps after two warm-up steps each; the CPU leg beside every GPU figure: the oracle on the host BLAS, one
                 # Schur column per thread scaled to m (config 4: its sequential SCMcolumn2 route in full, median of three)

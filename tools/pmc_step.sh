@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter figures of ONE bench step of a workload, per kernel and summed:
-#   [WORKLOAD=synth50k|dense4096|arrow|maxcut|synth50k_dense|synth50k_trace] [ROUND=r05] bash tools/pmc_step.sh
+#   [WORKLOAD=synth50k|dense4096|arrow|maxcut|synth50k_dense|synth50k_trace|band200] [ROUND=r05] bash tools/pmc_step.sh
 #   -> gpurun_out/${ROUND}_pmc_${WORKLOAD}.json   (copy to profiles/; bench.py reads it for roofline.traffic and roofline.step)
 # Three separate rocprofv3 --pmc passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes (HBM section): FETCH_SIZE (doubled:
 # gfx950 counts 64 B per 128-B request of wide coalesced reads), WRITE_SIZE (as is; both in KB), SQ_INSTS_VALU_MFMA_MOPS_F64

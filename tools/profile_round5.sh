@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 export ROUND=r05
 out=gpurun_out/prof_r05
 rm -rf $out; mkdir -p $out
-for w in ${WORKLOADS:-synth50k maxcut dense4096 arrow synth50k_dense synth50k_trace}; do
+for w in ${WORKLOADS:-synth50k maxcut dense4096 arrow synth50k_dense synth50k_trace band200}; do
   WORKLOAD=$w bash tools/pmc_step.sh > $out/pmc_$w.log 2>&1 && cp gpurun_out/r05_pmc_$w.json $out/ || { echo "pmc $w failed"; tail -5 $out/pmc_$w.log; }
   echo "pmc $w: $(grep '^step:' $out/pmc_$w.log)"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -o s -- python3 bench.py --workload $w --steps 5 --warmup 2 --no-cpu --no-secondary --no-back-solve > $out/bench_$w.json 2> $out/stats_$w.log \
