@@ -2900,6 +2900,11 @@ int csp_completion(csp_ctx* c, double* x, void* stream) {
           launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(mtA * ntN), cnt), blk, st, am, x, 1);
         }
         launch(c, KID_lf_completion, k_lf_completion, dim3(umax1(ntN * ntN), cnt), blk, st, am, x, 2);
+        // Cholesky of the nn x nn matrix at the head of the scratch: fronts of the one-workgroup class in ONE launch (k_mid_chol,
+        // mode 3) instead of three per 64 columns -- the chain of a completion on synth50k (tops + root: 27 launches) loses 11
+        if (use_mid(am.nnmax))
+          launch_lds(c, KID_mid_chol, k_mid_chol, dim3(cnt), dim3(1024), mid_chol_lds(am.nnmax), st, am, (double*)nullptr, (double*)nullptr, 3);
+        else
         for (int jb = 0; jb < am.nnmax; jb += LB) {
           launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, am, (double*)nullptr, (double*)nullptr, 3, jb, 1);
           const int mrem = am.nnmax - jb - 1;
