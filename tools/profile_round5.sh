@@ -15,7 +15,7 @@ for w in ${WORKLOADS:-synth50k maxcut dense4096 arrow synth50k_dense synth50k_tr
 done
 bash tools/trace_step.sh > $out/trace.log 2>&1; cp gpurun_out/trace_step.txt $out/r05_step_timeline.txt
 WORKLOAD=maxcut bash tools/trace_step.sh >> $out/trace.log 2>&1; cp gpurun_out/trace_step_maxcut.txt $out/r05_step_timeline_maxcut.txt
-timeout 600 python3 tools/shard_step_emul.py --mode subtree --top both > $out/emul.log 2>&1; cp gpurun_out/shard_step_emul.json $out/r05_shard_step_emul.json; grep -c emulated $out/emul.log
+timeout 600 python3 tools/shard_step_emul.py --mode subtree --top both --steps 30 > $out/emul.log 2>&1; cp gpurun_out/shard_step_emul.json $out/r05_shard_step_emul.json; grep -c emulated $out/emul.log
 # the full bench line LAST, with the PMC summaries of this very code in place (bench.py reads profiles/)
 mkdir -p profiles && cp $out/r05_pmc_*.json profiles/
 python3 bench.py --steps 20 --warmup 5 > $out/r05_bench_full.json 2> $out/bench_full.err; echo "bench rc=$?"; tail -c 300 $out/bench_full.err
