@@ -88,13 +88,12 @@ class _Problem:
             raise ValueError("b must have length m")
         A.sum_duplicates()
         rows = A.indices.astype(np.int64)
-        J = rows // n
-        I = rows - J * n
+        J, I = np.divmod(rows, n)                      # row index of A = i + n j
         if (I < J).any():
             raise ValueError("only lower-triangular entries (i >= j) are allowed in A")
-        # aggregate sparsity pattern + diagonal
-        key = np.unique(np.concatenate([J * n + I, np.arange(n, dtype=np.int64) * (n + 1)]))
-        pj, pi = key // n, key % n
+        # aggregate sparsity pattern + diagonal (the key j n + i of an entry IS its row index in A)
+        key = np.unique(np.concatenate([rows, np.arange(n, dtype=np.int64) * (n + 1)]))
+        pj, pi = np.divmod(key, n)
         cp = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.bincount(pj, minlength=n), out=cp[1:])
         pat = (n, cp, pi)
