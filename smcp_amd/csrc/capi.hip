@@ -672,7 +672,8 @@ void lf_assemble(csp_ctx* c, const MfmaArgs& a, int cnt, int nrhs, double* U, in
     // dependent loads, and 32 workgroups per front leave two or three positions per thread
     const int nfm = a.nnmax + a.namax;
     const int gx = (int64_t)cnt * nrhs * 32 < 2 * (int64_t)c->D.ncu ? std::max(32, std::min(128, (nfm * (nfm + 1) / 2 + 255) / 256)) : 32;
-    launch(c, KID_lf_assemble, k_lf_assemble, dim3(gx, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
+    if (a.nchmax <= 8) launch(c, KID_lf_assemble, k_lf_assemble<8>, dim3(gx, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
+    else launch(c, KID_lf_assemble, k_lf_assemble<16>, dim3(gx, cnt, nrhs), dim3(256), st, a, U, ldu, sgn);
     return;
   }
   const int nfmax = a.nnmax + a.namax;

@@ -322,6 +322,9 @@ __device__ inline LfCtx lf_ctx(const MfmaArgs& a, double* u, int64_t ldu) {
 // ---- phase 0: zero the update block and add the children (gather plan: one owner per position)
 // sgn 0: U = children, panel += children (U was cleared);  sgn 1: U += children, panel -= children;
 // sgn 2: U += children, panel += children
+// CH: contributions requested per round (16; 8 for fronts of at most eight children: a position of the root of synth50k sums
+// at most eight and the clamped requests beyond the list are wasted loads -- 63 -> see DESIGN)
+template <int CH>
 __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
   const int k = a.t.lev[blockIdx.y];
   const CliqueDesc d = a.t.cl[k];
@@ -341,15 +344,15 @@ __global__ void k_lf_assemble(MfmaArgs a, double* u, int64_t ldu, int sgn) {
     // positions: a position of the (64,128) fronts of synth50k sums 12.6 children on average, and with four per round
     // and a tail loop the chain was ~9 memory round trips (24 us for one right-hand side); the sum keeps its fixed order
     double acc = 0.0;
-    for (int64_t cc = c0; cc < c1; cc += 16) {
-      int32_t sx[16];
-      double vx[16];
+    for (int64_t cc = c0; cc < c1; cc += CH) {
+      int32_t sx[CH];
+      double vx[CH];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) sx[q] = a.t.gp_src[min(cc + q, c1 - 1)];
+      for (int q = 0; q < CH; ++q) sx[q] = a.t.gp_src[min(cc + q, c1 - 1)];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) vx[q] = ubase[sx[q]];
+      for (int q = 0; q < CH; ++q) vx[q] = ubase[sx[q]];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc += (cc + q < c1) ? vx[q] : 0.0;
+      for (int q = 0; q < CH; ++q) acc += (cc + q < c1) ? vx[q] : 0.0;
     }
     const int i = code & 0x7fff, j = (code >> 15) & 0x7fff;
     if (sgn) {
