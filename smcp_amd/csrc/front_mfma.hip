@@ -1316,6 +1316,7 @@ constexpr int GRAM_BLK = 128;   // columns of H per block
 constexpr int GRAM_KS = 64;     // slice of the long dimension staged per step
 constexpr int GRAM_LD = GRAM_BLK + 1;
 constexpr int GRAM_LDK = GRAM_KS + 2;   // k_gram_diag128: [column][k] image
+constexpr int GRAM_RZ = 8;              // workgroups per tile of the first stage of a two-stage k_gram_reduce
 
 template <bool DIAG>
 __global__ void __launch_bounds__(256) k_gram_partial(const double* G, int64_t ldg, int m, int64_t e_lo, int64_t e_hi,
@@ -1504,7 +1505,10 @@ __global__ void __launch_bounds__(64 * NW, (NW == 16 ? 2 : 1)) k_gram_diag128(co
 
 // H (m x m, ld ldh, both triangles) <- sum over chunks of the partial tiles (those of k_gram_diag128 and those of
 // k_leaf_pairs, front_leafgram.hip), in a fixed order
-__global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* H, int64_t ldh) {
+// part_out != null (first of two stages; several hundred chunks on 28 tile workgroups were 43 us of every Schur complement of
+// synth50k): gridDim.z workgroups per tile, workgroup z sums the chunks of its range into slot z of part_out -- the layout of
+// `partial` with gridDim.z chunks, which the second stage then reduces into H.  The order of the additions stays fixed.
+__global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* H, int64_t ldh, double* part_out) {
   int bi = 0, rem = blockIdx.y;
   while (rem > bi) { rem -= bi + 1; ++bi; }
   const int bj = rem;
@@ -1520,7 +1524,9 @@ __global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* 
   __shared__ double zs[4][256];
   const int idx = threadIdx.x & 255;    // element within the tile (column-major 16 x 16)
   const int z = threadIdx.x >> 8, nz = blockDim.x >> 8;
-  const int c0 = (int)(((int64_t)nchunk * z) / nz), c1 = (int)(((int64_t)nchunk * (z + 1)) / nz);
+  const int Z = part_out ? (int)gridDim.z : 1, zz = part_out ? (int)blockIdx.z : 0;
+  const int r0 = (int)(((int64_t)nchunk * zz) / Z), r1 = (int)(((int64_t)nchunk * (zz + 1)) / Z);       // this workgroup's chunks
+  const int c0 = r0 + (int)(((int64_t)(r1 - r0) * z) / nz), c1 = r0 + (int)(((int64_t)(r1 - r0) * (z + 1)) / nz);
   const double* p = partial + (int64_t)blockIdx.y * nchunk * (int64_t)(64 * 256) + (int64_t)t * 256 + idx;
   // eight independent partial sums (eight loads in flight; the order of the additions is fixed: deterministic)
   double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1536,6 +1542,10 @@ __global__ void k_gram_reduce(const double* partial, int nchunk, int m, double* 
     __syncthreads();
     if (z) return;
     for (int q = 1; q < nz; ++q) s += zs[q][idx];
+  }
+  if (part_out) {
+    part_out[((int64_t)blockIdx.y * Z + zz) * (int64_t)(64 * 256) + (int64_t)t * 256 + idx] = s;
+    return;
   }
   const int i = ci0 + tm * 16 + (idx & 15), j = cj0 + tn * 16 + (idx >> 4);
   if (i < ci0 + ni && j < cj0 + nj) {

@@ -1271,7 +1271,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
       spw = (int)(chunk / GRAM_KS);
       nchunk = std::max(1, (D.gsl_n + spw - 1) / spw);
       ngram = D.gsl_n > 0 ? nchunk : 0;
-      if (int rc = gram_reserve(c, m, nchunk + (leaf ? leafgram_slots(c) : 0))) return rc;
+      if (int rc = gram_reserve(c, m, nchunk + (leaf ? leafgram_slots(c) : 0) + GRAM_RZ)) return rc;
       if (leaf) { if (int rc = leafgram_partials(c, m, ids, st, D.gpart + (int64_t)ngram * (64 * 256), &nl)) return rc; }
     }
     c->gpre.valid = false; c->gpre.early_done = false;
@@ -1288,7 +1288,13 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
     const int c0 = early_done ? early : 0;
     if (D.gsl_n > 0 && nchunk > c0) gram_launch_chunks(c, m, spw, c0, nchunk, nchunk, st);
     if (side) { side->join(); delete side; }      // the leaf partials of the side branch
-    launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(ngram + nl >= 64 ? 1024 : 256), st, (const double*)D.gpart, ngram + nl, (int)m, H, ldh);
+    if (ngram + nl >= 256 && D.gpart_len >= (int64_t)(ngram + nl + GRAM_RZ) * (64 * 256)) {
+      // two stages: GRAM_RZ workgroups per tile, then their GRAM_RZ sums (slots behind the partial tiles: gram_reserve)
+      double* const stage = D.gpart + (int64_t)(ngram + nl) * (64 * 256);
+      launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1, GRAM_RZ), dim3(1024), st, (const double*)D.gpart, ngram + nl, (int)m, H, ldh, stage);
+      launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(256), st, (const double*)stage, GRAM_RZ, (int)m, H, ldh, (double*)nullptr);
+    } else
+    launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, 1), dim3(ngram + nl >= 64 ? 1024 : 256), st, (const double*)D.gpart, ngram + nl, (int)m, H, ldh, (double*)nullptr);
     HIPCHK(end_call(c));
     return 0;
   }
@@ -1313,7 +1319,7 @@ static int gram_accumulate(csp_ctx* c, int64_t nranges, const int64_t* ranges, d
       }
     coff += nc;
   }
-  launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(nchunk >= 64 ? 1024 : 256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh);
+  launch(c, KID_gram_reduce, k_gram_reduce, dim3(64, nblk), dim3(nchunk >= 64 ? 1024 : 256), st, (const double*)D.gpart, nchunk, (int)m, H, ldh, (double*)nullptr);
   HIPCHK(end_call(c));
   return 0;
 }
@@ -1364,7 +1370,7 @@ static int schur_gram(csp_ctx* c, const double* L, const double* Y, double* H, i
         const int spw = D.gsl_spw ? D.gsl_spw : (int)(chunk / GRAM_KS);
         const int nchunk = std::max(1, (D.gsl_n + spw - 1) / spw);
         const int ngram = D.gsl_n > 0 ? nchunk : 0;
-        if (gram_reserve(c, m, nchunk + leafgram_slots(c))) return;
+        if (gram_reserve(c, m, nchunk + leafgram_slots(c) + GRAM_RZ)) return;
         int nl = 0;
         if (leafgram_partials(c, m, nullptr, side, D.gpart + (int64_t)ngram * (64 * 256), &nl)) return;
         c->gpre.valid = true; c->gpre.ngram = ngram; c->gpre.nchunk = nchunk; c->gpre.spw = spw; c->gpre.nl = nl;
