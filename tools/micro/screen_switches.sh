@@ -1,5 +1,6 @@
+# one-repetition screen of run-time tunables on the headline (each line: one bench run of 20 steps)
 export REPS=1
-for spec in "SMCP_GRAM_NW:16 8" "SMCP_FTHR_CHOL:128 64 256" "SMCP_FTHR_PINV:256 128 512" "SMCP_FTHR_YAA:64 128" "SMCP_FTHR_YAA_MID:256 128 512" "SMCP_FAMT_G:0 1 2 3 4"; do
+for spec in ${SPECS:-"SMCP_GRAM_MINCHUNK:512 4096 8192 1024" "SMCP_N16_THR_LEAF:128 64 256" "SMCP_DIAG_THREADS:512 1024 256" "SMCP_POTRF_THREADS:1024 512" "SMCP_UPDP_PAD:0 8 16" "SMCP_LG_EARLY:1 0" "SMCP_SCALING_OVERLAP:1 0" "SMCP_AUX_PRIO1:1 0"}; do
   sw=${spec%%:*}; vals=${spec#*:}
-  bash tools/ab_switch.sh $sw "$vals" synth50k 20 | grep -v "^    "
+  bash tools/ab_switch.sh $sw "$vals" ${WL:-synth50k} 20 | grep -v "^    "
 done
