@@ -125,7 +125,37 @@ class ShardedSchur:
         """Cut the tree for the ranks of `group` (deterministic: every rank computes the same cut)."""
         import torch.distributed as dist
         from .shard import subtree_partition
-        return self._install_partition(dist.get_world_size(group), dist.get_rank(group))
+        P = self._install_partition(dist.get_world_size(group), dist.get_rank(group))
+        if self.top_by_constraint and not self._by_share_collectives_work(group):
+            self.top_by_constraint = False
+        return P
+
+    def _by_share_collectives_work(self, group):
+        """The top by constraint needs an all-to-all and a gather where the replicated top needs an all-gather and an all-reduce
+        only.  No multi-rank RCCL job has ever run in this build's environment: one tiny instance of each is tried when the
+        partition is set, the ranks agree on the outcome through an all-reduce (which every route needs anyway), and a backend
+        that refuses either sends ALL ranks to the replicated top instead of failing the first Schur complement."""
+        import torch.distributed as dist
+        world, rank = self._world(group)
+        if world == 1:
+            return True
+        ok = 1.0
+        try:
+            send = torch.arange(world, dtype=torch.float64, device=self.dev) + 10.0 * rank
+            recv = torch.empty(world, dtype=torch.float64, device=self.dev)
+            _all_to_all(recv, send, group)
+            got = [torch.empty(1, dtype=torch.float64, device=self.dev) for _ in range(world)] if rank == 0 else None
+            _gather_to(0, got, send[:1].clone(), group)
+            want = torch.arange(world, dtype=torch.float64) * 10.0 + rank
+            if not torch.equal(recv.cpu(), want) or (rank == 0 and [float(g) for g in got] != [10.0 * r for r in range(world)]):
+                ok = 0.0
+        except Exception as e:                               # (an unsupported collective raises on every rank alike)
+            import sys
+            print("smcp_amd: top-by-constraint collectives unavailable (%s): replicated top" % (repr(e)[:120],), file=sys.stderr)
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float64, device=self.dev)
+        _all_reduce(flag, group)                             # (sum: every rank must have succeeded)
+        return float(flag) > world - 0.5
 
     def _install_partition(self, world, rank):
         from .shard import subtree_partition
