@@ -782,43 +782,50 @@ bool use_mid(int rowsmax) {
 // the blkval array; mode 2: its Y_AA block, base = fac).  dinv: where the inverses of the diagonal blocks go (64 x 64 slots;
 // nullptr: the workspace's own).  Returns false when the route does not apply or its set-up fails (the caller takes the
 // per-step kernels); SMCP_FLOW=0: never.
-bool flow_chol(csp_ctx* c, hipStream_t st, double* A, int64_t ld, int n, double* dinv, const MfmaArgs* fa, int mode, int* info, int info_val) {
+bool flow_chol(csp_ctx* c, hipStream_t st, double* A, int64_t ld, int n, double* dinv, const MfmaArgs* fa, int mode, int* info, int info_val, int cnt = 1) {
   static int on = -1, wgs = 0;
   if (on < 0) { on = sw_on("SMCP_FLOW", 1); wgs = std::max(1, std::min(FLOW_MAXWG, sw_int("SMCP_FLOW_WG", FLOW_MAXWG))); }
   if (!on || use_generic(c) || n <= 2 * LB || n > FLOW_MAXN || !info) return false;
+  // several fronts of a level in one launch (cnt > 1: their cliques through fa->t.lev, n = the largest order): the fronts share
+  // the budget of workgroups of ONE launch (wgs: what may stand beside other launches on the chip), at least eight each
+  if (cnt < 1 || (cnt > 1 && (!fa || dinv || cnt > wgs / 8))) return false;
   static int attr = -1;
   if (attr < 0) attr = hipFuncSetAttribute((const void*)k_chol_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_BYTES) == hipSuccess ? 1 : 0;
   if (!attr) return false;
   const int nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
   csp_ctx::FlowWs& W = c->flow_ws[st == c->aux_stream[0] && st ? 1 : (st == c->aux_stream[1] && st ? 2 : 0)];
-  if (W.cap_nt < nt) {
+  if (W.cap_nt < nt || W.cap_fronts < cnt) {
     // (the buffers may be in use by a launch still queued on this stream: hipFree waits for the device)
+    const int ntc = std::max(nt, W.cap_nt), ntilesc = ntc * (ntc + 1) / 2, frc = std::max(cnt, W.cap_fronts);
     for (void* q : {(void*)W.P, (void*)W.dinv, (void*)W.flags}) if (q) (void)hipFree(q);
     W = csp_ctx::FlowWs();
     int64_t junk = 0;
-    if (dev_alloc(&W.P, (int64_t)ntiles * 4096, junk) || dev_alloc(&W.dinv, (int64_t)nt * 4096, junk) ||
-        hipMalloc((void**)&W.flags, sizeof(unsigned) * (size_t)(ntiles + nt + 4)) != hipSuccess ||
-        hipMemset(W.flags, 0, sizeof(unsigned) * (size_t)(ntiles + nt + 4)) != hipSuccess) {
+    if (dev_alloc(&W.P, (int64_t)frc * ntilesc * 4096, junk) || dev_alloc(&W.dinv, (int64_t)frc * ntc * 4096, junk) ||
+        hipMalloc((void**)&W.flags, sizeof(unsigned) * (size_t)frc * (size_t)(ntilesc + ntc + 4)) != hipSuccess ||
+        hipMemset(W.flags, 0, sizeof(unsigned) * (size_t)frc * (size_t)(ntilesc + ntc + 4)) != hipSuccess) {
       (void)hipGetLastError();
       for (void* q : {(void*)W.P, (void*)W.dinv, (void*)W.flags}) if (q) (void)hipFree(q);
       W = csp_ctx::FlowWs();
       return false;
     }
-    c->D.bytes += junk + (int64_t)sizeof(unsigned) * (ntiles + nt + 4);
-    W.cap_nt = nt;
+    c->D.bytes += junk + (int64_t)sizeof(unsigned) * frc * (ntilesc + ntc + 4);
+    W.cap_nt = ntc; W.cap_fronts = frc;
   }
-  auto it = c->flow_plans.find(n);
+  const int wgs_front = cnt > 1 ? wgs / cnt : (n > 2048 ? (wgs * 10) / 7 : wgs);
+  if ((int64_t)ntiles > (int64_t)FLOW_MAXOWN * wgs_front) return false;      // (a workgroup tracks at most FLOW_MAXOWN tiles)
+  const int plan_key = n * 1024 + std::min(1023, wgs_front);
+  auto it = c->flow_plans.find(plan_key);
   if (it == c->flow_plans.end()) {
     std::vector<int32_t> optr, otile;
     // (beyond order 2048 -- 528 tiles -- more workgroups: the trailing updates, not the chain of diagonal tiles, set the time there;
     // 160: three such launches of three processes sharing the GPU still fit the chip side by side, two workgroups per CU)
-    flow_make_plan(n, n > 2048 ? (wgs * 10) / 7 : wgs, optr, otile);
+    flow_make_plan(n, wgs_front, optr, otile);
     csp_ctx::FlowPlanDev P;
     P.nwg = (int)optr.size() - 1;
     int64_t junk = 0;
     if (dev_upload(&P.own_ptr, optr, junk) || dev_upload(&P.own_tile, otile, junk)) { (void)hipGetLastError(); return false; }
     c->D.bytes += junk;
-    it = c->flow_plans.emplace(n, P).first;
+    it = c->flow_plans.emplace(plan_key, P).first;
   }
   FlowArgs f;
   f.A = A; f.ld = ld; f.n = n;
@@ -831,11 +838,13 @@ bool flow_chol(csp_ctx* c, hipStream_t st, double* A, int64_t ld, int n, double*
   f.info = info; f.info_val = info_val;
   f.cl = fa ? fa->t.cl : nullptr; f.lev = fa ? fa->t.lev : nullptr; f.mode = mode; f.nsn1 = fa ? fa->t.nsn1 : 1;
   f.dbg = nullptr;
+  // (per-front slices of the workspace: the layout of the largest order n this launch was given)
+  f.p_stride = (int64_t)ntiles * 4096; f.dinv_stride = (int64_t)nt * 4096; f.flag_stride = ntiles + nt + 4;
   static int stamps = -1;
   if (stamps < 0) stamps = sw_on("SMCP_FLOW_STAMPS", 0);
   static long long* dbg = nullptr;
   if (stamps) { if (!dbg) (void)hipMalloc((void**)&dbg, sizeof(long long) * 16 * FLOW_MAXWG); f.dbg = dbg; }
-  launch_lds(c, KID_chol_flow, k_chol_flow, dim3(it->second.nwg), dim3(256), FLOW_LDS_BYTES, st, f);
+  launch_lds(c, KID_chol_flow, k_chol_flow, dim3(it->second.nwg, cnt), dim3(256), FLOW_LDS_BYTES, st, f);
   if (stamps && dbg) {           // timing studies: what the workgroups spent their time on, on stderr
     std::vector<long long> h((size_t)8 * it->second.nwg);
     (void)hipStreamSynchronize(st);
@@ -875,7 +884,9 @@ void lf_factor_yaa(csp_ctx* c, const MfmaArgs& a, int cnt, double* fac, hipStrea
     launch_lds(c, KID_mid_chol, k_mid_chol, dim3(cnt), dim3(1024), mid_chol_lds(a.namax), st, a, (double*)nullptr, fac, 2);
     return;
   }
-  if (cnt == 1 && flow_chol(c, st, fac, 0, a.namax, nullptr, &a, 2, a.t.info, 0)) return;
+  // (one front, or the fronts of the level side by side in one launch -- config 4: levels of three and five fronts with
+  // separators of 300 - 500 rows were 8 + 5 steps of three launches each)
+  if (flow_chol(c, st, fac, 0, a.namax, nullptr, &a, 2, a.t.info, 0, cnt)) return;
   for (int jb = 0; jb < a.namax; jb += LB) {
     launch_lds(c, KID_lf_diag, k_lf_diag, dim3(cnt), diag_blk(), LF_DIAG_LDS, st, a, (double*)nullptr, fac, 2, jb, 1);
     const int mrem = a.namax - jb - 1;

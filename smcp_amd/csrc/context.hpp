@@ -252,10 +252,10 @@ struct csp_ctx {
   bool lazy_status = false;             // csp_lazy_status: failure flags are latched on the device, read by csp_status
   // one-launch blocked Cholesky with in-launch tile dataflow (front_flow.hip): workspace per stream in use (caller's, side 0,
   // side 1: two such launches may run side by side) and the ownership plans by matrix order
-  struct FlowWs { double* P = nullptr; double* dinv = nullptr; unsigned* flags = nullptr; int cap_nt = 0; unsigned epoch = 0; };
+  struct FlowWs { double* P = nullptr; double* dinv = nullptr; unsigned* flags = nullptr; int cap_nt = 0, cap_fronts = 0; unsigned epoch = 0; };
   FlowWs flow_ws[3];
   struct FlowPlanDev { int nwg = 0; int32_t* own_ptr = nullptr; int32_t* own_tile = nullptr; };
-  std::map<int, FlowPlanDev> flow_plans;
+  std::map<int, FlowPlanDev> flow_plans;     // key: order * 1024 + workgroups
   double placement_probe[2] = {0.0, 0.0};   // CSP_TUNE_PLACEMENT: probe time before / after, ms
   bool flags_clean = false;             // lazy mode: the last thing done to the flags was k_latch_status (which leaves them zero)
   int launch_err = 0;                   // first failed kernel launch of the running call (launch helpers); read by end_call

@@ -46,6 +46,9 @@ struct FlowArgs {
   // leading dimension nn), mode 2 = its Y_AA block in A (update layout: na x na); info / info_val then follow from the clique
   const CliqueDesc* cl; const int32_t* lev; int mode; int nsn1;
   long long* dbg;                    // timing studies (SMCP_FLOW_STAMPS=1): per workgroup 8 words -- ticks idle / updating / factoring / panel, counts of each
+  // several fronts of one level side by side (gridDim.y of them, front f = clique lev[f]): every front has its own slice of the
+  // workspace (P, dinv, flags: strides in elements) laid out for the LARGEST order n; a front's own order comes from its clique
+  int64_t p_stride, dinv_stride; int flag_stride;
 };
 
 __host__ __device__ inline int flow_tile_id(int i, int k) { return i * (i + 1) / 2 + k; }
@@ -99,18 +102,21 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs a) {
   double* const s16 = T1 + 64 * FLOW_LD;         // 1024 doubles: the 16 x 16 block inverses, then the scratch of the inverse's assembly
   __shared__ int s_pick, s_ti, s_tk, s_pg, s_fuse;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = a.n, nt = (n + 63) >> 6, ntiles = nt * (nt + 1) / 2;
+  const int ntL = (a.n + 63) >> 6, ntilesL = ntL * (ntL + 1) / 2;       // the layout of the flags (and the plan): the largest order
+  int n = a.n;
   if (a.lev) {
-    const int kc = a.lev[0];
+    const int kc = a.lev[blockIdx.y];
     const CliqueDesc d = a.cl[kc];
-    if (a.mode == 0) { a.A += d.blk; a.ld = d.nn + d.na; } else { a.A += d.upd; a.ld = d.na; }
+    if (a.mode == 0) { a.A += d.blk; a.ld = d.nn + d.na; n = d.nn; } else { a.A += d.upd; a.ld = d.na; n = d.na; }
     a.info += kc / a.nsn1; a.info_val = kc % a.nsn1 + 1;
+    a.P += (int64_t)blockIdx.y * a.p_stride; a.dinv += (int64_t)blockIdx.y * a.dinv_stride; a.flags += (int64_t)blockIdx.y * a.flag_stride;
   }
+  const int nt = (n + 63) >> 6;
   if (*a.info) return;                             // (an earlier level of this factorisation has failed: as the per-step kernels)
   const int64_t ld = a.ld;
   unsigned* const pflag = a.flags;
-  unsigned* const dflag = a.flags + ntiles;
-  unsigned* const abortf = dflag + nt;
+  unsigned* const dflag = a.flags + ntilesL;
+  unsigned* const abortf = dflag + ntL;
   const unsigned epoch = a.epoch;
   const int t0 = a.own_ptr[blockIdx.x], cnt = a.own_ptr[blockIdx.x + 1] - t0;
   // scheduling state of the first wave: lane l <-> own tile l
@@ -118,7 +124,7 @@ __global__ void __launch_bounds__(256) k_chol_flow(FlowArgs a) {
   bool fin = true;
   if (wave == 0 && lane < cnt) {
     const int packed = a.own_tile[t0 + lane];
-    ti = packed >> 16; tk = packed & 0xffff; fin = false;
+    ti = packed >> 16; tk = packed & 0xffff; fin = ti >= nt;      // (a tile beyond this front's own order: nothing to do, nobody waits for it)
   }
   long long tlast = wall_clock64();
   long long tmark = tlast, acct[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sub[4] = {0, 0, 0, 0}, tsub = 0;

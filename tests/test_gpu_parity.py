@@ -51,6 +51,21 @@ GPU_PATTERNS["diag"] = lambda: problems.band_pattern(15, 0)          # LP case: 
 GPU_PATTERNS["dense600"] = lambda: problems.band_pattern(600, 599)
 GPU_PATTERNS["arrow_one"] = lambda: problems.nested_block_arrow_pattern(nsub=1, nmid=2, nleaf_per_mid=2, leaf=(3, 9), mid=(6, 20), top=(40, 300),
                                                                         root=310, seed=9)
+# three top fronts in ONE level whose separators (300, 200 and 150 rows of a 310-column root) are beyond the one-workgroup class:
+# their chol(Y_AA) runs side by side in one launch of the one-launch blocked Cholesky (front_flow.hip, gridDim.y = 3; orders 5 / 4 / 3
+# tiles against a plan laid out for 5)
+def _three_tops_pattern():
+    root = np.arange(130, 440)
+    cl = [(root, root)]
+    for s_, na in enumerate((300, 200, 150)):
+        own = np.arange(40 * s_, 40 * s_ + 40)
+        sep = root[np.sort(np.random.default_rng(90 + s_).choice(len(root), size=na, replace=False))]
+        cl.append((own, np.concatenate([own, sep])))
+    cl.append((np.arange(120, 130), np.concatenate([np.arange(120, 130), root[:20]])))
+    return problems._from_cliques(440, cl)
+
+
+GPU_PATTERNS["three_tops"] = _three_tops_pattern
 # families (front_fam.hip: small parents swept together with their childless children): largest member sizes,
 # odd sizes with few children, and nine children per parent (one more than the waves of a workgroup: no family)
 GPU_PATTERNS["fam_max"] = lambda: problems.nested_block_arrow_pattern(nsub=1, nmid=3, nleaf_per_mid=8, leaf=(16, 32),
